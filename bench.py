@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the hot path (BASELINE.json): fwd + loss + bwd Mpixels/s at
+1920x1080 on 1 M synthetic Gaussians, SH degree 3 (config 3), one view per GPU.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+A step = gsr_forward (project + SH + binning + per-tile sort + composite) + the L1/SSIM
+loss head and its pullback + gsr_backward (composite backward + per-Gaussian backward),
+with all inputs already resident in HBM, plus — for N > 1 — the single RCCL all-reduce
+of the 59·N-float gradient arena.  Rank r renders view r of the batch (weak scaling:
+per-GPU work is fixed, `value` counts the pixels of all views).
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     — dominant kernel: algorithmic HBM bytes per launch / mean launch time
+                 (HIP events on the launch stream, gsr_profile_*), against 8 TB/s;
+  cpu_baseline — the oracle (C restatement of the reference algorithm, OpenMP) timed on
+                 this host's cores on the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import gsr_pkg  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(stage, N, V, D, P, T, C=3, K=16):
+    """SURVEY.md §8(d) per-stage algorithmic HBM bytes (one launch = one view)."""
+    return {
+        "preprocess": 40 * N + 8 * N + 12 * K * V + 39 * V,
+        "tile_scan": 8 * T,
+        "scatter": 8 * N + 12 * V + 12 * D,
+        "tile_sort": 12 * D + 12 * D + 8 * D + 8 * T,
+        "composite_fwd": (28 + 4 * C) * D + 8 * T + (4 * C + 8) * P,
+        "composite_bwd": (4 * C + 8) * P + 8 * T + (28 + 4 * C) * D + 4 * (C + 6) * D,
+        "pergauss_bwd": 4 * N + (87 + 12 * K) * V + (44 + 12 * K) * N,
+        "zero_acc": 4 * (C + 6) * N,
+        "loss_fwd": 72 * P,
+        "loss_bwd": 84 * P + 24 * P,
+    }[stage]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--seed", type=int, default=1003)
+    ap.add_argument("--no-loss", action="store_true", help="config 2 style: random cotangent instead of L1/SSIM")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--views", type=int, default=8, help="size of the multi-view batch the poses are drawn from")
+    args = ap.parse_args()
+
+    pkg = gsr_pkg.load()
+    D = pkg.distributed
+    rank, world, local = D.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (the product path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    W, H, N, deg = args.width, args.height, args.n, args.sh_degree
+    s = pkg.synthetic.make_scene(N, W, H, deg, args.seed)
+    K = s.shs.shape[1]
+    view = rank % args.views
+    if world == 1:
+        R, t = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)  # §8(d): R = I, t = 0
+    else:
+        R, t = pkg.synthetic.view_pose(view, args.views)
+    cam = pkg.Camera(W, H, tuple(s.focal), (0.5, 0.5), R, t)
+    to = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    params = [to(s.means), to(s.shs), to(s.opacities.reshape(-1, 1)), to(s.scales), to(s.rotations)]
+    target = to(pkg.synthetic.make_target(W, H, args.seed + view))
+    vpix_fixed = to(pkg.synthetic.make_vpixels(W, H, 3, args.seed + view))
+    rast = pkg.rasterizer.GaussianRasterizer(W, H, mode="rgb", device=dev)
+    arena = torch.empty(D.arena_numel(N, K), device=dev, dtype=torch.float32)
+    bg = (0.0, 0.0, 0.0)
+
+    def step():
+        img = rast.forward_raw(*params, cam, deg, bg)
+        if args.no_loss:
+            vp = vpix_fixed
+        else:
+            _, vp = pkg.fused_ssim.l1_ssim_loss(rast, img, target)
+        rast.backward_raw(vp, *params, cam, deg, bg, arena=arena)
+        D.allreduce_arena(arena)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    rast.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    prof = rast.profile_read()
+    rast.profile(False)
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    P, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+    Dn, V = int(rast.stats.n_rendered), int(rast.stats.n_visible)
+    ms_step = 1e3 * dt / args.steps
+    value = world * P / (dt / args.steps) / 1e6
+
+    stages = {k: (ms / max(c, 1), c) for k, (ms, c) in prof.items() if c > 0}
+    dom = max(stages, key=lambda k: stages[k][0] * stages[k][1])
+    dom_ms = stages[dom][0]
+    dom_bytes = algorithmic_bytes(dom, N, V, Dn, P, T, 3, K)
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom)
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "algorithmic_bytes": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
+                "stages_ms": {k: round(v[0], 4) for k, v in stages.items()},
+                "whole_step_algorithmic_GBps": round(
+                    sum(algorithmic_bytes(k, N, V, Dn, P, T, 3, K) for k in stages) / (ms_step * 1e-3) / 1e9, 2)}
+
+    out = {
+        "metric": "fwd+bwd Mpixels/s @1920x1080, 1M Gaussians SH=3",
+        "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": ("config3: 1M Gaussians, SH deg 3, 1920x1080, fwd + L1/0.2*DSSIM loss + bwd"
+                                if not args.no_loss and (N, W, H, deg) == (1_000_000, 1920, 1080, 3) else
+                                f"N={N} SH{deg} {W}x{H} fwd{'' if args.no_loss else '+loss'}+bwd"),
+                   "n_gaussians": N, "visible": V, "tile_instances": Dn, "views_per_gpu": 1,
+                   "parallelism": f"view-parallel x{world}, 1 all-reduce of {arena.numel() * 4 / 1e6:.0f} MB"},
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(pkg, s, W, H, deg, args)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pkg, s, W, H, deg, args):
+    """The oracle (line-for-line C restatement of the reference algorithm; the reference
+    itself has no CPU path) on this host's cores: one full step of the same workload."""
+    from oracle import oracle as orc
+    cores = orc.num_threads()
+    cam = orc.Camera(W, H, s.focal)
+    tgt = pkg.synthetic.make_target(W, H, args.seed)
+    t0 = time.perf_counter()
+    st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg)
+    if args.no_loss:
+        vp = pkg.synthetic.make_vpixels(W, H, 3, args.seed)
+    else:
+        _, vp = orc.loss_head(st.image, tgt)
+    orc.backward(st, vp, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, deterministic=False)
+    dt = time.perf_counter() - t0
+    return {"value": round(W * H / dt / 1e6, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": f"1 full step of the same workload ({dt:.1f} s wall)"}
+
+
+if __name__ == "__main__":
+    main()

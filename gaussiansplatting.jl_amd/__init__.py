@@ -5,3 +5,16 @@ the host-side mirror of the reference's `GaussianRasterizer` / `rasterize` /
 `∇rasterize` / `fused_ssim` interface.  Import via `gsr_pkg.load()`.
 """
 from . import synthetic  # noqa: F401
+from . import _lib  # noqa: F401
+from .camera import Camera  # noqa: F401
+
+
+def __getattr__(name):
+    # torch-dependent modules are imported lazily
+    if name in ("rasterizer", "fused_ssim", "distributed"):
+        import importlib
+        return importlib.import_module(f"{__name__}.{name}")
+    if name in ("GaussianRasterizer", "rasterize", "grad_rasterize", "n_color_features"):
+        from . import rasterizer
+        return getattr(rasterizer, name)
+    raise AttributeError(name)

@@ -1,0 +1,123 @@
+"""ctypes binding of libgsr_hip.so — field-for-field mirror of include/gsr.h.
+
+The product path has no CPU fallback: if the HIP library is missing or fails to
+load, importing anything that needs it raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gsr.h")
+
+GSR_OK, GSR_E_INVALID_ARG, GSR_E_OOM, GSR_E_HIP, GSR_E_STATE = 0, -1, -2, -3, -4
+MODES = {"rgb": 3, "rgbd": 5, "rgbdn": 8}
+
+(BUF_RADII, BUF_GRAD_MEANS2D, BUF_N_CONTRIB, BUF_FINAL_T, BUF_TILE_RANGES, BUF_VALUES_SORTED, BUF_GEOM0, BUF_GEOM1,
+ BUF_GEOM2, BUF_GEOM3, BUF_RECT, BUF_GRAD_ACC0, BUF_GRAD_ACC1) = range(13)
+
+
+class GsrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"gsr error {code}: {msg}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("mode", C.c_int32), ("near_plane", C.c_float),
+                ("far_plane", C.c_float), ("radius_clip", C.c_int32), ("blur_eps", C.c_float)]
+
+
+class Inputs(C.Structure):
+    _fields_ = [("n", C.c_int32), ("n_coeffs", C.c_int32), ("sh_degree", C.c_int32), ("means", C.c_void_p),
+                ("shs", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
+                ("background", C.c_float * 3)]
+
+
+class CameraS(C.Structure):
+    _fields_ = [("R", C.c_float * 9), ("t", C.c_float * 3), ("focal", C.c_float * 2), ("principal", C.c_float * 2),
+                ("camera_center", C.c_float * 3), ("R_dev", C.c_void_p), ("t_dev", C.c_void_p)]
+
+
+class Aux(C.Structure):
+    _fields_ = [("covisibilities", C.c_void_p), ("uncertainties", C.c_void_p)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_rendered", C.c_int64), ("n_visible", C.c_int32), ("max_tile_instances", C.c_int32)]
+
+
+class Grads(C.Structure):
+    _fields_ = [("vmeans", C.c_void_p), ("vshs", C.c_void_p), ("vopacities", C.c_void_p), ("vscales", C.c_void_p),
+                ("vrotations", C.c_void_p), ("vR", C.c_void_p), ("vt", C.c_void_p)]
+
+
+EXPORTS = ["gsr_create", "gsr_destroy", "gsr_release_scene_buffers", "gsr_memory_usage", "gsr_forward",
+           "gsr_backward", "gsr_buffer", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_loss_l1_ssim",
+           "gsr_allreduce_grads", "gsr_last_error_string", "gsr_version", "gsr_profile_enable",
+           "gsr_profile_stage_count", "gsr_profile_stage_name", "gsr_profile_read"]
+
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:], r.stderr[-4000:])
+    if r.returncode != 0:
+        raise RuntimeError("building libgsr_hip.so failed")
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
+    lib.gsr_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    lib.gsr_destroy.argtypes = [vp]
+    lib.gsr_release_scene_buffers.argtypes = [vp]
+    lib.gsr_memory_usage.argtypes = [vp]
+    lib.gsr_memory_usage.restype = C.c_int64
+    lib.gsr_forward.argtypes = [vp, C.POINTER(Inputs), C.POINTER(CameraS), vp, C.POINTER(Aux), vp, C.POINTER(Stats)]
+    lib.gsr_backward.argtypes = [vp, C.POINTER(Inputs), C.POINTER(CameraS), vp, C.POINTER(Grads), vp]
+    lib.gsr_buffer.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.gsr_ssim_forward.argtypes = [i32, i32, i32, i32, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp]
+    lib.gsr_ssim_backward.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_loss_l1_ssim.argtypes = [vp, vp, vp, f32, vp, vp, vp]
+    lib.gsr_allreduce_grads.argtypes = [vp, vp, C.c_size_t, vp]
+    lib.gsr_profile_enable.argtypes = [vp, i32]
+    lib.gsr_profile_stage_name.argtypes = [i32]
+    lib.gsr_profile_stage_name.restype = C.c_char_p
+    lib.gsr_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int), i32]
+    lib.gsr_last_error_string.restype = C.c_char_p
+    lib.gsr_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise GsrError(rc, load().gsr_last_error_string().decode())
+
+
+_hip = None
+
+
+def memcpy_d2d_async(dst: int, src: int, nbytes: int, stream: int):
+    """hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, stream) — plumbing for the state views."""
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    rc = _hip.hipMemcpyAsync(C.c_void_p(dst), C.c_void_p(src), C.c_size_t(nbytes), 3, C.c_void_p(stream))
+    if rc != 0:
+        raise RuntimeError(f"hipMemcpyAsync failed with code {rc}")

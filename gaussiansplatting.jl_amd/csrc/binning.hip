@@ -1,0 +1,202 @@
+// Tile binning: replaces cumsum! + duplicate_with_keys! + sortperm!/_permute! +
+// identify_tile_range! (reference: rasterizer.jl:333-378, utils.jl:56-120) with a
+// tile-binned counting scatter followed by an independent per-tile LDS sort.
+//
+//   preprocess     : per-tile occupancy histogram (atomic, in pergauss.hip)
+//   tile_scan      : exclusive scan over the T tile counts  -> tile ranges, D
+//   scatter        : each visible Gaussian drops (depth_bits<<32 | id) into its tiles' segments
+//   tile_sort      : one workgroup per tile sorts its segment in LDS by (depth, id) and writes
+//                    the sorted ids plus the packed, sorted splat stream the composite
+//                    kernels consume linearly
+//
+// The result equals a stable ascending sort of the reference's 64-bit (tile<<32 | depth)
+// keys with emit order by Gaussian id: within a tile, ascending depth
+// bits, ties by ascending id.  Unlike a global 64-bit radix sort this moves each instance
+// through HBM twice (8 B key out, 8 B key in) instead of ~8 passes x 12 B.
+#include "gsr_kernels.h"
+
+namespace {
+
+// ---- single-workgroup scan over tiles (T = 8160 at 1080p, 32400 at 4K) ----
+__global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint32_t* __restrict__ tile_count,
+                                                         uint32_t* __restrict__ tile_start,
+                                                         uint32_t* __restrict__ cursor,
+                                                         uint32_t* __restrict__ totals) {
+    __shared__ uint32_t wave_sums[16];
+    __shared__ uint32_t carry_s;
+    __shared__ uint32_t wave_max[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    uint32_t vmax = 0;
+    __syncthreads();
+    for (int base = 0; base < n_tiles; base += 1024) {
+        const int i = base + tid;
+        const uint32_t v = i < n_tiles ? tile_count[i] : 0u;
+        vmax = v > vmax ? v : vmax;
+        // inclusive wave scan
+        uint32_t x = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t y = __shfl_up(x, off);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) wave_sums[wave] = x;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (int w = 0; w < wave; w++) wave_off += wave_sums[w];
+        const uint32_t carry = carry_s;
+        const uint32_t excl = carry + wave_off + x - v;
+        if (i < n_tiles) {
+            tile_start[i] = excl;
+            cursor[i] = excl;
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = excl + v;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t y = __shfl_xor(vmax, off);
+        vmax = y > vmax ? y : vmax;
+    }
+    if (lane == 0) wave_max[wave] = vmax;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t m = 0;
+        for (int w = 0; w < 16; w++) m = wave_max[w] > m ? wave_max[w] : m;
+        tile_start[n_tiles] = carry_s;
+        totals[0] = carry_s;
+        totals[1] = m;
+        totals[3] = 0;  // slab allocator of the oversized-tile path
+    }
+    // number of tiles whose list does not fit the LDS sort (they get a global-scratch slab each)
+    uint32_t big = 0;
+    for (int i = tid; i < n_tiles; i += 1024) big += tile_count[i] > GSR_SORT_LDS_CAP ? 1u : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) big += __shfl_xor(big, off);
+    __syncthreads();
+    if (lane == 0) wave_sums[wave] = big;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t b = 0;
+        for (int w = 0; w < 16; w++) b += wave_sums[w];
+        totals[2] = b;
+    }
+}
+
+// ---- counting scatter (duplicate_with_keys! restated per tile; utils.jl:96-119) ----
+__global__ __launch_bounds__(256) void scatter_kernel(int n, int grid_x, const int32_t* __restrict__ radii,
+                                                      const ushort4* __restrict__ rect,
+                                                      const float4* __restrict__ g2,
+                                                      uint32_t* __restrict__ cursor, uint64_t* __restrict__ keys) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (!(radii[i] > 0)) return;
+    const ushort4 r = rect[i];
+    const uint64_t key = ((uint64_t)__float_as_uint(g2[i].z) << 32) | (uint32_t)i;
+    for (int y = r.y; y < r.w; y++)
+        for (int x = r.x; x < r.z; x++) {
+            const uint32_t slot = atomicAdd(&cursor[y * grid_x + x], 1u);
+            keys[slot] = key;
+        }
+}
+
+// ---- per-tile sort ----
+// Bitonic network over `m` (power of two) keys held in `buf` (LDS or global scratch).
+__device__ __forceinline__ void bitonic_sort(uint64_t* buf, uint32_t m, int tid, int nthreads) {
+    for (uint32_t k = 2; k <= m; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < (m >> 1); t += nthreads) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const uint32_t ixj = i | j;
+                const uint64_t a = buf[i], b = buf[ixj];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    buf[i] = b;
+                    buf[ixj] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Load the tile's keys into `buf` (padded to a power of two with +inf), sort, and emit the
+// sorted ids + the packed splat stream.  Instantiated once on the LDS array and once on a
+// global slab so each copy uses ds_* / global_* instructions (no flat addressing).
+template <int CH>
+__device__ __forceinline__ void sort_and_emit(uint64_t* buf, uint32_t m, uint32_t n, uint32_t start, int tid,
+                                              const uint64_t* __restrict__ keys, const GsrGeom& geom,
+                                              const GsrStream& stream, uint32_t* __restrict__ values_sorted) {
+    for (uint32_t i = tid; i < m; i += 256) buf[i] = i < n ? keys[start + i] : ~0ull;
+    __syncthreads();
+    if (m > 1) bitonic_sort(buf, m, tid, 256);
+    for (uint32_t i = tid; i < n; i += 256) {
+        const uint64_t k = buf[i];
+        const uint32_t id = (uint32_t)k;
+        values_sorted[start + i] = id;
+        const float4 g0 = geom.g0[id], g1 = geom.g1[id], g2 = geom.g2[id];
+        stream.s0[start + i] = g0;
+        stream.s1[start + i] = g1;
+        stream.s2[start + i] = make_float4(g2.x, __uint_as_float(id), g2.z, 0.0f);
+        if (CH > 5) stream.s3[start + i] = geom.g3[id];
+    }
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restrict__ tile_start,
+                                                        const uint64_t* __restrict__ keys,
+                                                        uint64_t* __restrict__ big_scratch,
+                                                        uint32_t big_scratch_stride,
+                                                        uint32_t* __restrict__ slab_counter, GsrGeom geom,
+                                                        GsrStream stream,
+                                                        uint32_t* __restrict__ values_sorted,
+                                                        uint32_t* __restrict__ ranges) {
+    __shared__ uint64_t skeys[GSR_SORT_LDS_CAP];
+    __shared__ uint32_t slab_s;
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
+    const uint32_t n = end - start;
+    if (tid == 0) {
+        // identify_tile_range! (utils.jl:56-78): empty tiles keep the (0,0) of the prior fill!
+        ranges[2 * tile] = n ? start : 0u;
+        ranges[2 * tile + 1] = n ? end : 0u;
+    }
+    if (n == 0) return;
+    uint32_t m = 1;
+    while (m < n) m <<= 1;
+    if (m <= GSR_SORT_LDS_CAP) {
+        sort_and_emit<CH>(skeys, m, n, start, tid, keys, geom, stream, values_sorted);
+    } else {
+        // oversized tile: same network through a global-scratch slab (rare; slabs are sized by
+        // the host from the scan's totals and handed out with one atomic per oversized tile)
+        if (tid == 0) slab_s = atomicAdd(slab_counter, 1u);
+        __syncthreads();
+        uint64_t* slab = big_scratch + (size_t)slab_s * big_scratch_stride;
+        sort_and_emit<CH>(slab, m, n, start, tid, keys, geom, stream, values_sorted);
+    }
+}
+
+}  // namespace
+
+void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count, uint32_t* tile_start,
+                          uint32_t* cursor, uint32_t* totals) {
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, tile_count, tile_start, cursor, totals);
+}
+
+void gsr_launch_scatter(hipStream_t s, int n, GsrCam cam, GsrGeom geom, uint32_t* cursor, uint64_t* keys) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, cam.grid_x, geom.radii, geom.rect,
+                       geom.g2, cursor, keys);
+}
+
+void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int channels, const uint32_t* tile_start, uint64_t* keys,
+                          uint64_t* big_scratch, uint32_t big_scratch_stride, uint32_t* slab_counter, GsrGeom geom,
+                          GsrStream stream, uint32_t* values_sorted, uint32_t* ranges) {
+    if (channels > 5)
+        hipLaunchKernelGGL(tile_sort_kernel<8>, dim3(n_tiles), dim3(256), 0, s, tile_start, keys, big_scratch,
+                           big_scratch_stride, slab_counter, geom, stream, values_sorted, ranges);
+    else
+        hipLaunchKernelGGL(tile_sort_kernel<3>, dim3(n_tiles), dim3(256), 0, s, tile_start, keys, big_scratch,
+                           big_scratch_stride, slab_counter, geom, stream, values_sorted, ranges);
+}

@@ -1,0 +1,306 @@
+// Per-tile alpha compositing, forward and backward.
+// Reference behaviour: src/rasterization/render.jl:1-130 (`render!`) and :132-286
+// (`∇render!`); SURVEY.md A.8 / A.9.
+//
+// One 256-thread workgroup (4 wave64) per 16x16 tile, lane <-> pixel.  The tile's
+// depth-sorted splat list is a contiguous slice of the packed stream written by
+// tile_sort (three coalesced float4 planes), staged through LDS in batches of 256
+// and read back with wave-uniform (broadcast) ds_read_b128.
+//
+// Backward: instead of the reference's (C+6) global float atomics per (pixel, splat)
+// (render.jl:242,275-282) every wave reduces its 64 lanes with DPP row operations,
+// the four waves meet in an LDS accumulator row, and one global atomic per
+// (tile, splat, component) leaves the workgroup.  Waves none of whose pixels are
+// touched by a splat skip it with a single ballot.
+#include "gsr_kernels.h"
+
+namespace {
+
+struct Bg { float v[8]; };
+
+template <int C> struct RecPlanes { static constexpr int N = C > 5 ? 4 : 3; };
+
+// feature c of a staged splat: rgb | depth | 1 | normal  (rasterizer.jl:380-385)
+template <int C>
+__device__ __forceinline__ void unpack_features(const float4& s1, const float4& s2, const float4& s3, float f[C]) {
+    f[0] = s1.z; f[1] = s1.w; f[2] = s2.x;
+    if (C > 3) { f[3] = s2.z; f[4] = 1.0f; }
+    if (C > 5) { f[5] = s3.x; f[6] = s3.y; f[7] = s3.z; }
+}
+
+// ---- wave64 sum via DPP (result valid in lanes 48..63) ----
+__device__ __forceinline__ float dpp_add(float v, const int ctrl, const int row_mask) {
+    // lanes whose row is masked off, or whose source is out of range, receive 0
+    int t;
+    switch (ctrl) {  // the control must be an immediate
+        case 0xB1: t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true); break;
+        case 0x4E: t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true); break;
+        case 0x141: t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true); break;
+        case 0x140: t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true); break;
+        case 0x142: t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false); break;
+        default: t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false); break;
+    }
+    (void)row_mask;
+    return v + __int_as_float(t);
+}
+__device__ __forceinline__ float wave_sum_hi(float v) {
+    v = dpp_add(v, 0xB1, 0xF);   // quad_perm [1,0,3,2]
+    v = dpp_add(v, 0x4E, 0xF);   // quad_perm [2,3,0,1]
+    v = dpp_add(v, 0x141, 0xF);  // row_half_mirror
+    v = dpp_add(v, 0x140, 0xF);  // row_mirror          -> every lane holds its row's sum
+    v = dpp_add(v, 0x142, 0xA);  // row_bcast:15 into rows 1,3
+    v = dpp_add(v, 0x143, 0xC);  // row_bcast:31 into rows 2,3 -> lanes 48..63 hold the wave sum
+    return v;
+}
+
+// ---------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------
+template <int C, bool AUX>
+__global__ __launch_bounds__(256) void composite_fwd_kernel(int W, int H, int grid_x,
+                                                            const uint32_t* __restrict__ tile_start,
+                                                            GsrStream stream, Bg bg, float* __restrict__ image,
+                                                            uint32_t* __restrict__ n_contrib,
+                                                            float* __restrict__ final_T, uint8_t* __restrict__ covis,
+                                                            float* __restrict__ uncert) {
+    __shared__ float4 l0[GSR_BATCH], l1[GSR_BATCH], l2[GSR_BATCH];
+    __shared__ float4 l3[C > 5 ? GSR_BATCH : 1];
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.y * grid_x + blockIdx.x;
+    const int px = blockIdx.x * GSR_TILE + (tid & 15), py = blockIdx.y * GSR_TILE + (tid >> 4);
+    const bool inside = px < W && py < H;
+    const float fx = (float)px, fy = (float)py;
+    const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
+    const int to_do = (int)(end - start);
+
+    bool done = !inside;
+    float T = 1.0f;
+    uint32_t last = 0;
+    float color[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) color[c] = 0.0f;
+    float unc = 0.0f;
+
+    for (int base = 0; base < to_do; base += GSR_BATCH) {
+        // Every pixel of the tile saturated: the reference keeps looping without effect
+        // (render.jl:79-80); leaving here is bit-identical.  Doubles as the WAR barrier.
+        if (__syncthreads_count(!done) == 0) break;
+        const int cnt = min(GSR_BATCH, to_do - base);
+        if (tid < cnt) {
+            const uint32_t idx = start + base + tid;
+            l0[tid] = stream.s0[idx];
+            l1[tid] = stream.s1[idx];
+            l2[tid] = stream.s2[idx];
+            if (C > 5) l3[tid] = stream.s3[idx];
+        }
+        __syncthreads();
+        if (!done) {
+            for (int j = 0; j < cnt; j++) {
+                const float4 a = l0[j], b = l1[j], c2 = l2[j];
+                const float dx = a.x - fx, dy = a.y - fy;
+                const float sigma = a.w * dx * dy + 0.5f * (a.z * (dx * dx) + b.x * (dy * dy));
+                if (sigma < 0.0f) continue;
+                const float alpha = fminf(0.99f, b.y * __expf(-sigma));
+                if (alpha < (1.0f / 255.0f)) continue;
+                const float Tn = T * (1.0f - alpha);
+                if (Tn < 1e-4f) { done = true; break; }
+                float f[C];
+                unpack_features<C>(b, c2, C > 5 ? l3[j] : c2, f);
+                const float w = alpha * T;
+#pragma unroll
+                for (int c = 0; c < C; c++) color[c] += f[c] * w;
+                if (AUX) {
+                    unc += w;
+                    if (covis && T > 0.5f) covis[__float_as_uint(c2.y)] = 1;
+                }
+                T = Tn;
+                last = (uint32_t)(base + j + 1);
+            }
+        }
+    }
+    if (inside) {
+        const size_t pi = (size_t)px + (size_t)W * py;
+        final_T[pi] = T;
+        n_contrib[pi] = last;
+#pragma unroll
+        for (int c = 0; c < C; c++) image[(size_t)C * pi + c] = color[c] + T * bg.v[c];
+        if (AUX && uncert) uncert[pi] = unc;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------
+// accumulator row per staged splat: [0..2] v rgb, [3] v opacity, [4..6] v conic,
+// [7..8] v mean2d, [9] v depth (C>=5), [10..12] v normal (C==8)
+template <int C> struct AccRow { static constexpr int N = C == 3 ? 9 : (C == 5 ? 10 : 13); static constexpr int STRIDE = N | 1; };
+
+template <int C>
+__global__ __launch_bounds__(256) void composite_bwd_kernel(int W, int H, int grid_x,
+                                                            const uint32_t* __restrict__ tile_start,
+                                                            GsrStream stream, Bg bg,
+                                                            const float* __restrict__ vpixels,
+                                                            const uint32_t* __restrict__ n_contrib,
+                                                            const float* __restrict__ final_T, GsrAcc acc) {
+    constexpr int NA = AccRow<C>::N, ST = AccRow<C>::STRIDE;
+    __shared__ float4 l0[GSR_BATCH], l1[GSR_BATCH], l2[GSR_BATCH];
+    __shared__ float4 l3[C > 5 ? GSR_BATCH : 1];
+    __shared__ float lacc[GSR_BATCH * ST];
+    __shared__ int tile_last_s;
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.y * grid_x + blockIdx.x;
+    const int px = blockIdx.x * GSR_TILE + (tid & 15), py = blockIdx.y * GSR_TILE + (tid >> 4);
+    const bool inside = px < W && py < H;
+    const float fx = (float)px, fy = (float)py;
+    const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
+    if (end == start) return;
+    const size_t pi = (size_t)px + (size_t)W * py;
+
+    const float T_final = inside ? final_T[pi] : 0.0f;
+    float T = T_final;
+    const int last_contributor = inside ? (int)n_contrib[pi] : 0;
+    float vp[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) vp[c] = inside ? vpixels[(size_t)C * pi + c] : 0.0f;
+    float bg_dot = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; c++) bg_dot += bg.v[c] * vp[c];
+    float accum_rec[C], last_color[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) { accum_rec[c] = 0.0f; last_color[c] = 0.0f; }
+    float last_alpha = 0.0f;
+
+    // Splats behind every pixel's last contributor are skipped by each lane in the reference
+    // (render.jl:223); start the back-to-front walk at the deepest one any pixel blended.
+    if (tid == 0) tile_last_s = 0;
+    __syncthreads();
+    {
+        int m = last_contributor;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
+        if ((tid & 63) == 0) atomicMax(&tile_last_s, m);
+    }
+    __syncthreads();
+    const int tile_last = tile_last_s;  // process list positions tile_last-1 ... 0
+
+    for (int base = 0; base < tile_last; base += GSR_BATCH) {
+        const int cnt = min(GSR_BATCH, tile_last - base);
+        __syncthreads();  // previous batch fully flushed
+        if (tid < cnt) {
+            const uint32_t idx = start + (uint32_t)(tile_last - 1 - base - tid);
+            l0[tid] = stream.s0[idx];
+            l1[tid] = stream.s1[idx];
+            l2[tid] = stream.s2[idx];
+            if (C > 5) l3[tid] = stream.s3[idx];
+        }
+#pragma unroll
+        for (int k = 0; k < NA; k++) lacc[tid * ST + k] = 0.0f;
+        __syncthreads();
+
+        for (int j = 0; j < cnt; j++) {
+            const int contributor = tile_last - 1 - base - j;  // 0-based position in the tile list
+            const float4 a = l0[j], b = l1[j], c2 = l2[j];
+            const float dx = a.x - fx, dy = a.y - fy;
+            const float o = b.y;
+            const float sigma = a.w * dx * dy + 0.5f * (a.z * (dx * dx) + b.x * (dy * dy));
+            const float G = __expf(-sigma);
+            const float alpha = fminf(0.99f, o * G);
+            const bool active = contributor < last_contributor && sigma >= 0.0f && alpha >= (1.0f / 255.0f);
+            if (__ballot(active) == 0ull) continue;  // wave-uniform: no pixel of this 16x4 strip is touched
+
+            float part[NA];
+#pragma unroll
+            for (int k = 0; k < NA; k++) part[k] = 0.0f;
+            if (active) {
+                T = T / (1.0f - alpha);
+                const float fac = alpha * T;
+                float f[C];
+                unpack_features<C>(b, c2, C > 5 ? l3[j] : c2, f);
+                float valpha = 0.0f;
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    accum_rec[c] = last_alpha * last_color[c] + (1.0f - last_alpha) * accum_rec[c];
+                    last_color[c] = f[c];
+                    valpha += (f[c] - accum_rec[c]) * vp[c];
+                }
+                valpha *= T;
+                valpha += (-T_final / (1.0f - alpha)) * bg_dot;
+                last_alpha = alpha;
+                const float vsigma = -o * G * valpha;
+                part[0] = fac * vp[0]; part[1] = fac * vp[1]; part[2] = fac * vp[2];
+                part[3] = G * valpha;
+                part[4] = 0.5f * vsigma * (dx * dx);
+                part[5] = 0.5f * vsigma * dx * dy;
+                part[6] = 0.5f * vsigma * (dy * dy);
+                part[7] = vsigma * (a.z * dx + a.w * dy);
+                part[8] = vsigma * (a.w * dx + b.x * dy);
+                if (C > 3) part[9] = fac * vp[3];  // depth feature; channel 4 (constant 1) is not a parameter
+                if (C > 5) { part[10] = fac * vp[5]; part[11] = fac * vp[6]; part[12] = fac * vp[7]; }
+            }
+#pragma unroll
+            for (int k = 0; k < NA; k++) part[k] = wave_sum_hi(part[k]);
+            if ((tid & 63) == 63) {
+#pragma unroll
+                for (int k = 0; k < NA; k++) atomicAdd(&lacc[j * ST + k], part[k]);
+            }
+        }
+        __syncthreads();
+        if (tid < cnt) {
+            float r[NA];
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < NA; k++) { r[k] = lacc[tid * ST + k]; any |= r[k] != 0.0f; }
+            if (any) {
+                const uint32_t id = __float_as_uint(l2[tid].y);
+                float* p0 = reinterpret_cast<float*>(acc.a0 + id);
+                float* p1 = reinterpret_cast<float*>(acc.a1 + id);
+                atomicAdd(p0 + 0, r[0]); atomicAdd(p0 + 1, r[1]); atomicAdd(p0 + 2, r[2]); atomicAdd(p0 + 3, r[3]);
+                atomicAdd(p1 + 0, r[4]); atomicAdd(p1 + 1, r[5]); atomicAdd(p1 + 2, r[6]);
+                float* pm = reinterpret_cast<float*>(acc.vmean2d + id);
+                atomicAdd(pm + 0, r[7]); atomicAdd(pm + 1, r[8]);
+                if (C > 3) atomicAdd(p1 + 3, r[9]);
+                if (C > 5) {
+                    float* p2 = reinterpret_cast<float*>(acc.a2 + id);
+                    atomicAdd(p2 + 0, r[10]); atomicAdd(p2 + 1, r[11]); atomicAdd(p2 + 2, r[12]);
+                }
+            }
+        }
+    }
+}
+
+Bg make_bg(const float* background, int channels) {
+    Bg b;
+    for (int c = 0; c < 8; c++) b.v[c] = (c < 3 && c < channels) ? background[c] : 0.0f;  // rasterizer.jl:411-414
+    return b;
+}
+
+}  // namespace
+
+void gsr_launch_composite_fwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start, GsrStream stream,
+                              const float* background, float* image, uint32_t* n_contrib, float* final_T,
+                              uint8_t* covis, float* uncert) {
+    dim3 grid(cam.grid_x, cam.grid_y), block(256);
+    Bg bg = make_bg(background, channels);
+    const bool aux = covis || uncert;
+#define LAUNCH(CC, AA)                                                                                             \
+    hipLaunchKernelGGL((composite_fwd_kernel<CC, AA>), grid, block, 0, s, cam.width, cam.height, cam.grid_x,       \
+                       tile_start, stream, bg, image, n_contrib, final_T, covis, uncert)
+    if (channels == 3) { if (aux) LAUNCH(3, true); else LAUNCH(3, false); }
+    else if (channels == 5) { if (aux) LAUNCH(5, true); else LAUNCH(5, false); }
+    else { if (aux) LAUNCH(8, true); else LAUNCH(8, false); }
+#undef LAUNCH
+}
+
+void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start, GsrStream stream,
+                              const float* background, const float* vpixels, const uint32_t* n_contrib,
+                              const float* final_T, GsrAcc acc) {
+    dim3 grid(cam.grid_x, cam.grid_y), block(256);
+    Bg bg = make_bg(background, channels);
+#define LAUNCH(CC)                                                                                                 \
+    hipLaunchKernelGGL((composite_bwd_kernel<CC>), grid, block, 0, s, cam.width, cam.height, cam.grid_x, tile_start, \
+                       stream, bg, vpixels, n_contrib, final_T, acc)
+    if (channels == 3) LAUNCH(3);
+    else if (channels == 5) LAUNCH(5);
+    else LAUNCH(8);
+#undef LAUNCH
+}

@@ -1,0 +1,483 @@
+// C ABI of libgsr_hip.so (include/gsr.h): handle object with grow-only scratch, argument
+// validation, kernel orchestration.  Mirrors the host side of the reference's
+// `GaussianRasterizer` / `rasterize` / `∇rasterize` (src/rasterization/rasterizer.jl:5-90,
+// 255-408, 416-550) — everything is enqueued on the caller's stream; the only host sync is
+// the instance-count read-back (rasterizer.jl:337).
+#include "../../include/gsr.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "gsr_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return fail(e_ == hipErrorOutOfMemory ? GSR_E_OOM : GSR_E_HIP, "%s failed: %s (%s:%d)", #expr,   \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                          \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;  // bytes
+    // grow-only, like the reference's scratch (rasterizer.jl:275-278,340-343)
+    int ensure(size_t bytes, float slack = 1.0f) {
+        if (bytes <= cap) return GSR_OK;
+        if (p) {
+            HIPCHK(hipFree(p));
+            p = nullptr;
+            cap = 0;
+        }
+        size_t want = (size_t)((double)bytes * slack);
+        want = (want + 255) & ~(size_t)255;
+        HIPCHK(hipMalloc(&p, want));
+        cap = want;
+        return GSR_OK;
+    }
+    int release() {
+        if (p) HIPCHK(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        return GSR_OK;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// Optional per-stage timing with HIP events on the caller's stream (gsr_profile_*).
+enum Stage { ST_PREPROCESS, ST_SCAN, ST_SCATTER, ST_SORT, ST_COMPOSITE_FWD, ST_LOSS_FWD, ST_LOSS_BWD, ST_ZERO_ACC,
+             ST_COMPOSITE_BWD, ST_PERGAUSS_BWD, ST_COUNT };
+const char* const kStageNames[ST_COUNT] = {"preprocess", "tile_scan", "scatter", "tile_sort", "composite_fwd",
+                                           "loss_fwd", "loss_bwd", "zero_acc", "composite_bwd", "pergauss_bwd"};
+struct Profiler {
+    bool on = false;
+    struct Rec { int stage; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void begin(int stage, hipStream_t s) {
+        if (!on) return;
+        Rec r{stage, get(), get()};
+        (void)hipEventRecord(r.a, s);
+        recs.push_back(r);
+    }
+    void end(hipStream_t s) {
+        if (!on || recs.empty()) return;
+        (void)hipEventRecord(recs.back().b, s);
+    }
+    void clear() {
+        for (auto& r : recs) { pool.push_back(r.a); pool.push_back(r.b); }
+        recs.clear();
+    }
+    void destroy() {
+        clear();
+        for (auto e : pool) (void)hipEventDestroy(e);
+        pool.clear();
+    }
+};
+
+bool valid_mode(int m) { return m == GSR_MODE_RGB || m == GSR_MODE_RGBD || m == GSR_MODE_RGBDN; }
+
+}  // namespace
+
+struct gsr_handle {
+    gsr_config cfg;
+    int grid_x, grid_y, n_tiles;
+    // ImageState (states.jl:99-111) + tile bookkeeping
+    DevBuf ranges, n_contrib, final_T, tile_count, tile_start, cursor, totals;
+    // GeometryState (states.jl:2-47), repacked as float4 planes
+    DevBuf g0, g1, g2, g3, radii, rect;
+    // BinningState (states.jl:66-85): unsorted keys, sorted ids, sorted splat stream
+    DevBuf keys, values_sorted, s0, s1, s2, s3, big_scratch;
+    // backward accumulators (rasterizer.jl:437-446)
+    DevBuf a0, a1, a2, vmean2d;
+    // loss-head scratch
+    DevBuf d0, d1, d2, partial;
+    uint32_t* host_totals = nullptr;  // pinned: D, max tile count, #oversized tiles, slab ctr, n_visible
+    bool fwd_valid = false;
+    int last_n = 0;
+    int64_t last_D = 0;
+    uint32_t last_max_tile = 0;
+    Profiler prof;
+
+    DevBuf* all[30];
+    int n_all = 0;
+};
+
+namespace {
+
+GsrCam make_cam(const gsr_handle* h, const gsr_camera* c) {
+    GsrCam k;
+    for (int r = 0; r < 3; r++)
+        for (int col = 0; col < 3; col++) k.R[r * 3 + col] = c->R[col * 3 + r];
+    for (int i = 0; i < 3; i++) { k.t[i] = c->t[i]; k.center[i] = c->camera_center[i]; }
+    for (int i = 0; i < 2; i++) { k.focal[i] = c->focal[i]; k.principal[i] = c->principal[i]; }
+    k.width = h->cfg.width; k.height = h->cfg.height;
+    k.grid_x = h->grid_x; k.grid_y = h->grid_y;
+    k.near_plane = h->cfg.near_plane; k.far_plane = h->cfg.far_plane;
+    k.radius_clip = h->cfg.radius_clip; k.blur_eps = h->cfg.blur_eps;
+    k.R_dev = c->R_dev; k.t_dev = c->t_dev;
+    return k;
+}
+
+GsrGeom geom_of(const gsr_handle* h) {
+    return GsrGeom{h->g0.as<float4>(), h->g1.as<float4>(), h->g2.as<float4>(), h->g3.as<float4>(),
+                   h->radii.as<int32_t>(), h->rect.as<ushort4>()};
+}
+GsrStream stream_of(const gsr_handle* h) {
+    return GsrStream{h->s0.as<float4>(), h->s1.as<float4>(), h->s2.as<float4>(), h->s3.as<float4>()};
+}
+GsrAcc acc_of(const gsr_handle* h) {
+    return GsrAcc{h->a0.as<float4>(), h->a1.as<float4>(), h->a2.as<float4>(), h->vmean2d.as<float2>()};
+}
+
+int check_inputs(const gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam) {
+    if (!h || !in || !cam) return fail(GSR_E_INVALID_ARG, "null handle / inputs / camera");
+    if (in->n < 0) return fail(GSR_E_INVALID_ARG, "n = %d < 0", in->n);
+    if (in->sh_degree < 0 || in->sh_degree > 3) return fail(GSR_E_INVALID_ARG, "sh_degree = %d not in 0..3", in->sh_degree);
+    if (in->n_coeffs < (in->sh_degree + 1) * (in->sh_degree + 1) || in->n_coeffs > 16)
+        return fail(GSR_E_INVALID_ARG, "n_coeffs = %d does not hold degree %d", in->n_coeffs, in->sh_degree);
+    if (in->n > 0 && (!in->means || !in->shs || !in->opacities || !in->scales || !in->rotations))
+        return fail(GSR_E_INVALID_ARG, "null input array");
+    if (((uintptr_t)in->rotations & 15) != 0) return fail(GSR_E_INVALID_ARG, "rotations must be 16-byte aligned");
+    if ((cam->R_dev == nullptr) != (cam->t_dev == nullptr))
+        return fail(GSR_E_INVALID_ARG, "R_dev and t_dev must be given together");
+    return GSR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gsr_last_error_string(void) { return g_err; }
+const char* gsr_version(void) { return "gsr-hip 0.1 (gfx950)"; }
+
+int gsr_create(const gsr_config* cfg, gsr_handle** out) {
+    if (!cfg || !out) return fail(GSR_E_INVALID_ARG, "null config / out");
+    if (cfg->width <= 0 || cfg->height <= 0) return fail(GSR_E_INVALID_ARG, "bad resolution %dx%d", cfg->width, cfg->height);
+    if (!valid_mode(cfg->mode)) return fail(GSR_E_INVALID_ARG, "Invalid render mode: %d (3=rgb, 5=rgbd, 8=rgbdn)", cfg->mode);
+    if (!(cfg->near_plane < cfg->far_plane)) return fail(GSR_E_INVALID_ARG, "near_plane >= far_plane");
+    gsr_handle* h = new (std::nothrow) gsr_handle();
+    if (!h) return fail(GSR_E_OOM, "host allocation failed");
+    h->cfg = *cfg;
+    h->grid_x = (cfg->width + GSR_TILE - 1) / GSR_TILE;
+    h->grid_y = (cfg->height + GSR_TILE - 1) / GSR_TILE;
+    if (h->grid_x > 65535 || h->grid_y > 65535) { delete h; return fail(GSR_E_INVALID_ARG, "resolution too large"); }
+    h->n_tiles = h->grid_x * h->grid_y;
+    DevBuf* list[] = {&h->ranges, &h->n_contrib, &h->final_T, &h->tile_count, &h->tile_start, &h->cursor, &h->totals,
+                      &h->g0, &h->g1, &h->g2, &h->g3, &h->radii, &h->rect, &h->keys, &h->values_sorted, &h->s0,
+                      &h->s1, &h->s2, &h->s3, &h->big_scratch, &h->a0, &h->a1, &h->a2, &h->vmean2d, &h->d0, &h->d1,
+                      &h->d2, &h->partial};
+    for (DevBuf* b : list) h->all[h->n_all++] = b;
+    const size_t P = (size_t)cfg->width * cfg->height, T = (size_t)h->n_tiles;
+    int rc = GSR_OK;
+    if ((rc = h->ranges.ensure(2 * T * 4)) || (rc = h->n_contrib.ensure(P * 4)) || (rc = h->final_T.ensure(P * 4)) ||
+        (rc = h->tile_count.ensure(T * 4)) || (rc = h->tile_start.ensure((T + 1) * 4)) ||
+        (rc = h->cursor.ensure(T * 4)) || (rc = h->totals.ensure(8 * 4))) {
+        gsr_destroy(h);
+        return rc;
+    }
+    hipError_t e = hipHostMalloc((void**)&h->host_totals, 8 * sizeof(uint32_t), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        gsr_destroy(h);
+        return fail(GSR_E_HIP, "hipHostMalloc failed: %s", hipGetErrorString(e));
+    }
+    (void)hipMemset(h->ranges.p, 0, 2 * T * 4);
+    *out = h;
+    return GSR_OK;
+}
+
+int gsr_destroy(gsr_handle* h) {
+    if (!h) return GSR_OK;
+    for (int i = 0; i < h->n_all; i++) h->all[i]->release();
+    if (h->host_totals) (void)hipHostFree(h->host_totals);
+    h->prof.destroy();
+    delete h;
+    return GSR_OK;
+}
+
+int gsr_release_scene_buffers(gsr_handle* h) {
+    if (!h) return fail(GSR_E_INVALID_ARG, "null handle");
+    DevBuf* scene[] = {&h->g0, &h->g1, &h->g2, &h->g3, &h->radii, &h->rect, &h->keys, &h->values_sorted, &h->s0, &h->s1,
+                       &h->s2, &h->s3, &h->big_scratch, &h->a0, &h->a1, &h->a2, &h->vmean2d};
+    for (DevBuf* b : scene) {
+        int rc = b->release();
+        if (rc) return rc;
+    }
+    h->fwd_valid = false;
+    h->last_n = 0;
+    h->last_D = 0;
+    return GSR_OK;
+}
+
+int64_t gsr_memory_usage(const gsr_handle* h) {
+    if (!h) return 0;
+    int64_t s = 0;
+    for (int i = 0; i < h->n_all; i++) s += (int64_t)h->all[i]->cap;
+    return s;
+}
+
+int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, float* image_out, const gsr_aux* aux,
+                void* stream_v, gsr_stats* stats) {
+    int rc = check_inputs(h, in, cam);
+    if (rc) return rc;
+    if (!image_out) return fail(GSR_E_INVALID_ARG, "null image_out");
+    hipStream_t s = (hipStream_t)stream_v;
+    const int C = h->cfg.mode, n = in->n;
+    const size_t P = (size_t)h->cfg.width * h->cfg.height, T = (size_t)h->n_tiles;
+    h->fwd_valid = false;
+
+    const size_t nn = n > 0 ? (size_t)n : 1;
+    if ((rc = h->g0.ensure(nn * 16)) || (rc = h->g1.ensure(nn * 16)) || (rc = h->g2.ensure(nn * 16)) ||
+        (rc = h->radii.ensure(nn * 4)) || (rc = h->rect.ensure(nn * 8)) || (C > 5 && (rc = h->g3.ensure(nn * 16))))
+        return rc;
+
+    GsrCam k = make_cam(h, cam);
+    uint32_t* totals = h->totals.as<uint32_t>();
+    HIPCHK(hipMemsetAsync(h->tile_count.p, 0, T * 4, s));
+    HIPCHK(hipMemsetAsync(totals, 0, 8 * 4, s));
+    h->prof.begin(ST_PREPROCESS, s);
+    gsr_launch_preprocess(s, n, in->n_coeffs, in->sh_degree, C, in->means, in->scales, in->rotations, in->opacities,
+                          in->shs, k, geom_of(h), h->tile_count.as<uint32_t>(), totals + 4);
+    h->prof.end(s);
+    h->prof.begin(ST_SCAN, s);
+    gsr_launch_tile_scan(s, h->n_tiles, h->tile_count.as<uint32_t>(), h->tile_start.as<uint32_t>(),
+                         h->cursor.as<uint32_t>(), totals);
+    h->prof.end(s);
+    HIPCHK(hipGetLastError());
+    // the one host sync of the path: instance count D (reference: rasterizer.jl:337)
+    HIPCHK(hipMemcpyAsync(h->host_totals, totals, 8 * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const uint64_t D = h->host_totals[0];
+    const uint32_t max_tile = h->host_totals[1], n_big = h->host_totals[2];
+    h->last_n = n;
+    h->last_D = (int64_t)D;
+    h->last_max_tile = max_tile;
+    if (stats) {
+        stats->n_rendered = (int64_t)D;
+        stats->n_visible = (int32_t)h->host_totals[4];
+        stats->max_tile_instances = (int32_t)max_tile;
+    }
+    if (D == 0) {
+        // rasterizer.jl:283,338: all-zero image, background not applied
+        HIPCHK(hipMemsetAsync(image_out, 0, P * C * 4, s));
+        HIPCHK(hipMemsetAsync(h->n_contrib.p, 0, P * 4, s));
+        HIPCHK(hipMemsetAsync(h->final_T.p, 0, P * 4, s));
+        HIPCHK(hipMemsetAsync(h->ranges.p, 0, 2 * T * 4, s));
+        if (aux && aux->uncertainties) HIPCHK(hipMemsetAsync(aux->uncertainties, 0, P * 4, s));
+        h->fwd_valid = true;
+        return GSR_OK;
+    }
+    const float slack = 1.25f;  // instance count drifts slowly between training steps
+    if ((rc = h->keys.ensure(D * 8, slack)) || (rc = h->values_sorted.ensure(D * 4, slack)) ||
+        (rc = h->s0.ensure(D * 16, slack)) || (rc = h->s1.ensure(D * 16, slack)) ||
+        (rc = h->s2.ensure(D * 16, slack)) || (C > 5 && (rc = h->s3.ensure(D * 16, slack))))
+        return rc;
+    uint32_t big_stride = 0;
+    if (n_big > 0) {
+        big_stride = 1;
+        while (big_stride < max_tile) big_stride <<= 1;
+        if ((rc = h->big_scratch.ensure((size_t)n_big * big_stride * 8))) return rc;
+    }
+    h->prof.begin(ST_SCATTER, s);
+    gsr_launch_scatter(s, n, k, geom_of(h), h->cursor.as<uint32_t>(), h->keys.as<uint64_t>());
+    h->prof.end(s);
+    h->prof.begin(ST_SORT, s);
+    gsr_launch_tile_sort(s, h->n_tiles, C, h->tile_start.as<uint32_t>(), h->keys.as<uint64_t>(),
+                         h->big_scratch.as<uint64_t>(), big_stride, totals + 3, geom_of(h), stream_of(h),
+                         h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>());
+    h->prof.end(s);
+    h->prof.begin(ST_COMPOSITE_FWD, s);
+    gsr_launch_composite_fwd(s, C, k, h->tile_start.as<uint32_t>(), stream_of(h), in->background, image_out,
+                             h->n_contrib.as<uint32_t>(), h->final_T.as<float>(),
+                             aux ? aux->covisibilities : nullptr, aux ? aux->uncertainties : nullptr);
+    h->prof.end(s);
+    HIPCHK(hipGetLastError());
+    h->fwd_valid = true;
+    return GSR_OK;
+}
+
+int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, const float* vpixels,
+                 const gsr_grads* g, void* stream_v) {
+    int rc = check_inputs(h, in, cam);
+    if (rc) return rc;
+    if (!vpixels || !g) return fail(GSR_E_INVALID_ARG, "null vpixels / grads");
+    if (!h->fwd_valid || h->last_n != in->n)
+        return fail(GSR_E_STATE, "gsr_backward without a matching gsr_forward on this handle");
+    if (in->n > 0 && (!g->vmeans || !g->vshs || !g->vopacities || !g->vscales || !g->vrotations))
+        return fail(GSR_E_INVALID_ARG, "null gradient buffer");
+    if ((g->vR == nullptr) != (g->vt == nullptr)) return fail(GSR_E_INVALID_ARG, "vR and vt must be given together");
+    if (((uintptr_t)g->vrotations & 15) != 0) return fail(GSR_E_INVALID_ARG, "vrotations must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream_v;
+    const int C = h->cfg.mode, n = in->n;
+    if (n == 0) return GSR_OK;
+    const size_t nn = (size_t)n;
+    if ((rc = h->a0.ensure(nn * 16)) || (rc = h->a1.ensure(nn * 16)) || (rc = h->vmean2d.ensure(nn * 8)) ||
+        (C > 5 && (rc = h->a2.ensure(nn * 16))))
+        return rc;
+    h->prof.begin(ST_ZERO_ACC, s);
+    HIPCHK(hipMemsetAsync(h->a0.p, 0, nn * 16, s));
+    HIPCHK(hipMemsetAsync(h->a1.p, 0, nn * 16, s));
+    HIPCHK(hipMemsetAsync(h->vmean2d.p, 0, nn * 8, s));
+    if (C > 5) HIPCHK(hipMemsetAsync(h->a2.p, 0, nn * 16, s));
+    if (g->vR) {
+        HIPCHK(hipMemsetAsync(g->vR, 0, 9 * 4, s));
+        HIPCHK(hipMemsetAsync(g->vt, 0, 3 * 4, s));
+    }
+    h->prof.end(s);
+    GsrCam k = make_cam(h, cam);
+    h->prof.begin(ST_COMPOSITE_BWD, s);
+    if (h->last_D > 0)
+        gsr_launch_composite_bwd(s, C, k, h->tile_start.as<uint32_t>(), stream_of(h), in->background, vpixels,
+                                 h->n_contrib.as<uint32_t>(), h->final_T.as<float>(), acc_of(h));
+    h->prof.end(s);
+    h->prof.begin(ST_PERGAUSS_BWD, s);
+    gsr_launch_pergauss_bwd(s, n, in->n_coeffs, in->sh_degree, C, in->means, in->scales, in->rotations, in->shs, k,
+                            geom_of(h), acc_of(h), g->vmeans, g->vshs, g->vopacities, g->vscales, g->vrotations,
+                            g->vR, g->vt);
+    h->prof.end(s);
+    HIPCHK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_buffer(const gsr_handle* h, int which, const void** dev_ptr, size_t* bytes) {
+    if (!h || !dev_ptr || !bytes) return fail(GSR_E_INVALID_ARG, "null argument");
+    const size_t n = (size_t)h->last_n, P = (size_t)h->cfg.width * h->cfg.height, T = (size_t)h->n_tiles;
+    const size_t D = (size_t)h->last_D;
+    const DevBuf* b = nullptr;
+    size_t sz = 0;
+    switch (which) {
+        case GSR_BUF_RADII: b = &h->radii; sz = n * 4; break;
+        case GSR_BUF_GRAD_MEANS2D: b = &h->vmean2d; sz = n * 8; break;
+        case GSR_BUF_N_CONTRIB: b = &h->n_contrib; sz = P * 4; break;
+        case GSR_BUF_FINAL_T: b = &h->final_T; sz = P * 4; break;
+        case GSR_BUF_TILE_RANGES: b = &h->ranges; sz = 2 * T * 4; break;
+        case GSR_BUF_VALUES_SORTED: b = &h->values_sorted; sz = D * 4; break;
+        case GSR_BUF_GEOM0: b = &h->g0; sz = n * 16; break;
+        case GSR_BUF_GEOM1: b = &h->g1; sz = n * 16; break;
+        case GSR_BUF_GEOM2: b = &h->g2; sz = n * 16; break;
+        case GSR_BUF_GEOM3: b = &h->g3; sz = h->cfg.mode > 5 ? n * 16 : 0; break;
+        case GSR_BUF_RECT: b = &h->rect; sz = n * 8; break;
+        case GSR_BUF_GRAD_ACC0: b = &h->a0; sz = n * 16; break;
+        case GSR_BUF_GRAD_ACC1: b = &h->a1; sz = n * 16; break;
+        default: return fail(GSR_E_INVALID_ARG, "unknown buffer id %d", which);
+    }
+    if (sz > b->cap) sz = 0;  // not produced yet
+    *dev_ptr = sz ? b->p : nullptr;
+    *bytes = sz;
+    return GSR_OK;
+}
+
+int gsr_ssim_forward(int W, int H, int CH, int B, const float* img, const float* ref, float C1, float C2, int train,
+                     float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, void* stream) {
+    if (W <= 0 || H <= 0 || CH <= 0 || B <= 0) return fail(GSR_E_INVALID_ARG, "bad SSIM shape");
+    if (!img || !ref || !ssim_map) return fail(GSR_E_INVALID_ARG, "null SSIM array");
+    if (train && (!dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12)) return fail(GSR_E_INVALID_ARG, "train needs the 3 partial maps");
+    if ((size_t)CH * B > 65535) return fail(GSR_E_INVALID_ARG, "CH*B too large");
+    gsr_launch_ssim_fwd((hipStream_t)stream, W, H, CH, B, img, ref, C1, C2, train, ssim_map, dm_dmu1, dm_dsigma1_sq,
+                        dm_dsigma12);
+    HIPCHK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_ssim_backward(int W, int H, int CH, int B, const float* img, const float* ref, const float* dL_dmap,
+                      const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg,
+                      void* stream) {
+    if (W <= 0 || H <= 0 || CH <= 0 || B <= 0) return fail(GSR_E_INVALID_ARG, "bad SSIM shape");
+    if (!img || !ref || !dL_dmap || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg)
+        return fail(GSR_E_INVALID_ARG, "null SSIM array");
+    if ((size_t)CH * B > 65535) return fail(GSR_E_INVALID_ARG, "CH*B too large");
+    gsr_launch_ssim_bwd((hipStream_t)stream, W, H, CH, B, img, ref, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
+                        dL_dimg);
+    HIPCHK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_loss_l1_ssim(gsr_handle* h, const float* image, const float* target, float lambda_dssim, float* loss_out,
+                     float* vpixels, void* stream) {
+    if (!h || !image || !target || !loss_out || !vpixels) return fail(GSR_E_INVALID_ARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int W = h->cfg.width, H = h->cfg.height, C = h->cfg.mode;
+    const size_t P = (size_t)W * H;
+    int rc;
+    if ((rc = h->d0.ensure(3 * P * 4)) || (rc = h->d1.ensure(3 * P * 4)) || (rc = h->d2.ensure(3 * P * 4)) ||
+        (rc = h->partial.ensure(2 * 4)))
+        return rc;
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;  // fused_ssim.jl:374
+    h->prof.begin(ST_LOSS_FWD, s);
+    gsr_launch_loss_fwd(s, W, H, C, image, target, C1, C2, h->d0.as<float>(), h->d1.as<float>(), h->d2.as<float>(),
+                        h->partial.as<float>());
+    h->prof.end(s);
+    h->prof.begin(ST_LOSS_BWD, s);
+    gsr_launch_loss_bwd(s, W, H, C, image, target, lambda_dssim, h->d0.as<float>(), h->d1.as<float>(),
+                        h->d2.as<float>(), h->partial.as<float>(), loss_out, vpixels);
+    h->prof.end(s);
+    HIPCHK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_profile_enable(gsr_handle* h, int on) {
+    if (!h) return fail(GSR_E_INVALID_ARG, "null handle");
+    h->prof.on = on != 0;
+    if (!on) h->prof.clear();
+    return GSR_OK;
+}
+
+int gsr_profile_stage_count(void) { return ST_COUNT; }
+const char* gsr_profile_stage_name(int stage) { return stage >= 0 && stage < ST_COUNT ? kStageNames[stage] : ""; }
+
+int gsr_profile_read(gsr_handle* h, double* ms_sum, int* launches, int reset) {
+    if (!h || !ms_sum || !launches) return fail(GSR_E_INVALID_ARG, "null argument");
+    for (int i = 0; i < ST_COUNT; i++) { ms_sum[i] = 0.0; launches[i] = 0; }
+    for (auto& r : h->prof.recs) {
+        float ms = 0.0f;
+        HIPCHK(hipEventSynchronize(r.b));
+        HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+        ms_sum[r.stage] += ms;
+        launches[r.stage] += 1;
+    }
+    if (reset) h->prof.clear();
+    return GSR_OK;
+}
+
+int gsr_allreduce_grads(void* nccl_comm, float* arena, size_t count, void* stream) {
+    typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    static allreduce_fn fn = nullptr;
+    if (!nccl_comm || !arena) return fail(GSR_E_INVALID_ARG, "null communicator / arena");
+    if (!fn) {
+        void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return fail(GSR_E_HIP, "cannot load librccl.so: %s", dlerror());
+        fn = (allreduce_fn)dlsym(lib, "ncclAllReduce");
+        if (!fn) return fail(GSR_E_HIP, "ncclAllReduce not found in librccl.so");
+    }
+    const int ncclFloat32 = 7, ncclSum = 0;
+    int r = fn(arena, arena, count, ncclFloat32, ncclSum, nccl_comm, (hipStream_t)stream);
+    if (r != 0) return fail(GSR_E_HIP, "ncclAllReduce failed with code %d", r);
+    return GSR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+// Internal interface between the C ABI (gsr_api.cpp) and the gfx950 kernels.
+// Not installed; include/gsr.h is the public boundary.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GSR_TILE 16         // GaussianSplatting.jl:55 BLOCK
+#define GSR_BATCH 256       // GaussianSplatting.jl:56 BLOCK_SIZE
+#define GSR_SORT_LDS_CAP 4096  // keys per tile sorted in LDS (32 KB); longer lists use the global path
+
+// Camera + config constants, passed BY VALUE as a kernel argument (lands in SGPRs).
+struct GsrCam {
+    float R[9];  // row-major R[r*3+c] (converted from the ABI's column-major)
+    float t[3];
+    float focal[2];
+    float principal[2];  // normalised
+    float center[3];
+    int width, height;
+    int grid_x, grid_y;
+    float near_plane, far_plane;
+    int radius_clip;
+    float blur_eps;
+    const float* R_dev;  // optional device overrides (column-major (3,3), (3))
+    const float* t_dev;
+};
+
+// Per-Gaussian geometry written by preprocess (SoA of float4 planes, 16 B/lane coalesced).
+struct GsrGeom {
+    float4* g0;      // mean2d.x, mean2d.y, conic.a, conic.b
+    float4* g1;      // conic.c, opacity, r, g
+    float4* g2;      // b, clamped bits, depth, unused
+    float4* g3;      // normal xyz (C == 8) or nullptr
+    int32_t* radii;
+    ushort4* rect;   // tile rect xmin,ymin,xmax,ymax
+};
+
+// Sorted per-instance splat stream written by tile_sort (same planes, id replaces clamped bits).
+struct GsrStream {
+    float4* s0;
+    float4* s1;
+    float4* s2;  // b, id (uint bits), depth, unused
+    float4* s3;  // normal (C == 8) or nullptr
+};
+
+struct GsrAcc {  // backward accumulators, zero-filled per call
+    float4* a0;      // v rgb, v opacity
+    float4* a1;      // v conic a,b,c, v depth
+    float4* a2;      // v normal (C == 8) or nullptr
+    float2* vmean2d; // exposed as gstate.∇means_2d
+};
+
+// ---- pergauss.hip (compiled with -ffp-contract=off: bit-reproducible fp32) ----
+void gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels, const float* means,
+                           const float* scales, const float* rots, const float* opac, const float* shs, GsrCam cam,
+                           GsrGeom geom, uint32_t* tile_count, uint32_t* n_visible);
+void gsr_launch_pergauss_bwd(hipStream_t s, int n, int K, int degree, int channels, const float* means,
+                             const float* scales, const float* rots, const float* shs, GsrCam cam, GsrGeom geom,
+                             GsrAcc acc, float* vmeans, float* vshs, float* vopac, float* vscales, float* vrots,
+                             float* vR, float* vt);
+
+// ---- binning.hip ----
+// exclusive scan of tile_count -> tile_start[T+1], cursor[T] = tile_start;
+// totals[0] = D, totals[1] = max count, totals[2] = #tiles over GSR_SORT_LDS_CAP, totals[3] = slab counter (0)
+void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count, uint32_t* tile_start,
+                          uint32_t* cursor, uint32_t* totals);
+void gsr_launch_scatter(hipStream_t s, int n, GsrCam cam, GsrGeom geom, uint32_t* cursor, uint64_t* keys);
+void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int channels, const uint32_t* tile_start, uint64_t* keys,
+                          uint64_t* big_scratch, uint32_t big_scratch_stride, uint32_t* slab_counter, GsrGeom geom,
+                          GsrStream stream, uint32_t* values_sorted, uint32_t* ranges);
+
+// ---- composite.hip ----
+void gsr_launch_composite_fwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start, GsrStream stream,
+                              const float* background, float* image, uint32_t* n_contrib, float* final_T,
+                              uint8_t* covis, float* uncert);
+void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start, GsrStream stream,
+                              const float* background, const float* vpixels, const uint32_t* n_contrib,
+                              const float* final_T, GsrAcc acc);
+
+// ---- ssim.hip ----
+void gsr_launch_ssim_fwd(hipStream_t s, int W, int H, int CH, int B, const float* img, const float* ref, float C1,
+                         float C2, int train, float* ssim_map, float* d0, float* d1, float* d2);
+void gsr_launch_ssim_bwd(hipStream_t s, int W, int H, int CH, int B, const float* img, const float* ref,
+                         const float* dL_dmap, const float* d0, const float* d1, const float* d2, float* dL_dimg);
+// fused loss head: image (C,W,H) vs target (W,H,3)
+void gsr_launch_loss_fwd(hipStream_t s, int W, int H, int C, const float* image, const float* target, float C1,
+                         float C2, float* d0, float* d1, float* d2, float* partial /* [2]: sum|x-y|, sum ssim */);
+void gsr_launch_loss_bwd(hipStream_t s, int W, int H, int C, const float* image, const float* target, float lambda,
+                         const float* d0, const float* d1, const float* d2, const float* partial, float* loss_out,
+                         float* vpixels);

@@ -1,0 +1,587 @@
+// Per-Gaussian kernels: fused preprocess (project! + spherical_harmonics! + tile
+// rect + per-tile occupancy count) and the fused per-Gaussian backward
+// (∇project! + ∇spherical_harmonics!).
+//
+// Reference behaviour: src/rasterization/projection.jl:39-257, 259-393,
+// spherical_harmonics.jl:1-181, utils.jl:14-29,122-142, render.jl:288-420.
+//
+// This translation unit is compiled with -ffp-contract=off: every fp32 expression
+// is evaluated as written (no FMA), so the discrete outputs (radii, tile rects) and
+// the per-Gaussian floats are bit-reproducible against the CPU oracle.  These
+// kernels are HBM-bound (192 B of SH per Gaussian), the extra VALU ops are free.
+#include "gsr_kernels.h"
+
+namespace {
+
+constexpr float SH0 = 0.28209479177387814f;
+constexpr float SH1 = 0.4886025119029199f;
+constexpr float SH2C1 = 1.0925484305920792f;
+constexpr float SH2C2 = -1.0925484305920792f;
+constexpr float SH2C3 = 0.31539156525252005f;
+constexpr float SH2C4 = -1.0925484305920792f;
+constexpr float SH2C5 = 0.5462742152960396f;
+constexpr float SH3C1 = -0.5900435899266435f;
+constexpr float SH3C2 = 2.890611442640554f;
+constexpr float SH3C3 = -0.4570457994644658f;
+constexpr float SH3C4 = 0.3731763325901154f;
+constexpr float SH3C5 = -0.4570457994644658f;
+constexpr float SH3C6 = 1.445305721320277f;
+constexpr float SH3C7 = -0.5900435899266435f;
+
+struct M33 { float m[3][3]; };
+struct M22 { float m[2][2]; };
+
+__device__ __forceinline__ M33 mul33(const M33& a, const M33& b) {
+    M33 o;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) o.m[i][j] = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j] + a.m[i][2] * b.m[2][j];
+    return o;
+}
+__device__ __forceinline__ M33 tr33(const M33& a) {
+    M33 o;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) o.m[i][j] = a.m[j][i];
+    return o;
+}
+__device__ __forceinline__ M33 add33(const M33& a, const M33& b) {
+    M33 o;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) o.m[i][j] = a.m[i][j] + b.m[i][j];
+    return o;
+}
+__device__ __forceinline__ M22 mul22(const M22& a, const M22& b) {
+    M22 o;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) o.m[i][j] = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j];
+    return o;
+}
+
+// world->camera rotation as row-major M33, honouring the device override (pose optimisation)
+__device__ __forceinline__ void load_pose(const GsrCam& cam, M33& R, float t[3]) {
+    if (cam.R_dev) {
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int r = 0; r < 3; r++) R.m[r][c] = cam.R_dev[c * 3 + r];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) R.m[r][c] = cam.R[r * 3 + c];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) t[k] = cam.t_dev ? cam.t_dev[k] : cam.t[k];
+}
+
+// render.jl:322-333
+__device__ __forceinline__ M33 quat2rot(const float4 q4, float qn[4], float& inv_norm) {
+    float n2 = q4.x * q4.x + q4.y * q4.y + q4.z * q4.z + q4.w * q4.w;
+    inv_norm = 1.0f / sqrtf(n2);
+    float w = q4.x * inv_norm, x = q4.y * inv_norm, y = q4.z * inv_norm, z = q4.w * inv_norm;
+    qn[0] = w; qn[1] = x; qn[2] = y; qn[3] = z;
+    float x2 = x * x, y2 = y * y, z2 = z * z, xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+    M33 R;
+    R.m[0][0] = 1.0f - 2.0f * (y2 + z2); R.m[1][0] = 2.0f * (xy + wz); R.m[2][0] = 2.0f * (xz - wy);
+    R.m[0][1] = 2.0f * (xy - wz); R.m[1][1] = 1.0f - 2.0f * (x2 + z2); R.m[2][1] = 2.0f * (yz + wx);
+    R.m[0][2] = 2.0f * (xz + wy); R.m[1][2] = 2.0f * (yz - wx); R.m[2][2] = 1.0f - 2.0f * (x2 + y2);
+    return R;
+}
+
+// render.jl:291-294
+__device__ __forceinline__ M33 cov3d(const M33& Rg, const float s[3], M33& M) {
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) M.m[r][c] = Rg.m[r][c] * s[c];
+    return mul33(M, tr33(M));
+}
+
+struct Persp {
+    float lim[2], lim_neg[2], txy[2], rz;
+    float J[2][3];
+};
+// shared part of projection.jl:259-287 / 289-353
+__device__ __forceinline__ Persp persp_common(const float mc[3], const GsrCam& cam) {
+    Persp p;
+    const int res[2] = {cam.width, cam.height};
+    p.rz = 1.0f / mc[2];
+    float rz2 = p.rz * p.rz;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        float tan_fov = (0.5f * (float)res[k]) / cam.focal[k];
+        float stf = 0.3f * tan_fov;
+        float pp = cam.principal[k] * (float)res[k];
+        p.lim[k] = ((float)res[k] - pp) / cam.focal[k] + stf;
+        p.lim_neg[k] = pp / cam.focal[k] + stf;
+        float v = mc[k] * p.rz;
+        float c = fmaxf(-p.lim_neg[k], v);
+        c = fminf(p.lim[k], c);
+        p.txy[k] = mc[2] * c;
+    }
+    p.J[0][0] = cam.focal[0] * p.rz; p.J[1][0] = 0.0f;
+    p.J[0][1] = 0.0f;                p.J[1][1] = cam.focal[1] * p.rz;
+    p.J[0][2] = -cam.focal[0] * p.txy[0] * rz2;
+    p.J[1][2] = -cam.focal[1] * p.txy[1] * rz2;
+    return p;
+}
+
+// utils.jl:14-29 get_rect; float ceil-div as gpu_cld
+__device__ __forceinline__ void get_rect(float mx, float my, int radius, int gx, int gy, int rmin[2], int rmax[2]) {
+    const float px[2] = {mx, my};
+    const int grid[2] = {gx, gy};
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        float lo = floorf((px[k] - (float)radius) / 16.0f);
+        float hi_arg = (px[k] + (float)radius) + 16.0f - 1.0f;
+        float hi = floorf(hi_arg / 16.0f);
+        int ilo = (int)lo, ihi = (int)hi;
+        rmin[k] = ilo < 0 ? 0 : (ilo > grid[k] ? grid[k] : ilo);
+        rmax[k] = ihi < 0 ? 0 : (ihi > grid[k] ? grid[k] : ihi);
+    }
+}
+
+template <int DEG>
+__device__ __forceinline__ void sh_basis(const float d[3], float b[16]) {
+    float x = d[0], y = d[1], z = d[2];
+    b[0] = SH0;
+    if (DEG > 0) {
+        b[1] = -SH1 * y; b[2] = SH1 * z; b[3] = -SH1 * x;
+    }
+    if (DEG > 1) {
+        float x2 = x * x, y2 = y * y, z2 = z * z, xy = x * y, xz = x * z, yz = y * z;
+        b[4] = SH2C1 * xy; b[5] = SH2C2 * yz; b[6] = SH2C3 * (2.0f * z2 - x2 - y2);
+        b[7] = SH2C4 * xz; b[8] = SH2C5 * (x2 - y2);
+        if (DEG > 2) {
+            b[9] = SH3C1 * y * (3.0f * x2 - y2);
+            b[10] = SH3C2 * xy * z;
+            b[11] = SH3C3 * y * (4.0f * z2 - x2 - y2);
+            b[12] = SH3C4 * z * (2.0f * z2 - 3.0f * x2 - 3.0f * y2);
+            b[13] = SH3C5 * x * (4.0f * z2 - x2 - y2);
+            b[14] = SH3C6 * z * (x2 - y2);
+            b[15] = SH3C7 * x * (x2 - 3.0f * y2);
+        }
+    }
+}
+
+// projection.jl:14-27
+__device__ __forceinline__ void gaussian_normal(const M33& Rw, const M33& Rg, const float s[3], const float mc[3],
+                                                float n[3], int& k, float& sign) {
+    k = (s[0] <= s[1] && s[0] <= s[2]) ? 0 : (s[1] <= s[2]) ? 1 : 2;
+    float ax[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) ax[r] = k == 0 ? Rg.m[r][0] : (k == 1 ? Rg.m[r][1] : Rg.m[r][2]);
+    float nc[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) nc[r] = Rw.m[r][0] * ax[0] + Rw.m[r][1] * ax[1] + Rw.m[r][2] * ax[2];
+    float d = nc[0] * mc[0] + nc[1] * mc[1] + nc[2] * mc[2];
+    sign = d > 0.0f ? -1.0f : 1.0f;
+#pragma unroll
+    for (int r = 0; r < 3; r++) n[r] = sign * nc[r];
+}
+
+// ---------------------------------------------------------------------------------
+// preprocess: project! (projection.jl:69-129) + spherical_harmonics!
+// (spherical_harmonics.jl:12-17,41-74) + count_tiles_per_gaussian! (utils.jl:131-141),
+// and the per-tile occupancy histogram that replaces cumsum!/duplicate/sort-by-tile.
+// ---------------------------------------------------------------------------------
+template <int DEG>
+__global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int channels, const float* __restrict__ means,
+                                                         const float* __restrict__ scales,
+                                                         const float4* __restrict__ rots,
+                                                         const float* __restrict__ opac,
+                                                         const float* __restrict__ shs, GsrCam cam, GsrGeom geom,
+                                                         uint32_t* __restrict__ tile_count,
+                                                         uint32_t* __restrict__ n_visible) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool visible = false;
+    if (i < n) {
+        M33 R; float t[3];
+        load_pose(cam, R, t);
+        const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+        float mc[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) mc[r] = (R.m[r][0] * p[0] + R.m[r][1] * p[1] + R.m[r][2] * p[2]) + t[r];
+        int radius = 0;
+        float m2[2] = {0, 0}, conic[3] = {0, 0, 0};
+        M33 Rg; float s[3];
+        if (cam.near_plane < mc[2] && mc[2] < cam.far_plane) {
+            float qn[4], inv_norm;
+            Rg = quat2rot(rots[i], qn, inv_norm);
+            s[0] = scales[3 * i]; s[1] = scales[3 * i + 1]; s[2] = scales[3 * i + 2];
+            M33 M;
+            M33 Sigma = cov3d(Rg, s, M);
+            M33 Sc = mul33(mul33(R, Sigma), tr33(R));
+            Persp pr = persp_common(mc, cam);
+            const int res[2] = {cam.width, cam.height};
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                float pp = cam.principal[k] * (float)res[k];
+                m2[k] = pr.rz * cam.focal[k] * mc[k] + pp;
+            }
+            float JS[2][3];
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++)
+                    JS[a][b] = pr.J[a][0] * Sc.m[0][b] + pr.J[a][1] * Sc.m[1][b] + pr.J[a][2] * Sc.m[2][b];
+            M22 S2;
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+                    S2.m[a][b] = JS[a][0] * pr.J[b][0] + JS[a][1] * pr.J[b][1] + JS[a][2] * pr.J[b][2];
+            // add_blur (render.jl:387-396)
+            S2.m[0][0] = S2.m[0][0] + cam.blur_eps;
+            S2.m[1][1] = S2.m[1][1] + cam.blur_eps;
+            float det = S2.m[0][0] * S2.m[1][1] - S2.m[0][1] * S2.m[1][0];
+            if (det > 0.0f) {
+                // inverse (render.jl:368-381)
+                float det_inv = 1.0f / det;
+                float tmp = -S2.m[0][1] * det_inv;
+                conic[0] = S2.m[1][1] * det_inv; conic[1] = tmp; conic[2] = S2.m[0][0] * det_inv;
+                // max_eigval_2D (render.jl:415-420)
+                float mid = 0.5f * (S2.m[0][0] + S2.m[1][1]);
+                float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+                int rad = (int)ceilf(3.0f * sqrtf(lam));
+                bool off = (m2[0] + (float)rad) <= 0.0f || (m2[0] - (float)rad) >= (float)res[0] ||
+                           (m2[1] + (float)rad) <= 0.0f || (m2[1] - (float)rad) >= (float)res[1];
+                if (rad > cam.radius_clip && !off) radius = rad;
+            }
+        }
+        geom.radii[i] = radius;
+        if (radius > 0) {
+            visible = true;
+            // SH colour
+            const float* sh = shs + (size_t)3 * K * i;
+            float d[3] = {p[0] - cam.center[0], p[1] - cam.center[1], p[2] - cam.center[2]};
+            float inv = 1.0f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            d[0] *= inv; d[1] *= inv; d[2] *= inv;
+            float b[16];
+            sh_basis<DEG>(d, b);
+            constexpr int NB = (DEG + 1) * (DEG + 1);
+            float rgb[3];
+            uint32_t clamp_bits = 0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float res = b[0] * sh[c];
+#pragma unroll
+                for (int k = 1; k < NB; k++) res = res + b[k] * sh[3 * k + c];
+                res = res + 0.5f + 1.1920929e-7f;
+                if (res < 0.0f) clamp_bits |= 1u << c;
+                rgb[c] = fmaxf(0.0f, res);
+            }
+            geom.g0[i] = make_float4(m2[0], m2[1], conic[0], conic[1]);
+            geom.g1[i] = make_float4(conic[2], opac[i], rgb[0], rgb[1]);
+            geom.g2[i] = make_float4(rgb[2], __uint_as_float(clamp_bits), mc[2], 0.0f);
+            if (channels > 5) {
+                float nn[3]; int k; float sg;
+                gaussian_normal(R, Rg, s, mc, nn, k, sg);
+                geom.g3[i] = make_float4(nn[0], nn[1], nn[2], 0.0f);
+            }
+            int rmin[2], rmax[2];
+            get_rect(m2[0], m2[1], radius, cam.grid_x, cam.grid_y, rmin, rmax);
+            geom.rect[i] = make_ushort4((unsigned short)rmin[0], (unsigned short)rmin[1], (unsigned short)rmax[0],
+                                        (unsigned short)rmax[1]);
+            for (int y = rmin[1]; y < rmax[1]; y++)
+                for (int x = rmin[0]; x < rmax[0]; x++) atomicAdd(&tile_count[y * cam.grid_x + x], 1u);
+        } else {
+            geom.rect[i] = make_ushort4(0, 0, 0, 0);
+        }
+    }
+    unsigned long long m = __ballot(visible);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_visible, (uint32_t)__popcll(m));
+}
+
+// ---------------------------------------------------------------------------------
+// fused ∇project! (projection.jl:170-256) + ∇spherical_harmonics!
+// (spherical_harmonics.jl:32-37,76-181).  Every output element is written exactly
+// once (zeros for culled Gaussians and for SH bands above the active degree), so the
+// 59·N-float gradient arena needs no memset.
+// ---------------------------------------------------------------------------------
+template <int DEG>
+__global__ __launch_bounds__(256) void pergauss_bwd_kernel(int n, int K, int channels, const float* __restrict__ means,
+                                                           const float* __restrict__ scales,
+                                                           const float4* __restrict__ rots,
+                                                           const float* __restrict__ shs, GsrCam cam, GsrGeom geom,
+                                                           GsrAcc acc, float* __restrict__ vmeans,
+                                                           float* __restrict__ vshs, float* __restrict__ vopac,
+                                                           float* __restrict__ vscales, float4* __restrict__ vrots,
+                                                           float* __restrict__ vR_out, float* __restrict__ vt_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float poseR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, poset[3] = {0, 0, 0};
+    if (i < n) {
+        float* vsh = vshs + (size_t)3 * K * i;
+        if (!(geom.radii[i] > 0)) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) { vmeans[3 * i + c] = 0.0f; vscales[3 * i + c] = 0.0f; }
+            vrots[i] = make_float4(0, 0, 0, 0);
+            vopac[i] = 0.0f;
+            for (int k = 0; k < 3 * K; k++) vsh[k] = 0.0f;
+        } else {
+            const float4 a0 = acc.a0[i], a1 = acc.a1[i];
+            const float2 vm2 = acc.vmean2d[i];
+            const float4 g0 = geom.g0[i], g1 = geom.g1[i], g2 = geom.g2[i];
+            vopac[i] = a0.w;
+            M33 R; float t[3];
+            load_pose(cam, R, t);
+            // ---- ∇project ----
+            M22 Ci, vCi;
+            Ci.m[0][0] = g0.z; Ci.m[1][0] = g0.w; Ci.m[0][1] = g0.w; Ci.m[1][1] = g1.x;
+            vCi.m[0][0] = a1.x; vCi.m[1][0] = a1.y; vCi.m[0][1] = a1.y; vCi.m[1][1] = a1.z;
+            M22 nC;
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) nC.m[a][b] = -Ci.m[a][b];
+            M22 vS2 = mul22(mul22(nC, vCi), Ci);  // ∇inverse (render.jl:383-385)
+            const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+            float mc[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) mc[r] = (R.m[r][0] * p[0] + R.m[r][1] * p[1] + R.m[r][2] * p[2]) + t[r];
+            const float4 q4 = rots[i];
+            float qn[4], inv_norm;
+            M33 Rg = quat2rot(q4, qn, inv_norm);
+            const float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+            M33 M;
+            M33 Sigma = cov3d(Rg, s, M);
+            M33 Sc = mul33(mul33(R, Sigma), tr33(R));
+            Persp pr = persp_common(mc, cam);
+            const float rz = pr.rz, rz2 = rz * rz, rz3 = rz2 * rz;
+            const float* f = cam.focal;
+            // ∇perspective_projection (projection.jl:289-353)
+            float JtV[3][2];
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) JtV[a][b] = pr.J[0][a] * vS2.m[0][b] + pr.J[1][a] * vS2.m[1][b];
+            M33 vSc;
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) vSc.m[a][b] = JtV[a][0] * pr.J[0][b] + JtV[a][1] * pr.J[1][b];
+            float A[2][3], B[2][3], vJ[2][3];
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) {
+                    A[a][b] = vS2.m[a][0] * pr.J[0][b] + vS2.m[a][1] * pr.J[1][b];
+                    B[a][b] = vS2.m[0][a] * pr.J[0][b] + vS2.m[1][a] * pr.J[1][b];
+                }
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) {
+                    float u = A[a][0] * Sc.m[b][0] + A[a][1] * Sc.m[b][1] + A[a][2] * Sc.m[b][2];
+                    float v = B[a][0] * Sc.m[0][b] + B[a][1] * Sc.m[1][b] + B[a][2] * Sc.m[2][b];
+                    vJ[a][b] = u + v;
+                }
+            float vx = f[0] * rz * vm2.x;
+            float vy = f[1] * rz * vm2.y;
+            float vz = -rz2 * (f[0] * mc[0] * vm2.x + f[1] * mc[1] * vm2.y);
+            float rx = mc[0] * rz, ry = mc[1] * rz;
+            if (-pr.lim_neg[0] <= rx && rx <= pr.lim[0]) vx += -f[0] * rz2 * vJ[0][2];
+            else vz += -f[0] * rz3 * vJ[0][2] * pr.txy[0];
+            if (-pr.lim_neg[1] <= ry && ry <= pr.lim[1]) vy += -f[1] * rz2 * vJ[1][2];
+            else vz += -f[1] * rz3 * vJ[1][2] * pr.txy[1];
+            vz += -f[0] * rz2 * vJ[0][0] - f[1] * rz2 * vJ[1][1] + 2.0f * f[0] * pr.txy[0] * rz3 * vJ[0][2] +
+                  2.0f * f[1] * pr.txy[1] * rz3 * vJ[1][2];
+            float vmc[3] = {vx, vy, vz};
+            if (channels > 3) vmc[2] = vmc[2] + a1.w;  // vdepth (projection.jl:218-222)
+            // ∇pos_world_to_cam, ∇covar_world_to_cam
+            float vmean[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) vmean[c] = R.m[0][c] * vmc[0] + R.m[1][c] * vmc[1] + R.m[2][c] * vmc[2];
+            M33 vSigma = mul33(mul33(tr33(R), vSc), R);
+            if (vR_out) {
+                M33 vR0;
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) vR0.m[r][c] = vmc[r] * p[c];
+                M33 u = mul33(mul33(vSc, R), tr33(Sigma));
+                M33 v = mul33(mul33(tr33(vSc), R), Sigma);
+                M33 vR2 = add33(add33(vR0, u), v);
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) poseR[c * 3 + r] = fabsf(vR2.m[r][c]) > 1e-7f ? vR2.m[r][c] : 0.0f;
+                    poset[r] = fabsf(vmc[r]) > 1e-7f ? vmc[r] : 0.0f;
+                }
+            }
+            // normal channel (projection.jl:227-235)
+            M33 vRg;
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) vRg.m[a][b] = 0.0f;
+            if (channels > 5) {
+                const float4 a2 = acc.a2[i];
+                float nn[3]; int k; float sg;
+                gaussian_normal(R, Rg, s, mc, nn, k, sg);
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    float g = R.m[0][r] * a2.x + R.m[1][r] * a2.y + R.m[2][r] * a2.z;
+                    float v = sg * g;
+                    if (k == 0) vRg.m[r][0] = v; else if (k == 1) vRg.m[r][1] = v; else vRg.m[r][2] = v;
+                }
+            }
+            // ∇quat_scale_to_cov (render.jl:302-320)
+            M33 S;
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) S.m[a][b] = 0.0f;
+            S.m[0][0] = s[0]; S.m[1][1] = s[1]; S.m[2][2] = s[2];
+            M33 vM = mul33(add33(vSigma, tr33(vSigma)), M);
+            M33 vRq = add33(mul33(vM, S), vRg);
+            float vs[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                vs[c] = Rg.m[0][c] * vM.m[0][c] + Rg.m[1][c] * vM.m[1][c] + Rg.m[2][c] * vM.m[2][c];
+            // ∇unnorm_quat2rot (render.jl:335-366)
+            const float w = qn[0], x = qn[1], y = qn[2], z = qn[3];
+#define V(i_, j_) vRq.m[(i_) - 1][(j_) - 1]
+            float vqn[4];
+            vqn[0] = 2.0f * (x * (V(3, 2) - V(2, 3)) + y * (V(1, 3) - V(3, 1)) + z * (V(2, 1) - V(1, 2)));
+            vqn[1] = 2.0f * (-2.0f * x * (V(2, 2) + V(3, 3)) + y * (V(2, 1) + V(1, 2)) + z * (V(3, 1) + V(1, 3)) +
+                             w * (V(3, 2) - V(2, 3)));
+            vqn[2] = 2.0f * (x * (V(2, 1) + V(1, 2)) - 2.0f * y * (V(1, 1) + V(3, 3)) + z * (V(3, 2) + V(2, 3)) +
+                             w * (V(1, 3) - V(3, 1)));
+            vqn[3] = 2.0f * (x * (V(3, 1) + V(1, 3)) + y * (V(3, 2) + V(2, 3)) - 2.0f * z * (V(1, 1) + V(2, 2)) +
+                             w * (V(2, 1) - V(1, 2)));
+#undef V
+            float dq = vqn[0] * qn[0] + vqn[1] * qn[1] + vqn[2] * qn[2] + vqn[3] * qn[3];
+            float vq[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) vq[k] = (vqn[k] - dq * qn[k]) * inv_norm;
+            vrots[i] = make_float4(vq[0], vq[1], vq[2], vq[3]);
+#pragma unroll
+            for (int c = 0; c < 3; c++) vscales[3 * i + c] = vs[c];
+
+            // ---- ∇SH ----
+            const float* sh = shs + (size_t)3 * K * i;
+            const uint32_t clamp_bits = __float_as_uint(g2.y);
+            float vc[3] = {a0.x * (1.0f - (float)(clamp_bits & 1u)), a0.y * (1.0f - (float)((clamp_bits >> 1) & 1u)),
+                           a0.z * (1.0f - (float)((clamp_bits >> 2) & 1u))};
+            float d0[3] = {p[0] - cam.center[0], p[1] - cam.center[1], p[2] - cam.center[2]};
+            float inv = 1.0f / sqrtf(d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2]);
+            const float dx = d0[0] * inv, dy = d0[1] * inv, dz = d0[2] * inv;
+            const float dir[3] = {dx, dy, dz};
+            float b[16];
+            sh_basis<DEG>(dir, b);
+            constexpr int NB = (DEG + 1) * (DEG + 1);
+#pragma unroll
+            for (int k = 0; k < NB; k++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) vsh[3 * k + c] = b[k] * vc[c];
+            for (int k = 3 * NB; k < 3 * K; k++) vsh[k] = 0.0f;
+            float dcx[3] = {0, 0, 0}, dcy[3] = {0, 0, 0}, dcz[3] = {0, 0, 0};
+#define SHC(k_, c_) sh[3 * (k_) + (c_)]
+            if (DEG > 0) {
+                const float x = dx, y = dy, z = dz;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    dcx[c] = -SH1 * SHC(3, c); dcy[c] = -SH1 * SHC(1, c); dcz[c] = SH1 * SHC(2, c);
+                }
+                if (DEG > 1) {
+                    float x2 = x * x, y2 = y * y, z2 = z * z, xy = x * y, xz = x * z, yz = y * z;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        dcx[c] = dcx[c] + SH2C1 * y * SHC(4, c) + SH2C3 * 2.0f * -x * SHC(6, c) +
+                                 SH2C4 * z * SHC(7, c) + SH2C5 * 2.0f * x * SHC(8, c);
+                        dcy[c] = dcy[c] + SH2C1 * x * SHC(4, c) + SH2C2 * z * SHC(5, c) +
+                                 SH2C3 * 2.0f * -y * SHC(6, c) + SH2C5 * 2.0f * -y * SHC(8, c);
+                        dcz[c] = dcz[c] + SH2C2 * y * SHC(5, c) + SH2C3 * 4.0f * z * SHC(6, c) + SH2C4 * x * SHC(7, c);
+                    }
+                    if (DEG > 2) {
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            dcx[c] = dcx[c] + SH3C1 * SHC(9, c) * 3.0f * 2.0f * xy + SH3C2 * SHC(10, c) * yz +
+                                     SH3C3 * SHC(11, c) * -2.0f * xy + SH3C4 * SHC(12, c) * -3.0f * 2.0f * xz +
+                                     SH3C5 * SHC(13, c) * (-3.0f * x2 + 4.0f * z2 - y2) +
+                                     SH3C6 * SHC(14, c) * 2.0f * xz + SH3C7 * SHC(15, c) * 3.0f * (x2 - y2);
+                            dcy[c] = dcy[c] + SH3C1 * SHC(9, c) * 3.0f * (x2 - y2) + SH3C2 * SHC(10, c) * xz +
+                                     SH3C3 * SHC(11, c) * (-3.0f * y2 + 4.0f * z2 - x2) +
+                                     SH3C4 * SHC(12, c) * -3.0f * 2.0f * yz + SH3C5 * SHC(13, c) * -2.0f * xy +
+                                     SH3C6 * SHC(14, c) * -2.0f * yz + SH3C7 * SHC(15, c) * -3.0f * 2.0f * xy;
+                            dcz[c] = dcz[c] + SH3C2 * SHC(10, c) * xy + SH3C3 * SHC(11, c) * 4.0f * 2.0f * yz +
+                                     SH3C4 * SHC(12, c) * 3.0f * (2.0f * z2 - x2 - y2) +
+                                     SH3C5 * SHC(13, c) * 4.0f * 2.0f * xz + SH3C6 * SHC(14, c) * (x2 - y2);
+                        }
+                    }
+                }
+            }
+#undef SHC
+            float vdir[3];
+            vdir[0] = dcx[0] * vc[0] + dcx[1] * vc[1] + dcx[2] * vc[2];
+            vdir[1] = dcy[0] * vc[0] + dcy[1] * vc[1] + dcy[2] * vc[2];
+            vdir[2] = dcz[0] * vc[0] + dcz[1] * vc[1] + dcz[2] * vc[2];
+            // ∇normalize (spherical_harmonics.jl:174-181)
+            float s2 = d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2];
+            float inv_s = 1.0f / sqrtf(s2 * s2 * s2);
+            float vmsh[3];
+            vmsh[0] = ((s2 - d0[0] * d0[0]) * vdir[0] - d0[1] * d0[0] * vdir[1] - d0[2] * d0[0] * vdir[2]) * inv_s;
+            vmsh[1] = (-d0[0] * d0[1] * vdir[0] + (s2 - d0[1] * d0[1]) * vdir[1] - d0[2] * d0[1] * vdir[2]) * inv_s;
+            vmsh[2] = (-d0[0] * d0[2] * vdir[0] - d0[1] * d0[2] * vdir[1] + (s2 - d0[2] * d0[2]) * vdir[2]) * inv_s;
+#pragma unroll
+            for (int c = 0; c < 3; c++) vmeans[3 * i + c] = vmean[c] + vmsh[c];
+        }
+    }
+    if (vR_out) {  // projection.jl:243-256: thresholded per Gaussian, then summed (wave sum -> 1 atomic / wave)
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            float v = k < 9 ? poseR[k] : poset[k - 9];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if ((threadIdx.x & 63) == 0 && v != 0.0f) atomicAdd(k < 9 ? &vR_out[k] : &vt_out[k - 9], v);
+        }
+    }
+}
+
+}  // namespace
+
+void gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels, const float* means,
+                           const float* scales, const float* rots, const float* opac, const float* shs, GsrCam cam,
+                           GsrGeom geom, uint32_t* tile_count, uint32_t* n_visible) {
+    if (n <= 0) return;
+    dim3 grid((n + 255) / 256), block(256);
+    const float4* r4 = reinterpret_cast<const float4*>(rots);
+#define LAUNCH(D)                                                                                                  \
+    hipLaunchKernelGGL(preprocess_kernel<D>, grid, block, 0, s, n, K, channels, means, scales, r4, opac, shs, cam, \
+                       geom, tile_count, n_visible)
+    switch (degree) {
+        case 0: LAUNCH(0); break;
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        default: LAUNCH(3); break;
+    }
+#undef LAUNCH
+}
+
+void gsr_launch_pergauss_bwd(hipStream_t s, int n, int K, int degree, int channels, const float* means,
+                             const float* scales, const float* rots, const float* shs, GsrCam cam, GsrGeom geom,
+                             GsrAcc acc, float* vmeans, float* vshs, float* vopac, float* vscales, float* vrots,
+                             float* vR, float* vt) {
+    if (n <= 0) return;
+    dim3 grid((n + 255) / 256), block(256);
+    const float4* r4 = reinterpret_cast<const float4*>(rots);
+    float4* vr4 = reinterpret_cast<float4*>(vrots);
+#define LAUNCH(D)                                                                                                 \
+    hipLaunchKernelGGL(pergauss_bwd_kernel<D>, grid, block, 0, s, n, K, channels, means, scales, r4, shs, cam,    \
+                       geom, acc, vmeans, vshs, vopac, vscales, vr4, vR, vt)
+    switch (degree) {
+        case 0: LAUNCH(0); break;
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        default: LAUNCH(3); break;
+    }
+#undef LAUNCH
+}

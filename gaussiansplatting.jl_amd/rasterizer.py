@@ -1,0 +1,309 @@
+"""Host-side mirror of the reference's rasterizer operator
+(src/rasterization/rasterizer.jl): `GaussianRasterizer` (lines 5-90), its functor
+prologue (200-253), `rasterize` (255-408), `∇rasterize` (416-550) and the
+`ChainRulesCore.rrule` (552-573, here a `torch.autograd.Function`).
+
+All compute happens in libgsr_hip.so through the C ABI of include/gsr.h; torch is
+used only for device memory, streams and autograd plumbing.  There is no CPU path:
+tensors must live on a HIP device and the library must be present.
+
+Tensor shapes are the C-order equivalents of the reference's column-major arrays
+(identical memory): means `(N,3)` ≙ `(3,N)`, shs `(N,K,3)` ≙ `(3,K,N)`, rotations
+`(N,4)` (w,x,y,z), opacities `(N,1)`, image `(H,W,C)` ≙ `(C,W,H)`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .camera import Camera
+
+
+def n_color_features(mode: str) -> int:
+    """rasterizer.jl:47-51"""
+    if mode not in L.MODES:
+        raise ValueError(f"Invalid render mode: `{mode}`.")
+    return L.MODES[mode]
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t: torch.Tensor, name: str, shape=None):
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a HIP device tensor (no CPU path)")
+    if t.dtype != torch.float32:
+        raise ValueError(f"{name} must be float32")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+    return t
+
+
+class GaussianRasterizer:
+    """GaussianRasterizer(kab; width, height, mode=:rgbd, near_plane=0.2, far_plane=1000)
+    — rasterizer.jl:60-90.  Owns the grow-only scratch (gstate/bstate/istate) and the
+    output image; supports one outstanding forward→backward pair."""
+
+    def __init__(self, width: int, height: int, mode: str = "rgbd", near_plane: float = 0.2,
+                 far_plane: float = 1000.0, device="cuda", radius_clip: int = 3, blur_eps: float = 0.3):
+        self.mode = mode
+        self.channels = n_color_features(mode)
+        self.width, self.height = int(width), int(height)
+        self.grid = ((self.width + 15) // 16, (self.height + 15) // 16)
+        self.near_plane, self.far_plane = float(near_plane), float(far_plane)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("GaussianRasterizer needs a HIP device (no CPU path)")
+        self._lib = L.load()
+        cfg = L.Config(self.width, self.height, self.channels, self.near_plane, self.far_plane, int(radius_clip),
+                       float(blur_eps))
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(self._lib.gsr_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        # rast.image — the returned image aliases rasterizer memory (rasterizer.jl:407)
+        self.image = torch.zeros(self.height, self.width, self.channels, device=self.device)
+        self.stats = L.Stats()
+        self._n = 0
+
+    @classmethod
+    def for_camera(cls, camera: Camera, **kw):
+        """GaussianRasterizer(kab, camera; kwargs...) — rasterizer.jl:37-40"""
+        return cls(camera.width, camera.height, **kw)
+
+    def close(self):
+        """KA.unsafe_free!(rast) — rasterizer.jl:136-145"""
+        if getattr(self, "_h", None):
+            self._lib.gsr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def release_scene_buffers(self):
+        """release_scene_buffers!(rast) — rasterizer.jl:111-123"""
+        L.check(self._lib.gsr_release_scene_buffers(self._h))
+
+    def memory_usage(self) -> int:
+        """memory_usage(rast) — rasterizer.jl:127-134"""
+        return int(self._lib.gsr_memory_usage(self._h)) + self.image.numel() * 4
+
+    # ---- per-stage kernel timing (HIP events on the launch stream) ----
+    def profile(self, on: bool = True):
+        L.check(self._lib.gsr_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self, reset: bool = True) -> dict:
+        """{stage: (total_ms, launches)} since the last reset; waits for the recorded events."""
+        ns = self._lib.gsr_profile_stage_count()
+        ms, cnt = (C.c_double * ns)(), (C.c_int * ns)()
+        L.check(self._lib.gsr_profile_read(self._h, ms, cnt, 1 if reset else 0))
+        return {self._lib.gsr_profile_stage_name(i).decode(): (ms[i], cnt[i]) for i in range(ns)}
+
+    # ---- views into gstate / bstate / istate ----
+    def _buffer(self, which: int, dtype, shape):
+        p, sz = C.c_void_p(), C.c_size_t()
+        L.check(self._lib.gsr_buffer(self._h, which, C.byref(p), C.byref(sz)))
+        n = int(np.prod(shape))
+        itemsize = torch.empty((), dtype=dtype).element_size()
+        if sz.value < n * itemsize or not p.value:
+            raise RuntimeError("buffer not produced yet")
+        # copy out through hipMemcpy on the current stream (torch owns no view of library memory)
+        out = torch.empty(shape, dtype=dtype, device=self.device)
+        L.memcpy_d2d_async(out.data_ptr(), p.value, n * itemsize, torch.cuda.current_stream().cuda_stream)
+        return out
+
+    @property
+    def radii(self):
+        """gstate.radii (Int32, N) — read by densification (strategy.jl:85-86)"""
+        return self._buffer(L.BUF_RADII, torch.int32, (self._n,))
+
+    @property
+    def grad_means_2d(self):
+        """gstate.∇means_2d (2,N) — valid after the backward"""
+        return self._buffer(L.BUF_GRAD_MEANS2D, torch.float32, (self._n, 2))
+
+    @property
+    def n_contrib(self):
+        return self._buffer(L.BUF_N_CONTRIB, torch.int32, (self.height, self.width))
+
+    @property
+    def accum_alpha(self):
+        """istate.accum_α: the final transmittance T"""
+        return self._buffer(L.BUF_FINAL_T, torch.float32, (self.height, self.width))
+
+    @property
+    def ranges(self):
+        return self._buffer(L.BUF_TILE_RANGES, torch.int32, (self.grid[0] * self.grid[1], 2))
+
+    @property
+    def values_sorted(self):
+        return self._buffer(L.BUF_VALUES_SORTED, torch.int32, (int(self.stats.n_rendered),))
+
+    def geometry(self):
+        """means_2d, conics, depths, rgbs, clamped, tile rects of the last forward."""
+        n = self._n
+        g0 = self._buffer(L.BUF_GEOM0, torch.float32, (n, 4))
+        g1 = self._buffer(L.BUF_GEOM1, torch.float32, (n, 4))
+        g2 = self._buffer(L.BUF_GEOM2, torch.float32, (n, 4))
+        rect = self._buffer(L.BUF_RECT, torch.int16, (n, 4))
+        out = dict(means2d=g0[:, :2], conics=torch.stack([g0[:, 2], g0[:, 3], g1[:, 0]], 1), opacities=g1[:, 1],
+                   rgbs=torch.stack([g1[:, 2], g1[:, 3], g2[:, 0]], 1), clamped_bits=g2[:, 1].view(torch.int32),
+                   depths=g2[:, 2], rect=rect)
+        if self.channels > 5:
+            out["normals"] = self._buffer(L.BUF_GEOM3, torch.float32, (n, 4))[:, :3]
+        return out
+
+    # ---- functor prologue: rasterizer.jl:200-253 ----
+    def __call__(self, means_3d, opacities, scales, rotations, sh_color, sh_remainder, R_w2c=None, t_w2c=None, *,
+                 camera: Camera, sh_degree: int, background=(0.0, 0.0, 0.0), covisibilities=None,
+                 uncertainties=None):
+        shs = sh_color if sh_remainder is None or sh_remainder.numel() == 0 else torch.cat([sh_color, sh_remainder], 1)
+        opacities_act = torch.sigmoid(opacities)
+        if scales.shape[-1] == 1:  # isotropic
+            scales = scales.expand(-1, 3)
+        scales_act = torch.exp(scales)
+        return rasterize(means_3d, shs.contiguous(), opacities_act, scales_act.contiguous(), rotations, R_w2c, t_w2c,
+                         rast=self, camera=camera, sh_degree=sh_degree, background=background,
+                         covisibilities=covisibilities, uncertainties=uncertainties)
+
+    # ---- raw entry points used by rasterize / ∇rasterize ----
+    def _inputs(self, means_3d, shs, opacities, scales, rotations, sh_degree, background):
+        n = means_3d.shape[0]
+        _chk(means_3d, "means_3d", (n, 3)); _chk(scales, "scales", (n, 3)); _chk(rotations, "rotations", (n, 4))
+        _chk(shs, "shs"); _chk(opacities, "opacities")
+        if shs.dim() != 3 or shs.shape[0] != n or shs.shape[2] != 3:
+            raise ValueError(f"shs has shape {tuple(shs.shape)}, expected (N,K,3)")
+        if opacities.numel() != n:
+            raise ValueError("opacities must have N elements")
+        inp = L.Inputs(n, int(shs.shape[1]), int(sh_degree), means_3d.data_ptr(), shs.data_ptr(),
+                       opacities.data_ptr(), scales.data_ptr(), rotations.data_ptr(),
+                       (C.c_float * 3)(*[float(b) for b in background]))
+        return inp
+
+    def _camera(self, camera: Camera, R_w2c, t_w2c):
+        if (camera.width, camera.height) != (self.width, self.height):
+            raise ValueError("camera resolution does not match the rasterizer")
+        cs = L.CameraS()
+        R = np.asarray(camera.R, np.float32)
+        for c in range(3):
+            for r in range(3):
+                cs.R[c * 3 + r] = float(R[r, c])
+        cc = camera.camera_center
+        for k in range(3):
+            cs.t[k] = float(camera.t[k])
+            cs.camera_center[k] = float(cc[k])
+        for k in range(2):
+            cs.focal[k] = float(camera.focal[k])
+            cs.principal[k] = float(camera.principal[k])
+        if R_w2c is not None:
+            # pose-optimisation variant (examples/pose_opt.jl): device (3,3) column-major == torch R.T.contiguous()
+            _chk(R_w2c, "R_w2c", (3, 3)); _chk(t_w2c, "t_w2c", (3,))
+            cs.R_dev, cs.t_dev = R_w2c.data_ptr(), t_w2c.data_ptr()
+        return cs
+
+    def forward_raw(self, means_3d, shs, opacities, scales, rotations, camera, sh_degree, background, R_w2c=None,
+                    t_w2c=None, covisibilities=None, uncertainties=None, image_out=None):
+        inp = self._inputs(means_3d, shs, opacities, scales, rotations, sh_degree, background)
+        cs = self._camera(camera, R_w2c, t_w2c)
+        img = self.image if image_out is None else _chk(image_out, "image_out", (self.height, self.width, self.channels))
+        aux = None
+        if covisibilities is not None or uncertainties is not None:
+            aux = L.Aux(None if covisibilities is None else covisibilities.data_ptr(),
+                        None if uncertainties is None else uncertainties.data_ptr())
+        with torch.cuda.device(self.device):
+            L.check(self._lib.gsr_forward(self._h, C.byref(inp), C.byref(cs), _ptr(img),
+                                          None if aux is None else C.byref(aux), _stream(), C.byref(self.stats)))
+        self._n = inp.n
+        return img
+
+    def backward_raw(self, vpixels, means_3d, shs, opacities, scales, rotations, camera, sh_degree, background,
+                     R_w2c=None, t_w2c=None, arena: Optional[torch.Tensor] = None):
+        """∇rasterize.  Returns (vmeans, vshs, vopacities, vscales, vrot, vR, vt); when `arena`
+        (a flat float32 tensor of (11+3K)·N elements, 59·N at K=16) is given the five gradients
+        are views into it, laid out [vrot | vmeans | vshs | vopacities | vscales] for one
+        collective (vrot first keeps its 16-byte alignment for any N)."""
+        inp = self._inputs(means_3d, shs, opacities, scales, rotations, sh_degree, background)
+        cs = self._camera(camera, R_w2c, t_w2c)
+        _chk(vpixels, "vpixels", (self.height, self.width, self.channels))
+        n, K = inp.n, inp.n_coeffs
+        sizes = [4 * n, 3 * n, 3 * K * n, n, 3 * n]
+        if arena is None:
+            arena = torch.empty(sum(sizes), device=self.device, dtype=torch.float32)
+        elif arena.numel() != sum(sizes):
+            raise ValueError("arena has the wrong size")
+        offs = np.cumsum([0] + sizes)
+        vrot = arena[offs[0]:offs[1]].view(n, 4)
+        vmeans = arena[offs[1]:offs[2]].view(n, 3)
+        vshs = arena[offs[2]:offs[3]].view(n, K, 3)
+        vopac = arena[offs[3]:offs[4]].view(*opacities.shape)
+        vscales = arena[offs[4]:offs[5]].view(n, 3)
+        if vrot.data_ptr() % 16:
+            raise ValueError("arena must be 16-byte aligned")
+        vR = vt = None
+        if R_w2c is not None:
+            vR = torch.empty(3, 3, device=self.device)
+            vt = torch.empty(3, device=self.device)
+        g = L.Grads(vmeans.data_ptr(), vshs.data_ptr(), vopac.data_ptr(), vscales.data_ptr(), vrot.data_ptr(),
+                    None if vR is None else vR.data_ptr(), None if vt is None else vt.data_ptr())
+        with torch.cuda.device(self.device):
+            L.check(self._lib.gsr_backward(self._h, C.byref(inp), C.byref(cs), _ptr(vpixels), C.byref(g), _stream()))
+        return vmeans, vshs, vopac, vscales, vrot, vR, vt
+
+
+class _Rasterize(torch.autograd.Function):
+    """ChainRulesCore.rrule(::typeof(rasterize), ...) — rasterizer.jl:552-573."""
+
+    @staticmethod
+    def forward(ctx, means_3d, shs, opacities, scales, rotations, R_w2c, t_w2c, rast, camera, sh_degree, background,
+                covisibilities, uncertainties):
+        args = [a.detach().contiguous() for a in (means_3d, shs, opacities, scales, rotations)]
+        Rd = None if R_w2c is None else R_w2c.detach().contiguous()
+        td = None if t_w2c is None else t_w2c.detach().contiguous()
+        img = rast.forward_raw(*args, camera, sh_degree, background, Rd, td, covisibilities, uncertainties)
+        ctx.rast, ctx.camera, ctx.sh_degree, ctx.background = rast, camera, sh_degree, background
+        ctx.pose = (Rd, td)
+        ctx.save_for_backward(*args)
+        return img
+
+    @staticmethod
+    def backward(ctx, vpixels):
+        means_3d, shs, opacities, scales, rotations = ctx.saved_tensors
+        Rd, td = ctx.pose
+        vm, vs, vo, vsc, vr, vR, vt = ctx.rast.backward_raw(
+            vpixels.contiguous(), means_3d, shs, opacities, scales, rotations, ctx.camera, ctx.sh_degree,
+            ctx.background, Rd, td)
+        return vm, vs, vo, vsc, vr, vR, vt, None, None, None, None, None, None
+
+
+def rasterize(means_3d, shs, opacities, scales, rotations, R_w2c=None, t_w2c=None, *, rast: GaussianRasterizer,
+              camera: Camera, sh_degree: int, background=(0.0, 0.0, 0.0), covisibilities=None, uncertainties=None):
+    """rasterize(means_3d, shs, opacities, scales, rotations, R_w2c, t_w2c; rast, camera,
+    sh_degree, background, covisibilities, uncertainties) — rasterizer.jl:255-408.
+    opacities / scales are the activated values.  Returns `rast.image` (aliased, overwritten by
+    the next call), shape (H,W,C).  R_w2c is the device (3,3) array in the reference's
+    column-major order, i.e. the transpose of a row-major torch matrix."""
+    return _Rasterize.apply(means_3d, shs, opacities, scales, rotations, R_w2c, t_w2c, rast, camera, sh_degree,
+                            tuple(float(b) for b in background), covisibilities, uncertainties)
+
+
+def grad_rasterize(vpixels, means_3d, shs, scales, rotations, opacities, radii=None, R_w2c=None, t_w2c=None, *,
+                   rast: GaussianRasterizer, camera: Camera, sh_degree: int, background=(0.0, 0.0, 0.0)):
+    """∇rasterize(vpixels, means_3d, shs, scales, rotations, opacities, radii, R_w2c, t_w2c; ...)
+    — rasterizer.jl:416-550 (argument order as in the reference; `radii` is taken from the
+    rasterizer state)."""
+    return rast.backward_raw(vpixels, means_3d, shs, opacities, scales, rotations, camera, sh_degree, background,
+                             R_w2c, t_w2c)

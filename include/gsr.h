@@ -1,0 +1,198 @@
+/*
+ * gsr.h — C ABI of libgsr_hip.so, the MI355X (gfx950) drop-in for the differentiable
+ * rasterizer of GaussianSplatting.jl.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the
+ * reference repository, `src/rasterization/` unless stated).  Conventions:
+ *   - every pointer marked "device" is a HIP device address owned by the caller; the
+ *     library never frees or retains it beyond the call;
+ *   - array layouts are the reference's (Julia column-major): means (3,N), scales (3,N),
+ *     rotations (4,N) as (w,x,y,z), opacities (1,N), shs (3,K,N), image (C,W,H) channel
+ *     fastest, n_contrib / final_T (W,H) x fastest, tile_ranges (2,T);
+ *   - all work is enqueued on the `stream` argument (a hipStream_t passed as void*);
+ *     the only host synchronisation is the instance-count read-back inside gsr_forward
+ *     (the reference has the same one: rasterizer.jl:337);
+ *   - every function returns 0 on success or a negative GSR_E_* code; no C++ exception
+ *     crosses this boundary; gsr_last_error_string() describes the last failure on the
+ *     calling thread;
+ *   - a handle supports one outstanding forward -> backward pair (as the reference's
+ *     GaussianRasterizer object does, rasterizer.jl:13-15); distinct handles are
+ *     independent.
+ */
+#ifndef GSR_H
+#define GSR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_API __attribute__((visibility("default")))
+
+enum {
+    GSR_OK = 0,
+    GSR_E_INVALID_ARG = -1, /* reference: @assert / error() in rasterizer.jl:51,66-68,281 */
+    GSR_E_OOM = -2,
+    GSR_E_HIP = -3,         /* a HIP runtime call failed */
+    GSR_E_STATE = -4        /* backward without a matching forward */
+};
+
+/* Number of blended feature channels (rasterizer.jl:47-51 `n_color_features`). */
+enum { GSR_MODE_RGB = 3, GSR_MODE_RGBD = 5, GSR_MODE_RGBDN = 8 };
+
+/* Replaces the keyword arguments of `GaussianRasterizer(kab; width, height, mode,
+ * near_plane, far_plane)` (rasterizer.jl:60-65) and the constants hard-coded in
+ * `rasterize` (radius_clip = 3, blur_eps = 0.3: rasterizer.jl:294-295,505).  Unlike the
+ * reference (rasterizer.jl:66) width/height need not be multiples of 16: partial tiles
+ * are masked. */
+typedef struct gsr_config {
+    int32_t width, height;
+    int32_t mode;        /* GSR_MODE_* */
+    float near_plane;    /* 0.2  */
+    float far_plane;     /* 1000 */
+    int32_t radius_clip; /* 3 px */
+    float blur_eps;      /* 0.3  */
+} gsr_config;
+
+/* Positional arguments of `rasterize(means_3d, shs, opacities, scales, rotations, ...)`
+ * (rasterizer.jl:255-267).  opacities / scales are the ACTIVATED values, as the
+ * reference's functor prologue produces them (rasterizer.jl:228-248). */
+typedef struct gsr_inputs {
+    int32_t n;              /* number of Gaussians */
+    int32_t n_coeffs;       /* K: SH coefficients stored per Gaussian (1, 4, 9 or 16) */
+    int32_t sh_degree;      /* active degree, (sh_degree+1)^2 <= K */
+    const float* means;     /* device (3,N) */
+    const float* shs;       /* device (3,K,N) */
+    const float* opacities; /* device (1,N) */
+    const float* scales;    /* device (3,N) */
+    const float* rotations; /* device (4,N), 16-byte aligned (simd.jl:1-11) */
+    float background[3];    /* keyword `background` */
+} gsr_inputs;
+
+/* The fields `rasterize` reads from `camera::Camera` (rasterizer.jl:285-291,310,321;
+ * camera.jl:2-16).  R_dev/t_dev are the optional positional `R_w2c`, `t_w2c` device
+ * arrays of the pose-optimisation variant (rasterizer.jl:261, projection.jl:71-75);
+ * when non-NULL they override R/t. */
+typedef struct gsr_camera {
+    float R[9];             /* world->camera rotation, column-major */
+    float t[3];
+    float focal[2];         /* pixels */
+    float principal[2];     /* normalised to [0,1] (projection.jl:268) */
+    float camera_center[3];
+    const float* R_dev;     /* device (3,3) column-major or NULL */
+    const float* t_dev;     /* device (3) or NULL */
+} gsr_camera;
+
+/* Optional side outputs of `render!` (render.jl:7-8,109-112,128); keywords
+ * `covisibilities`, `uncertainties` of rasterize (rasterizer.jl:265-266). */
+typedef struct gsr_aux {
+    uint8_t* covisibilities; /* device (N) Bool, set to 1 where T > 0.5, never cleared; or NULL */
+    float* uncertainties;    /* device (W,H); or NULL */
+} gsr_aux;
+
+typedef struct gsr_stats {
+    int64_t n_rendered;         /* D: tile instances (rasterizer.jl:337) */
+    int32_t n_visible;          /* V: count(radii > 0) */
+    int32_t max_tile_instances; /* longest per-tile list */
+} gsr_stats;
+
+/* Cotangents returned by `∇rasterize` (rasterizer.jl:549): caller-provided device
+ * buffers, fully overwritten (culled Gaussians and SH bands above sh_degree get exact
+ * zeros, projection.jl:172-176).  Gradients are w.r.t. the ACTIVATED opacity/scale.
+ * vR/vt (pose optimisation, projection.jl:243-256) may be NULL. */
+typedef struct gsr_grads {
+    float* vmeans;     /* (3,N) */
+    float* vshs;       /* (3,K,N) */
+    float* vopacities; /* (1,N) */
+    float* vscales;    /* (3,N) */
+    float* vrotations; /* (4,N) */
+    float* vR;         /* (3,3) column-major or NULL */
+    float* vt;         /* (3) or NULL */
+} gsr_grads;
+
+typedef struct gsr_handle gsr_handle;
+
+/* GaussianRasterizer(kab; width, height, mode, ...) — rasterizer.jl:60-90. */
+GSR_API int gsr_create(const gsr_config* cfg, gsr_handle** out);
+/* KA.unsafe_free!(rast) — rasterizer.jl:136-145. */
+GSR_API int gsr_destroy(gsr_handle* h);
+/* release_scene_buffers!(rast) — rasterizer.jl:111-123. */
+GSR_API int gsr_release_scene_buffers(gsr_handle* h);
+/* memory_usage(rast) — rasterizer.jl:127-134 (device bytes owned by the handle). */
+GSR_API int64_t gsr_memory_usage(const gsr_handle* h);
+
+/* rasterize(...) — rasterizer.jl:255-408: project! + spherical_harmonics! +
+ * count_tiles_per_gaussian! + cumsum! + duplicate_with_keys! + sortperm!/_permute! +
+ * identify_tile_range! + render!.  Writes image_out (C,W,H); returns an all-zero image
+ * when nothing is visible (rasterizer.jl:338).  aux and stats may be NULL. */
+GSR_API int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, float* image_out,
+                        const gsr_aux* aux, void* stream, gsr_stats* stats);
+
+/* ∇rasterize(vpixels, ...) — rasterizer.jl:416-550 (the pullback of the rrule,
+ * rasterizer.jl:552-573): ∇render! + ∇project! + ∇spherical_harmonics!.
+ * vpixels: device (C,W,H).  `in`/`cam` must be the ones given to gsr_forward. */
+GSR_API int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, const float* vpixels,
+                         const gsr_grads* grads, void* stream);
+
+/* Views into the state the reference keeps in rast.gstate / bstate / istate
+ * (states.jl:2-111); valid until the next gsr_forward / release on this handle.
+ * gsr_buffer() copies nothing: it returns the device address and byte size. */
+enum {
+    GSR_BUF_RADII = 0,         /* int32 (N)        gstate.radii — read by densification (strategy.jl:85-86) */
+    GSR_BUF_GRAD_MEANS2D = 1,  /* float (2,N)      gstate.∇means_2d, valid after gsr_backward */
+    GSR_BUF_N_CONTRIB = 2,     /* uint32 (W,H)     istate.n_contrib */
+    GSR_BUF_FINAL_T = 3,       /* float (W,H)      istate.accum_α */
+    GSR_BUF_TILE_RANGES = 4,   /* uint32 (2,T)     istate.ranges */
+    GSR_BUF_VALUES_SORTED = 5, /* uint32 (D)       bstate.gaussian_values_sorted (0-based ids) */
+    GSR_BUF_GEOM0 = 6,         /* float4 (N): mean2d.x, mean2d.y, conic.a, conic.b   (stale where radii==0) */
+    GSR_BUF_GEOM1 = 7,         /* float4 (N): conic.c, opacity, rgb.r, rgb.g */
+    GSR_BUF_GEOM2 = 8,         /* float4 (N): rgb.b, clamped bits (uint32: bit c = channel c), depth, unused */
+    GSR_BUF_GEOM3 = 9,         /* float4 (N): normal.xyz (mode RGBDN only) */
+    GSR_BUF_RECT = 10,         /* uint16 x4 (N): tile rect xmin,ymin,xmax,ymax (utils.jl:18-29) */
+    GSR_BUF_GRAD_ACC0 = 11,    /* float4 (N): v rgb, v opacity   (after gsr_backward) */
+    GSR_BUF_GRAD_ACC1 = 12     /* float4 (N): v conic a,b,c, v depth */
+};
+GSR_API int gsr_buffer(const gsr_handle* h, int which, const void** dev_ptr, size_t* bytes);
+
+/* _fused_ssim / fused_ssim_bwd — src/fused_ssim.jl:373-408.  Arrays are (W,H,CH,B),
+ * x fastest.  With train == 0 the three partial-derivative maps may be NULL. */
+GSR_API int gsr_ssim_forward(int W, int H, int CH, int B, const float* img, const float* ref, float C1, float C2,
+                             int train, float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12,
+                             void* stream);
+GSR_API int gsr_ssim_backward(int W, int H, int CH, int B, const float* img, const float* ref, const float* dL_dmap,
+                              const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
+                              float* dL_dimg, void* stream);
+
+/* The photometric loss head of Trainer.step! — src/training.jl:656,684-694:
+ *   image = features[1:3,:,:]; permute to (W,H,3,1);
+ *   L = (1-lambda)*mean|image-target| + lambda*(1-mean(fused_ssim(image; ref=target)))
+ * and its pullback to the rasterizer output.  image: device (C,W,H) as written by
+ * gsr_forward; target: device (W,H,3); loss_out: device scalar; vpixels: device (C,W,H)
+ * (channels >= 3 zeroed).  Scratch is owned by the handle. */
+GSR_API int gsr_loss_l1_ssim(gsr_handle* h, const float* image, const float* target, float lambda_dssim,
+                             float* loss_out, float* vpixels, void* stream);
+
+/* New (no reference counterpart): sum the per-view gradient arena over
+ * the ranks of an RCCL communicator (ncclComm_t passed as void*).  librccl is resolved
+ * lazily with dlopen, so single-GPU users need not have it. */
+GSR_API int gsr_allreduce_grads(void* nccl_comm, float* arena, size_t count, void* stream);
+
+/* New (measurement; the reference has no profiling hooks): per-stage kernel
+ * timing with HIP events recorded on the caller's stream around each launch.  While
+ * enabled, every gsr_forward / gsr_backward / gsr_loss_l1_ssim appends one event pair per
+ * stage; gsr_profile_read() waits for them and returns, per stage, the summed
+ * milliseconds and the number of launches (arrays of gsr_profile_stage_count() entries). */
+GSR_API int gsr_profile_enable(gsr_handle* h, int on);
+GSR_API int gsr_profile_stage_count(void);
+GSR_API const char* gsr_profile_stage_name(int stage);
+GSR_API int gsr_profile_read(gsr_handle* h, double* ms_sum, int* launches, int reset);
+
+GSR_API const char* gsr_last_error_string(void);
+GSR_API const char* gsr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H */

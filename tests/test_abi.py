@@ -1,0 +1,57 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads,
+and exports every symbol include/gsr.h declares.  No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg._lib
+    if not os.path.exists(L.LIB_PATH):
+        L.build()
+    lib = L.load()
+    hdr = open(L.HEADER_PATH).read()
+    declared = sorted(set(re.findall(r"GSR_API\s+[\w\s\*]+?\b(gsr_\w+)\s*\(", hdr)))
+    assert declared, "no GSR_API declarations parsed"
+    assert sorted(L.EXPORTS) == declared
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.gsr_version()
+
+
+def test_struct_sizes_match_header(pkg):
+    L = pkg._lib
+    # include/gsr.h layouts (x86-64 SysV): catches a drifting binding
+    assert C.sizeof(L.Config) == 28
+    assert C.sizeof(L.Inputs) == 16 + 5 * 8 + 12 + 4
+    assert C.sizeof(L.CameraS) == (9 + 3 + 2 + 2 + 3) * 4 + 4 + 16
+    assert C.sizeof(L.Stats) == 16
+    assert C.sizeof(L.Grads) == 56
+
+
+def test_invalid_arguments_fail_before_touching_the_gpu(pkg):
+    """Error behaviour of the reference: error("Invalid render mode") (rasterizer.jl:51,68)."""
+    L = pkg._lib
+    lib = L.load()
+    h = C.c_void_p()
+    cfg = L.Config(64, 48, 4, 0.2, 1000.0, 3, 0.3)  # mode 4 does not exist
+    assert lib.gsr_create(C.byref(cfg), C.byref(h)) == L.GSR_E_INVALID_ARG
+    assert b"Invalid render mode" in lib.gsr_last_error_string()
+    cfg = L.Config(0, 48, 3, 0.2, 1000.0, 3, 0.3)
+    assert lib.gsr_create(C.byref(cfg), C.byref(h)) == L.GSR_E_INVALID_ARG
+    assert lib.gsr_forward(None, None, None, None, None, None, None) == L.GSR_E_INVALID_ARG
+    assert lib.gsr_backward(None, None, None, None, None, None) == L.GSR_E_INVALID_ARG
+    with pytest.raises(L.GsrError):
+        L.check(L.GSR_E_INVALID_ARG)
+
+
+def test_host_mirror_rejects_cpu_tensors(pkg):
+    import torch
+    with pytest.raises(ValueError):
+        pkg.rasterizer.GaussianRasterizer(64, 48, mode="rgb", device="cpu")
+    with pytest.raises(ValueError):
+        pkg.rasterizer.n_color_features("rgba")
+    with pytest.raises(ValueError):
+        pkg.fused_ssim._fused_ssim(torch.zeros(1, 3, 16, 16), torch.zeros(1, 3, 16, 16))

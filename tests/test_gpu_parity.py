@@ -1,0 +1,288 @@
+"""-m gpu parity tests: the HIP path, called through the C ABI, against the CPU oracle on
+the same seeded inputs.
+
+Tolerances:
+  * integer / index outputs (radii, tile rects, tile ranges, sorted ids): EXACT — the
+    per-Gaussian kernels are compiled without FMA contraction and evaluate the same fp32
+    expressions as the oracle;
+  * per-Gaussian floats (means2d, conics, depths, rgbs): |Δ| <= 1e-6·|x| + 1e-7;
+  * image / final T: |Δ| <= 1e-4 on >= 99.99 % of values (exp() differs by ~1 ulp, which
+    can flip the α<1/255 and T<1e-4 decisions of single (pixel, splat) pairs);
+  * n_contrib: <= 1e-3 of pixels may differ on tiny scenes;
+  * gradients: ‖Δ‖₂/‖g‖₂ <= 1e-4 per tensor (fp32 atomics / reassociation against the
+    oracle's double-precision deterministic accumulation).
+"""
+import numpy as np
+import pytest
+import torch
+
+import scenes
+from hip_helpers import HipRun, dev, frac_bad, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(pkg, orc, n, W, H, deg, seed, sigma_px=3.0, view=None):
+    s = pkg.synthetic.make_scene(n, W, H, deg, seed, sigma_px=sigma_px)
+    if view is None:
+        cam = orc.Camera(W, H, s.focal)
+    else:
+        R, t = pkg.synthetic.view_pose(view)
+        cam = orc.Camera(W, H, s.focal, R=R, t=t)
+    return s, cam
+
+
+def _compare_forward(st, run, img):
+    geo = {k: v.cpu().numpy() for k, v in run.rast.geometry().items()}
+    radii = run.rast.radii.cpu().numpy()
+    assert np.array_equal(radii, st.radii), "radii must match exactly"
+    vis = st.radii > 0
+    assert run.rast.stats.n_visible == int(vis.sum())
+    assert run.rast.stats.n_rendered == st.n_rendered
+    for name, ref in (("means2d", st.means2d), ("conics", st.conics), ("depths", st.depths), ("rgbs", st.rgbs)):
+        assert frac_bad(geo[name][vis], ref[vis], 1e-6, 1e-7) == 0.0, name
+    cb = geo["clamped_bits"][vis]
+    ref_bits = (st.clamped[vis].astype(np.int32) * np.array([1, 2, 4])).sum(1)
+    assert np.array_equal(cb, ref_bits)
+    rect = geo["rect"].astype(np.int64)
+    tiles = (rect[:, 2] - rect[:, 0]) * (rect[:, 3] - rect[:, 1])
+    assert np.array_equal(tiles, st.tiles_touched), "tile counts per Gaussian must match exactly"
+    if st.normals is not None:
+        assert frac_bad(geo["normals"][vis], st.normals[vis], 1e-6, 1e-7) == 0.0
+    if st.n_rendered > 0:
+        assert np.array_equal(run.rast.ranges.cpu().numpy().astype(np.uint32), st.ranges)
+        assert np.array_equal(run.rast.values_sorted.cpu().numpy().astype(np.uint32), st.values_sorted)
+    im = img.cpu().numpy()
+    assert im.shape == st.image.shape
+    assert frac_bad(im, st.image, 0.0, 1e-4) <= 1e-4, np.abs(im - st.image).max()
+    assert frac_bad(run.rast.accum_alpha.cpu().numpy(), st.accum_alpha, 0.0, 1e-4) <= 1e-4
+    nc = run.rast.n_contrib.cpu().numpy().astype(np.uint32)
+    assert (nc != st.n_contrib).mean() <= 1e-3
+
+
+def _compare_backward(g, out, vis):
+    vm, vs, vo, vsc, vr, vR, vt = [None if o is None else o.cpu().numpy() for o in out]
+    assert rel_l2(vm, g.vmeans) <= 1e-4
+    assert rel_l2(vs, g.vshs) <= 1e-4
+    assert rel_l2(vo.reshape(-1), g.vopacities) <= 1e-4
+    assert rel_l2(vsc, g.vscales) <= 1e-4
+    assert rel_l2(vr, g.vrots) <= 1e-4
+    # culled Gaussians: exact zeros
+    assert not vm[~vis].any() and not vs[~vis].any() and not vsc[~vis].any() and not vr[~vis].any()
+    return vR, vt
+
+
+@pytest.mark.parametrize("mode,deg,seed,W,H,n", [
+    ("rgb", 3, 101, 64, 48, 300), ("rgb", 0, 102, 64, 48, 300), ("rgbd", 1, 103, 80, 64, 400),
+    ("rgbdn", 2, 104, 64, 48, 300), ("rgb", 3, 105, 200, 120, 3000), ("rgb", 2, 106, 64, 40, 500),
+])
+def test_forward_backward_vs_oracle(pkg, orc, mode, deg, seed, W, H, n):
+    s, cam = _scene(pkg, orc, n, W, H, deg, seed, sigma_px=4.0, view=3)
+    bg = (0.3, 0.1, 0.6)
+    st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, background=bg, mode=mode)
+    run = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, bg, mode)
+    img = run.forward()
+    _compare_forward(st, run, img)
+    C = st.image.shape[2]
+    vp = np.random.default_rng(seed).standard_normal((H, W, C)).astype(np.float32)
+    g = orc.backward(st, vp, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, background=bg)
+    out = run.backward(vp)
+    _compare_backward(g, out, st.radii > 0)
+    assert rel_l2(run.rast.grad_means_2d.cpu().numpy(), g.vmeans2d) <= 1e-4
+
+
+def test_k_padded_sh_storage(pkg, orc):
+    """sh_degree below the stored band count (training ramps the degree, training.jl:577-585):
+    bands above the active degree are ignored forward and get zero gradient."""
+    s = pkg.synthetic.make_scene(300, 64, 48, 1, 7, sigma_px=4.0, K=16)
+    cam = orc.Camera(64, 48, s.focal)
+    st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, 1)
+    run = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, 1)
+    _compare_forward(st, run, run.forward())
+    vp = pkg.synthetic.make_vpixels(64, 48, 3, 7) * 1e4
+    g = orc.backward(st, vp, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, 1)
+    out = run.backward(vp)
+    _compare_backward(g, out, st.radii > 0)
+    assert not out[1][:, 4:, :].any()
+
+
+def test_pose_gradient_and_device_pose(pkg, orc):
+    s, cam = _scene(pkg, orc, 300, 64, 48, 2, 33, sigma_px=4.0, view=1)
+    st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, 2, mode="rgbd")
+    run = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, 2, mode="rgbd", pose_dev=True)
+    _compare_forward(st, run, run.forward())
+    vp = np.random.default_rng(3).standard_normal((48, 64, 5)).astype(np.float32)
+    g = orc.backward(st, vp, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, 2, pose_grad=True)
+    vR, vt = _compare_backward(g, run.backward(vp), st.radii > 0)
+    # torch (3,3) row-major memory == the ABI's column-major 9 floats
+    assert rel_l2(vR.reshape(-1), g.vR) <= 1e-4
+    assert rel_l2(vt, g.vt) <= 1e-4
+
+
+def test_covisibilities_and_uncertainties(pkg, orc):
+    s, cam = _scene(pkg, orc, 400, 64, 48, 0, 44, sigma_px=4.0)
+    st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, 0, want_covis=True, want_uncert=True)
+    run = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, 0, want_covis=True, want_uncert=True)
+    _compare_forward(st, run, run.forward())
+    assert (run.covis.cpu().numpy() != st.covisibilities).mean() <= 5e-3
+    assert frac_bad(run.unc.cpu().numpy(), st.uncertainties, 0, 1e-4) <= 1e-4
+
+
+def test_empty_scene(pkg, orc):
+    """rasterizer.jl:338: nothing visible -> all-zero image (no background), zero gradients."""
+    s = pkg.synthetic.make_scene(64, 64, 48, 0, 5)
+    means = s.means.copy()
+    means[:, 2] = -3.0
+    cam = orc.Camera(64, 48, s.focal)
+    run = HipRun(pkg, means, s.shs, s.opacities, s.scales, s.rotations, cam, 0, (1, 1, 1))
+    img = run.forward()
+    assert run.rast.stats.n_rendered == 0 and not img.cpu().numpy().any()
+    out = run.backward(np.ones((48, 64, 3), np.float32))
+    assert all(not o.cpu().numpy().any() for o in out[:5])
+
+
+def test_oversized_tile_uses_global_sort_path(pkg, orc):
+    """> 4096 instances in one tile: the tile sort leaves LDS for the global-scratch slab."""
+    n = 6000
+    rng = np.random.default_rng(9)
+    s = pkg.synthetic.make_scene(n, 32, 32, 0, 9)
+    means = np.stack([rng.uniform(-0.05, 0.05, n), rng.uniform(-0.05, 0.05, n), rng.uniform(2, 8, n)], 1).astype(np.float32)
+    cam = orc.Camera(32, 32, s.focal)
+    opac = np.full(n, 0.02, np.float32)
+    st = orc.forward(means, s.shs, opac, s.scales * 3, s.rotations, cam, 0)
+    assert (st.ranges[:, 1] - st.ranges[:, 0]).max() > 4096
+    run = HipRun(pkg, means, s.shs, opac, s.scales * 3, s.rotations, cam, 0)
+    _compare_forward(st, run, run.forward())
+    assert run.rast.stats.max_tile_instances > 4096
+
+
+# ---- the reference's own integration scenes (K13-K15) through the HIP path ----
+def test_k13_rgbdn_grid_scene(pkg, orc):
+    sc, cam = scenes.grid_scene_rgbdn()
+    run = HipRun(pkg, sc["means"], sc["shs"], sc["opac"], sc["scales"], sc["rots"], cam, 0, mode="rgbdn")
+    img = run.forward().cpu().numpy()
+    assert img.shape == (48, 64, 8)
+    alpha = img[:, :, 4]
+    cov = alpha > 0.5
+    assert cov.any() and np.abs(img[:, :, 5]).max() < 1e-4 and np.abs(img[:, :, 6]).max() < 1e-4
+    assert np.allclose(img[:, :, 7][cov], -alpha[cov], atol=1e-3)
+    vp = np.zeros_like(img)
+    vp[:, :, 5:8] = np.random.default_rng(0).standard_normal((48, 64, 3))
+    vrot = run.backward(vp)[4].cpu().numpy()
+    assert np.isfinite(vrot).all() and np.abs(vrot).max() > 0
+
+
+def test_k14_background_identity(pkg, orc):
+    sc, cam = scenes.sky_test_scene()
+    bg = np.array([0.2, 0.7, 0.4], np.float32)
+
+    def render(b):
+        return HipRun(pkg, sc["means"], sc["shs"], sc["opac"], sc["scales"], sc["rots"], cam, 0, b,
+                      "rgbd").forward().cpu().numpy().copy()
+
+    in_kernel = render(bg)[:, :, :3]
+    zeroed = render((0, 0, 0))
+    alpha = zeroed[:, :, 4]
+    assert alpha.min() < 1e-3 and ((alpha > 0.05) & (alpha < 0.95)).any() and alpha.max() > 0.3
+    assert np.abs(in_kernel - (zeroed[:, :, :3] + (1 - alpha)[:, :, None] * bg)).max() < 1e-5
+
+
+def test_k15_sky_dome(pkg, orc):
+    sc, cam = scenes.sky_dome_scene()
+    run = HipRun(pkg, sc["means"], sc["shs"], sc["opac"], sc["scales"], sc["rots"], cam, 0, mode="rgbd")
+    img = run.forward().cpu().numpy()
+    alpha = img[:, :, 4]
+    assert alpha.min() > 0.98
+    op = alpha > 0.99
+    for c, e in enumerate((0.2, 0.4, 0.9)):
+        assert np.allclose(img[:, :, c][op], e, atol=1e-2)
+
+
+# ---- SSIM + loss head ----
+@pytest.mark.parametrize("shape", [(2, 3, 128, 128), (1, 3, 37, 53), (1, 1, 16, 16)])
+def test_ssim_vs_oracle(pkg, orc, shape):
+    rng = np.random.default_rng(5)
+    x = rng.uniform(size=shape).astype(np.float32)
+    y = rng.uniform(size=shape).astype(np.float32)
+    m, d0, d1, d2 = orc.ssim_forward(x, y, train=True)
+    F = pkg.fused_ssim
+    hm, h0, h1, h2 = F._fused_ssim(dev(x), dev(y), train=True)
+    for a, b in ((hm, m), (h0, d0), (h1, d1), (h2, d2)):
+        assert np.array_equal(a.cpu().numpy(), b), "SSIM maps are bit-exact (no FMA contraction)"
+    dl = rng.standard_normal(shape).astype(np.float32)
+    g = orc.ssim_backward(x, y, dl, d0, d1, d2)
+    hg = F.fused_ssim_bwd(dev(x), dev(y), dev(dl), h0, h1, h2)
+    assert np.array_equal(hg.cpu().numpy(), g)
+
+
+def test_ssim_known_answers_and_autograd(pkg):
+    F = pkg.fused_ssim
+    ones, zeros = torch.ones(1, 3, 16, 16).cuda(), torch.zeros(1, 3, 16, 16).cuda()
+    assert abs(float(F.fused_ssim(ones, zeros).mean())) < 1e-4
+    assert abs(float(F.fused_ssim(ones, ones).mean()) - 1) < 1e-6
+    x = torch.zeros(1, 3, 16, 16)
+    x[:, :, 0:4, 0:4] = 0.25; x[:, :, 0:4, 4:8] = 0.5; x[:, :, 12:16, 8:12] = 0.75; x[:, :, 12:16, 12:16] = 1.0
+    assert abs(float(F.fused_ssim(x.cuda(), ones).mean()) - 0.1035) < 1e-3
+    xr = torch.rand(2, 3, 64, 64).cuda().requires_grad_(True)
+    ref = torch.rand(2, 3, 64, 64).cuda()
+    F.fused_ssim(xr, ref).mean().backward()
+    assert xr.grad is not None and torch.isfinite(xr.grad).all() and float(xr.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("mode", ["rgb", "rgbd"])
+def test_loss_head_vs_oracle(pkg, orc, mode):
+    W, H = 72, 40
+    s, cam = _scene(pkg, orc, 500, W, H, 1, 77, sigma_px=4.0)
+    st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, 1, mode=mode)
+    tgt = pkg.synthetic.make_target(W, H, 77)
+    loss, vp = orc.loss_head(st.image, tgt)
+    run = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, 1, mode=mode)
+    # feed the oracle's image so only the loss head is compared
+    hl, hv = pkg.fused_ssim.l1_ssim_loss(run.rast, dev(st.image), dev(tgt))
+    torch.cuda.synchronize()
+    assert abs(float(hl) - float(loss)) <= 1e-5 * max(1.0, abs(float(loss)))
+    assert rel_l2(hv.cpu().numpy(), vp) <= 1e-5
+    assert not hv.cpu().numpy()[:, :, 3:].any()
+
+
+def test_functor_autograd_end_to_end(pkg, orc):
+    """rast(points, opacities, scales, rotations, f_dc, f_rest; camera, sh_degree) under autograd:
+    raw-parameter gradients = activated gradients x activation derivatives (rasterizer.jl:200-253)."""
+    W, H, deg = 64, 48, 2
+    s, cam = _scene(pkg, orc, 300, W, H, deg, 55, sigma_px=4.0)
+    camera = pkg.Camera(W, H, tuple(s.focal))
+    rast = pkg.rasterizer.GaussianRasterizer(W, H, mode="rgb")
+    p = [dev(s.means), dev(s.opacities_raw.reshape(-1, 1)), dev(s.scales_raw), dev(s.rotations), dev(s.shs[:, :1]),
+         dev(s.shs[:, 1:])]
+    for t in p:
+        t.requires_grad_(True)
+    img = rast(*p, camera=camera, sh_degree=deg)
+    w = dev(np.random.default_rng(1).standard_normal((H, W, 3)))
+    (img * w).sum().backward()
+    st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg)
+    g = orc.backward(st, w.cpu().numpy(), s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg)
+    o = s.opacities.astype(np.float64)
+    assert rel_l2(p[0].grad.cpu().numpy(), g.vmeans) <= 1e-4
+    assert rel_l2(p[1].grad.cpu().numpy().reshape(-1), g.vopacities * o * (1 - o)) <= 1e-4
+    assert rel_l2(p[2].grad.cpu().numpy(), g.vscales * s.scales) <= 1e-4
+    assert rel_l2(p[3].grad.cpu().numpy(), g.vrots) <= 1e-4
+    assert rel_l2(p[4].grad.cpu().numpy(), g.vshs[:, :1]) <= 1e-4
+    assert rel_l2(p[5].grad.cpu().numpy(), g.vshs[:, 1:]) <= 1e-4
+
+
+def test_state_errors(pkg):
+    """gsr_backward without a matching forward -> GSR_E_STATE; bad shapes -> ValueError."""
+    s = pkg.synthetic.make_scene(32, 64, 48, 0, 3)
+    cam = pkg.Camera(64, 48, tuple(s.focal))
+    rast = pkg.rasterizer.GaussianRasterizer(64, 48, mode="rgb")
+    t = [dev(s.means), dev(s.shs), dev(s.opacities.reshape(-1, 1)), dev(s.scales), dev(s.rotations)]
+    with pytest.raises(pkg._lib.GsrError) as e:
+        rast.backward_raw(torch.zeros(48, 64, 3).cuda(), *t, cam, 0, (0, 0, 0))
+    assert e.value.code == pkg._lib.GSR_E_STATE
+    with pytest.raises(ValueError):
+        rast.forward_raw(t[0][:, :2].contiguous(), *t[1:], cam, 0, (0, 0, 0))
+    with pytest.raises(pkg._lib.GsrError):
+        rast.forward_raw(*t, cam, 2, (0, 0, 0))  # K=1 cannot hold degree 2
+    assert rast.memory_usage() > 0
+    rast.release_scene_buffers()
+    rast.forward_raw(*t, cam, 0, (0, 0, 0))

@@ -80,6 +80,9 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (there is no CPU fallback)")
+    # torch bundles its own libamdhip64.so.7; it must be the first HIP runtime in the process,
+    # otherwise two runtimes get loaded and the second one finds no device.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
     lib.gsr_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]

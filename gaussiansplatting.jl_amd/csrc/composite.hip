@@ -94,28 +94,31 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(int W, int H, int gr
             if (C > 5) l3[tid] = stream.s3[idx];
         }
         __syncthreads();
-        if (!done) {
-            for (int j = 0; j < cnt; j++) {
-                const float4 a = l0[j], b = l1[j], c2 = l2[j];
-                const float dx = a.x - fx, dy = a.y - fy;
-                const float sigma = a.w * dx * dy + 0.5f * (a.z * (dx * dx) + b.x * (dy * dy));
-                if (sigma < 0.0f) continue;
-                const float alpha = fminf(0.99f, b.y * __expf(-sigma));
-                if (alpha < (1.0f / 255.0f)) continue;
-                const float Tn = T * (1.0f - alpha);
-                if (Tn < 1e-4f) { done = true; break; }
-                float f[C];
-                unpack_features<C>(b, c2, C > 5 ? l3[j] : c2, f);
-                const float w = alpha * T;
+        // Branch-free inner loop: a lane that is done, or whose pixel this splat does not
+        // touch, blends with weight 0 (exactly what `continue`/`break` leave behind,
+        // render.jl:92-101); divergent exec-mask bookkeeping costs more than the 4 FMAs.
+#pragma unroll 4
+        for (int j = 0; j < cnt; j++) {
+            const float4 a = l0[j], b = l1[j], c2 = l2[j];
+            const float dx = a.x - fx, dy = a.y - fy;
+            const float sigma = a.w * dx * dy + 0.5f * (a.z * (dx * dx) + b.x * (dy * dy));
+            const float alpha = fminf(0.99f, b.y * __expf(-sigma));
+            const float Tn = T * (1.0f - alpha);
+            bool ok = !done && sigma >= 0.0f && alpha >= (1.0f / 255.0f);
+            const bool stop = ok && Tn < 1e-4f;
+            done = done || stop;
+            ok = ok && !stop;
+            float f[C];
+            unpack_features<C>(b, c2, C > 5 ? l3[j] : c2, f);
+            const float w = ok ? alpha * T : 0.0f;
 #pragma unroll
-                for (int c = 0; c < C; c++) color[c] += f[c] * w;
-                if (AUX) {
-                    unc += w;
-                    if (covis && T > 0.5f) covis[__float_as_uint(c2.y)] = 1;
-                }
-                T = Tn;
-                last = (uint32_t)(base + j + 1);
+            for (int c = 0; c < C; c++) color[c] += f[c] * w;
+            if (AUX) {
+                unc += w;
+                if (covis && ok && T > 0.5f) covis[__float_as_uint(c2.y)] = 1;
             }
+            T = ok ? Tn : T;
+            last = ok ? (uint32_t)(base + j + 1) : last;
         }
     }
     if (inside) {
@@ -135,6 +138,8 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(int W, int H, int gr
 // [7..8] v mean2d, [9] v depth (C>=5), [10..12] v normal (C==8)
 template <int C> struct AccRow { static constexpr int N = C == 3 ? 9 : (C == 5 ? 10 : 13); static constexpr int STRIDE = N | 1; };
 
+constexpr int BWD_BATCH = 128;  // splats staged per round in the backward (LDS: 4 wave-private accumulator slabs)
+
 template <int C>
 __global__ __launch_bounds__(256) void composite_bwd_kernel(int W, int H, int grid_x,
                                                             const uint32_t* __restrict__ tile_start,
@@ -143,11 +148,16 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int W, int H, int gr
                                                             const uint32_t* __restrict__ n_contrib,
                                                             const float* __restrict__ final_T, GsrAcc acc) {
     constexpr int NA = AccRow<C>::N, ST = AccRow<C>::STRIDE;
-    __shared__ float4 l0[GSR_BATCH], l1[GSR_BATCH], l2[GSR_BATCH];
-    __shared__ float4 l3[C > 5 ? GSR_BATCH : 1];
-    __shared__ float lacc[GSR_BATCH * ST];
+    constexpr int BB = BWD_BATCH;
+    __shared__ float4 l0[BB], l1[BB], l2[BB];
+    __shared__ float4 l3[C > 5 ? BB : 1];
+    // One accumulator slab per wave: a wave stores its reduced partials with plain ds_write
+    // (no LDS atomics: hipcc wraps those in a per-lane "atomic optimizer" loop), and a
+    // per-wave bit mask records which rows it touched so nothing has to be zero-filled.
+    __shared__ float lacc[4][BB * ST];
+    __shared__ unsigned long long lmask[4][BB / 64];
     __shared__ int tile_last_s;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.y * grid_x + blockIdx.x;
     const int px = blockIdx.x * GSR_TILE + (tid & 15), py = blockIdx.y * GSR_TILE + (tid >> 4);
     const bool inside = px < W && py < H;
@@ -165,6 +175,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int W, int H, int gr
     float bg_dot = 0.0f;
 #pragma unroll
     for (int c = 0; c < C; c++) bg_dot += bg.v[c] * vp[c];
+    const float bgT = -T_final * bg_dot;
     float accum_rec[C], last_color[C];
 #pragma unroll
     for (int c = 0; c < C; c++) { accum_rec[c] = 0.0f; last_color[c] = 0.0f; }
@@ -178,13 +189,13 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int W, int H, int gr
         int m = last_contributor;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
-        if ((tid & 63) == 0) atomicMax(&tile_last_s, m);
+        if (lane == 0) atomicMax(&tile_last_s, m);
     }
     __syncthreads();
     const int tile_last = tile_last_s;  // process list positions tile_last-1 ... 0
 
-    for (int base = 0; base < tile_last; base += GSR_BATCH) {
-        const int cnt = min(GSR_BATCH, tile_last - base);
+    for (int base = 0; base < tile_last; base += BB) {
+        const int cnt = min(BB, tile_last - base);
         __syncthreads();  // previous batch fully flushed
         if (tid < cnt) {
             const uint32_t idx = start + (uint32_t)(tile_last - 1 - base - tid);
@@ -193,10 +204,12 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int W, int H, int gr
             l2[tid] = stream.s2[idx];
             if (C > 5) l3[tid] = stream.s3[idx];
         }
-#pragma unroll
-        for (int k = 0; k < NA; k++) lacc[tid * ST + k] = 0.0f;
         __syncthreads();
 
+        unsigned long long touched[BB / 64];
+#pragma unroll
+        for (int w = 0; w < BB / 64; w++) touched[w] = 0ull;
+        float* const my = lacc[wave];
         for (int j = 0; j < cnt; j++) {
             const int contributor = tile_last - 1 - base - j;  // 0-based position in the tile list
             const float4 a = l0[j], b = l1[j], c2 = l2[j];
@@ -207,12 +220,17 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int W, int H, int gr
             const float alpha = fminf(0.99f, o * G);
             const bool active = contributor < last_contributor && sigma >= 0.0f && alpha >= (1.0f / 255.0f);
             if (__ballot(active) == 0ull) continue;  // wave-uniform: no pixel of this 16x4 strip is touched
+#pragma unroll
+            for (int w = 0; w < BB / 64; w++)
+                if ((j >> 6) == w) touched[w] |= 1ull << (j & 63);
 
             float part[NA];
 #pragma unroll
             for (int k = 0; k < NA; k++) part[k] = 0.0f;
             if (active) {
-                T = T / (1.0f - alpha);
+                // T /= (1-α) and -T_final/(1-α) (render.jl:237,259) share one hardware reciprocal
+                const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
+                T = T * rinv;
                 const float fac = alpha * T;
                 float f[C];
                 unpack_features<C>(b, c2, C > 5 ? l3[j] : c2, f);
@@ -224,7 +242,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int W, int H, int gr
                     valpha += (f[c] - accum_rec[c]) * vp[c];
                 }
                 valpha *= T;
-                valpha += (-T_final / (1.0f - alpha)) * bg_dot;
+                valpha += bgT * rinv;
                 last_alpha = alpha;
                 const float vsigma = -o * G * valpha;
                 part[0] = fac * vp[0]; part[1] = fac * vp[1]; part[2] = fac * vp[2];
@@ -239,17 +257,29 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int W, int H, int gr
             }
 #pragma unroll
             for (int k = 0; k < NA; k++) part[k] = wave_sum_hi(part[k]);
-            if ((tid & 63) == 63) {
+            if (lane == 63) {
 #pragma unroll
-                for (int k = 0; k < NA; k++) atomicAdd(&lacc[j * ST + k], part[k]);
+                for (int k = 0; k < NA; k++) my[j * ST + k] = part[k];
             }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int w = 0; w < BB / 64; w++) lmask[wave][w] = touched[w];
         }
         __syncthreads();
         if (tid < cnt) {
             float r[NA];
+#pragma unroll
+            for (int k = 0; k < NA; k++) r[k] = 0.0f;
             bool any = false;
 #pragma unroll
-            for (int k = 0; k < NA; k++) { r[k] = lacc[tid * ST + k]; any |= r[k] != 0.0f; }
+            for (int w = 0; w < 4; w++) {
+                if ((lmask[w][tid >> 6] >> (tid & 63)) & 1ull) {
+                    any = true;
+#pragma unroll
+                    for (int k = 0; k < NA; k++) r[k] += lacc[w][tid * ST + k];
+                }
+            }
             if (any) {
                 const uint32_t id = __float_as_uint(l2[tid].y);
                 float* p0 = reinterpret_cast<float*>(acc.a0 + id);

@@ -424,7 +424,7 @@ int gsr_loss_l1_ssim(gsr_handle* h, const float* image, const float* target, flo
     const size_t P = (size_t)W * H;
     int rc;
     if ((rc = h->d0.ensure(3 * P * 4)) || (rc = h->d1.ensure(3 * P * 4)) || (rc = h->d2.ensure(3 * P * 4)) ||
-        (rc = h->partial.ensure(2 * 4)))
+        (rc = h->partial.ensure((size_t)h->n_tiles * 3 * 2 * 4)))
         return rc;
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;  // fused_ssim.jl:374
     h->prof.begin(ST_LOSS_FWD, s);

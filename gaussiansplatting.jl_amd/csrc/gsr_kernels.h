@@ -83,7 +83,7 @@ void gsr_launch_ssim_bwd(hipStream_t s, int W, int H, int CH, int B, const float
                          const float* dL_dmap, const float* d0, const float* d1, const float* d2, float* dL_dimg);
 // fused loss head: image (C,W,H) vs target (W,H,3)
 void gsr_launch_loss_fwd(hipStream_t s, int W, int H, int C, const float* image, const float* target, float C1,
-                         float C2, float* d0, float* d1, float* d2, float* partial /* [2]: sum|x-y|, sum ssim */);
+                         float C2, float* d0, float* d1, float* d2, float* partial /* [3T][2]: per-workgroup sum|x-y|, sum ssim */);
 void gsr_launch_loss_bwd(hipStream_t s, int W, int H, int C, const float* image, const float* target, float lambda,
                          const float* d0, const float* d1, const float* d2, const float* partial, float* loss_out,
                          float* vpixels);

@@ -132,8 +132,14 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(Src src, int W, int H, fl
         }
     }
     if (LOSS) {
+        // one partial pair per workgroup; 24k workgroups hammering two words with atomics
+        // serialise at ~12 ns each (MI355X_MICROARCH.md "fanin")
         const float a = block_sum(l1, red), b = block_sum(sv, red);
-        if (tid == 0) { atomicAdd(&partial[0], a); atomicAdd(&partial[1], b); }
+        if (tid == 0) {
+            const size_t blk = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+            partial[2 * blk] = a;
+            partial[2 * blk + 1] = b;
+        }
     }
 }
 
@@ -198,11 +204,19 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(Src src, int W, int H, co
     }
 }
 
-__global__ void loss_finish_kernel(const float* __restrict__ partial, float lambda, float inv_count,
-                                   float* __restrict__ loss_out) {
-    const float l1 = partial[0] * inv_count;
-    const float s = 1.0f - partial[1] * inv_count;
-    loss_out[0] = (1.0f - lambda) * l1 + lambda * s;
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ partial, int n_blocks,
+                                                          float lambda, float inv_count,
+                                                          float* __restrict__ loss_out) {
+    __shared__ float red[4];
+    float a = 0.0f, b = 0.0f;
+    for (int i = threadIdx.x; i < n_blocks; i += 256) { a += partial[2 * i]; b += partial[2 * i + 1]; }
+    a = block_sum(a, red);
+    b = block_sum(b, red);
+    if (threadIdx.x == 0) {
+        const float l1 = a * inv_count;
+        const float s = 1.0f - b * inv_count;
+        loss_out[0] = (1.0f - lambda) * l1 + lambda * s;
+    }
 }
 
 // zero the non-RGB channels of vpixels (C > 3): the loss head only sees features[1:3]
@@ -235,7 +249,6 @@ void gsr_launch_ssim_bwd(hipStream_t s, int W, int H, int CH, int B, const float
 void gsr_launch_loss_fwd(hipStream_t s, int W, int H, int C, const float* image, const float* target, float C1,
                          float C2, float* d0, float* d1, float* d2, float* partial) {
     RasterSrc src{image, target, W, H, C};
-    (void)hipMemsetAsync(partial, 0, 2 * sizeof(float), s);
     hipLaunchKernelGGL((ssim_fwd_kernel<RasterSrc, true>), ssim_grid(W, H, 3), dim3(256), 0, s, src, W, H, C1, C2, 1,
                        (float*)nullptr, d0, d1, d2, partial);
 }
@@ -253,5 +266,7 @@ void gsr_launch_loss_bwd(hipStream_t s, int W, int H, int C, const float* image,
     hipLaunchKernelGGL((ssim_bwd_kernel<RasterSrc, true>), ssim_grid(W, H, 3), dim3(256), 0, s, src, W, H,
                        (const float*)nullptr, -lambda * inv_count, (1.0f - lambda) * inv_count, d0, d1, d2, vpixels,
                        C);
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, s, partial, lambda, inv_count, loss_out);
+    const dim3 g = ssim_grid(W, H, 3);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, s, partial, (int)(g.x * g.y * g.z), lambda,
+                       inv_count, loss_out);
 }

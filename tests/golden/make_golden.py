@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.npz.
+
+These fixtures are produced by the CPU ORACLE (oracle/gsr_oracle.c), not by the
+reference: the reference is GPU-only Julia and cannot run in the build image
+(SURVEY.md §0, §8c), and it ships no golden vectors of its own.  They freeze inputs +
+every intermediate + all gradients of three tiny scenes (one per render mode) and one
+SSIM case, so that (a) the oracle cannot drift silently and (b) the HIP path is checked
+against committed numbers on the GPU box, where /root/reference does not exist.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import gsr_pkg  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = [("rgb", 3, 201, 64, 48, 150), ("rgbd", 1, 202, 64, 48, 150), ("rgbdn", 2, 203, 48, 40, 120)]
+
+
+def scene_case(pkg, mode, deg, seed, W, H, n):
+    s = pkg.synthetic.make_scene(n, W, H, deg, seed, sigma_px=4.0)
+    R, t = pkg.synthetic.view_pose(2)
+    cam = orc.Camera(W, H, s.focal, R=R, t=t)
+    bg = np.array([0.25, 0.5, 0.125], np.float32)
+    st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, background=bg, mode=mode)
+    C = st.image.shape[2]
+    vp = np.random.default_rng(seed).standard_normal((H, W, C)).astype(np.float32)
+    g = orc.backward(st, vp, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, background=bg,
+                     pose_grad=True)
+    return dict(
+        mode=mode, sh_degree=deg, width=W, height=H, focal=np.asarray(s.focal, np.float32), R=R, t=t, background=bg,
+        means=s.means, shs=s.shs, opacities=s.opacities, scales=s.scales, rotations=s.rotations, vpixels=vp,
+        radii=st.radii, means2d=st.means2d, conics=st.conics, depths=st.depths, rgbs=st.rgbs, clamped=st.clamped,
+        tiles_touched=st.tiles_touched, n_rendered=st.n_rendered, ranges=st.ranges, values_sorted=st.values_sorted,
+        image=st.image, n_contrib=st.n_contrib, accum_alpha=st.accum_alpha,
+        normals=st.normals if st.normals is not None else np.zeros((0, 3), np.float32),
+        vmeans=g.vmeans, vshs=g.vshs, vopacities=g.vopacities, vscales=g.vscales, vrots=g.vrots, vR=g.vR, vt=g.vt,
+        vmeans2d=g.vmeans2d)
+
+
+def ssim_case():
+    rng = np.random.default_rng(204)
+    x = rng.uniform(size=(1, 3, 37, 53)).astype(np.float32)
+    y = rng.uniform(size=(1, 3, 37, 53)).astype(np.float32)
+    m, d0, d1, d2 = orc.ssim_forward(x, y, train=True)
+    dl = rng.standard_normal(x.shape).astype(np.float32)
+    g = orc.ssim_backward(x, y, dl, d0, d1, d2)
+    img = np.ascontiguousarray(np.transpose(x[0], (1, 2, 0)))
+    loss, vp = orc.loss_head(img, y[0])
+    return dict(img=x, ref=y, ssim_map=m, dm_dmu1=d0, dm_dsigma1_sq=d1, dm_dsigma12=d2, dL_dmap=dl, dL_dimg=g,
+                loss=loss, vpixels=vp)
+
+
+def main():
+    pkg = gsr_pkg.load()
+    for mode, deg, seed, W, H, n in CASES:
+        np.savez_compressed(os.path.join(HERE, f"scene_{mode}.npz"), **scene_case(pkg, mode, deg, seed, W, H, n))
+    np.savez_compressed(os.path.join(HERE, "ssim.npz"), **ssim_case())
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,78 @@
+"""Committed golden fixtures (tests/golden/*.npz, produced by tests/golden/make_golden.py
+from the oracle): CPU — the oracle still reproduces them bit for bit; GPU — the HIP path
+matches them within the stated tolerances, with no oracle in the loop."""
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MODES = ["rgb", "rgbd", "rgbdn"]
+
+
+def load(name):
+    return dict(np.load(os.path.join(HERE, name)))
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_oracle_reproduces_golden(orc, mode):
+    f = load(f"scene_{mode}.npz")
+    cam = orc.Camera(int(f["width"]), int(f["height"]), tuple(f["focal"]), R=f["R"], t=f["t"])
+    deg = int(f["sh_degree"])
+    st = orc.forward(f["means"], f["shs"], f["opacities"], f["scales"], f["rotations"], cam, deg,
+                     background=f["background"], mode=mode)
+    for k in ("radii", "means2d", "conics", "depths", "rgbs", "clamped", "tiles_touched", "ranges", "values_sorted",
+              "image", "n_contrib", "accum_alpha"):
+        assert np.array_equal(getattr(st, k), f[k]), k
+    g = orc.backward(st, f["vpixels"], f["means"], f["shs"], f["opacities"], f["scales"], f["rotations"], cam, deg,
+                     background=f["background"], pose_grad=True)
+    for k in ("vmeans", "vshs", "vopacities", "vscales", "vrots", "vR", "vt", "vmeans2d"):
+        assert np.array_equal(getattr(g, k), f[k]), k
+
+
+def test_oracle_reproduces_golden_ssim(orc):
+    f = load("ssim.npz")
+    m, d0, d1, d2 = orc.ssim_forward(f["img"], f["ref"], train=True)
+    assert np.array_equal(m, f["ssim_map"]) and np.array_equal(d0, f["dm_dmu1"])
+    assert np.array_equal(orc.ssim_backward(f["img"], f["ref"], f["dL_dmap"], d0, d1, d2), f["dL_dimg"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", MODES)
+def test_hip_matches_golden(pkg, mode):
+    import torch
+    from hip_helpers import dev, frac_bad, rel_l2
+    f = load(f"scene_{mode}.npz")
+    W, H, deg = int(f["width"]), int(f["height"]), int(f["sh_degree"])
+    cam = pkg.Camera(W, H, tuple(float(x) for x in f["focal"]), (0.5, 0.5), f["R"], f["t"])
+    rast = pkg.rasterizer.GaussianRasterizer(W, H, mode=mode)
+    t = [dev(f["means"]), dev(f["shs"]), dev(f["opacities"].reshape(-1, 1)), dev(f["scales"]), dev(f["rotations"])]
+    bg = tuple(float(b) for b in f["background"])
+    Rd, td = dev(np.asarray(f["R"], np.float32).T), dev(f["t"])
+    img = rast.forward_raw(*t, cam, deg, bg, Rd, td)
+    torch.cuda.synchronize()
+    assert np.array_equal(rast.radii.cpu().numpy(), f["radii"])
+    assert rast.stats.n_rendered == int(f["n_rendered"])
+    assert np.array_equal(rast.ranges.cpu().numpy().astype(np.uint32), f["ranges"])
+    assert np.array_equal(rast.values_sorted.cpu().numpy().astype(np.uint32), f["values_sorted"])
+    vis = f["radii"] > 0
+    geo = rast.geometry()
+    assert frac_bad(geo["means2d"].cpu().numpy()[vis], f["means2d"][vis], 1e-6, 1e-7) == 0
+    assert frac_bad(geo["conics"].cpu().numpy()[vis], f["conics"][vis], 1e-6, 1e-7) == 0
+    assert frac_bad(img.cpu().numpy(), f["image"], 0, 1e-4) <= 1e-4
+    out = rast.backward_raw(dev(f["vpixels"]), *t, cam, deg, bg, Rd, td)
+    torch.cuda.synchronize()
+    names = ["vmeans", "vshs", "vopacities", "vscales", "vrots", "vR", "vt"]
+    for o, k in zip(out, names):
+        assert rel_l2(o.cpu().numpy().reshape(-1), f[k].reshape(-1)) <= 1e-4, k
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden_ssim(pkg):
+    from hip_helpers import dev
+    f = load("ssim.npz")
+    F = pkg.fused_ssim
+    m, d0, d1, d2 = F._fused_ssim(dev(f["img"]), dev(f["ref"]), train=True)
+    assert np.array_equal(m.cpu().numpy(), f["ssim_map"])
+    g = F.fused_ssim_bwd(dev(f["img"]), dev(f["ref"]), dev(f["dL_dmap"]), d0, d1, d2)
+    assert np.array_equal(g.cpu().numpy(), f["dL_dimg"])

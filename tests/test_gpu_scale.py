@@ -1,0 +1,104 @@
+"""-m gpu tests at BASELINE.json's sizes.  Config 2 (100 k Gaussians, 1080p) is compared
+with the oracle in full; config 3 (1 M) forward vs oracle + size-independent properties;
+config 5 (5 M, 3840x2160) properties only (the oracle would take minutes):
+sortedness of every tile list, Σ ranges = D, background-composite identity, backward
+linearity in the cotangent, run-to-run determinism of the forward."""
+import numpy as np
+import pytest
+import torch
+
+from hip_helpers import HipRun, dev, frac_bad, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _tile_lists_sorted(run, st_depths=None):
+    ranges = run.rast.ranges.cpu().numpy().astype(np.int64)
+    vals = run.rast.values_sorted.cpu().numpy().astype(np.int64)
+    depths = run.rast.geometry()["depths"].cpu().numpy()
+    D = int(run.rast.stats.n_rendered)
+    ln = ranges[:, 1] - ranges[:, 0]
+    assert ln.sum() == D and (ln >= 0).all()
+    nz = ln > 0
+    order = np.argsort(ranges[nz, 0])
+    s, e = ranges[nz, 0][order], ranges[nz, 1][order]
+    assert s[0] == 0 and e[-1] == D and np.array_equal(s[1:], e[:-1]), "tile ranges must tile [0, D)"
+    d = depths[vals]
+    dbits = d.view(np.uint32).astype(np.int64)
+    key = (dbits << 32) | vals
+    inc = np.diff(key) > 0
+    boundary = np.zeros(D - 1, bool)
+    boundary[e[:-1] - 1] = True
+    assert (inc | boundary).all(), "every tile list is strictly ascending in (depth bits, id)"
+    return ln
+
+
+def test_config2_100k_1080p_full_oracle_compare(pkg, orc):
+    W, H, n, deg, seed = 1920, 1080, 100_000, 3, 1002
+    s = pkg.synthetic.make_scene(n, W, H, deg, seed)
+    cam = orc.Camera(W, H, s.focal)
+    st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg)
+    run = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg)
+    img = run.forward().cpu().numpy()
+    assert np.array_equal(run.rast.radii.cpu().numpy(), st.radii)
+    assert run.rast.stats.n_rendered == st.n_rendered
+    assert np.array_equal(run.rast.ranges.cpu().numpy().astype(np.uint32), st.ranges)
+    assert np.array_equal(run.rast.values_sorted.cpu().numpy().astype(np.uint32), st.values_sorted)
+    assert frac_bad(img, st.image, 0, 1e-4) <= 1e-4
+    assert (run.rast.n_contrib.cpu().numpy().astype(np.uint32) != st.n_contrib).mean() <= 1e-4
+    vp = pkg.synthetic.make_vpixels(W, H, 3, seed)
+    g = orc.backward(st, vp, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg)
+    out = [o.cpu().numpy() for o in run.backward(vp)[:5]]
+    for o, ref, name in zip(out, (g.vmeans, g.vshs, g.vopacities, g.vscales, g.vrots), "means shs opac scales rots".split()):
+        assert rel_l2(o.reshape(-1), ref.reshape(-1)) <= 1e-4, name
+        assert frac_bad(o.reshape(-1), ref.reshape(-1), 1e-3, 1e-6 * np.abs(ref).max()) <= 1e-3, name
+    _tile_lists_sorted(run)
+
+
+def _properties(pkg, orc, n, W, H, seed, with_oracle_fwd):
+    deg = 3
+    s = pkg.synthetic.make_scene(n, W, H, deg, seed)
+    cam = orc.Camera(W, H, s.focal)
+    bg = (0.2, 0.7, 0.4)
+    run = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, (0, 0, 0))
+    img0 = run.forward().clone()
+    T = run.rast.accum_alpha
+    assert float(T.min()) >= 0 and float(T.max()) <= 1
+    ln = _tile_lists_sorted(run)
+    nc = run.rast.n_contrib.cpu().numpy().reshape(H, W)
+    gx = (W + 15) // 16
+    ty, tx = np.meshgrid(np.arange(H) // 16, np.arange(W) // 16, indexing="ij")
+    assert (nc <= ln[ty * gx + tx]).all()
+    # determinism of the forward
+    img1 = run.forward()
+    assert torch.equal(img0, img1)
+    if with_oracle_fwd:
+        st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg)
+        assert np.array_equal(run.rast.radii.cpu().numpy(), st.radii)
+        assert np.array_equal(run.rast.values_sorted.cpu().numpy().astype(np.uint32), st.values_sorted)
+        assert frac_bad(img0.cpu().numpy(), st.image, 0, 1e-4) <= 1e-4
+    # background-composite identity (reference test "Sky composite identity", runtests.jl:760-797)
+    runb = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, bg)
+    imgb = runb.forward()
+    comp = img0 + T.unsqueeze(-1) * torch.tensor(bg, device="cuda")
+    assert float((imgb - comp).abs().max()) < 1e-5
+    # backward is linear in the cotangent
+    v1 = dev(pkg.synthetic.make_vpixels(W, H, 3, seed))
+    v2 = dev(pkg.synthetic.make_vpixels(W, H, 3, seed + 1))
+    g1 = [o.clone() for o in run.backward(v1.cpu().numpy())[:5]]
+    g2 = [o.clone() for o in run.backward(v2.cpu().numpy())[:5]]
+    g12 = run.backward((v1 + 2 * v2).cpu().numpy())[:5]
+    for a, b, c in zip(g1, g2, g12):
+        ref = (a + 2 * b)
+        assert float((c - ref).norm() / ref.norm()) < 1e-4
+    assert all(torch.isfinite(o).all() for o in g12)
+    vis = run.rast.radii > 0
+    assert not g12[0][~vis].any() and not g12[1][~vis].any()
+
+
+def test_config3_1m_1080p(pkg, orc):
+    _properties(pkg, orc, 1_000_000, 1920, 1080, 1003, with_oracle_fwd=True)
+
+
+def test_config5_5m_4k(pkg, orc):
+    _properties(pkg, orc, 5_000_000, 3840, 2160, 1005, with_oracle_fwd=False)

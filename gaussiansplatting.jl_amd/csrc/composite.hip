@@ -13,6 +13,7 @@
 // (tile, splat, component) leaves the workgroup.  Waves none of whose pixels are
 // touched by a splat skip it with a single ballot.
 #include "gsr_kernels.h"
+#include "wave_reduce.h"
 
 namespace {
 
@@ -158,6 +159,9 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int W, int H, int gr
     __shared__ unsigned long long lmask[4][BB / 64];
     __shared__ int tile_last_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const gsr::LaneBits lane_bits(lane);
+    const int red_slot = gsr::wave_reduce_index<NA>(lane);  // which partial this lane ends up holding
+    const bool red_writer = gsr::wave_reduce_writer(lane);
     const int tile = blockIdx.y * grid_x + blockIdx.x;
     const int px = blockIdx.x * GSR_TILE + (tid & 15), py = blockIdx.y * GSR_TILE + (tid >> 4);
     const bool inside = px < W && py < H;
@@ -224,9 +228,9 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int W, int H, int gr
             for (int w = 0; w < BB / 64; w++)
                 if ((j >> 6) == w) touched[w] |= 1ull << (j & 63);
 
-            float part[NA];
+            float part[16];
 #pragma unroll
-            for (int k = 0; k < NA; k++) part[k] = 0.0f;
+            for (int k = 0; k < 16; k++) part[k] = 0.0f;
             if (active) {
                 // T /= (1-α) and -T_final/(1-α) (render.jl:237,259) share one hardware reciprocal
                 const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
@@ -255,12 +259,9 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int W, int H, int gr
                 if (C > 3) part[9] = fac * vp[3];  // depth feature; channel 4 (constant 1) is not a parameter
                 if (C > 5) { part[10] = fac * vp[5]; part[11] = fac * vp[6]; part[12] = fac * vp[7]; }
             }
-#pragma unroll
-            for (int k = 0; k < NA; k++) part[k] = wave_sum_hi(part[k]);
-            if (lane == 63) {
-#pragma unroll
-                for (int k = 0; k < NA; k++) my[j * ST + k] = part[k];
-            }
+            // transposed wave64 reduction: ~3·NA/2 + 6 VALU ops, then ONE ds_write for all NA sums
+            const float total = gsr::wave_reduce_transposed<NA>(part, lane_bits);
+            if (red_writer) my[j * ST + red_slot] = total;
         }
         if (lane == 0) {
 #pragma unroll

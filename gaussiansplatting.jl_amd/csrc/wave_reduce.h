@@ -1,0 +1,115 @@
+// Transposed multi-value wave64 reduction for gfx950.
+//
+// Reduces N per-lane values (N <= 16) across the 64 lanes of a wave with ~3N/2 + 6 VALU
+// ops instead of 6N: at every butterfly level two values are *paired* — one half of the
+// lanes carries on with the first, the other half with the second — so the number of live
+// registers halves per level.  Levels, in order:
+//   bit 5  v_permlane32_swap (lanes 32-63 <-> 0-31)          2 ops / pair
+//   bit 4  v_permlane16_swap (odd rows <-> even rows)         2 ops / pair
+//   bit 3  DPP row_ror:8                                      2 v_cndmask + 1 v_add_dpp / pair
+//   bit 0  DPP quad_perm [1,0,3,2]                            2 v_cndmask + 1 v_add_dpp / pair
+//   bit 1  DPP quad_perm [2,3,0,1]   (plain add, 1 value left)
+//   bit 2  DPP row_shr:4             (plain add; no xor-4 DPP exists, so only lanes with
+//                                     bit 2 set end up with both halves)
+// Afterwards every lane with (lane & 4) != 0 holds the complete 64-lane sum of one of the N
+// inputs; which one is given by wave_reduce_index<N>(lane).  The caller stores with one
+// ds_write per wave from the lanes wave_reduce_writer(lane) selects.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gsr {
+
+__device__ __forceinline__ float dpp_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_xor2(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_ror8(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_shr4(float v) {  // lane i <- lane i-4 within the row, 0 for i < 4
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xF, 0xF, true));
+}
+
+// sum over the lane pair (i, i^32): lanes 0-31 get a's, lanes 32-63 get b's
+__device__ __forceinline__ float pair_swap32(float a, float b) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// sum over (i, i^16): even rows get a's, odd rows get b's
+__device__ __forceinline__ float pair_swap16(float a, float b) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+struct LaneBits {
+    bool b0, b3, hi, odd_row;
+    __device__ __forceinline__ explicit LaneBits(int lane)
+        : b0(lane & 1), b3(lane & 8), hi(lane & 32), odd_row(lane & 16) {}
+};
+
+// One pairing level over n live values -> (n+1)/2 live values.  KIND: 0 swap32, 1 swap16, 2 ror8, 3 xor1.
+template <int KIND>
+__device__ __forceinline__ float pair_level(float a, float b, const LaneBits& L) {
+    if (KIND == 0) return pair_swap32(a, b);
+    if (KIND == 1) return pair_swap16(a, b);
+    const bool bit = KIND == 2 ? L.b3 : L.b0;
+    const float send = bit ? a : b, keep = bit ? b : a;
+    return keep + (KIND == 2 ? dpp_ror8(send) : dpp_xor1(send));
+}
+template <int KIND>
+__device__ __forceinline__ float single_level(float a, const LaneBits& L) {
+    if (KIND == 0) return pair_swap32(a, a);
+    if (KIND == 1) return pair_swap16(a, a);
+    return a + (KIND == 2 ? dpp_ror8(a) : dpp_xor1(a));
+}
+
+template <int N, int KIND>
+__device__ __forceinline__ void net_level(float (&v)[16], const LaneBits& L) {
+    constexpr int H = N / 2;
+#pragma unroll
+    for (int p = 0; p < H; p++) v[p] = pair_level<KIND>(v[2 * p], v[2 * p + 1], L);
+    if (N & 1) v[H] = single_level<KIND>(v[N - 1], L);
+}
+
+// In: v[0..N-1] per-lane partials.  Out: return value = the full wave sum of input
+// number wave_reduce_index<N>(lane).
+template <int N>
+__device__ __forceinline__ float wave_reduce_transposed(float (&v)[16], const LaneBits& L) {
+    static_assert(N >= 1 && N <= 16, "at most 16 values per network");
+    constexpr int N1 = (N + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2;
+    net_level<N, 0>(v, L);
+    net_level<N1, 1>(v, L);
+    net_level<N2, 2>(v, L);
+    net_level<N3, 3>(v, L);
+    float r = v[0];
+    r = r + dpp_xor2(r);
+    r = r + dpp_shr4(r);
+    return r;
+}
+
+// Lanes whose result is complete and which are pairwise distinct per input (bit 1 clear, bit 2 set).
+__device__ __forceinline__ bool wave_reduce_writer(int lane) { return (lane & 6) == 4; }
+
+// Which input a lane ends up holding (the same network run on indices).
+template <int N>
+__device__ __forceinline__ int wave_reduce_index(int lane) {
+    int idx[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) idx[i] = i;
+    const bool bits[4] = {(lane & 32) != 0, (lane & 16) != 0, (lane & 8) != 0, (lane & 1) != 0};
+    int n = N;
+#pragma unroll
+    for (int lvl = 0; lvl < 4; lvl++) {
+        const int h = n / 2;
+#pragma unroll
+        for (int p = 0; p < 8; p++)
+            if (p < h) idx[p] = bits[lvl] ? idx[2 * p + 1] : idx[2 * p];
+        if (n & 1) idx[h] = idx[n - 1];
+        n = (n + 1) / 2;
+    }
+    return idx[0];
+}
+
+}  // namespace gsr

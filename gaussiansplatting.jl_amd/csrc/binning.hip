@@ -121,11 +121,43 @@ __device__ __forceinline__ void bitonic_sort(uint64_t* buf, uint32_t m, int tid,
     }
 }
 
+// Conservative 16-bit row mask of an instance: bit r is set unless NO pixel of row r of the
+// tile can reach alpha >= 1/255 (render.jl:95), i.e. unless the ellipse
+// {sigma <= ln(255*opacity)} misses the row's pixel centres.  The composite kernels use it
+// only to skip work; every surviving (pixel, splat) pair still runs the exact test, so the
+// slack below never changes a result.
+__device__ __forceinline__ uint32_t instance_row_mask(const float4 g0, const float4 g1, int X0, int Y0) {
+    const float mx = g0.x, my = g0.y, a = g0.z, b = g0.w, c = g1.x, o = g1.y;
+    const float tau = __logf(255.0f * o) + 2e-3f;  // sigma <= tau  <=>  alpha >= 1/255 (with slack)
+    if (!(tau >= 0.0f)) return 0u;                  // opacity < 1/255: never blended
+    if (!(a > 0.0f)) return 0xFFFFu;                // degenerate conic: no culling
+    const float eps = 0.02f;
+    const float dx_lo = mx - (float)(X0 + 15), dx_hi = mx - (float)X0;  // dx = mx - px over the tile's columns
+    const float inv_a = 1.0f / a;
+    uint32_t m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const float dy = my - (float)(Y0 + r);
+        const float bd = b * dy;
+        const float disc = bd * bd - a * (c * dy * dy - 2.0f * tau);
+        if (disc >= 0.0f) {
+            const float s = __fsqrt_rn(disc);
+            const float lo = (-bd - s) * inv_a, hi = (-bd + s) * inv_a;
+            const float slack = eps * (1.0f + fabsf(lo) + fabsf(hi));
+            if (hi + slack >= dx_lo && lo - slack <= dx_hi) m |= 1u << r;
+        } else if (disc > -1e-3f * (bd * bd + fabsf(a * c * dy * dy) + 2.0f * a * tau)) {
+            m |= 1u << r;  // numerically on the boundary: keep
+        }
+    }
+    return m;
+}
+
 // Load the tile's keys into `buf` (padded to a power of two with +inf), sort, and emit the
 // sorted ids + the packed splat stream.  Instantiated once on the LDS array and once on a
 // global slab so each copy uses ds_* / global_* instructions (no flat addressing).
 template <int CH>
 __device__ __forceinline__ void sort_and_emit(uint64_t* buf, uint32_t m, uint32_t n, uint32_t start, int tid,
+                                              int X0, int Y0,
                                               const uint64_t* __restrict__ keys, const GsrGeom& geom,
                                               const GsrStream& stream, uint32_t* __restrict__ values_sorted) {
     for (uint32_t i = tid; i < m; i += 256) buf[i] = i < n ? keys[start + i] : ~0ull;
@@ -138,7 +170,8 @@ __device__ __forceinline__ void sort_and_emit(uint64_t* buf, uint32_t m, uint32_
         const float4 g0 = geom.g0[id], g1 = geom.g1[id], g2 = geom.g2[id];
         stream.s0[start + i] = g0;
         stream.s1[start + i] = g1;
-        stream.s2[start + i] = make_float4(g2.x, __uint_as_float(id), g2.z, 0.0f);
+        stream.s2[start + i] = make_float4(g2.x, __uint_as_float(id), g2.z,
+                                           __uint_as_float(instance_row_mask(g0, g1, X0, Y0)));
         if (CH > 5) stream.s3[start + i] = geom.g3[id];
     }
 }
@@ -148,8 +181,8 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restri
                                                         const uint64_t* __restrict__ keys,
                                                         uint64_t* __restrict__ big_scratch,
                                                         uint32_t big_scratch_stride,
-                                                        uint32_t* __restrict__ slab_counter, GsrGeom geom,
-                                                        GsrStream stream,
+                                                        uint32_t* __restrict__ slab_counter, int grid_x,
+                                                        GsrGeom geom, GsrStream stream,
                                                         uint32_t* __restrict__ values_sorted,
                                                         uint32_t* __restrict__ ranges) {
     __shared__ uint64_t skeys[GSR_SORT_LDS_CAP];
@@ -163,17 +196,18 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restri
         ranges[2 * tile + 1] = n ? end : 0u;
     }
     if (n == 0) return;
+    const int X0 = (tile % grid_x) * GSR_TILE, Y0 = (tile / grid_x) * GSR_TILE;
     uint32_t m = 1;
     while (m < n) m <<= 1;
     if (m <= GSR_SORT_LDS_CAP) {
-        sort_and_emit<CH>(skeys, m, n, start, tid, keys, geom, stream, values_sorted);
+        sort_and_emit<CH>(skeys, m, n, start, tid, X0, Y0, keys, geom, stream, values_sorted);
     } else {
         // oversized tile: same network through a global-scratch slab (rare; slabs are sized by
         // the host from the scan's totals and handed out with one atomic per oversized tile)
         if (tid == 0) slab_s = atomicAdd(slab_counter, 1u);
         __syncthreads();
         uint64_t* slab = big_scratch + (size_t)slab_s * big_scratch_stride;
-        sort_and_emit<CH>(slab, m, n, start, tid, keys, geom, stream, values_sorted);
+        sort_and_emit<CH>(slab, m, n, start, tid, X0, Y0, keys, geom, stream, values_sorted);
     }
 }
 
@@ -190,13 +224,13 @@ void gsr_launch_scatter(hipStream_t s, int n, GsrCam cam, GsrGeom geom, uint32_t
                        geom.g2, cursor, keys);
 }
 
-void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int channels, const uint32_t* tile_start, uint64_t* keys,
+void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start, uint64_t* keys,
                           uint64_t* big_scratch, uint32_t big_scratch_stride, uint32_t* slab_counter, GsrGeom geom,
                           GsrStream stream, uint32_t* values_sorted, uint32_t* ranges) {
     if (channels > 5)
         hipLaunchKernelGGL(tile_sort_kernel<8>, dim3(n_tiles), dim3(256), 0, s, tile_start, keys, big_scratch,
-                           big_scratch_stride, slab_counter, geom, stream, values_sorted, ranges);
+                           big_scratch_stride, slab_counter, grid_x, geom, stream, values_sorted, ranges);
     else
         hipLaunchKernelGGL(tile_sort_kernel<3>, dim3(n_tiles), dim3(256), 0, s, tile_start, keys, big_scratch,
-                           big_scratch_stride, slab_counter, geom, stream, values_sorted, ranges);
+                           big_scratch_stride, slab_counter, grid_x, geom, stream, values_sorted, ranges);
 }

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(int W, int H, int gr
                                                             float* __restrict__ uncert) {
     __shared__ float4 l0[GSR_BATCH], l1[GSR_BATCH], l2[GSR_BATCH];
     __shared__ float4 l3[C > 5 ? GSR_BATCH : 1];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t strip_bits = 0xFu << (4 * (tid >> 6));  // this wave's 4 pixel rows
     const int tile = blockIdx.y * grid_x + blockIdx.x;
     const int px = blockIdx.x * GSR_TILE + (tid & 15), py = blockIdx.y * GSR_TILE + (tid >> 4);
     const bool inside = px < W && py < H;
@@ -95,31 +96,40 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(int W, int H, int gr
             if (C > 5) l3[tid] = stream.s3[idx];
         }
         __syncthreads();
-        // Branch-free inner loop: a lane that is done, or whose pixel this splat does not
-        // touch, blends with weight 0 (exactly what `continue`/`break` leave behind,
-        // render.jl:92-101); divergent exec-mask bookkeeping costs more than the 4 FMAs.
-#pragma unroll 4
-        for (int j = 0; j < cnt; j++) {
-            const float4 a = l0[j], b = l1[j], c2 = l2[j];
-            const float dx = a.x - fx, dy = a.y - fy;
-            const float sigma = a.w * dx * dy + 0.5f * (a.z * (dx * dx) + b.x * (dy * dy));
-            const float alpha = fminf(0.99f, b.y * __expf(-sigma));
-            const float Tn = T * (1.0f - alpha);
-            bool ok = !done && sigma >= 0.0f && alpha >= (1.0f / 255.0f);
-            const bool stop = ok && Tn < 1e-4f;
-            done = done || stop;
-            ok = ok && !stop;
-            float f[C];
-            unpack_features<C>(b, c2, C > 5 ? l3[j] : c2, f);
-            const float w = ok ? alpha * T : 0.0f;
+        // Per-wave worklist: lane l looks at splat c0+l's row mask (emitted by tile_sort) and
+        // one ballot yields the splats that can touch this wave's 16x4 pixel strip; the rest
+        // (56 % at the BASELINE configs) are never visited.  Visiting order stays ascending.
+        for (int c0 = 0; c0 < cnt; c0 += 64) {
+            const int jj = c0 + lane;
+            const bool cand = jj < cnt && (__float_as_uint(l2[jj].w) & strip_bits) != 0u;
+            unsigned long long m = __ballot(cand);
+            if (__ballot(!done) == 0ull) m = 0ull;  // the whole strip has saturated
+            while (m) {
+                const int j = c0 + __builtin_ctzll(m);
+                m &= m - 1;
+                // Branch-free body: a lane that is done, or whose pixel this splat does not
+                // touch, blends with weight 0 (what `continue`/`break` leave behind, render.jl:92-101).
+                const float4 a = l0[j], b = l1[j], c2 = l2[j];
+                const float dx = a.x - fx, dy = a.y - fy;
+                const float sigma = a.w * dx * dy + 0.5f * (a.z * (dx * dx) + b.x * (dy * dy));
+                const float alpha = fminf(0.99f, b.y * __expf(-sigma));
+                const float Tn = T * (1.0f - alpha);
+                bool ok = !done && sigma >= 0.0f && alpha >= (1.0f / 255.0f);
+                const bool stop = ok && Tn < 1e-4f;
+                done = done || stop;
+                ok = ok && !stop;
+                float f[C];
+                unpack_features<C>(b, c2, C > 5 ? l3[j] : c2, f);
+                const float w = ok ? alpha * T : 0.0f;
 #pragma unroll
-            for (int c = 0; c < C; c++) color[c] += f[c] * w;
-            if (AUX) {
-                unc += w;
-                if (covis && ok && T > 0.5f) covis[__float_as_uint(c2.y)] = 1;
+                for (int c = 0; c < C; c++) color[c] += f[c] * w;
+                if (AUX) {
+                    unc += w;
+                    if (covis && ok && T > 0.5f) covis[__float_as_uint(c2.y)] = 1;
+                }
+                T = ok ? Tn : T;
+                last = ok ? (uint32_t)(base + j + 1) : last;
             }
-            T = ok ? Tn : T;
-            last = ok ? (uint32_t)(base + j + 1) : last;
         }
     }
     if (inside) {
@@ -159,6 +169,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int W, int H, int gr
     __shared__ unsigned long long lmask[4][BB / 64];
     __shared__ int tile_last_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t strip_bits = 0xFu << (4 * wave);  // this wave's 4 pixel rows
     const gsr::LaneBits lane_bits(lane);
     const int red_slot = gsr::wave_reduce_index<NA>(lane);  // which partial this lane ends up holding
     const bool red_writer = gsr::wave_reduce_writer(lane);
@@ -188,12 +199,14 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int W, int H, int gr
     // Splats behind every pixel's last contributor are skipped by each lane in the reference
     // (render.jl:223); start the back-to-front walk at the deepest one any pixel blended.
     if (tid == 0) tile_last_s = 0;
+    int wave_last;  // deepest list position any pixel of this wave's strip blended
     __syncthreads();
     {
         int m = last_contributor;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
         if (lane == 0) atomicMax(&tile_last_s, m);
+        wave_last = m;
     }
     __syncthreads();
     const int tile_last = tile_last_s;  // process list positions tile_last-1 ... 0
@@ -214,7 +227,14 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int W, int H, int gr
 #pragma unroll
         for (int w = 0; w < BB / 64; w++) touched[w] = 0ull;
         float* const my = lacc[wave];
-        for (int j = 0; j < cnt; j++) {
+        for (int c0 = 0; c0 < cnt; c0 += 64) {
+          const int jj = c0 + lane;
+          const bool cand = jj < cnt && (__float_as_uint(l2[jj].w) & strip_bits) != 0u &&
+                            (tile_last - 1 - base - jj) < wave_last;
+          unsigned long long wl = __ballot(cand);  // splats whose footprint can touch this strip
+          while (wl) {
+            const int j = c0 + __builtin_ctzll(wl);
+            wl &= wl - 1;
             const int contributor = tile_last - 1 - base - j;  // 0-based position in the tile list
             const float4 a = l0[j], b = l1[j], c2 = l2[j];
             const float dx = a.x - fx, dy = a.y - fy;
@@ -262,6 +282,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int W, int H, int gr
             // transposed wave64 reduction: ~3·NA/2 + 6 VALU ops, then ONE ds_write for all NA sums
             const float total = gsr::wave_reduce_transposed<NA>(part, lane_bits);
             if (red_writer) my[j * ST + red_slot] = total;
+          }
         }
         if (lane == 0) {
 #pragma unroll

@@ -306,7 +306,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     gsr_launch_scatter(s, n, k, geom_of(h), h->cursor.as<uint32_t>(), h->keys.as<uint64_t>());
     h->prof.end(s);
     h->prof.begin(ST_SORT, s);
-    gsr_launch_tile_sort(s, h->n_tiles, C, h->tile_start.as<uint32_t>(), h->keys.as<uint64_t>(),
+    gsr_launch_tile_sort(s, h->n_tiles, h->grid_x, C, h->tile_start.as<uint32_t>(), h->keys.as<uint64_t>(),
                          h->big_scratch.as<uint64_t>(), big_stride, totals + 3, geom_of(h), stream_of(h),
                          h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>());
     h->prof.end(s);

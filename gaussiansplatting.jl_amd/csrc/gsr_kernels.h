@@ -38,7 +38,7 @@ struct GsrGeom {
 struct GsrStream {
     float4* s0;
     float4* s1;
-    float4* s2;  // b, id (uint bits), depth, unused
+    float4* s2;  // b, id (uint bits), depth, row mask (uint bits: rows of the tile the splat can touch)
     float4* s3;  // normal (C == 8) or nullptr
 };
 
@@ -64,7 +64,7 @@ void gsr_launch_pergauss_bwd(hipStream_t s, int n, int K, int degree, int channe
 void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count, uint32_t* tile_start,
                           uint32_t* cursor, uint32_t* totals);
 void gsr_launch_scatter(hipStream_t s, int n, GsrCam cam, GsrGeom geom, uint32_t* cursor, uint64_t* keys);
-void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int channels, const uint32_t* tile_start, uint64_t* keys,
+void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start, uint64_t* keys,
                           uint64_t* big_scratch, uint32_t big_scratch_stride, uint32_t* slab_counter, GsrGeom geom,
                           GsrStream stream, uint32_t* values_sorted, uint32_t* ranges);
 

@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
+LIB_PATH = os.environ.get("GSR_HIP_LIB", os.path.join(_HERE, "libgsr_hip.so"))  # override: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gsr.h")
 
 GSR_OK, GSR_E_INVALID_ARG, GSR_E_OOM, GSR_E_HIP, GSR_E_STATE = 0, -1, -2, -3, -4

@@ -149,10 +149,16 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(int W, int H, int gr
 // [7..8] v mean2d, [9] v depth (C>=5), [10..12] v normal (C==8)
 template <int C> struct AccRow { static constexpr int N = C == 3 ? 9 : (C == 5 ? 10 : 13); static constexpr int STRIDE = N | 1; };
 
-constexpr int BWD_BATCH = 128;  // splats staged per round in the backward (LDS: 4 wave-private accumulator slabs)
+#ifndef GSR_BWD_BATCH
+#define GSR_BWD_BATCH 128
+#endif
+#ifndef GSR_BWD_MINWAVES
+#define GSR_BWD_MINWAVES 1
+#endif
+constexpr int BWD_BATCH = GSR_BWD_BATCH;  // splats staged per round in the backward (LDS: 4 wave-private accumulator slabs)
 
 template <int C>
-__global__ __launch_bounds__(256) void composite_bwd_kernel(int W, int H, int grid_x,
+__global__ __launch_bounds__(256, GSR_BWD_MINWAVES) void composite_bwd_kernel(int W, int H, int grid_x,
                                                             const uint32_t* __restrict__ tile_start,
                                                             GsrStream stream, Bg bg,
                                                             const float* __restrict__ vpixels,
@@ -191,10 +197,11 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int W, int H, int gr
 #pragma unroll
     for (int c = 0; c < C; c++) bg_dot += bg.v[c] * vp[c];
     const float bgT = -T_final * bg_dot;
-    float accum_rec[C], last_color[C];
-#pragma unroll
-    for (int c = 0; c < C; c++) { accum_rec[c] = 0.0f; last_color[c] = 0.0f; }
-    float last_alpha = 0.0f;
+    // The reference carries accum_rec[c], last_color[c], last_alpha per channel and forms
+    //   vα = Σ_c (color[c] - accum_rec[c])·v[c]            (render.jl:245-252).
+    // Only the dot product with the pixel cotangent is ever used, so the state is folded to
+    // one scalar A = accum_rec·v with the same recurrence  A' = α·(color·v) + (1-α)·A.
+    float A = 0.0f;
 
     // Splats behind every pixel's last contributor are skipped by each lane in the reference
     // (render.jl:223); start the back-to-front walk at the deepest one any pixel blended.
@@ -258,22 +265,19 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int W, int H, int gr
                 const float fac = alpha * T;
                 float f[C];
                 unpack_features<C>(b, c2, C > 5 ? l3[j] : c2, f);
-                float valpha = 0.0f;
+                float cv = f[0] * vp[0];
 #pragma unroll
-                for (int c = 0; c < C; c++) {
-                    accum_rec[c] = last_alpha * last_color[c] + (1.0f - last_alpha) * accum_rec[c];
-                    last_color[c] = f[c];
-                    valpha += (f[c] - accum_rec[c]) * vp[c];
-                }
-                valpha *= T;
-                valpha += bgT * rinv;
-                last_alpha = alpha;
+                for (int c = 1; c < C; c++) cv += f[c] * vp[c];
+                const float d = cv - A;                 // (color - accum_rec)·v
+                const float valpha = d * T + bgT * rinv;
+                A = A + alpha * d;                      // α·cv + (1-α)·A for the next (nearer) splat
                 const float vsigma = -o * G * valpha;
+                const float hs = 0.5f * vsigma;
                 part[0] = fac * vp[0]; part[1] = fac * vp[1]; part[2] = fac * vp[2];
                 part[3] = G * valpha;
-                part[4] = 0.5f * vsigma * (dx * dx);
-                part[5] = 0.5f * vsigma * dx * dy;
-                part[6] = 0.5f * vsigma * (dy * dy);
+                part[4] = hs * (dx * dx);
+                part[5] = hs * (dx * dy);
+                part[6] = hs * (dy * dy);
                 part[7] = vsigma * (a.z * dx + a.w * dy);
                 part[8] = vsigma * (a.w * dx + b.x * dy);
                 if (C > 3) part[9] = fac * vp[3];  // depth feature; channel 4 (constant 1) is not a parameter
@@ -302,7 +306,11 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int W, int H, int gr
                     for (int k = 0; k < NA; k++) r[k] += lacc[w][tid * ST + k];
                 }
             }
+#ifdef GSR_EXPERIMENT_NO_FLUSH
+            if (any && r[0] == 12345.678f) {
+#else
             if (any) {
+#endif
                 const uint32_t id = __float_as_uint(l2[tid].y);
                 float* p0 = reinterpret_cast<float*>(acc.a0 + id);
                 float* p1 = reinterpret_cast<float*>(acc.a1 + id);

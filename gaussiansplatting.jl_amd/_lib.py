@@ -16,8 +16,8 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gsr.h")
 GSR_OK, GSR_E_INVALID_ARG, GSR_E_OOM, GSR_E_HIP, GSR_E_STATE = 0, -1, -2, -3, -4
 MODES = {"rgb": 3, "rgbd": 5, "rgbdn": 8}
 
-(BUF_RADII, BUF_GRAD_MEANS2D, BUF_N_CONTRIB, BUF_FINAL_T, BUF_TILE_RANGES, BUF_VALUES_SORTED, BUF_GEOM0, BUF_GEOM1,
- BUF_GEOM2, BUF_GEOM3, BUF_RECT, BUF_GRAD_ACC0, BUF_GRAD_ACC1) = range(13)
+(BUF_RADII, BUF_GRAD_MEANS2D, BUF_N_CONTRIB, BUF_FINAL_T, BUF_TILE_RANGES, BUF_VALUES_SORTED, BUF_GEOM, BUF_NORMALS,
+ BUF_INST_POS, BUF_GRAD_ROWS) = range(10)
 
 
 class GsrError(RuntimeError):

@@ -4,7 +4,7 @@
 //
 //   preprocess     : per-tile occupancy histogram (atomic, in pergauss.hip)
 //   tile_scan      : exclusive scan over the T tile counts  -> tile ranges, D
-//   scatter        : each visible Gaussian drops (depth_bits<<32 | id) into its tiles' segments
+//   scatter        : each visible Gaussian drops (depth_bits<<32 | id) into its tiles' segments (pergauss.hip)
 //   tile_sort      : one workgroup per tile sorts its segment in LDS by (depth, id) and writes
 //                    the sorted ids plus the packed, sorted splat stream the composite
 //                    kernels consume linearly
@@ -21,7 +21,9 @@ namespace {
 __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint32_t* __restrict__ tile_count,
                                                          uint32_t* __restrict__ tile_start,
                                                          uint32_t* __restrict__ cursor,
-                                                         uint32_t* __restrict__ totals) {
+                                                         uint32_t* __restrict__ totals, int n_blocks,
+                                                         const uint32_t* __restrict__ bsum,
+                                                         uint32_t* __restrict__ bpre) {
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t carry_s;
     __shared__ uint32_t wave_max[16];
@@ -82,23 +84,29 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint
         for (int w = 0; w < 16; w++) b += wave_sums[w];
         totals[2] = b;
     }
-}
-
-// ---- counting scatter (duplicate_with_keys! restated per tile; utils.jl:96-119) ----
-__global__ __launch_bounds__(256) void scatter_kernel(int n, int grid_x, const int32_t* __restrict__ radii,
-                                                      const ushort4* __restrict__ rect,
-                                                      const float4* __restrict__ g2,
-                                                      uint32_t* __restrict__ cursor, uint64_t* __restrict__ keys) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    if (!(radii[i] > 0)) return;
-    const ushort4 r = rect[i];
-    const uint64_t key = ((uint64_t)__float_as_uint(g2[i].z) << 32) | (uint32_t)i;
-    for (int y = r.y; y < r.w; y++)
-        for (int x = r.x; x < r.z; x++) {
-            const uint32_t slot = atomicAdd(&cursor[y * grid_x + x], 1u);
-            keys[slot] = key;
+    // second scan: per-block sums of tile-rect areas -> bpre (offsets into inst_pos)
+    __syncthreads();
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n_blocks; base += 1024) {
+        const int i = base + tid;
+        const uint32_t v = i < n_blocks ? bsum[i] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t y = __shfl_up(x, off);
+            if (lane >= off) x += y;
         }
+        if (lane == 63) wave_sums[wave] = x;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (int w = 0; w < wave; w++) wave_off += wave_sums[w];
+        const uint32_t excl = carry_s + wave_off + x - v;
+        if (i < n_blocks) bpre[i] = excl;
+        __syncthreads();
+        if (tid == 1023) carry_s = excl + v;
+        __syncthreads();
+    }
 }
 
 // ---- per-tile sort ----
@@ -159,7 +167,8 @@ template <int CH>
 __device__ __forceinline__ void sort_and_emit(uint64_t* buf, uint32_t m, uint32_t n, uint32_t start, int tid,
                                               int X0, int Y0,
                                               const uint64_t* __restrict__ keys, const GsrGeom& geom,
-                                              const GsrStream& stream, uint32_t* __restrict__ values_sorted) {
+                                              const GsrStream& stream, uint32_t* __restrict__ values_sorted,
+                                              uint32_t* __restrict__ inst_pos) {
     for (uint32_t i = tid; i < m; i += 256) buf[i] = i < n ? keys[start + i] : ~0ull;
     __syncthreads();
     if (m > 1) bitonic_sort(buf, m, tid, 256);
@@ -167,12 +176,18 @@ __device__ __forceinline__ void sort_and_emit(uint64_t* buf, uint32_t m, uint32_
         const uint64_t k = buf[i];
         const uint32_t id = (uint32_t)k;
         values_sorted[start + i] = id;
-        const float4 g0 = geom.g0[id], g1 = geom.g1[id], g2 = geom.g2[id];
-        stream.s0[start + i] = g0;
-        stream.s1[start + i] = g1;
-        stream.s2[start + i] = make_float4(g2.x, __uint_as_float(id), g2.z,
-                                           __uint_as_float(instance_row_mask(g0, g1, X0, Y0)));
-        if (CH > 5) stream.s3[start + i] = geom.g3[id];
+        const GsrGeoRec rec = geom.rec[id];  // one 64-byte line per gather
+        stream.s0[start + i] = rec.q0;
+        stream.s1[start + i] = rec.q1;
+        stream.s2[start + i] = make_float4(rec.q2.x, __uint_as_float(id), rec.q2.z,
+                                           __uint_as_float(instance_row_mask(rec.q0, rec.q1, X0, Y0)));
+        if (CH > 5) stream.s3[start + i] = geom.normal[id];
+        // slot of this instance among its Gaussian's covered tiles (row-major over the rect, the
+        // emit order of duplicate_with_keys!, utils.jl:112) -> where the backward finds its row
+        const uint32_t lo = __float_as_uint(rec.q3.x), hi = __float_as_uint(rec.q3.y);
+        const uint32_t x0 = lo & 0xFFFFu, y0 = lo >> 16, x1 = hi & 0xFFFFu;
+        const uint32_t slot = ((uint32_t)(Y0 / GSR_TILE) - y0) * (x1 - x0) + ((uint32_t)(X0 / GSR_TILE) - x0);
+        inst_pos[geom.bpre[id >> 8] + __float_as_uint(rec.q2.w) + slot] = start + i;
     }
 }
 
@@ -184,7 +199,8 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restri
                                                         uint32_t* __restrict__ slab_counter, int grid_x,
                                                         GsrGeom geom, GsrStream stream,
                                                         uint32_t* __restrict__ values_sorted,
-                                                        uint32_t* __restrict__ ranges) {
+                                                        uint32_t* __restrict__ ranges,
+                                                        uint32_t* __restrict__ inst_pos) {
     __shared__ uint64_t skeys[GSR_SORT_LDS_CAP];
     __shared__ uint32_t slab_s;
     const int tile = blockIdx.x, tid = threadIdx.x;
@@ -200,37 +216,32 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restri
     uint32_t m = 1;
     while (m < n) m <<= 1;
     if (m <= GSR_SORT_LDS_CAP) {
-        sort_and_emit<CH>(skeys, m, n, start, tid, X0, Y0, keys, geom, stream, values_sorted);
+        sort_and_emit<CH>(skeys, m, n, start, tid, X0, Y0, keys, geom, stream, values_sorted, inst_pos);
     } else {
         // oversized tile: same network through a global-scratch slab (rare; slabs are sized by
         // the host from the scan's totals and handed out with one atomic per oversized tile)
         if (tid == 0) slab_s = atomicAdd(slab_counter, 1u);
         __syncthreads();
         uint64_t* slab = big_scratch + (size_t)slab_s * big_scratch_stride;
-        sort_and_emit<CH>(slab, m, n, start, tid, X0, Y0, keys, geom, stream, values_sorted);
+        sort_and_emit<CH>(slab, m, n, start, tid, X0, Y0, keys, geom, stream, values_sorted, inst_pos);
     }
 }
 
 }  // namespace
 
 void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count, uint32_t* tile_start,
-                          uint32_t* cursor, uint32_t* totals) {
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, tile_count, tile_start, cursor, totals);
-}
-
-void gsr_launch_scatter(hipStream_t s, int n, GsrCam cam, GsrGeom geom, uint32_t* cursor, uint64_t* keys) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, cam.grid_x, geom.radii, geom.rect,
-                       geom.g2, cursor, keys);
+                          uint32_t* cursor, uint32_t* totals, int n_blocks, const uint32_t* bsum, uint32_t* bpre) {
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, tile_count, tile_start, cursor, totals,
+                       n_blocks, bsum, bpre);
 }
 
 void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start, uint64_t* keys,
                           uint64_t* big_scratch, uint32_t big_scratch_stride, uint32_t* slab_counter, GsrGeom geom,
-                          GsrStream stream, uint32_t* values_sorted, uint32_t* ranges) {
+                          GsrStream stream, uint32_t* values_sorted, uint32_t* ranges, uint32_t* inst_pos) {
     if (channels > 5)
         hipLaunchKernelGGL(tile_sort_kernel<8>, dim3(n_tiles), dim3(256), 0, s, tile_start, keys, big_scratch,
-                           big_scratch_stride, slab_counter, grid_x, geom, stream, values_sorted, ranges);
+                           big_scratch_stride, slab_counter, grid_x, geom, stream, values_sorted, ranges, inst_pos);
     else
         hipLaunchKernelGGL(tile_sort_kernel<3>, dim3(n_tiles), dim3(256), 0, s, tile_start, keys, big_scratch,
-                           big_scratch_stride, slab_counter, grid_x, geom, stream, values_sorted, ranges);
+                           big_scratch_stride, slab_counter, grid_x, geom, stream, values_sorted, ranges, inst_pos);
 }

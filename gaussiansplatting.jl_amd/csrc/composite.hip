@@ -8,10 +8,11 @@
 // and read back with wave-uniform (broadcast) ds_read_b128.
 //
 // Backward: instead of the reference's (C+6) global float atomics per (pixel, splat)
-// (render.jl:242,275-282) every wave reduces its 64 lanes with DPP row operations,
-// the four waves meet in an LDS accumulator row, and one global atomic per
-// (tile, splat, component) leaves the workgroup.  Waves none of whose pixels are
-// touched by a splat skip it with a single ballot.
+// (render.jl:242,275-282) every wave reduces its 64 lanes with a transposed DPP /
+// permlane-swap network, the four waves meet in wave-private LDS slabs, and one 64-byte
+// gradient ROW per (tile, splat) instance leaves the workgroup as plain stores; the
+// per-Gaussian kernel sums a Gaussian's rows.  Waves whose 16x4 strip a splat cannot
+// touch never visit it (row masks + ballot worklist).
 #include "gsr_kernels.h"
 #include "wave_reduce.h"
 
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256, GSR_BWD_MINWAVES) void composite_bwd_kernel(in
                                                             GsrStream stream, Bg bg,
                                                             const float* __restrict__ vpixels,
                                                             const uint32_t* __restrict__ n_contrib,
-                                                            const float* __restrict__ final_T, GsrAcc acc) {
+                                                            const float* __restrict__ final_T, GsrInst inst) {
     constexpr int NA = AccRow<C>::N, ST = AccRow<C>::STRIDE;
     constexpr int BB = BWD_BATCH;
     __shared__ float4 l0[BB], l1[BB], l2[BB];
@@ -306,23 +307,15 @@ __global__ __launch_bounds__(256, GSR_BWD_MINWAVES) void composite_bwd_kernel(in
                     for (int k = 0; k < NA; k++) r[k] += lacc[w][tid * ST + k];
                 }
             }
-#ifdef GSR_EXPERIMENT_NO_FLUSH
-            if (any && r[0] == 12345.678f) {
-#else
             if (any) {
-#endif
-                const uint32_t id = __float_as_uint(l2[tid].y);
-                float* p0 = reinterpret_cast<float*>(acc.a0 + id);
-                float* p1 = reinterpret_cast<float*>(acc.a1 + id);
-                atomicAdd(p0 + 0, r[0]); atomicAdd(p0 + 1, r[1]); atomicAdd(p0 + 2, r[2]); atomicAdd(p0 + 3, r[3]);
-                atomicAdd(p1 + 0, r[4]); atomicAdd(p1 + 1, r[5]); atomicAdd(p1 + 2, r[6]);
-                float* pm = reinterpret_cast<float*>(acc.vmean2d + id);
-                atomicAdd(pm + 0, r[7]); atomicAdd(pm + 1, r[8]);
-                if (C > 3) atomicAdd(p1 + 3, r[9]);
-                if (C > 5) {
-                    float* p2 = reinterpret_cast<float*>(acc.a2 + id);
-                    atomicAdd(p2 + 0, r[10]); atomicAdd(p2 + 1, r[11]); atomicAdd(p2 + 2, r[12]);
-                }
+                // one 64-byte gradient row per instance, plain stores (rows are zero-filled per
+                // backward): the per-Gaussian kernel sums a Gaussian's rows in a fixed order —
+                // no fp32 atomics (35 M per view before), bit-reproducible gradients
+                float4* row = inst.rows + (size_t)4 * (start + (uint32_t)(tile_last - 1 - base - tid));
+                row[0] = make_float4(r[0], r[1], r[2], r[3]);
+                row[1] = make_float4(r[4], r[5], r[6], C > 3 ? r[9 < NA ? 9 : 0] : 0.0f);
+                row[2] = make_float4(r[7], r[8], C > 5 ? r[10 < NA ? 10 : 0] : 0.0f, C > 5 ? r[11 < NA ? 11 : 0] : 0.0f);
+                if (C > 5) row[3] = make_float4(r[12 < NA ? 12 : 0], 0.0f, 0.0f, 0.0f);
             }
         }
     }
@@ -353,12 +346,12 @@ void gsr_launch_composite_fwd(hipStream_t s, int channels, GsrCam cam, const uin
 
 void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start, GsrStream stream,
                               const float* background, const float* vpixels, const uint32_t* n_contrib,
-                              const float* final_T, GsrAcc acc) {
+                              const float* final_T, GsrInst inst) {
     dim3 grid(cam.grid_x, cam.grid_y), block(256);
     Bg bg = make_bg(background, channels);
 #define LAUNCH(CC)                                                                                                 \
     hipLaunchKernelGGL((composite_bwd_kernel<CC>), grid, block, 0, s, cam.width, cam.height, cam.grid_x, tile_start, \
-                       stream, bg, vpixels, n_contrib, final_T, acc)
+                       stream, bg, vpixels, n_contrib, final_T, inst)
     if (channels == 3) LAUNCH(3);
     else if (channels == 5) LAUNCH(5);
     else LAUNCH(8);

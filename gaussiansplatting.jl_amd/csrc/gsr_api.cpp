@@ -108,12 +108,12 @@ struct gsr_handle {
     int grid_x, grid_y, n_tiles;
     // ImageState (states.jl:99-111) + tile bookkeeping
     DevBuf ranges, n_contrib, final_T, tile_count, tile_start, cursor, totals;
-    // GeometryState (states.jl:2-47), repacked as float4 planes
-    DevBuf g0, g1, g2, g3, radii, rect;
+    // GeometryState (states.jl:2-47), repacked as one 64-byte record per Gaussian
+    DevBuf geo, gnormal, radii, bsum, bpre;
     // BinningState (states.jl:66-85): unsorted keys, sorted ids, sorted splat stream
     DevBuf keys, values_sorted, s0, s1, s2, s3, big_scratch;
-    // backward accumulators (rasterizer.jl:437-446)
-    DevBuf a0, a1, a2, vmean2d;
+    // backward: per-instance gradient rows + instance position map; gstate.∇means_2d
+    DevBuf rows, inst_pos, vmean2d;
     // loss-head scratch
     DevBuf d0, d1, d2, partial;
     uint32_t* host_totals = nullptr;  // pinned: D, max tile count, #oversized tiles, slab ctr, n_visible
@@ -144,15 +144,13 @@ GsrCam make_cam(const gsr_handle* h, const gsr_camera* c) {
 }
 
 GsrGeom geom_of(const gsr_handle* h) {
-    return GsrGeom{h->g0.as<float4>(), h->g1.as<float4>(), h->g2.as<float4>(), h->g3.as<float4>(),
-                   h->radii.as<int32_t>(), h->rect.as<ushort4>()};
+    return GsrGeom{h->geo.as<GsrGeoRec>(), h->gnormal.as<float4>(), h->radii.as<int32_t>(), h->bsum.as<uint32_t>(),
+                   h->bpre.as<uint32_t>()};
 }
 GsrStream stream_of(const gsr_handle* h) {
     return GsrStream{h->s0.as<float4>(), h->s1.as<float4>(), h->s2.as<float4>(), h->s3.as<float4>()};
 }
-GsrAcc acc_of(const gsr_handle* h) {
-    return GsrAcc{h->a0.as<float4>(), h->a1.as<float4>(), h->a2.as<float4>(), h->vmean2d.as<float2>()};
-}
+GsrInst inst_of(const gsr_handle* h) { return GsrInst{h->rows.as<float4>(), h->inst_pos.as<uint32_t>()}; }
 
 int check_inputs(const gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam) {
     if (!h || !in || !cam) return fail(GSR_E_INVALID_ARG, "null handle / inputs / camera");
@@ -188,8 +186,8 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
     if (h->grid_x > 65535 || h->grid_y > 65535) { delete h; return fail(GSR_E_INVALID_ARG, "resolution too large"); }
     h->n_tiles = h->grid_x * h->grid_y;
     DevBuf* list[] = {&h->ranges, &h->n_contrib, &h->final_T, &h->tile_count, &h->tile_start, &h->cursor, &h->totals,
-                      &h->g0, &h->g1, &h->g2, &h->g3, &h->radii, &h->rect, &h->keys, &h->values_sorted, &h->s0,
-                      &h->s1, &h->s2, &h->s3, &h->big_scratch, &h->a0, &h->a1, &h->a2, &h->vmean2d, &h->d0, &h->d1,
+                      &h->geo, &h->gnormal, &h->radii, &h->bsum, &h->bpre, &h->keys, &h->values_sorted, &h->s0,
+                      &h->s1, &h->s2, &h->s3, &h->big_scratch, &h->rows, &h->inst_pos, &h->vmean2d, &h->d0, &h->d1,
                       &h->d2, &h->partial};
     for (DevBuf* b : list) h->all[h->n_all++] = b;
     const size_t P = (size_t)cfg->width * cfg->height, T = (size_t)h->n_tiles;
@@ -221,8 +219,8 @@ int gsr_destroy(gsr_handle* h) {
 
 int gsr_release_scene_buffers(gsr_handle* h) {
     if (!h) return fail(GSR_E_INVALID_ARG, "null handle");
-    DevBuf* scene[] = {&h->g0, &h->g1, &h->g2, &h->g3, &h->radii, &h->rect, &h->keys, &h->values_sorted, &h->s0, &h->s1,
-                       &h->s2, &h->s3, &h->big_scratch, &h->a0, &h->a1, &h->a2, &h->vmean2d};
+    DevBuf* scene[] = {&h->geo, &h->gnormal, &h->radii, &h->bsum, &h->bpre, &h->keys, &h->values_sorted, &h->s0, &h->s1,
+                       &h->s2, &h->s3, &h->big_scratch, &h->rows, &h->inst_pos, &h->vmean2d};
     for (DevBuf* b : scene) {
         int rc = b->release();
         if (rc) return rc;
@@ -251,8 +249,10 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     h->fwd_valid = false;
 
     const size_t nn = n > 0 ? (size_t)n : 1;
-    if ((rc = h->g0.ensure(nn * 16)) || (rc = h->g1.ensure(nn * 16)) || (rc = h->g2.ensure(nn * 16)) ||
-        (rc = h->radii.ensure(nn * 4)) || (rc = h->rect.ensure(nn * 8)) || (C > 5 && (rc = h->g3.ensure(nn * 16))))
+    const int n_blocks = (n + 255) / 256;
+    if ((rc = h->geo.ensure(nn * 64)) || (rc = h->radii.ensure(nn * 4)) || (rc = h->vmean2d.ensure(nn * 8)) ||
+        (rc = h->bsum.ensure((size_t)(n_blocks + 1) * 4)) || (rc = h->bpre.ensure((size_t)(n_blocks + 1) * 4)) ||
+        (C > 5 && (rc = h->gnormal.ensure(nn * 16))))
         return rc;
 
     GsrCam k = make_cam(h, cam);
@@ -265,7 +265,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     h->prof.end(s);
     h->prof.begin(ST_SCAN, s);
     gsr_launch_tile_scan(s, h->n_tiles, h->tile_count.as<uint32_t>(), h->tile_start.as<uint32_t>(),
-                         h->cursor.as<uint32_t>(), totals);
+                         h->cursor.as<uint32_t>(), totals, n_blocks, h->bsum.as<uint32_t>(), h->bpre.as<uint32_t>());
     h->prof.end(s);
     HIPCHK(hipGetLastError());
     // the one host sync of the path: instance count D (reference: rasterizer.jl:337)
@@ -293,6 +293,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     }
     const float slack = 1.25f;  // instance count drifts slowly between training steps
     if ((rc = h->keys.ensure(D * 8, slack)) || (rc = h->values_sorted.ensure(D * 4, slack)) ||
+        (rc = h->inst_pos.ensure(D * 4, slack)) || (rc = h->rows.ensure(D * 64, slack)) ||
         (rc = h->s0.ensure(D * 16, slack)) || (rc = h->s1.ensure(D * 16, slack)) ||
         (rc = h->s2.ensure(D * 16, slack)) || (C > 5 && (rc = h->s3.ensure(D * 16, slack))))
         return rc;
@@ -308,7 +309,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     h->prof.begin(ST_SORT, s);
     gsr_launch_tile_sort(s, h->n_tiles, h->grid_x, C, h->tile_start.as<uint32_t>(), h->keys.as<uint64_t>(),
                          h->big_scratch.as<uint64_t>(), big_stride, totals + 3, geom_of(h), stream_of(h),
-                         h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>());
+                         h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>(), h->inst_pos.as<uint32_t>());
     h->prof.end(s);
     h->prof.begin(ST_COMPOSITE_FWD, s);
     gsr_launch_composite_fwd(s, C, k, h->tile_start.as<uint32_t>(), stream_of(h), in->background, image_out,
@@ -334,15 +335,9 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
     hipStream_t s = (hipStream_t)stream_v;
     const int C = h->cfg.mode, n = in->n;
     if (n == 0) return GSR_OK;
-    const size_t nn = (size_t)n;
-    if ((rc = h->a0.ensure(nn * 16)) || (rc = h->a1.ensure(nn * 16)) || (rc = h->vmean2d.ensure(nn * 8)) ||
-        (C > 5 && (rc = h->a2.ensure(nn * 16))))
-        return rc;
     h->prof.begin(ST_ZERO_ACC, s);
-    HIPCHK(hipMemsetAsync(h->a0.p, 0, nn * 16, s));
-    HIPCHK(hipMemsetAsync(h->a1.p, 0, nn * 16, s));
-    HIPCHK(hipMemsetAsync(h->vmean2d.p, 0, nn * 8, s));
-    if (C > 5) HIPCHK(hipMemsetAsync(h->a2.p, 0, nn * 16, s));
+    // rows not touched by any pixel must read as zero in the per-Gaussian sum
+    if (h->last_D > 0) HIPCHK(hipMemsetAsync(h->rows.p, 0, (size_t)h->last_D * 64, s));
     if (g->vR) {
         HIPCHK(hipMemsetAsync(g->vR, 0, 9 * 4, s));
         HIPCHK(hipMemsetAsync(g->vt, 0, 3 * 4, s));
@@ -352,12 +347,12 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
     h->prof.begin(ST_COMPOSITE_BWD, s);
     if (h->last_D > 0)
         gsr_launch_composite_bwd(s, C, k, h->tile_start.as<uint32_t>(), stream_of(h), in->background, vpixels,
-                                 h->n_contrib.as<uint32_t>(), h->final_T.as<float>(), acc_of(h));
+                                 h->n_contrib.as<uint32_t>(), h->final_T.as<float>(), inst_of(h));
     h->prof.end(s);
     h->prof.begin(ST_PERGAUSS_BWD, s);
     gsr_launch_pergauss_bwd(s, n, in->n_coeffs, in->sh_degree, C, in->means, in->scales, in->rotations, in->shs, k,
-                            geom_of(h), acc_of(h), g->vmeans, g->vshs, g->vopacities, g->vscales, g->vrotations,
-                            g->vR, g->vt);
+                            geom_of(h), inst_of(h), h->vmean2d.as<float2>(), g->vmeans, g->vshs, g->vopacities,
+                            g->vscales, g->vrotations, g->vR, g->vt);
     h->prof.end(s);
     HIPCHK(hipGetLastError());
     return GSR_OK;
@@ -376,13 +371,10 @@ int gsr_buffer(const gsr_handle* h, int which, const void** dev_ptr, size_t* byt
         case GSR_BUF_FINAL_T: b = &h->final_T; sz = P * 4; break;
         case GSR_BUF_TILE_RANGES: b = &h->ranges; sz = 2 * T * 4; break;
         case GSR_BUF_VALUES_SORTED: b = &h->values_sorted; sz = D * 4; break;
-        case GSR_BUF_GEOM0: b = &h->g0; sz = n * 16; break;
-        case GSR_BUF_GEOM1: b = &h->g1; sz = n * 16; break;
-        case GSR_BUF_GEOM2: b = &h->g2; sz = n * 16; break;
-        case GSR_BUF_GEOM3: b = &h->g3; sz = h->cfg.mode > 5 ? n * 16 : 0; break;
-        case GSR_BUF_RECT: b = &h->rect; sz = n * 8; break;
-        case GSR_BUF_GRAD_ACC0: b = &h->a0; sz = n * 16; break;
-        case GSR_BUF_GRAD_ACC1: b = &h->a1; sz = n * 16; break;
+        case GSR_BUF_GEOM: b = &h->geo; sz = n * 64; break;
+        case GSR_BUF_NORMALS: b = &h->gnormal; sz = h->cfg.mode > 5 ? n * 16 : 0; break;
+        case GSR_BUF_INST_POS: b = &h->inst_pos; sz = D * 4; break;
+        case GSR_BUF_GRAD_ROWS: b = &h->rows; sz = D * 64; break;
         default: return fail(GSR_E_INVALID_ARG, "unknown buffer id %d", which);
     }
     if (sz > b->cap) sz = 0;  // not produced yet

@@ -24,49 +24,58 @@ struct GsrCam {
     const float* t_dev;
 };
 
-// Per-Gaussian geometry written by preprocess (SoA of float4 planes, 16 B/lane coalesced).
+// Per-Gaussian geometry written by preprocess: ONE 64-byte record per Gaussian (a gather by
+// id — the tile sort does 5.7 M of them per view — touches a single cache line).
+//   q0 = mean2d.x, mean2d.y, conic.a, conic.b
+//   q1 = conic.c, opacity, r, g
+//   q2 = b, clamped bits (u32), depth, lpre (u32: exclusive prefix of tile-rect areas inside the
+//        Gaussian's 256-wide block; + bpre[i >> 8] = offset of its instances in inst_pos)
+//   q3 = rect xmin | ymin << 16, rect xmax | ymax << 16 (u32), unused, unused
+struct GsrGeoRec { float4 q0, q1, q2, q3; };
 struct GsrGeom {
-    float4* g0;      // mean2d.x, mean2d.y, conic.a, conic.b
-    float4* g1;      // conic.c, opacity, r, g
-    float4* g2;      // b, clamped bits, depth, unused
-    float4* g3;      // normal xyz (C == 8) or nullptr
+    GsrGeoRec* rec;
+    float4* normal;   // camera-space normal (C == 8) or nullptr
     int32_t* radii;
-    ushort4* rect;   // tile rect xmin,ymin,xmax,ymax
+    uint32_t* bsum;   // per 256-Gaussian block: sum of tile-rect areas (scanned into bpre by tile_scan)
+    uint32_t* bpre;
 };
 
-// Sorted per-instance splat stream written by tile_sort (same planes, id replaces clamped bits).
+// Sorted per-instance splat stream written by tile_sort (planes of float4, coalesced).
 struct GsrStream {
-    float4* s0;
-    float4* s1;
+    float4* s0;  // mean2d.x, mean2d.y, conic.a, conic.b
+    float4* s1;  // conic.c, opacity, r, g
     float4* s2;  // b, id (uint bits), depth, row mask (uint bits: rows of the tile the splat can touch)
     float4* s3;  // normal (C == 8) or nullptr
 };
 
-struct GsrAcc {  // backward accumulators, zero-filled per call
-    float4* a0;      // v rgb, v opacity
-    float4* a1;      // v conic a,b,c, v depth
-    float4* a2;      // v normal (C == 8) or nullptr
-    float2* vmean2d; // exposed as gstate.∇means_2d
+// Backward: per-INSTANCE gradient rows (plain stores, no atomics) + the map from a
+// Gaussian's k-th covered tile to its sorted position, so the per-Gaussian kernel can sum
+// its rows in a fixed order (deterministic gradients).
+//   row = 4 x float4: {v r, v g, v b, v opacity}, {v conic a,b,c, v depth}, {v mean2d x,y, v normal x,y}, {v normal z,-,-,-}
+struct GsrInst {
+    float4* rows;        // D x 4 float4, zero-filled per backward
+    uint32_t* inst_pos;  // D: sorted position of instance (goff(i) + k)
 };
 
 // ---- pergauss.hip (compiled with -ffp-contract=off: bit-reproducible fp32) ----
 void gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels, const float* means,
                            const float* scales, const float* rots, const float* opac, const float* shs, GsrCam cam,
                            GsrGeom geom, uint32_t* tile_count, uint32_t* n_visible);
+void gsr_launch_scatter(hipStream_t s, int n, GsrCam cam, GsrGeom geom, uint32_t* cursor, uint64_t* keys);
 void gsr_launch_pergauss_bwd(hipStream_t s, int n, int K, int degree, int channels, const float* means,
                              const float* scales, const float* rots, const float* shs, GsrCam cam, GsrGeom geom,
-                             GsrAcc acc, float* vmeans, float* vshs, float* vopac, float* vscales, float* vrots,
-                             float* vR, float* vt);
+                             GsrInst inst, float2* vmean2d, float* vmeans, float* vshs, float* vopac,
+                             float* vscales, float* vrots, float* vR, float* vt);
 
 // ---- binning.hip ----
-// exclusive scan of tile_count -> tile_start[T+1], cursor[T] = tile_start;
+// exclusive scan of tile_count -> tile_start[T+1], cursor[T] = tile_start; and of the per-block
+// rect-area sums bsum[nb] -> bpre[nb];
 // totals[0] = D, totals[1] = max count, totals[2] = #tiles over GSR_SORT_LDS_CAP, totals[3] = slab counter (0)
 void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count, uint32_t* tile_start,
-                          uint32_t* cursor, uint32_t* totals);
-void gsr_launch_scatter(hipStream_t s, int n, GsrCam cam, GsrGeom geom, uint32_t* cursor, uint64_t* keys);
+                          uint32_t* cursor, uint32_t* totals, int n_blocks, const uint32_t* bsum, uint32_t* bpre);
 void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start, uint64_t* keys,
                           uint64_t* big_scratch, uint32_t big_scratch_stride, uint32_t* slab_counter, GsrGeom geom,
-                          GsrStream stream, uint32_t* values_sorted, uint32_t* ranges);
+                          GsrStream stream, uint32_t* values_sorted, uint32_t* ranges, uint32_t* inst_pos);
 
 // ---- composite.hip ----
 void gsr_launch_composite_fwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start, GsrStream stream,
@@ -74,7 +83,7 @@ void gsr_launch_composite_fwd(hipStream_t s, int channels, GsrCam cam, const uin
                               uint8_t* covis, float* uncert);
 void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start, GsrStream stream,
                               const float* background, const float* vpixels, const uint32_t* n_contrib,
-                              const float* final_T, GsrAcc acc);
+                              const float* final_T, GsrInst inst);
 
 // ---- ssim.hip ----
 void gsr_launch_ssim_fwd(hipStream_t s, int W, int H, int CH, int B, const float* img, const float* ref, float C1,

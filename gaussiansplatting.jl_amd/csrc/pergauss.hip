@@ -10,6 +10,7 @@
 // the per-Gaussian floats are bit-reproducible against the CPU oracle.  These
 // kernels are HBM-bound (192 B of SH per Gaussian), the extra VALU ops are free.
 #include "gsr_kernels.h"
+#include "wave_reduce.h"
 
 namespace {
 
@@ -202,6 +203,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
                                                          uint32_t* __restrict__ n_visible) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     bool visible = false;
+    uint32_t area = 0, clamp_bits = 0;
+    float m2[2] = {0, 0}, conic[3] = {0, 0, 0}, rgb[3] = {0, 0, 0}, mc_z = 0.0f;
+    int rmin[2] = {0, 0}, rmax[2] = {0, 0};
     if (i < n) {
         M33 R; float t[3];
         load_pose(cam, R, t);
@@ -209,8 +213,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
         float mc[3];
 #pragma unroll
         for (int r = 0; r < 3; r++) mc[r] = (R.m[r][0] * p[0] + R.m[r][1] * p[1] + R.m[r][2] * p[2]) + t[r];
+        mc_z = mc[2];
         int radius = 0;
-        float m2[2] = {0, 0}, conic[3] = {0, 0, 0};
         M33 Rg; float s[3];
         if (cam.near_plane < mc[2] && mc[2] < cam.far_plane) {
             float qn[4], inv_norm;
@@ -267,8 +271,6 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
             float b[16];
             sh_basis<DEG>(d, b);
             constexpr int NB = (DEG + 1) * (DEG + 1);
-            float rgb[3];
-            uint32_t clamp_bits = 0;
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 float res = b[0] * sh[c];
@@ -278,22 +280,43 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
                 if (res < 0.0f) clamp_bits |= 1u << c;
                 rgb[c] = fmaxf(0.0f, res);
             }
-            geom.g0[i] = make_float4(m2[0], m2[1], conic[0], conic[1]);
-            geom.g1[i] = make_float4(conic[2], opac[i], rgb[0], rgb[1]);
-            geom.g2[i] = make_float4(rgb[2], __uint_as_float(clamp_bits), mc[2], 0.0f);
             if (channels > 5) {
                 float nn[3]; int k; float sg;
                 gaussian_normal(R, Rg, s, mc, nn, k, sg);
-                geom.g3[i] = make_float4(nn[0], nn[1], nn[2], 0.0f);
+                geom.normal[i] = make_float4(nn[0], nn[1], nn[2], 0.0f);
             }
-            int rmin[2], rmax[2];
             get_rect(m2[0], m2[1], radius, cam.grid_x, cam.grid_y, rmin, rmax);
-            geom.rect[i] = make_ushort4((unsigned short)rmin[0], (unsigned short)rmin[1], (unsigned short)rmax[0],
-                                        (unsigned short)rmax[1]);
+            area = (uint32_t)((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]));
             for (int y = rmin[1]; y < rmax[1]; y++)
                 for (int x = rmin[0]; x < rmax[0]; x++) atomicAdd(&tile_count[y * cam.grid_x + x], 1u);
-        } else {
-            geom.rect[i] = make_ushort4(0, 0, 0, 0);
+        }
+    }
+    // Exclusive scan of the tile-rect areas inside the block: with bpre[block] (tile_scan) it
+    // gives every Gaussian the offset of its instance slots in inst_pos — the reference's
+    // cumsum!(tiles_touched) (rasterizer.jl:333-335), restated hierarchically.
+    {
+        __shared__ uint32_t wsum[4];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        uint32_t x = area;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t y = __shfl_up(x, off);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        const uint32_t lpre = woff + x - area;
+        if (threadIdx.x == 255) geom.bsum[blockIdx.x] = lpre + area;
+        if (visible) {
+            GsrGeoRec rec;
+            rec.q0 = make_float4(m2[0], m2[1], conic[0], conic[1]);
+            rec.q1 = make_float4(conic[2], opac[i], rgb[0], rgb[1]);
+            rec.q2 = make_float4(rgb[2], __uint_as_float(clamp_bits), mc_z, __uint_as_float(lpre));
+            rec.q3 = make_float4(__uint_as_float((uint32_t)rmin[0] | ((uint32_t)rmin[1] << 16)),
+                                 __uint_as_float((uint32_t)rmax[0] | ((uint32_t)rmax[1] << 16)), 0.0f, 0.0f);
+            geom.rec[i] = rec;
         }
     }
     unsigned long long m = __ballot(visible);
@@ -311,24 +334,92 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(int n, int K, int cha
                                                            const float* __restrict__ scales,
                                                            const float4* __restrict__ rots,
                                                            const float* __restrict__ shs, GsrCam cam, GsrGeom geom,
-                                                           GsrAcc acc, float* __restrict__ vmeans,
+                                                           GsrInst inst, float2* __restrict__ vmean2d_out,
+                                                           float* __restrict__ vmeans,
                                                            float* __restrict__ vshs, float* __restrict__ vopac,
                                                            float* __restrict__ vscales, float4* __restrict__ vrots,
                                                            float* __restrict__ vR_out, float* __restrict__ vt_out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     float poseR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, poset[3] = {0, 0, 0};
+    const bool visible = i < n && geom.radii[i] > 0;
+
+    // ---- sum this Gaussian's per-instance gradient rows (written by composite_bwd) ----
+    // acc: [0..2] v rgb, [3] v opacity, [4..6] v conic, [7] v depth, [8..9] v mean2d, [10..12] v normal
+    GsrGeoRec rec;
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) acc[k] = 0.0f;
+    uint32_t area = 0, goff = 0;
+    if (visible) {
+        rec = geom.rec[i];
+        const uint32_t lo = __float_as_uint(rec.q3.x), hi = __float_as_uint(rec.q3.y);
+        area = ((hi & 0xFFFFu) - (lo & 0xFFFFu)) * ((hi >> 16) - (lo >> 16));
+        goff = geom.bpre[i >> 8] + __float_as_uint(rec.q2.w);
+    }
+    constexpr uint32_t BIG = 48;  // larger footprints are summed by the whole wave
+    if (area <= BIG) {
+        for (uint32_t k = 0; k < area; k++) {  // fixed order -> bit-reproducible gradients
+            const float4* row = inst.rows + (size_t)4 * inst.inst_pos[goff + k];
+            const float4 f0 = row[0], f1 = row[1], f2 = row[2];
+            acc[0] += f0.x; acc[1] += f0.y; acc[2] += f0.z; acc[3] += f0.w;
+            acc[4] += f1.x; acc[5] += f1.y; acc[6] += f1.z; acc[7] += f1.w;
+            acc[8] += f2.x; acc[9] += f2.y;
+            if (channels > 5) {
+                const float4 f3 = row[3];
+                acc[10] += f2.z; acc[11] += f2.w; acc[12] += f3.x;
+            }
+        }
+    }
+    {
+        __shared__ float bounce[4][16];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const gsr::LaneBits lb(lane);
+        const int slot = gsr::wave_reduce_index<13>(lane);
+        unsigned long long big = __ballot(area > BIG);
+        while (big) {
+            const int src = __builtin_ctzll(big);
+            big &= big - 1;
+            const uint32_t a = __shfl(area, src), o = __shfl(goff, src);
+            float part[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) part[k] = 0.0f;
+            for (uint32_t k = lane; k < a; k += 64) {
+                const float4* row = inst.rows + (size_t)4 * inst.inst_pos[o + k];
+                const float4 f0 = row[0], f1 = row[1], f2 = row[2];
+                part[0] += f0.x; part[1] += f0.y; part[2] += f0.z; part[3] += f0.w;
+                part[4] += f1.x; part[5] += f1.y; part[6] += f1.z; part[7] += f1.w;
+                part[8] += f2.x; part[9] += f2.y;
+                if (channels > 5) {
+                    const float4 f3 = row[3];
+                    part[10] += f2.z; part[11] += f2.w; part[12] += f3.x;
+                }
+            }
+            const float total = gsr::wave_reduce_transposed<13>(part, lb);
+            if (gsr::wave_reduce_writer(lane)) bounce[wave][slot] = total;
+            __builtin_amdgcn_wave_barrier();
+            if (lane == src) {
+#pragma unroll
+                for (int k = 0; k < 13; k++) acc[k] = bounce[wave][k];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
     if (i < n) {
         float* vsh = vshs + (size_t)3 * K * i;
-        if (!(geom.radii[i] > 0)) {
+        if (!visible) {
 #pragma unroll
             for (int c = 0; c < 3; c++) { vmeans[3 * i + c] = 0.0f; vscales[3 * i + c] = 0.0f; }
             vrots[i] = make_float4(0, 0, 0, 0);
             vopac[i] = 0.0f;
+            vmean2d_out[i] = make_float2(0.0f, 0.0f);
             for (int k = 0; k < 3 * K; k++) vsh[k] = 0.0f;
         } else {
-            const float4 a0 = acc.a0[i], a1 = acc.a1[i];
-            const float2 vm2 = acc.vmean2d[i];
-            const float4 g0 = geom.g0[i], g1 = geom.g1[i], g2 = geom.g2[i];
+            const float4 a0 = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            const float4 a1 = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            const float2 vm2 = make_float2(acc[8], acc[9]);
+            vmean2d_out[i] = vm2;  // gstate.∇means_2d, read by densification (strategy.jl:85-86)
+            const float4 g0 = rec.q0, g1 = rec.q1, g2 = rec.q2;
             vopac[i] = a0.w;
             M33 R; float t[3];
             load_pose(cam, R, t);
@@ -423,7 +514,7 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(int n, int K, int cha
 #pragma unroll
                 for (int b = 0; b < 3; b++) vRg.m[a][b] = 0.0f;
             if (channels > 5) {
-                const float4 a2 = acc.a2[i];
+                const float4 a2 = make_float4(acc[10], acc[11], acc[12], 0.0f);
                 float nn[3]; int k; float sg;
                 gaussian_normal(R, Rg, s, mc, nn, k, sg);
 #pragma unroll
@@ -546,7 +637,31 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(int n, int K, int cha
     }
 }
 
+// ---- counting scatter (duplicate_with_keys! restated per tile; utils.jl:96-119) ----
+__global__ __launch_bounds__(256) void scatter_kernel(int n, int grid_x, const int32_t* __restrict__ radii,
+                                                      const GsrGeoRec* __restrict__ rec,
+                                                      uint32_t* __restrict__ cursor, uint64_t* __restrict__ keys) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (!(radii[i] > 0)) return;
+    const float4 q2 = rec[i].q2, q3 = rec[i].q3;
+    const uint32_t lo = __float_as_uint(q3.x), hi = __float_as_uint(q3.y);
+    const int x0 = lo & 0xFFFFu, y0 = lo >> 16, x1 = hi & 0xFFFFu, y1 = hi >> 16;
+    const uint64_t key = ((uint64_t)__float_as_uint(q2.z) << 32) | (uint32_t)i;
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++) {
+            const uint32_t slot = atomicAdd(&cursor[y * grid_x + x], 1u);
+            keys[slot] = key;
+        }
+}
+
 }  // namespace
+
+void gsr_launch_scatter(hipStream_t s, int n, GsrCam cam, GsrGeom geom, uint32_t* cursor, uint64_t* keys) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, cam.grid_x, geom.radii, geom.rec,
+                       cursor, keys);
+}
 
 void gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels, const float* means,
                            const float* scales, const float* rots, const float* opac, const float* shs, GsrCam cam,
@@ -568,15 +683,15 @@ void gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels
 
 void gsr_launch_pergauss_bwd(hipStream_t s, int n, int K, int degree, int channels, const float* means,
                              const float* scales, const float* rots, const float* shs, GsrCam cam, GsrGeom geom,
-                             GsrAcc acc, float* vmeans, float* vshs, float* vopac, float* vscales, float* vrots,
-                             float* vR, float* vt) {
+                             GsrInst inst, float2* vmean2d, float* vmeans, float* vshs, float* vopac,
+                             float* vscales, float* vrots, float* vR, float* vt) {
     if (n <= 0) return;
     dim3 grid((n + 255) / 256), block(256);
     const float4* r4 = reinterpret_cast<const float4*>(rots);
     float4* vr4 = reinterpret_cast<float4*>(vrots);
 #define LAUNCH(D)                                                                                                 \
     hipLaunchKernelGGL(pergauss_bwd_kernel<D>, grid, block, 0, s, n, K, channels, means, scales, r4, shs, cam,    \
-                       geom, acc, vmeans, vshs, vopac, vscales, vr4, vR, vt)
+                       geom, inst, vmean2d, vmeans, vshs, vopac, vscales, vr4, vR, vt)
     switch (degree) {
         case 0: LAUNCH(0); break;
         case 1: LAUNCH(1); break;

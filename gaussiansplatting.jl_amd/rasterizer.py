@@ -156,15 +156,14 @@ class GaussianRasterizer:
     def geometry(self):
         """means_2d, conics, depths, rgbs, clamped, tile rects of the last forward."""
         n = self._n
-        g0 = self._buffer(L.BUF_GEOM0, torch.float32, (n, 4))
-        g1 = self._buffer(L.BUF_GEOM1, torch.float32, (n, 4))
-        g2 = self._buffer(L.BUF_GEOM2, torch.float32, (n, 4))
-        rect = self._buffer(L.BUF_RECT, torch.int16, (n, 4))
-        out = dict(means2d=g0[:, :2], conics=torch.stack([g0[:, 2], g0[:, 3], g1[:, 0]], 1), opacities=g1[:, 1],
-                   rgbs=torch.stack([g1[:, 2], g1[:, 3], g2[:, 0]], 1), clamped_bits=g2[:, 1].view(torch.int32),
-                   depths=g2[:, 2], rect=rect)
+        g = self._buffer(L.BUF_GEOM, torch.float32, (n, 16))
+        gi = g.view(torch.int32)
+        lo, hi = gi[:, 12], gi[:, 13]
+        rect = torch.stack([lo & 0xFFFF, lo >> 16, hi & 0xFFFF, hi >> 16], 1)
+        out = dict(means2d=g[:, 0:2], conics=g[:, 2:5], opacities=g[:, 5], rgbs=g[:, 6:9], clamped_bits=gi[:, 9],
+                   depths=g[:, 10], rect=rect)
         if self.channels > 5:
-            out["normals"] = self._buffer(L.BUF_GEOM3, torch.float32, (n, 4))[:, :3]
+            out["normals"] = self._buffer(L.BUF_NORMALS, torch.float32, (n, 4))[:, :3]
         return out
 
     # ---- functor prologue: rasterizer.jl:200-253 ----

@@ -146,13 +146,13 @@ enum {
     GSR_BUF_FINAL_T = 3,       /* float (W,H)      istate.accum_α */
     GSR_BUF_TILE_RANGES = 4,   /* uint32 (2,T)     istate.ranges */
     GSR_BUF_VALUES_SORTED = 5, /* uint32 (D)       bstate.gaussian_values_sorted (0-based ids) */
-    GSR_BUF_GEOM0 = 6,         /* float4 (N): mean2d.x, mean2d.y, conic.a, conic.b   (stale where radii==0) */
-    GSR_BUF_GEOM1 = 7,         /* float4 (N): conic.c, opacity, rgb.r, rgb.g */
-    GSR_BUF_GEOM2 = 8,         /* float4 (N): rgb.b, clamped bits (uint32: bit c = channel c), depth, unused */
-    GSR_BUF_GEOM3 = 9,         /* float4 (N): normal.xyz (mode RGBDN only) */
-    GSR_BUF_RECT = 10,         /* uint16 x4 (N): tile rect xmin,ymin,xmax,ymax (utils.jl:18-29) */
-    GSR_BUF_GRAD_ACC0 = 11,    /* float4 (N): v rgb, v opacity   (after gsr_backward) */
-    GSR_BUF_GRAD_ACC1 = 12     /* float4 (N): v conic a,b,c, v depth */
+    GSR_BUF_GEOM = 6,          /* 16 x 32-bit (N): one 64-byte record per Gaussian (stale where radii == 0):
+                                *   [0..1] mean2d, [2..4] conic a,b,c, [5] opacity, [6..8] rgb, [9] clamped bits (u32,
+                                *   bit c = channel c), [10] depth, [11] u32 instance-slot prefix inside the 256-block,
+                                *   [12] u32 rect xmin|ymin<<16, [13] u32 rect xmax|ymax<<16 (utils.jl:18-29), [14..15] - */
+    GSR_BUF_NORMALS = 7,       /* float4 (N): camera-space normal (mode RGBDN only) */
+    GSR_BUF_INST_POS = 8,      /* uint32 (D): sorted position of every (Gaussian, covered tile) instance */
+    GSR_BUF_GRAD_ROWS = 9      /* 16 x float (D): per-instance gradient rows of the last gsr_backward */
 };
 GSR_API int gsr_buffer(const gsr_handle* h, int which, const void** dev_ptr, size_t* bytes);
 

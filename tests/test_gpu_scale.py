@@ -87,11 +87,13 @@ def _properties(pkg, orc, n, W, H, seed, with_oracle_fwd):
     v2 = dev(pkg.synthetic.make_vpixels(W, H, 3, seed + 1))
     g1 = [o.clone() for o in run.backward(v1.cpu().numpy())[:5]]
     g2 = [o.clone() for o in run.backward(v2.cpu().numpy())[:5]]
-    g12 = run.backward((v1 + 2 * v2).cpu().numpy())[:5]
+    g12 = [o.clone() for o in run.backward((v1 + 2 * v2).cpu().numpy())[:5]]
     for a, b, c in zip(g1, g2, g12):
         ref = (a + 2 * b)
         assert float((c - ref).norm() / ref.norm()) < 1e-4
     assert all(torch.isfinite(o).all() for o in g12)
+    g12b = run.backward((v1 + 2 * v2).cpu().numpy())[:5]
+    assert all(torch.equal(a, b) for a, b in zip(g12, g12b)), "gradients are bit-deterministic"
     vis = run.rast.radii > 0
     assert not g12[0][~vis].any() and not g12[1][~vis].any()
 

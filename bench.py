@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--no-loss", action="store_true", help="config 2 style: random cotangent instead of L1/SSIM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--views", type=int, default=8, help="size of the multi-view batch the poses are drawn from")
+    ap.add_argument("--reference-lists", action="store_true",
+                    help="keep the reference's (Gaussian, tile) instance lists instead of exact footprint culling")
     args = ap.parse_args()
 
     pkg = gsr_pkg.load()
@@ -89,7 +91,7 @@ def main():
     params = [to(s.means), to(s.shs), to(s.opacities.reshape(-1, 1)), to(s.scales), to(s.rotations)]
     target = to(pkg.synthetic.make_target(W, H, args.seed + view))
     vpix_fixed = to(pkg.synthetic.make_vpixels(W, H, 3, args.seed + view))
-    rast = pkg.rasterizer.GaussianRasterizer(W, H, mode="rgb", device=dev)
+    rast = pkg.rasterizer.GaussianRasterizer(W, H, mode="rgb", device=dev, exact_tile_cull=not args.reference_lists)
     arena = torch.empty(D.arena_numel(N, K), device=dev, dtype=torch.float32)
     bg = (0.0, 0.0, 0.0)
 
@@ -156,6 +158,7 @@ def main():
                                 if not args.no_loss and (N, W, H, deg) == (1_000_000, 1920, 1080, 3) else
                                 f"N={N} SH{deg} {W}x{H} fwd{'' if args.no_loss else '+loss'}+bwd"),
                    "n_gaussians": N, "visible": V, "tile_instances": Dn, "views_per_gpu": 1,
+                   "tile_lists": "reference" if args.reference_lists else "exact footprint cull (same outputs)",
                    "parallelism": f"view-parallel x{world}, 1 all-reduce of {arena.numel() * 4 / 1e6:.0f} MB"},
         "roofline": roofline,
     }

@@ -15,6 +15,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gsr.h")
 
 GSR_OK, GSR_E_INVALID_ARG, GSR_E_OOM, GSR_E_HIP, GSR_E_STATE = 0, -1, -2, -3, -4
 MODES = {"rgb": 3, "rgbd": 5, "rgbdn": 8}
+FLAG_EXACT_TILE_CULL = 1
 
 (BUF_RADII, BUF_GRAD_MEANS2D, BUF_N_CONTRIB, BUF_FINAL_T, BUF_TILE_RANGES, BUF_VALUES_SORTED, BUF_GEOM, BUF_NORMALS,
  BUF_INST_POS, BUF_GRAD_ROWS) = range(10)
@@ -28,7 +29,7 @@ class GsrError(RuntimeError):
 
 class Config(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("mode", C.c_int32), ("near_plane", C.c_float),
-                ("far_plane", C.c_float), ("radius_clip", C.c_int32), ("blur_eps", C.c_float)]
+                ("far_plane", C.c_float), ("radius_clip", C.c_int32), ("blur_eps", C.c_float), ("flags", C.c_uint32)]
 
 
 class Inputs(C.Structure):

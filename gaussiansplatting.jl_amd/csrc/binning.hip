@@ -14,6 +14,7 @@
 // bits, ties by ascending id.  Unlike a global 64-bit radix sort this moves each instance
 // through HBM twice (8 B key out, 8 B key in) instead of ~8 passes x 12 B.
 #include "gsr_kernels.h"
+#include "tile_mask.h"
 
 namespace {
 
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint
         if (tid == 1023) carry_s = excl + v;
         __syncthreads();
     }
+    if (tid == 0) totals[5] = carry_s;  // sum of tile-rect areas = number of instance slots in inst_pos
 }
 
 // ---- per-tile sort ----
@@ -127,37 +129,6 @@ __device__ __forceinline__ void bitonic_sort(uint64_t* buf, uint32_t m, int tid,
             __syncthreads();
         }
     }
-}
-
-// Conservative 16-bit row mask of an instance: bit r is set unless NO pixel of row r of the
-// tile can reach alpha >= 1/255 (render.jl:95), i.e. unless the ellipse
-// {sigma <= ln(255*opacity)} misses the row's pixel centres.  The composite kernels use it
-// only to skip work; every surviving (pixel, splat) pair still runs the exact test, so the
-// slack below never changes a result.
-__device__ __forceinline__ uint32_t instance_row_mask(const float4 g0, const float4 g1, int X0, int Y0) {
-    const float mx = g0.x, my = g0.y, a = g0.z, b = g0.w, c = g1.x, o = g1.y;
-    const float tau = __logf(255.0f * o) + 2e-3f;  // sigma <= tau  <=>  alpha >= 1/255 (with slack)
-    if (!(tau >= 0.0f)) return 0u;                  // opacity < 1/255: never blended
-    if (!(a > 0.0f)) return 0xFFFFu;                // degenerate conic: no culling
-    const float eps = 0.02f;
-    const float dx_lo = mx - (float)(X0 + 15), dx_hi = mx - (float)X0;  // dx = mx - px over the tile's columns
-    const float inv_a = 1.0f / a;
-    uint32_t m = 0;
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const float dy = my - (float)(Y0 + r);
-        const float bd = b * dy;
-        const float disc = bd * bd - a * (c * dy * dy - 2.0f * tau);
-        if (disc >= 0.0f) {
-            const float s = __fsqrt_rn(disc);
-            const float lo = (-bd - s) * inv_a, hi = (-bd + s) * inv_a;
-            const float slack = eps * (1.0f + fabsf(lo) + fabsf(hi));
-            if (hi + slack >= dx_lo && lo - slack <= dx_hi) m |= 1u << r;
-        } else if (disc > -1e-3f * (bd * bd + fabsf(a * c * dy * dy) + 2.0f * a * tau)) {
-            m |= 1u << r;  // numerically on the boundary: keep
-        }
-    }
-    return m;
 }
 
 // Load the tile's keys into `buf` (padded to a power of two with +inf), sort, and emit the

@@ -121,6 +121,7 @@ struct gsr_handle {
     int last_n = 0;
     int64_t last_D = 0;
     uint32_t last_max_tile = 0;
+    int64_t last_slots = 0;
     Profiler prof;
 
     DevBuf* all[30];
@@ -139,6 +140,7 @@ GsrCam make_cam(const gsr_handle* h, const gsr_camera* c) {
     k.grid_x = h->grid_x; k.grid_y = h->grid_y;
     k.near_plane = h->cfg.near_plane; k.far_plane = h->cfg.far_plane;
     k.radius_clip = h->cfg.radius_clip; k.blur_eps = h->cfg.blur_eps;
+    k.exact_cull = (h->cfg.flags & GSR_FLAG_EXACT_TILE_CULL) ? 1 : 0;
     k.R_dev = c->R_dev; k.t_dev = c->t_dev;
     return k;
 }
@@ -178,6 +180,7 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
     if (cfg->width <= 0 || cfg->height <= 0) return fail(GSR_E_INVALID_ARG, "bad resolution %dx%d", cfg->width, cfg->height);
     if (!valid_mode(cfg->mode)) return fail(GSR_E_INVALID_ARG, "Invalid render mode: %d (3=rgb, 5=rgbd, 8=rgbdn)", cfg->mode);
     if (!(cfg->near_plane < cfg->far_plane)) return fail(GSR_E_INVALID_ARG, "near_plane >= far_plane");
+    if (cfg->flags & ~(uint32_t)GSR_FLAG_EXACT_TILE_CULL) return fail(GSR_E_INVALID_ARG, "unknown flags 0x%x", cfg->flags);
     gsr_handle* h = new (std::nothrow) gsr_handle();
     if (!h) return fail(GSR_E_OOM, "host allocation failed");
     h->cfg = *cfg;
@@ -273,9 +276,11 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     HIPCHK(hipStreamSynchronize(s));
     const uint64_t D = h->host_totals[0];
     const uint32_t max_tile = h->host_totals[1], n_big = h->host_totals[2];
+    const uint64_t D_slots = h->host_totals[5];  // >= D; == D unless exact culling dropped tiles
     h->last_n = n;
     h->last_D = (int64_t)D;
     h->last_max_tile = max_tile;
+    h->last_slots = (int64_t)D_slots;
     if (stats) {
         stats->n_rendered = (int64_t)D;
         stats->n_visible = (int32_t)h->host_totals[4];
@@ -293,7 +298,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     }
     const float slack = 1.25f;  // instance count drifts slowly between training steps
     if ((rc = h->keys.ensure(D * 8, slack)) || (rc = h->values_sorted.ensure(D * 4, slack)) ||
-        (rc = h->inst_pos.ensure(D * 4, slack)) || (rc = h->rows.ensure(D * 64, slack)) ||
+        (rc = h->inst_pos.ensure(D_slots * 4, slack)) || (rc = h->rows.ensure(D * 64, slack)) ||
         (rc = h->s0.ensure(D * 16, slack)) || (rc = h->s1.ensure(D * 16, slack)) ||
         (rc = h->s2.ensure(D * 16, slack)) || (C > 5 && (rc = h->s3.ensure(D * 16, slack))))
         return rc;
@@ -303,6 +308,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
         while (big_stride < max_tile) big_stride <<= 1;
         if ((rc = h->big_scratch.ensure((size_t)n_big * big_stride * 8))) return rc;
     }
+    if (k.exact_cull) HIPCHK(hipMemsetAsync(h->inst_pos.p, 0xFF, D_slots * 4, s));  // culled slots stay invalid
     h->prof.begin(ST_SCATTER, s);
     gsr_launch_scatter(s, n, k, geom_of(h), h->cursor.as<uint32_t>(), h->keys.as<uint64_t>());
     h->prof.end(s);
@@ -373,7 +379,7 @@ int gsr_buffer(const gsr_handle* h, int which, const void** dev_ptr, size_t* byt
         case GSR_BUF_VALUES_SORTED: b = &h->values_sorted; sz = D * 4; break;
         case GSR_BUF_GEOM: b = &h->geo; sz = n * 64; break;
         case GSR_BUF_NORMALS: b = &h->gnormal; sz = h->cfg.mode > 5 ? n * 16 : 0; break;
-        case GSR_BUF_INST_POS: b = &h->inst_pos; sz = D * 4; break;
+        case GSR_BUF_INST_POS: b = &h->inst_pos; sz = (size_t)h->last_slots * 4; break;
         case GSR_BUF_GRAD_ROWS: b = &h->rows; sz = D * 64; break;
         default: return fail(GSR_E_INVALID_ARG, "unknown buffer id %d", which);
     }

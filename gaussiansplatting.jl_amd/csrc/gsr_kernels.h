@@ -20,6 +20,7 @@ struct GsrCam {
     float near_plane, far_plane;
     int radius_clip;
     float blur_eps;
+    int exact_cull;      // GSR_FLAG_EXACT_TILE_CULL
     const float* R_dev;  // optional device overrides (column-major (3,3), (3))
     const float* t_dev;
 };

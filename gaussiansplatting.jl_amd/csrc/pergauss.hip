@@ -10,6 +10,7 @@
 // the per-Gaussian floats are bit-reproducible against the CPU oracle.  These
 // kernels are HBM-bound (192 B of SH per Gaussian), the extra VALU ops are free.
 #include "gsr_kernels.h"
+#include "tile_mask.h"
 #include "wave_reduce.h"
 
 namespace {
@@ -287,8 +288,16 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
             }
             get_rect(m2[0], m2[1], radius, cam.grid_x, cam.grid_y, rmin, rmax);
             area = (uint32_t)((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]));
+            const float tau = footprint_tau(opac[i]);
             for (int y = rmin[1]; y < rmax[1]; y++)
-                for (int x = rmin[0]; x < rmax[0]; x++) atomicAdd(&tile_count[y * cam.grid_x + x], 1u);
+                for (int x = rmin[0]; x < rmax[0]; x++) {
+                    // exact-cull mode: a tile none of whose pixels can reach alpha >= 1/255 gets no
+                    // instance (the reference keeps it and skips it pixel by pixel, render.jl:95)
+                    if (cam.exact_cull && !tile_may_touch(m2[0], m2[1], conic[0], conic[1], conic[2], tau,
+                                                          x * GSR_TILE, y * GSR_TILE))
+                        continue;
+                    atomicAdd(&tile_count[y * cam.grid_x + x], 1u);
+                }
         }
     }
     // Exclusive scan of the tile-rect areas inside the block: with bpre[block] (tile_scan) it
@@ -359,7 +368,9 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(int n, int K, int cha
     constexpr uint32_t BIG = 48;  // larger footprints are summed by the whole wave
     if (area <= BIG) {
         for (uint32_t k = 0; k < area; k++) {  // fixed order -> bit-reproducible gradients
-            const float4* row = inst.rows + (size_t)4 * inst.inst_pos[goff + k];
+            const uint32_t pos = inst.inst_pos[goff + k];
+            if (pos == 0xFFFFFFFFu) continue;  // tile culled by the exact footprint test
+            const float4* row = inst.rows + (size_t)4 * pos;
             const float4 f0 = row[0], f1 = row[1], f2 = row[2];
             acc[0] += f0.x; acc[1] += f0.y; acc[2] += f0.z; acc[3] += f0.w;
             acc[4] += f1.x; acc[5] += f1.y; acc[6] += f1.z; acc[7] += f1.w;
@@ -384,7 +395,9 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(int n, int K, int cha
 #pragma unroll
             for (int k = 0; k < 16; k++) part[k] = 0.0f;
             for (uint32_t k = lane; k < a; k += 64) {
-                const float4* row = inst.rows + (size_t)4 * inst.inst_pos[o + k];
+                const uint32_t pos = inst.inst_pos[o + k];
+                if (pos == 0xFFFFFFFFu) continue;
+                const float4* row = inst.rows + (size_t)4 * pos;
                 const float4 f0 = row[0], f1 = row[1], f2 = row[2];
                 part[0] += f0.x; part[1] += f0.y; part[2] += f0.z; part[3] += f0.w;
                 part[4] += f1.x; part[5] += f1.y; part[6] += f1.z; part[7] += f1.w;
@@ -638,18 +651,22 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(int n, int K, int cha
 }
 
 // ---- counting scatter (duplicate_with_keys! restated per tile; utils.jl:96-119) ----
-__global__ __launch_bounds__(256) void scatter_kernel(int n, int grid_x, const int32_t* __restrict__ radii,
+__global__ __launch_bounds__(256) void scatter_kernel(int n, int grid_x, int exact_cull,
+                                                      const int32_t* __restrict__ radii,
                                                       const GsrGeoRec* __restrict__ rec,
                                                       uint32_t* __restrict__ cursor, uint64_t* __restrict__ keys) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     if (!(radii[i] > 0)) return;
-    const float4 q2 = rec[i].q2, q3 = rec[i].q3;
+    const float4 q0 = rec[i].q0, q1 = rec[i].q1, q2 = rec[i].q2, q3 = rec[i].q3;
     const uint32_t lo = __float_as_uint(q3.x), hi = __float_as_uint(q3.y);
     const int x0 = lo & 0xFFFFu, y0 = lo >> 16, x1 = hi & 0xFFFFu, y1 = hi >> 16;
     const uint64_t key = ((uint64_t)__float_as_uint(q2.z) << 32) | (uint32_t)i;
+    const float tau = footprint_tau(q1.y);
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++) {
+            if (exact_cull && !tile_may_touch(q0.x, q0.y, q0.z, q0.w, q1.x, tau, x * GSR_TILE, y * GSR_TILE))
+                continue;  // the same test, on the same floats, as the count in preprocess
             const uint32_t slot = atomicAdd(&cursor[y * grid_x + x], 1u);
             keys[slot] = key;
         }
@@ -659,7 +676,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(int n, int grid_x, const i
 
 void gsr_launch_scatter(hipStream_t s, int n, GsrCam cam, GsrGeom geom, uint32_t* cursor, uint64_t* keys) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, cam.grid_x, geom.radii, geom.rec,
+    hipLaunchKernelGGL(scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, cam.grid_x, cam.exact_cull, geom.radii, geom.rec,
                        cursor, keys);
 }
 

@@ -56,7 +56,8 @@ class GaussianRasterizer:
     output image; supports one outstanding forward→backward pair."""
 
     def __init__(self, width: int, height: int, mode: str = "rgbd", near_plane: float = 0.2,
-                 far_plane: float = 1000.0, device="cuda", radius_clip: int = 3, blur_eps: float = 0.3):
+                 far_plane: float = 1000.0, device="cuda", radius_clip: int = 3, blur_eps: float = 0.3,
+                 exact_tile_cull: bool = False):
         self.mode = mode
         self.channels = n_color_features(mode)
         self.width, self.height = int(width), int(height)
@@ -66,8 +67,11 @@ class GaussianRasterizer:
         if self.device.type != "cuda":
             raise ValueError("GaussianRasterizer needs a HIP device (no CPU path)")
         self._lib = L.load()
+        # exact_tile_cull: drop (Gaussian, tile) instances that cannot reach alpha >= 1/255 anywhere
+        # in the tile; outputs are unchanged, the internal lists are no longer the reference's
+        self.exact_tile_cull = bool(exact_tile_cull)
         cfg = L.Config(self.width, self.height, self.channels, self.near_plane, self.far_plane, int(radius_clip),
-                       float(blur_eps))
+                       float(blur_eps), L.FLAG_EXACT_TILE_CULL if exact_tile_cull else 0)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             L.check(self._lib.gsr_create(C.byref(cfg), C.byref(h)))

@@ -54,7 +54,15 @@ typedef struct gsr_config {
     float far_plane;     /* 1000 */
     int32_t radius_clip; /* 3 px */
     float blur_eps;      /* 0.3  */
+    uint32_t flags;      /* GSR_FLAG_* */
 } gsr_config;
+
+/* Exact footprint culling at binning: a (Gaussian, tile) instance none of whose pixels can
+ * reach alpha >= 1/255 is not emitted at all.  The reference emits it and then skips it
+ * pixel by pixel (render.jl:95), so image and gradients are unchanged (bit-identical);
+ * only the internal lists shrink (n_rendered, ranges, values_sorted, n_contrib count
+ * positions in the culled lists).  Off: lists are exactly the reference's. */
+#define GSR_FLAG_EXACT_TILE_CULL 1u
 
 /* Positional arguments of `rasterize(means_3d, shs, opacities, scales, rotations, ...)`
  * (rasterizer.jl:255-267).  opacities / scales are the ACTIVATED values, as the

@@ -19,7 +19,7 @@ const LIB = get(ENV, "GSR_HIP_LIB", "libgsr_hip.so")
 
 struct GsrConfig
     width::Int32; height::Int32; mode::Int32
-    near_plane::Float32; far_plane::Float32; radius_clip::Int32; blur_eps::Float32
+    near_plane::Float32; far_plane::Float32; radius_clip::Int32; blur_eps::Float32; flags::UInt32
 end
 struct GsrInputs
     n::Int32; n_coeffs::Int32; sh_degree::Int32
@@ -50,11 +50,12 @@ mutable struct HipNativeRasterizer
 end
 
 function HipNativeRasterizer(; width::Int, height::Int, mode::Symbol = :rgbd,
-                             near_plane::Float32 = 0.2f0, far_plane::Float32 = 1000f0)
+                             near_plane::Float32 = 0.2f0, far_plane::Float32 = 1000f0,
+                             exact_tile_cull::Bool = false)
     c = GaussianSplatting.n_color_features(mode)
     h = Ref{Ptr{Cvoid}}()
     check(ccall((:gsr_create, LIB), Cint, (Ref{GsrConfig}, Ref{Ptr{Cvoid}}),
-        GsrConfig(width, height, c, near_plane, far_plane, 3, 0.3f0), h))
+        GsrConfig(width, height, c, near_plane, far_plane, 3, 0.3f0, exact_tile_cull ? 1 : 0), h))
     r = HipNativeRasterizer(h[], AMDGPU.zeros(Float32, c, width, height), mode, width, height)
     finalizer(x -> ccall((:gsr_destroy, LIB), Cint, (Ptr{Cvoid},), x.handle), r)
     return r

@@ -180,6 +180,37 @@ def test_large_footprints_and_deterministic_gradients(pkg, orc):
         assert torch.equal(a, b), "backward must be bit-deterministic"
 
 
+@pytest.mark.parametrize("mode,deg,seed,W,H,n", [("rgb", 3, 301, 200, 120, 3000), ("rgbdn", 1, 302, 96, 80, 800)])
+def test_exact_tile_cull_changes_lists_not_results(pkg, orc, mode, deg, seed, W, H, n):
+    """GSR_FLAG_EXACT_TILE_CULL: instances that cannot reach alpha >= 1/255 anywhere in their tile
+    are not emitted.  Image and final T are BIT-identical to the reference-list mode, gradients
+    agree with the oracle, every culled tile list is a subsequence of the reference's."""
+    s, cam = _scene(pkg, orc, n, W, H, deg, seed, sigma_px=4.0, view=5)
+    opac = s.opacities.copy()
+    opac[::3] *= 0.05  # plenty of faint splats: small effective footprints
+    bg = (0.1, 0.2, 0.3)
+    st = orc.forward(s.means, s.shs, opac, s.scales, s.rotations, cam, deg, background=bg, mode=mode)
+    ref = HipRun(pkg, s.means, s.shs, opac, s.scales, s.rotations, cam, deg, bg, mode)
+    cul = HipRun(pkg, s.means, s.shs, opac, s.scales, s.rotations, cam, deg, bg, mode, exact_tile_cull=True)
+    img_r, img_c = ref.forward().clone(), cul.forward().clone()
+    assert torch.equal(img_r, img_c)
+    assert torch.equal(ref.rast.accum_alpha, cul.rast.accum_alpha)
+    Dr, Dc = ref.rast.stats.n_rendered, cul.rast.stats.n_rendered
+    assert Dc < Dr == st.n_rendered
+    rr, rc = ref.rast.ranges.cpu().numpy(), cul.rast.ranges.cpu().numpy()
+    vr, vc = ref.rast.values_sorted.cpu().numpy(), cul.rast.values_sorted.cpu().numpy()
+    for t in range(rr.shape[0]):
+        a, b = vr[rr[t, 0]:rr[t, 1]], vc[rc[t, 0]:rc[t, 1]]
+        keep = np.isin(a, b)
+        assert np.array_equal(a[keep], b), "culled list must be an order-preserving subsequence"
+    C = st.image.shape[2]
+    vp = np.random.default_rng(seed).standard_normal((H, W, C)).astype(np.float32)
+    g = orc.backward(st, vp, s.means, s.shs, opac, s.scales, s.rotations, cam, deg, background=bg)
+    out = cul.backward(vp)
+    _compare_backward(g, out, st.radii > 0)
+    assert rel_l2(cul.rast.grad_means_2d.cpu().numpy(), g.vmeans2d) <= 1e-4
+
+
 # ---- the reference's own integration scenes (K13-K15) through the HIP path ----
 def test_k13_rgbdn_grid_scene(pkg, orc):
     sc, cam = scenes.grid_scene_rgbdn()

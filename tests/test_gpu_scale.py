@@ -98,6 +98,21 @@ def _properties(pkg, orc, n, W, H, seed, with_oracle_fwd):
     assert not g12[0][~vis].any() and not g12[1][~vis].any()
 
 
+def test_exact_cull_bit_identical_image_at_config3(pkg, orc):
+    n, W, H, deg, seed = 1_000_000, 1920, 1080, 3, 1003
+    s = pkg.synthetic.make_scene(n, W, H, deg, seed)
+    cam = orc.Camera(W, H, s.focal)
+    a = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg)
+    b = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, exact_tile_cull=True)
+    ia, ib = a.forward().clone(), b.forward().clone()
+    assert torch.equal(ia, ib) and torch.equal(a.rast.accum_alpha, b.rast.accum_alpha)
+    assert b.rast.stats.n_rendered < 0.9 * a.rast.stats.n_rendered
+    vp = pkg.synthetic.make_vpixels(W, H, 3, seed)
+    ga, gb = a.backward(vp)[:5], b.backward(vp)[:5]
+    for x, y in zip(ga, gb):
+        assert float((x - y).norm() / x.norm()) < 1e-5  # same terms, different summation slots
+
+
 def test_config3_1m_1080p(pkg, orc):
     _properties(pkg, orc, 1_000_000, 1920, 1080, 1003, with_oracle_fwd=True)
 

@@ -204,15 +204,22 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(Src src, int W, int H, co
     }
 }
 
-__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ partial, int n_blocks,
-                                                          float lambda, float inv_count,
-                                                          float* __restrict__ loss_out) {
-    __shared__ float red[4];
+__global__ __launch_bounds__(1024) void loss_finish_kernel(const float* __restrict__ partial, int n_blocks,
+                                                           float lambda, float inv_count,
+                                                           float* __restrict__ loss_out) {
+    __shared__ float red[2][16];
     float a = 0.0f, b = 0.0f;
-    for (int i = threadIdx.x; i < n_blocks; i += 256) { a += partial[2 * i]; b += partial[2 * i + 1]; }
-    a = block_sum(a, red);
-    b = block_sum(b, red);
+    for (int i = threadIdx.x; i < n_blocks; i += 1024) {
+        const float2 p = reinterpret_cast<const float2*>(partial)[i];
+        a += p.x; b += p.y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        a = 0.0f; b = 0.0f;
+        for (int w = 0; w < 16; w++) { a += red[0][w]; b += red[1][w]; }
         const float l1 = a * inv_count;
         const float s = 1.0f - b * inv_count;
         loss_out[0] = (1.0f - lambda) * l1 + lambda * s;
@@ -267,6 +274,6 @@ void gsr_launch_loss_bwd(hipStream_t s, int W, int H, int C, const float* image,
                        (const float*)nullptr, -lambda * inv_count, (1.0f - lambda) * inv_count, d0, d1, d2, vpixels,
                        C);
     const dim3 g = ssim_grid(W, H, 3);
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, s, partial, (int)(g.x * g.y * g.z), lambda,
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, s, partial, (int)(g.x * g.y * g.z), lambda,
                        inv_count, loss_out);
 }

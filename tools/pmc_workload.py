@@ -33,7 +33,7 @@ cam = pkg.Camera(W, H, tuple(s.focal))
 to = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(dev)  # noqa: E731
 params = [to(s.means), to(s.shs), to(s.opacities.reshape(-1, 1)), to(s.scales), to(s.rotations)]
 target = to(pkg.synthetic.make_target(W, H, seed))
-rast = pkg.rasterizer.GaussianRasterizer(W, H, mode="rgb", device=dev)
+rast = pkg.rasterizer.GaussianRasterizer(W, H, mode="rgb", device=dev, exact_tile_cull=True)  # as bench.py
 arena = torch.empty(pkg.distributed.arena_numel(N, 16), device=dev)
 for _ in range(4):
     img = rast.forward_raw(*params, cam, deg, (0.0, 0.0, 0.0))

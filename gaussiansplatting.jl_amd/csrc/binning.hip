@@ -85,7 +85,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint
         for (int w = 0; w < 16; w++) b += wave_sums[w];
         totals[2] = b;
     }
-    // second scan: per-block sums of tile-rect areas -> bpre (offsets into inst_pos)
+    // second scan: per-block sums of tile-rect areas -> bpre (Gaussian-major instance-slot offsets)
     __syncthreads();
     if (tid == 0) carry_s = 0;
     __syncthreads();
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint
         if (tid == 1023) carry_s = excl + v;
         __syncthreads();
     }
-    if (tid == 0) totals[5] = carry_s;  // sum of tile-rect areas = number of instance slots in inst_pos
+    if (tid == 0) totals[5] = carry_s;  // sum of tile-rect areas = number of Gaussian-major instance slots (gradient rows)
 }
 
 // ---- per-tile sort ----
@@ -138,8 +138,7 @@ template <int CH>
 __device__ __forceinline__ void sort_and_emit(uint64_t* buf, uint32_t m, uint32_t n, uint32_t start, int tid,
                                               int X0, int Y0,
                                               const uint64_t* __restrict__ keys, const GsrGeom& geom,
-                                              const GsrStream& stream, uint32_t* __restrict__ values_sorted,
-                                              uint32_t* __restrict__ inst_pos) {
+                                              const GsrStream& stream, uint32_t* __restrict__ values_sorted) {
     for (uint32_t i = tid; i < m; i += 256) buf[i] = i < n ? keys[start + i] : ~0ull;
     __syncthreads();
     if (m > 1) bitonic_sort(buf, m, tid, 256);
@@ -150,15 +149,17 @@ __device__ __forceinline__ void sort_and_emit(uint64_t* buf, uint32_t m, uint32_
         const GsrGeoRec rec = geom.rec[id];  // one 64-byte line per gather
         stream.s0[start + i] = rec.q0;
         stream.s1[start + i] = rec.q1;
-        stream.s2[start + i] = make_float4(rec.q2.x, __uint_as_float(id), rec.q2.z,
-                                           __uint_as_float(instance_row_mask(rec.q0, rec.q1, X0, Y0)));
-        if (CH > 5) stream.s3[start + i] = geom.normal[id];
-        // slot of this instance among its Gaussian's covered tiles (row-major over the rect, the
-        // emit order of duplicate_with_keys!, utils.jl:112) -> where the backward finds its row
+        // Gaussian-major slot of this instance: offset of the Gaussian's rect (cumsum of
+        // tiles_touched, rasterizer.jl:333-335) + row-major rank of the tile inside the rect (the
+        // emit order of duplicate_with_keys!, utils.jl:112).  The backward writes the instance's
+        // gradient row there, so a Gaussian's rows are contiguous for the per-Gaussian sum.
         const uint32_t lo = __float_as_uint(rec.q3.x), hi = __float_as_uint(rec.q3.y);
         const uint32_t x0 = lo & 0xFFFFu, y0 = lo >> 16, x1 = hi & 0xFFFFu;
-        const uint32_t slot = ((uint32_t)(Y0 / GSR_TILE) - y0) * (x1 - x0) + ((uint32_t)(X0 / GSR_TILE) - x0);
-        inst_pos[geom.bpre[id >> 8] + __float_as_uint(rec.q2.w) + slot] = start + i;
+        const uint32_t slot = geom.bpre[id >> 8] + __float_as_uint(rec.q2.w) +
+                              ((uint32_t)(Y0 / GSR_TILE) - y0) * (x1 - x0) + ((uint32_t)(X0 / GSR_TILE) - x0);
+        stream.s2[start + i] = make_float4(rec.q2.x, __uint_as_float(slot), rec.q2.z,
+                                           __uint_as_float(instance_row_mask(rec.q0, rec.q1, X0, Y0)));
+        if (CH > 5) stream.s3[start + i] = geom.normal[id];
     }
 }
 
@@ -170,8 +171,7 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restri
                                                         uint32_t* __restrict__ slab_counter, int grid_x,
                                                         GsrGeom geom, GsrStream stream,
                                                         uint32_t* __restrict__ values_sorted,
-                                                        uint32_t* __restrict__ ranges,
-                                                        uint32_t* __restrict__ inst_pos) {
+                                                        uint32_t* __restrict__ ranges) {
     __shared__ uint64_t skeys[GSR_SORT_LDS_CAP];
     __shared__ uint32_t slab_s;
     const int tile = blockIdx.x, tid = threadIdx.x;
@@ -187,14 +187,14 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restri
     uint32_t m = 1;
     while (m < n) m <<= 1;
     if (m <= GSR_SORT_LDS_CAP) {
-        sort_and_emit<CH>(skeys, m, n, start, tid, X0, Y0, keys, geom, stream, values_sorted, inst_pos);
+        sort_and_emit<CH>(skeys, m, n, start, tid, X0, Y0, keys, geom, stream, values_sorted);
     } else {
         // oversized tile: same network through a global-scratch slab (rare; slabs are sized by
         // the host from the scan's totals and handed out with one atomic per oversized tile)
         if (tid == 0) slab_s = atomicAdd(slab_counter, 1u);
         __syncthreads();
         uint64_t* slab = big_scratch + (size_t)slab_s * big_scratch_stride;
-        sort_and_emit<CH>(slab, m, n, start, tid, X0, Y0, keys, geom, stream, values_sorted, inst_pos);
+        sort_and_emit<CH>(slab, m, n, start, tid, X0, Y0, keys, geom, stream, values_sorted);
     }
 }
 
@@ -208,11 +208,11 @@ void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count
 
 void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start, uint64_t* keys,
                           uint64_t* big_scratch, uint32_t big_scratch_stride, uint32_t* slab_counter, GsrGeom geom,
-                          GsrStream stream, uint32_t* values_sorted, uint32_t* ranges, uint32_t* inst_pos) {
+                          GsrStream stream, uint32_t* values_sorted, uint32_t* ranges) {
     if (channels > 5)
         hipLaunchKernelGGL(tile_sort_kernel<8>, dim3(n_tiles), dim3(256), 0, s, tile_start, keys, big_scratch,
-                           big_scratch_stride, slab_counter, grid_x, geom, stream, values_sorted, ranges, inst_pos);
+                           big_scratch_stride, slab_counter, grid_x, geom, stream, values_sorted, ranges);
     else
         hipLaunchKernelGGL(tile_sort_kernel<3>, dim3(n_tiles), dim3(256), 0, s, tile_start, keys, big_scratch,
-                           big_scratch_stride, slab_counter, grid_x, geom, stream, values_sorted, ranges, inst_pos);
+                           big_scratch_stride, slab_counter, grid_x, geom, stream, values_sorted, ranges);
 }

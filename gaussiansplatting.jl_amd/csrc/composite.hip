@@ -63,7 +63,9 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(int W, int H, int gr
                                                             const uint32_t* __restrict__ tile_start,
                                                             GsrStream stream, Bg bg, float* __restrict__ image,
                                                             uint32_t* __restrict__ n_contrib,
-                                                            float* __restrict__ final_T, uint8_t* __restrict__ covis,
+                                                            float* __restrict__ final_T,
+                                                            const uint32_t* __restrict__ values_sorted,
+                                                            uint8_t* __restrict__ covis,
                                                             float* __restrict__ uncert) {
     __shared__ float4 l0[GSR_BATCH], l1[GSR_BATCH], l2[GSR_BATCH];
     __shared__ float4 l3[C > 5 ? GSR_BATCH : 1];
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(int W, int H, int gr
                 for (int c = 0; c < C; c++) color[c] += f[c] * w;
                 if (AUX) {
                     unc += w;
-                    if (covis && ok && T > 0.5f) covis[__float_as_uint(c2.y)] = 1;
+                    if (covis && ok && T > 0.5f) covis[values_sorted[start + base + j]] = 1;
                 }
                 T = ok ? Tn : T;
                 last = ok ? (uint32_t)(base + j + 1) : last;
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(256, GSR_BWD_MINWAVES) void composite_bwd_kernel(in
                 // one 64-byte gradient row per instance, plain stores (rows are zero-filled per
                 // backward): the per-Gaussian kernel sums a Gaussian's rows in a fixed order —
                 // no fp32 atomics (35 M per view before), bit-reproducible gradients
-                float4* row = inst.rows + (size_t)4 * (start + (uint32_t)(tile_last - 1 - base - tid));
+                float4* row = inst.rows + (size_t)4 * __float_as_uint(l2[tid].y);  // Gaussian-major slot
                 row[0] = make_float4(r[0], r[1], r[2], r[3]);
                 row[1] = make_float4(r[4], r[5], r[6], C > 3 ? r[9 < NA ? 9 : 0] : 0.0f);
                 row[2] = make_float4(r[7], r[8], C > 5 ? r[10 < NA ? 10 : 0] : 0.0f, C > 5 ? r[11 < NA ? 11 : 0] : 0.0f);
@@ -331,13 +333,13 @@ Bg make_bg(const float* background, int channels) {
 
 void gsr_launch_composite_fwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start, GsrStream stream,
                               const float* background, float* image, uint32_t* n_contrib, float* final_T,
-                              uint8_t* covis, float* uncert) {
+                              const uint32_t* values_sorted, uint8_t* covis, float* uncert) {
     dim3 grid(cam.grid_x, cam.grid_y), block(256);
     Bg bg = make_bg(background, channels);
     const bool aux = covis || uncert;
 #define LAUNCH(CC, AA)                                                                                             \
     hipLaunchKernelGGL((composite_fwd_kernel<CC, AA>), grid, block, 0, s, cam.width, cam.height, cam.grid_x,       \
-                       tile_start, stream, bg, image, n_contrib, final_T, covis, uncert)
+                       tile_start, stream, bg, image, n_contrib, final_T, values_sorted, covis, uncert)
     if (channels == 3) { if (aux) LAUNCH(3, true); else LAUNCH(3, false); }
     else if (channels == 5) { if (aux) LAUNCH(5, true); else LAUNCH(5, false); }
     else { if (aux) LAUNCH(8, true); else LAUNCH(8, false); }

@@ -113,7 +113,7 @@ struct gsr_handle {
     // BinningState (states.jl:66-85): unsorted keys, sorted ids, sorted splat stream
     DevBuf keys, values_sorted, s0, s1, s2, s3, big_scratch;
     // backward: per-instance gradient rows + instance position map; gstate.∇means_2d
-    DevBuf rows, inst_pos, vmean2d;
+    DevBuf rows, vmean2d;
     // loss-head scratch
     DevBuf d0, d1, d2, partial;
     uint32_t* host_totals = nullptr;  // pinned: D, max tile count, #oversized tiles, slab ctr, n_visible
@@ -152,7 +152,7 @@ GsrGeom geom_of(const gsr_handle* h) {
 GsrStream stream_of(const gsr_handle* h) {
     return GsrStream{h->s0.as<float4>(), h->s1.as<float4>(), h->s2.as<float4>(), h->s3.as<float4>()};
 }
-GsrInst inst_of(const gsr_handle* h) { return GsrInst{h->rows.as<float4>(), h->inst_pos.as<uint32_t>()}; }
+GsrInst inst_of(const gsr_handle* h) { return GsrInst{h->rows.as<float4>()}; }
 
 int check_inputs(const gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam) {
     if (!h || !in || !cam) return fail(GSR_E_INVALID_ARG, "null handle / inputs / camera");
@@ -190,14 +190,14 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
     h->n_tiles = h->grid_x * h->grid_y;
     DevBuf* list[] = {&h->ranges, &h->n_contrib, &h->final_T, &h->tile_count, &h->tile_start, &h->cursor, &h->totals,
                       &h->geo, &h->gnormal, &h->radii, &h->bsum, &h->bpre, &h->keys, &h->values_sorted, &h->s0,
-                      &h->s1, &h->s2, &h->s3, &h->big_scratch, &h->rows, &h->inst_pos, &h->vmean2d, &h->d0, &h->d1,
+                      &h->s1, &h->s2, &h->s3, &h->big_scratch, &h->rows, &h->vmean2d, &h->d0, &h->d1,
                       &h->d2, &h->partial};
     for (DevBuf* b : list) h->all[h->n_all++] = b;
     const size_t P = (size_t)cfg->width * cfg->height, T = (size_t)h->n_tiles;
     int rc = GSR_OK;
     if ((rc = h->ranges.ensure(2 * T * 4)) || (rc = h->n_contrib.ensure(P * 4)) || (rc = h->final_T.ensure(P * 4)) ||
-        (rc = h->tile_count.ensure(T * 4)) || (rc = h->tile_start.ensure((T + 1) * 4)) ||
-        (rc = h->cursor.ensure(T * 4)) || (rc = h->totals.ensure(8 * 4))) {
+        (rc = h->tile_count.ensure((T + 2) * 4)) || (rc = h->tile_start.ensure((T + 1) * 4)) ||
+        (rc = h->cursor.ensure((T + 2) * 4)) || (rc = h->totals.ensure(8 * 4))) {
         gsr_destroy(h);
         return rc;
     }
@@ -223,7 +223,7 @@ int gsr_destroy(gsr_handle* h) {
 int gsr_release_scene_buffers(gsr_handle* h) {
     if (!h) return fail(GSR_E_INVALID_ARG, "null handle");
     DevBuf* scene[] = {&h->geo, &h->gnormal, &h->radii, &h->bsum, &h->bpre, &h->keys, &h->values_sorted, &h->s0, &h->s1,
-                       &h->s2, &h->s3, &h->big_scratch, &h->rows, &h->inst_pos, &h->vmean2d};
+                       &h->s2, &h->s3, &h->big_scratch, &h->rows, &h->vmean2d};
     for (DevBuf* b : scene) {
         int rc = b->release();
         if (rc) return rc;
@@ -298,7 +298,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     }
     const float slack = 1.25f;  // instance count drifts slowly between training steps
     if ((rc = h->keys.ensure(D * 8, slack)) || (rc = h->values_sorted.ensure(D * 4, slack)) ||
-        (rc = h->inst_pos.ensure(D_slots * 4, slack)) || (rc = h->rows.ensure(D * 64, slack)) ||
+        (rc = h->rows.ensure(D_slots * 64, slack)) ||
         (rc = h->s0.ensure(D * 16, slack)) || (rc = h->s1.ensure(D * 16, slack)) ||
         (rc = h->s2.ensure(D * 16, slack)) || (C > 5 && (rc = h->s3.ensure(D * 16, slack))))
         return rc;
@@ -308,18 +308,17 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
         while (big_stride < max_tile) big_stride <<= 1;
         if ((rc = h->big_scratch.ensure((size_t)n_big * big_stride * 8))) return rc;
     }
-    if (k.exact_cull) HIPCHK(hipMemsetAsync(h->inst_pos.p, 0xFF, D_slots * 4, s));  // culled slots stay invalid
     h->prof.begin(ST_SCATTER, s);
     gsr_launch_scatter(s, n, k, geom_of(h), h->cursor.as<uint32_t>(), h->keys.as<uint64_t>());
     h->prof.end(s);
     h->prof.begin(ST_SORT, s);
     gsr_launch_tile_sort(s, h->n_tiles, h->grid_x, C, h->tile_start.as<uint32_t>(), h->keys.as<uint64_t>(),
                          h->big_scratch.as<uint64_t>(), big_stride, totals + 3, geom_of(h), stream_of(h),
-                         h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>(), h->inst_pos.as<uint32_t>());
+                         h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>());
     h->prof.end(s);
     h->prof.begin(ST_COMPOSITE_FWD, s);
     gsr_launch_composite_fwd(s, C, k, h->tile_start.as<uint32_t>(), stream_of(h), in->background, image_out,
-                             h->n_contrib.as<uint32_t>(), h->final_T.as<float>(),
+                             h->n_contrib.as<uint32_t>(), h->final_T.as<float>(), h->values_sorted.as<uint32_t>(),
                              aux ? aux->covisibilities : nullptr, aux ? aux->uncertainties : nullptr);
     h->prof.end(s);
     HIPCHK(hipGetLastError());
@@ -343,7 +342,7 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
     if (n == 0) return GSR_OK;
     h->prof.begin(ST_ZERO_ACC, s);
     // rows not touched by any pixel must read as zero in the per-Gaussian sum
-    if (h->last_D > 0) HIPCHK(hipMemsetAsync(h->rows.p, 0, (size_t)h->last_D * 64, s));
+    if (h->last_D > 0) HIPCHK(hipMemsetAsync(h->rows.p, 0, (size_t)h->last_slots * 64, s));
     if (g->vR) {
         HIPCHK(hipMemsetAsync(g->vR, 0, 9 * 4, s));
         HIPCHK(hipMemsetAsync(g->vt, 0, 3 * 4, s));
@@ -379,8 +378,7 @@ int gsr_buffer(const gsr_handle* h, int which, const void** dev_ptr, size_t* byt
         case GSR_BUF_VALUES_SORTED: b = &h->values_sorted; sz = D * 4; break;
         case GSR_BUF_GEOM: b = &h->geo; sz = n * 64; break;
         case GSR_BUF_NORMALS: b = &h->gnormal; sz = h->cfg.mode > 5 ? n * 16 : 0; break;
-        case GSR_BUF_INST_POS: b = &h->inst_pos; sz = (size_t)h->last_slots * 4; break;
-        case GSR_BUF_GRAD_ROWS: b = &h->rows; sz = D * 64; break;
+        case GSR_BUF_GRAD_ROWS: b = &h->rows; sz = (size_t)h->last_slots * 64; break;
         default: return fail(GSR_E_INVALID_ARG, "unknown buffer id %d", which);
     }
     if (sz > b->cap) sz = 0;  // not produced yet

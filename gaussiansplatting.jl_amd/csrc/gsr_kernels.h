@@ -30,7 +30,7 @@ struct GsrCam {
 //   q0 = mean2d.x, mean2d.y, conic.a, conic.b
 //   q1 = conic.c, opacity, r, g
 //   q2 = b, clamped bits (u32), depth, lpre (u32: exclusive prefix of tile-rect areas inside the
-//        Gaussian's 256-wide block; + bpre[i >> 8] = offset of its instances in inst_pos)
+//        Gaussian's 256-wide block; + bpre[i >> 8] = Gaussian-major slot of its first instance)
 //   q3 = rect xmin | ymin << 16, rect xmax | ymax << 16 (u32), unused, unused
 struct GsrGeoRec { float4 q0, q1, q2, q3; };
 struct GsrGeom {
@@ -45,17 +45,16 @@ struct GsrGeom {
 struct GsrStream {
     float4* s0;  // mean2d.x, mean2d.y, conic.a, conic.b
     float4* s1;  // conic.c, opacity, r, g
-    float4* s2;  // b, id (uint bits), depth, row mask (uint bits: rows of the tile the splat can touch)
+    float4* s2;  // b, slot (uint bits: Gaussian-major instance slot), depth, row mask (uint bits: tile rows touched)
     float4* s3;  // normal (C == 8) or nullptr
 };
 
-// Backward: per-INSTANCE gradient rows (plain stores, no atomics) + the map from a
-// Gaussian's k-th covered tile to its sorted position, so the per-Gaussian kernel can sum
-// its rows in a fixed order (deterministic gradients).
+// Backward: per-INSTANCE gradient rows (plain stores, no atomics), indexed by the
+// Gaussian-major instance slot, so the rows of one Gaussian are contiguous and the
+// per-Gaussian kernel sums them in a fixed order (deterministic gradients).
 //   row = 4 x float4: {v r, v g, v b, v opacity}, {v conic a,b,c, v depth}, {v mean2d x,y, v normal x,y}, {v normal z,-,-,-}
 struct GsrInst {
-    float4* rows;        // D x 4 float4, zero-filled per backward
-    uint32_t* inst_pos;  // D: sorted position of instance (goff(i) + k)
+    float4* rows;  // D_slots x 4 float4, zero-filled per backward
 };
 
 // ---- pergauss.hip (compiled with -ffp-contract=off: bit-reproducible fp32) ----
@@ -76,12 +75,12 @@ void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count
                           uint32_t* cursor, uint32_t* totals, int n_blocks, const uint32_t* bsum, uint32_t* bpre);
 void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start, uint64_t* keys,
                           uint64_t* big_scratch, uint32_t big_scratch_stride, uint32_t* slab_counter, GsrGeom geom,
-                          GsrStream stream, uint32_t* values_sorted, uint32_t* ranges, uint32_t* inst_pos);
+                          GsrStream stream, uint32_t* values_sorted, uint32_t* ranges);
 
 // ---- composite.hip ----
 void gsr_launch_composite_fwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start, GsrStream stream,
                               const float* background, float* image, uint32_t* n_contrib, float* final_T,
-                              uint8_t* covis, float* uncert);
+                              const uint32_t* values_sorted, uint8_t* covis, float* uncert);
 void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start, GsrStream stream,
                               const float* background, const float* vpixels, const uint32_t* n_contrib,
                               const float* final_T, GsrInst inst);

@@ -289,19 +289,34 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
             get_rect(m2[0], m2[1], radius, cam.grid_x, cam.grid_y, rmin, rmax);
             area = (uint32_t)((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]));
             const float tau = footprint_tau(opac[i]);
-            for (int y = rmin[1]; y < rmax[1]; y++)
-                for (int x = rmin[0]; x < rmax[0]; x++) {
-                    // exact-cull mode: a tile none of whose pixels can reach alpha >= 1/255 gets no
-                    // instance (the reference keeps it and skips it pixel by pixel, render.jl:95)
-                    if (cam.exact_cull && !tile_may_touch(m2[0], m2[1], conic[0], conic[1], conic[2], tau,
-                                                          x * GSR_TILE, y * GSR_TILE))
-                        continue;
-                    atomicAdd(&tile_count[y * cam.grid_x + x], 1u);
+            // Per-tile occupancy histogram.  Horizontally adjacent tiles are consecutive 32-bit
+            // counters, so an aligned pair is bumped by ONE 64-bit atomic (device-scope atomics
+            // execute memory-side on MI355X and are the bound of this kernel).
+            // exact-cull mode: a tile none of whose pixels can reach alpha >= 1/255 gets no
+            // instance (the reference keeps it and skips it pixel by pixel, render.jl:95).
+            for (int y = rmin[1]; y < rmax[1]; y++) {
+                int x = rmin[0];
+                while (x < rmax[0]) {
+                    const int t = y * cam.grid_x + x;
+                    const bool pair = !(t & 1) && x + 1 < rmax[0];
+                    const uint32_t c0 = (!cam.exact_cull || tile_may_touch(m2[0], m2[1], conic[0], conic[1], conic[2],
+                                                                         tau, x * GSR_TILE, y * GSR_TILE)) ? 1u : 0u;
+                    uint32_t c1 = 0u;
+                    if (pair)
+                        c1 = (!cam.exact_cull || tile_may_touch(m2[0], m2[1], conic[0], conic[1], conic[2], tau,
+                                                               (x + 1) * GSR_TILE, y * GSR_TILE)) ? 1u : 0u;
+                    if (pair && (c0 | c1))
+                        atomicAdd(reinterpret_cast<unsigned long long*>(tile_count + t),
+                                  (unsigned long long)c0 | ((unsigned long long)c1 << 32));
+                    else if (c0)
+                        atomicAdd(tile_count + t, 1u);
+                    x += pair ? 2 : 1;
                 }
+            }
         }
     }
     // Exclusive scan of the tile-rect areas inside the block: with bpre[block] (tile_scan) it
-    // gives every Gaussian the offset of its instance slots in inst_pos — the reference's
+    // gives every Gaussian the offset of its instance slots (gradient rows) — the reference's
     // cumsum!(tiles_touched) (rasterizer.jl:333-335), restated hierarchically.
     {
         __shared__ uint32_t wsum[4];
@@ -368,9 +383,7 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(int n, int K, int cha
     constexpr uint32_t BIG = 48;  // larger footprints are summed by the whole wave
     if (area <= BIG) {
         for (uint32_t k = 0; k < area; k++) {  // fixed order -> bit-reproducible gradients
-            const uint32_t pos = inst.inst_pos[goff + k];
-            if (pos == 0xFFFFFFFFu) continue;  // tile culled by the exact footprint test
-            const float4* row = inst.rows + (size_t)4 * pos;
+            const float4* row = inst.rows + (size_t)4 * (goff + k);  // contiguous; culled / untouched slots are zero
             const float4 f0 = row[0], f1 = row[1], f2 = row[2];
             acc[0] += f0.x; acc[1] += f0.y; acc[2] += f0.z; acc[3] += f0.w;
             acc[4] += f1.x; acc[5] += f1.y; acc[6] += f1.z; acc[7] += f1.w;
@@ -395,9 +408,7 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(int n, int K, int cha
 #pragma unroll
             for (int k = 0; k < 16; k++) part[k] = 0.0f;
             for (uint32_t k = lane; k < a; k += 64) {
-                const uint32_t pos = inst.inst_pos[o + k];
-                if (pos == 0xFFFFFFFFu) continue;
-                const float4* row = inst.rows + (size_t)4 * pos;
+                const float4* row = inst.rows + (size_t)4 * (o + k);
                 const float4 f0 = row[0], f1 = row[1], f2 = row[2];
                 part[0] += f0.x; part[1] += f0.y; part[2] += f0.z; part[3] += f0.w;
                 part[4] += f1.x; part[5] += f1.y; part[6] += f1.z; part[7] += f1.w;
@@ -663,13 +674,30 @@ __global__ __launch_bounds__(256) void scatter_kernel(int n, int grid_x, int exa
     const int x0 = lo & 0xFFFFu, y0 = lo >> 16, x1 = hi & 0xFFFFu, y1 = hi >> 16;
     const uint64_t key = ((uint64_t)__float_as_uint(q2.z) << 32) | (uint32_t)i;
     const float tau = footprint_tau(q1.y);
-    for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) {
-            if (exact_cull && !tile_may_touch(q0.x, q0.y, q0.z, q0.w, q1.x, tau, x * GSR_TILE, y * GSR_TILE))
-                continue;  // the same test, on the same floats, as the count in preprocess
-            const uint32_t slot = atomicAdd(&cursor[y * grid_x + x], 1u);
-            keys[slot] = key;
+    // the same tests, on the same floats, as the count in preprocess; paired 64-bit atomics return
+    // both tiles' slots at once
+    for (int y = y0; y < y1; y++) {
+        int x = x0;
+        while (x < x1) {
+            const int t = y * grid_x + x;
+            const bool pair = !(t & 1) && x + 1 < x1;
+            const uint32_t c0 = (!exact_cull || tile_may_touch(q0.x, q0.y, q0.z, q0.w, q1.x, tau, x * GSR_TILE,
+                                                               y * GSR_TILE)) ? 1u : 0u;
+            uint32_t c1 = 0u;
+            if (pair)
+                c1 = (!exact_cull || tile_may_touch(q0.x, q0.y, q0.z, q0.w, q1.x, tau, (x + 1) * GSR_TILE,
+                                                    y * GSR_TILE)) ? 1u : 0u;
+            if (pair && (c0 | c1)) {
+                const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(cursor + t),
+                                                         (unsigned long long)c0 | ((unsigned long long)c1 << 32));
+                if (c0) keys[(uint32_t)old] = key;
+                if (c1) keys[(uint32_t)(old >> 32)] = key;
+            } else if (c0) {
+                keys[atomicAdd(cursor + t, 1u)] = key;
+            }
+            x += pair ? 2 : 1;
         }
+    }
 }
 
 }  // namespace

@@ -30,31 +30,6 @@ __device__ __forceinline__ void unpack_features(const float4& s1, const float4& 
     if (C > 5) { f[5] = s3.x; f[6] = s3.y; f[7] = s3.z; }
 }
 
-// ---- wave64 sum via DPP (result valid in lanes 48..63) ----
-__device__ __forceinline__ float dpp_add(float v, const int ctrl, const int row_mask) {
-    // lanes whose row is masked off, or whose source is out of range, receive 0
-    int t;
-    switch (ctrl) {  // the control must be an immediate
-        case 0xB1: t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true); break;
-        case 0x4E: t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true); break;
-        case 0x141: t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true); break;
-        case 0x140: t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true); break;
-        case 0x142: t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false); break;
-        default: t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false); break;
-    }
-    (void)row_mask;
-    return v + __int_as_float(t);
-}
-__device__ __forceinline__ float wave_sum_hi(float v) {
-    v = dpp_add(v, 0xB1, 0xF);   // quad_perm [1,0,3,2]
-    v = dpp_add(v, 0x4E, 0xF);   // quad_perm [2,3,0,1]
-    v = dpp_add(v, 0x141, 0xF);  // row_half_mirror
-    v = dpp_add(v, 0x140, 0xF);  // row_mirror          -> every lane holds its row's sum
-    v = dpp_add(v, 0x142, 0xA);  // row_bcast:15 into rows 1,3
-    v = dpp_add(v, 0x143, 0xC);  // row_bcast:31 into rows 2,3 -> lanes 48..63 hold the wave sum
-    return v;
-}
-
 // ---------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------
@@ -153,71 +128,84 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(int W, int H, int gr
 template <int C> struct AccRow { static constexpr int N = C == 3 ? 9 : (C == 5 ? 10 : 13); static constexpr int STRIDE = N | 1; };
 
 #ifndef GSR_BWD_BATCH
-#define GSR_BWD_BATCH 128
+#define GSR_BWD_BATCH 64
 #endif
-#ifndef GSR_BWD_MINWAVES
-#define GSR_BWD_MINWAVES 1
+#ifndef GSR_BWD_PPL
+#define GSR_BWD_PPL 4
 #endif
-constexpr int BWD_BATCH = GSR_BWD_BATCH;  // splats staged per round in the backward (LDS: 4 wave-private accumulator slabs)
+constexpr int BWD_BATCH = GSR_BWD_BATCH;  // splats staged per round (LDS: one accumulator slab per wave)
 
-template <int C>
-__global__ __launch_bounds__(256, GSR_BWD_MINWAVES) void composite_bwd_kernel(int W, int H, int grid_x,
-                                                            const uint32_t* __restrict__ tile_start,
-                                                            GsrStream stream, Bg bg,
-                                                            const float* __restrict__ vpixels,
-                                                            const uint32_t* __restrict__ n_contrib,
-                                                            const float* __restrict__ final_T, GsrInst inst) {
+// PPL = pixels per lane.  PPL == 1: 4 waves per tile, a wave owns a 16x4 strip.  PPL == 2:
+// 2 waves per tile, a wave owns 16x8 pixels and lane l the pixels (x, y) and (x, y+4).
+// PPL == 4 (default): ONE wave64 per tile, lane l owns (x, y), (x, y+4), (x, y+8), (x, y+12).
+// The LDS reads, the cross-lane reduction and the row store — ~60 % of the instructions of a
+// visited (strip, splat) pair — are paid once for 2x / 4x the pixels (measured at config 3:
+// 1.115 / 0.975 / 0.917 ms for PPL = 1 / 2 / 4).
+template <int C, int PPL>
+__global__ __launch_bounds__(256 / PPL) void composite_bwd_kernel(int W, int H, int grid_x,
+                                                                const uint32_t* __restrict__ tile_start,
+                                                                GsrStream stream, Bg bg,
+                                                                const float* __restrict__ vpixels,
+                                                                const uint32_t* __restrict__ n_contrib,
+                                                                const float* __restrict__ final_T, GsrInst inst) {
     constexpr int NA = AccRow<C>::N, ST = AccRow<C>::STRIDE;
-    constexpr int BB = BWD_BATCH;
+    constexpr int BB = BWD_BATCH, NT = 256 / PPL, NW = NT / 64, ROWS = 4 * PPL;
+    static_assert(BB <= NT && BB % 64 == 0, "one staging thread per splat");
     __shared__ float4 l0[BB], l1[BB], l2[BB];
     __shared__ float4 l3[C > 5 ? BB : 1];
     // One accumulator slab per wave: a wave stores its reduced partials with plain ds_write
     // (no LDS atomics: hipcc wraps those in a per-lane "atomic optimizer" loop), and a
     // per-wave bit mask records which rows it touched so nothing has to be zero-filled.
-    __shared__ float lacc[4][BB * ST];
-    __shared__ unsigned long long lmask[4][BB / 64];
+    __shared__ float lacc[NW][BB * ST];
+    __shared__ unsigned long long lmask[NW][BB / 64];
     __shared__ int tile_last_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t strip_bits = 0xFu << (4 * wave);  // this wave's 4 pixel rows
+    const uint32_t strip_bits = ((1u << ROWS) - 1u) << (ROWS * wave);  // this wave's pixel rows
     const gsr::LaneBits lane_bits(lane);
     const int red_slot = gsr::wave_reduce_index<NA>(lane);  // which partial this lane ends up holding
     const bool red_writer = gsr::wave_reduce_writer(lane);
     const int tile = blockIdx.y * grid_x + blockIdx.x;
-    const int px = blockIdx.x * GSR_TILE + (tid & 15), py = blockIdx.y * GSR_TILE + (tid >> 4);
-    const bool inside = px < W && py < H;
-    const float fx = (float)px, fy = (float)py;
+    const int px = blockIdx.x * GSR_TILE + (lane & 15);
+    const int py0 = blockIdx.y * GSR_TILE + ROWS * wave + (lane >> 4);
+    const float fx = (float)px;
     const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
     if (end == start) return;
-    const size_t pi = (size_t)px + (size_t)W * py;
 
-    const float T_final = inside ? final_T[pi] : 0.0f;
-    float T = T_final;
-    const int last_contributor = inside ? (int)n_contrib[pi] : 0;
-    float vp[C];
+    // per-pixel state (PPL pixels per lane: rows py0 and py0 + 4)
+    float fy[PPL], T[PPL], A[PPL], bgT[PPL], vp[PPL][C];
+    int last_contributor[PPL];
+    int wave_last = 0;  // deepest list position any pixel of this wave blended
 #pragma unroll
-    for (int c = 0; c < C; c++) vp[c] = inside ? vpixels[(size_t)C * pi + c] : 0.0f;
-    float bg_dot = 0.0f;
+    for (int q = 0; q < PPL; q++) {
+        const int py = py0 + 4 * q;
+        const bool inside = px < W && py < H;
+        const size_t pi = (size_t)px + (size_t)W * py;
+        fy[q] = (float)py;
+        const float T_final = inside ? final_T[pi] : 0.0f;
+        T[q] = T_final;
+        last_contributor[q] = inside ? (int)n_contrib[pi] : 0;
+        float bg_dot = 0.0f;
 #pragma unroll
-    for (int c = 0; c < C; c++) bg_dot += bg.v[c] * vp[c];
-    const float bgT = -T_final * bg_dot;
-    // The reference carries accum_rec[c], last_color[c], last_alpha per channel and forms
-    //   vα = Σ_c (color[c] - accum_rec[c])·v[c]            (render.jl:245-252).
-    // Only the dot product with the pixel cotangent is ever used, so the state is folded to
-    // one scalar A = accum_rec·v with the same recurrence  A' = α·(color·v) + (1-α)·A.
-    float A = 0.0f;
+        for (int c = 0; c < C; c++) {
+            vp[q][c] = inside ? vpixels[(size_t)C * pi + c] : 0.0f;
+            bg_dot += bg.v[c] * vp[q][c];
+        }
+        bgT[q] = -T_final * bg_dot;
+        // The reference carries accum_rec[c], last_color[c], last_alpha per channel and forms
+        //   vα = Σ_c (color[c] - accum_rec[c])·v[c]            (render.jl:245-252).
+        // Only the dot product with the pixel cotangent is ever used, so the state is folded to
+        // one scalar A = accum_rec·v with the same recurrence  A' = α·(color·v) + (1-α)·A.
+        A[q] = 0.0f;
+        wave_last = max(wave_last, last_contributor[q]);
+    }
 
     // Splats behind every pixel's last contributor are skipped by each lane in the reference
     // (render.jl:223); start the back-to-front walk at the deepest one any pixel blended.
     if (tid == 0) tile_last_s = 0;
-    int wave_last;  // deepest list position any pixel of this wave's strip blended
     __syncthreads();
-    {
-        int m = last_contributor;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
-        if (lane == 0) atomicMax(&tile_last_s, m);
-        wave_last = m;
-    }
+    for (int off = 32; off > 0; off >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, off));
+    if (lane == 0) atomicMax(&tile_last_s, wave_last);
     __syncthreads();
     const int tile_last = tile_last_s;  // process list positions tile_last-1 ... 0
 
@@ -241,53 +229,66 @@ __global__ __launch_bounds__(256, GSR_BWD_MINWAVES) void composite_bwd_kernel(in
           const int jj = c0 + lane;
           const bool cand = jj < cnt && (__float_as_uint(l2[jj].w) & strip_bits) != 0u &&
                             (tile_last - 1 - base - jj) < wave_last;
-          unsigned long long wl = __ballot(cand);  // splats whose footprint can touch this strip
+          unsigned long long wl = __ballot(cand);  // splats whose footprint can touch this wave's rows
           while (wl) {
             const int j = c0 + __builtin_ctzll(wl);
             wl &= wl - 1;
             const int contributor = tile_last - 1 - base - j;  // 0-based position in the tile list
             const float4 a = l0[j], b = l1[j], c2 = l2[j];
-            const float dx = a.x - fx, dy = a.y - fy;
             const float o = b.y;
-            const float sigma = a.w * dx * dy + 0.5f * (a.z * (dx * dx) + b.x * (dy * dy));
-            const float G = __expf(-sigma);
-            const float alpha = fminf(0.99f, o * G);
-            const bool active = contributor < last_contributor && sigma >= 0.0f && alpha >= (1.0f / 255.0f);
-            if (__ballot(active) == 0ull) continue;  // wave-uniform: no pixel of this 16x4 strip is touched
+            const float dx = a.x - fx;
+            const float hxx = 0.5f * (a.z * (dx * dx)), bdx = a.w * dx;
+            float dy[PPL], G[PPL], alpha[PPL];
+            bool active[PPL], any_active = false;
+#pragma unroll
+            for (int q = 0; q < PPL; q++) {
+                dy[q] = a.y - fy[q];
+                const float sigma = bdx * dy[q] + (hxx + 0.5f * (b.x * (dy[q] * dy[q])));
+                G[q] = __expf(-sigma);
+                alpha[q] = fminf(0.99f, o * G[q]);
+                active[q] = contributor < last_contributor[q] && sigma >= 0.0f && alpha[q] >= (1.0f / 255.0f);
+                any_active = any_active || active[q];
+            }
+            if (__ballot(any_active) == 0ull) continue;  // wave-uniform: none of this wave's pixels is touched
 #pragma unroll
             for (int w = 0; w < BB / 64; w++)
                 if ((j >> 6) == w) touched[w] |= 1ull << (j & 63);
 
+            float f[C];
+            unpack_features<C>(b, c2, C > 5 ? l3[j] : c2, f);
             float part[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) part[k] = 0.0f;
-            if (active) {
-                // T /= (1-α) and -T_final/(1-α) (render.jl:237,259) share one hardware reciprocal
-                const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
-                T = T * rinv;
-                const float fac = alpha * T;
-                float f[C];
-                unpack_features<C>(b, c2, C > 5 ? l3[j] : c2, f);
-                float cv = f[0] * vp[0];
 #pragma unroll
-                for (int c = 1; c < C; c++) cv += f[c] * vp[c];
-                const float d = cv - A;                 // (color - accum_rec)·v
-                const float valpha = d * T + bgT * rinv;
-                A = A + alpha * d;                      // α·cv + (1-α)·A for the next (nearer) splat
-                const float vsigma = -o * G * valpha;
-                const float hs = 0.5f * vsigma;
-                part[0] = fac * vp[0]; part[1] = fac * vp[1]; part[2] = fac * vp[2];
-                part[3] = G * valpha;
-                part[4] = hs * (dx * dx);
-                part[5] = hs * (dx * dy);
-                part[6] = hs * (dy * dy);
-                part[7] = vsigma * (a.z * dx + a.w * dy);
-                part[8] = vsigma * (a.w * dx + b.x * dy);
-                if (C > 3) part[9] = fac * vp[3];  // depth feature; channel 4 (constant 1) is not a parameter
-                if (C > 5) { part[10] = fac * vp[5]; part[11] = fac * vp[6]; part[12] = fac * vp[7]; }
+            for (int q = 0; q < PPL; q++) {
+                if (active[q]) {
+                    // T /= (1-α) and -T_final/(1-α) (render.jl:237,259) share one hardware reciprocal
+                    const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha[q]);
+                    T[q] = T[q] * rinv;
+                    const float fac = alpha[q] * T[q];
+                    float cv = f[0] * vp[q][0];
+#pragma unroll
+                    for (int c = 1; c < C; c++) cv += f[c] * vp[q][c];
+                    const float d = cv - A[q];                 // (color - accum_rec)·v
+                    const float valpha = d * T[q] + bgT[q] * rinv;
+                    A[q] = A[q] + alpha[q] * d;                // α·cv + (1-α)·A for the next (nearer) splat
+                    const float vsigma = -o * G[q] * valpha;
+                    const float hs = 0.5f * vsigma;
+                    part[0] += fac * vp[q][0]; part[1] += fac * vp[q][1]; part[2] += fac * vp[q][2];
+                    part[3] += G[q] * valpha;
+                    part[4] += hs * (dx * dx);
+                    part[5] += hs * (dx * dy[q]);
+                    part[6] += hs * (dy[q] * dy[q]);
+                    part[7] += vsigma * (a.z * dx + a.w * dy[q]);
+                    part[8] += vsigma * (a.w * dx + b.x * dy[q]);
+                    if (C > 3) part[9] += fac * vp[q][3];  // depth feature; channel 4 (constant 1) is not a parameter
+                    if (C > 5) { part[10] += fac * vp[q][5]; part[11] += fac * vp[q][6]; part[12] += fac * vp[q][7]; }
+                }
             }
             // transposed wave64 reduction: ~3·NA/2 + 6 VALU ops, then ONE ds_write for all NA sums
             const float total = gsr::wave_reduce_transposed<NA>(part, lane_bits);
+            // (storing the sums straight into the global row when NW == 1 measured 3 % slower than
+            // the LDS slab + coalesced 64-byte row stores below)
             if (red_writer) my[j * ST + red_slot] = total;
           }
         }
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(256, GSR_BWD_MINWAVES) void composite_bwd_kernel(in
             for (int k = 0; k < NA; k++) r[k] = 0.0f;
             bool any = false;
 #pragma unroll
-            for (int w = 0; w < 4; w++) {
+            for (int w = 0; w < NW; w++) {
                 if ((lmask[w][tid >> 6] >> (tid & 63)) & 1ull) {
                     any = true;
 #pragma unroll
@@ -349,11 +350,11 @@ void gsr_launch_composite_fwd(hipStream_t s, int channels, GsrCam cam, const uin
 void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start, GsrStream stream,
                               const float* background, const float* vpixels, const uint32_t* n_contrib,
                               const float* final_T, GsrInst inst) {
-    dim3 grid(cam.grid_x, cam.grid_y), block(256);
+    dim3 grid(cam.grid_x, cam.grid_y), block(256 / GSR_BWD_PPL);
     Bg bg = make_bg(background, channels);
 #define LAUNCH(CC)                                                                                                 \
-    hipLaunchKernelGGL((composite_bwd_kernel<CC>), grid, block, 0, s, cam.width, cam.height, cam.grid_x, tile_start, \
-                       stream, bg, vpixels, n_contrib, final_T, inst)
+    hipLaunchKernelGGL((composite_bwd_kernel<CC, GSR_BWD_PPL>), grid, block, 0, s, cam.width, cam.height,          \
+                       cam.grid_x, tile_start, stream, bg, vpixels, n_contrib, final_T, inst)
     if (channels == 3) LAUNCH(3);
     else if (channels == 5) LAUNCH(5);
     else LAUNCH(8);

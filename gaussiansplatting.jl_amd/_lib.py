@@ -59,7 +59,7 @@ class Grads(C.Structure):
 EXPORTS = ["gsr_create", "gsr_destroy", "gsr_release_scene_buffers", "gsr_memory_usage", "gsr_forward",
            "gsr_backward", "gsr_buffer", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_loss_l1_ssim",
            "gsr_allreduce_grads", "gsr_last_error_string", "gsr_version", "gsr_profile_enable",
-           "gsr_profile_stage_count", "gsr_profile_stage_name", "gsr_profile_read"]
+           "gsr_profile_stage_count", "gsr_profile_stage_name", "gsr_profile_read", "gsr_update_stats"]
 
 _lib = None
 
@@ -98,6 +98,7 @@ def load():
     lib.gsr_ssim_backward.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_loss_l1_ssim.argtypes = [vp, vp, vp, f32, vp, vp, vp]
     lib.gsr_allreduce_grads.argtypes = [vp, vp, C.c_size_t, vp]
+    lib.gsr_update_stats.argtypes = [vp, vp, vp, vp, vp]
     lib.gsr_profile_enable.argtypes = [vp, i32]
     lib.gsr_profile_stage_name.argtypes = [i32]
     lib.gsr_profile_stage_name.restype = C.c_char_p

@@ -117,7 +117,7 @@ struct gsr_handle {
     // loss-head scratch
     DevBuf d0, d1, d2, partial;
     uint32_t* host_totals = nullptr;  // pinned: D, max tile count, #oversized tiles, slab ctr, n_visible
-    bool fwd_valid = false;
+    bool fwd_valid = false, bwd_valid = false;
     int last_n = 0;
     int64_t last_D = 0;
     uint32_t last_max_tile = 0;
@@ -250,6 +250,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     const int C = h->cfg.mode, n = in->n;
     const size_t P = (size_t)h->cfg.width * h->cfg.height, T = (size_t)h->n_tiles;
     h->fwd_valid = false;
+    h->bwd_valid = false;
 
     const size_t nn = n > 0 ? (size_t)n : 1;
     const int n_blocks = (n + 255) / 256;
@@ -360,6 +361,7 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
                             g->vscales, g->vrotations, g->vR, g->vt);
     h->prof.end(s);
     HIPCHK(hipGetLastError());
+    h->bwd_valid = true;
     return GSR_OK;
 }
 
@@ -431,6 +433,15 @@ int gsr_loss_l1_ssim(gsr_handle* h, const float* image, const float* target, flo
     gsr_launch_loss_bwd(s, W, H, C, image, target, lambda_dssim, h->d0.as<float>(), h->d1.as<float>(),
                         h->d2.as<float>(), h->partial.as<float>(), loss_out, vpixels);
     h->prof.end(s);
+    HIPCHK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_update_stats(gsr_handle* h, int32_t* max_radii, float* accum_grad_means2d, float* denom, void* stream) {
+    if (!h || !max_radii || !accum_grad_means2d || !denom) return fail(GSR_E_INVALID_ARG, "null argument");
+    if (!h->fwd_valid || !h->bwd_valid) return fail(GSR_E_STATE, "gsr_update_stats needs a completed forward/backward pair");
+    gsr_launch_update_stats((hipStream_t)stream, h->last_n, h->radii.as<int32_t>(), h->vmean2d.as<float2>(),
+                            h->cfg.width, h->cfg.height, max_radii, accum_grad_means2d, denom);
     HIPCHK(hipGetLastError());
     return GSR_OK;
 }

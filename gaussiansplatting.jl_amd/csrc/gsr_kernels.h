@@ -67,6 +67,9 @@ void gsr_launch_pergauss_bwd(hipStream_t s, int n, int K, int degree, int channe
                              GsrInst inst, float2* vmean2d, float* vmeans, float* vshs, float* vopac,
                              float* vscales, float* vrots, float* vR, float* vt);
 
+void gsr_launch_update_stats(hipStream_t s, int n, const int32_t* radii, const float2* vmean2d, int width, int height,
+                             int32_t* max_radii, float* accum, float* denom);
+
 // ---- binning.hip ----
 // exclusive scan of tile_count -> tile_start[T+1], cursor[T] = tile_start; and of the per-block
 // rect-area sums bsum[nb] -> bpre[nb];

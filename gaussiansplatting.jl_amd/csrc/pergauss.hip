@@ -700,7 +700,31 @@ __global__ __launch_bounds__(256) void scatter_kernel(int n, int grid_x, int exa
     }
 }
 
+// _update_stats! (src/strategy.jl:118-136): densification statistics from the side outputs of
+// the last forward/backward pair (radii, ∇means_2d).
+__global__ __launch_bounds__(256) void update_stats_kernel(int n, const int32_t* __restrict__ radii,
+                                                           const float2* __restrict__ vmean2d, float res_x,
+                                                           float res_y, int32_t* __restrict__ max_radii,
+                                                           float* __restrict__ accum, float* __restrict__ denom) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int r = radii[i];
+    if (!(r > 0)) return;
+    max_radii[i] = max(max_radii[i], r);
+    const float2 g = vmean2d[i];
+    const float gx = g.x * res_x * 0.5f, gy = g.y * res_y * 0.5f;
+    accum[i] += sqrtf(gx * gx + gy * gy);
+    denom[i] += 1.0f;
+}
+
 }  // namespace
+
+void gsr_launch_update_stats(hipStream_t s, int n, const int32_t* radii, const float2* vmean2d, int width, int height,
+                             int32_t* max_radii, float* accum, float* denom) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(update_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, radii, vmean2d, (float)width,
+                       (float)height, max_radii, accum, denom);
+}
 
 void gsr_launch_scatter(hipStream_t s, int n, GsrCam cam, GsrGeom geom, uint32_t* cursor, uint64_t* keys) {
     if (n <= 0) return;

@@ -106,6 +106,17 @@ class GaussianRasterizer:
         """memory_usage(rast) — rasterizer.jl:127-134"""
         return int(self._lib.gsr_memory_usage(self._h)) + self.image.numel() * 4
 
+    def update_stats(self, max_radii, accum_grad_means_2d, denom):
+        """update_stats!(strategy, rast.gstate.radii, rast.gstate.∇means_2d, resolution) —
+        strategy.jl:107-136: in-place update of the densification statistics (int32 max_radii,
+        float32 accum, float32 denom; N elements each) from the last forward/backward pair."""
+        for t, dt in ((max_radii, torch.int32), (accum_grad_means_2d, torch.float32), (denom, torch.float32)):
+            if not (t.is_cuda and t.dtype == dt and t.is_contiguous() and t.numel() == self._n):
+                raise ValueError("statistics must be contiguous HIP tensors of N elements (int32 / float32 / float32)")
+        with torch.cuda.device(self.device):
+            L.check(self._lib.gsr_update_stats(self._h, max_radii.data_ptr(), accum_grad_means_2d.data_ptr(),
+                                               denom.data_ptr(), _stream()))
+
     # ---- per-stage kernel timing (HIP events on the launch stream) ----
     def profile(self, on: bool = True):
         L.check(self._lib.gsr_profile_enable(self._h, 1 if on else 0))

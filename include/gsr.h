@@ -164,6 +164,13 @@ enum {
 };
 GSR_API int gsr_buffer(const gsr_handle* h, int which, const void** dev_ptr, size_t* bytes);
 
+/* update_stats!(strategy, rast.gstate.radii, rast.gstate.∇means_2d, resolution) —
+ * src/strategy.jl:107-136 (`_update_stats!`): for every Gaussian visible in the last
+ * forward, max_radii = max(max_radii, radius), accum += ‖∇mean_2d · resolution · 0.5‖,
+ * denom += 1.  All three are caller-owned device arrays of N elements (the DefaultStrategy's
+ * densification state); needs a completed gsr_forward/gsr_backward pair on the handle. */
+GSR_API int gsr_update_stats(gsr_handle* h, int32_t* max_radii, float* accum_grad_means2d, float* denom, void* stream);
+
 /* _fused_ssim / fused_ssim_bwd — src/fused_ssim.jl:373-408.  Arrays are (W,H,CH,B),
  * x fastest.  With train == 0 the three partial-derivative maps may be NULL. */
 GSR_API int gsr_ssim_forward(int W, int H, int CH, int B, const float* img, const float* ref, float C1, float C2,

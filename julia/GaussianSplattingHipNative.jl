@@ -114,4 +114,9 @@ end
 radii(rast, n) = state_buffer(rast, 0, Int32, (n,))
 grad_means_2d(rast, n) = state_buffer(rast, 1, Float32, (2, n))
 
+# update_stats!(strategy, radii, ∇means_2d, resolution) (src/strategy.jl:107-116) without the copies
+update_stats!(strategy, rast::HipNativeRasterizer) = check(ccall((:gsr_update_stats, LIB), Cint,
+    (Ptr{Cvoid}, Ptr{Int32}, Ptr{Float32}, Ptr{Float32}, Ptr{Cvoid}), rast.handle,
+    Ptr{Int32}(UInt(pointer(strategy.max_radii))), dptr(strategy.accum_∇means_2d), dptr(strategy.denom), hipstream()))
+
 end # module

@@ -401,3 +401,15 @@ def loss_head(image_hwc, target_chw, lambda_dssim=np.float32(0.2)):
     vpix = np.zeros_like(image_hwc)
     vpix[:, :, :3] = np.transpose(g[0], (1, 2, 0))
     return np.float32(loss), vpix
+
+
+def update_stats(max_radii, accum, denom, radii, vmeans2d, width, height):
+    """_update_stats! (src/strategy.jl:118-136), in place on numpy arrays."""
+    vis = radii > 0
+    max_radii[vis] = np.maximum(max_radii[vis], radii[vis])
+    g = _f(vmeans2d)
+    gx = g[:, 0] * np.float32(width) * np.float32(0.5)
+    gy = g[:, 1] * np.float32(height) * np.float32(0.5)
+    nrm = np.sqrt(gx * gx + gy * gy, dtype=np.float32)
+    accum[vis] += nrm[vis]
+    denom[vis] += np.float32(1.0)

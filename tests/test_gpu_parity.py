@@ -325,6 +325,29 @@ def test_functor_autograd_end_to_end(pkg, orc):
     assert rel_l2(p[5].grad.cpu().numpy(), g.vshs[:, 1:]) <= 1e-4
 
 
+def test_update_stats_vs_oracle(pkg, orc):
+    """strategy.jl:107-136 `_update_stats!` on the side outputs of a forward/backward pair."""
+    s, cam = _scene(pkg, orc, 500, 96, 64, 1, 61, sigma_px=4.0)
+    st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, 1)
+    run = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, 1)
+    run.forward()
+    rng = np.random.default_rng(2)
+    mr = rng.integers(0, 30, 500).astype(np.int32)
+    acc = rng.uniform(size=500).astype(np.float32)
+    den = rng.integers(0, 5, 500).astype(np.float32)
+    d_mr, d_acc, d_den = dev(mr, torch.int32), dev(acc), dev(den)
+    with pytest.raises(pkg._lib.GsrError):
+        run.rast.update_stats(d_mr, d_acc, d_den)  # no backward yet
+    vp = np.random.default_rng(3).standard_normal((64, 96, 3)).astype(np.float32)
+    run.backward(vp)
+    run.rast.update_stats(d_mr, d_acc, d_den)
+    vm2 = run.rast.grad_means_2d.cpu().numpy()
+    orc.update_stats(mr, acc, den, st.radii, vm2, 96, 64)
+    assert np.array_equal(d_mr.cpu().numpy(), mr)
+    assert np.array_equal(d_den.cpu().numpy(), den)
+    assert np.allclose(d_acc.cpu().numpy(), acc, rtol=1e-6, atol=1e-7)
+
+
 def test_state_errors(pkg):
     """gsr_backward without a matching forward -> GSR_E_STATE; bad shapes -> ValueError."""
     s = pkg.synthetic.make_scene(32, 64, 48, 0, 3)

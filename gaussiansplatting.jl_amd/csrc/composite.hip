@@ -120,6 +120,91 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(int W, int H, int gr
     }
 }
 
+// Strip variant of the forward: one wave64 per 16x4 strip, four independent single-wave
+// workgroups per tile.  No workgroup barriers, a strip stops as soon as ITS pixels have
+// saturated, and a wave stages only the splats its row-mask ballot selected (the four strips
+// re-read the tile's stream through L2).  Same per-pixel arithmetic in the same order.
+template <int C, bool AUX>
+__global__ __launch_bounds__(64) void composite_fwd_strip_kernel(int W, int H, int grid_x,
+                                                                 const uint32_t* __restrict__ tile_start,
+                                                                 GsrStream stream, Bg bg, float* __restrict__ image,
+                                                                 uint32_t* __restrict__ n_contrib,
+                                                                 float* __restrict__ final_T,
+                                                                 const uint32_t* __restrict__ values_sorted,
+                                                                 uint8_t* __restrict__ covis,
+                                                                 float* __restrict__ uncert) {
+    __shared__ float4 l0[64], l1[64], l2[64];
+    __shared__ float4 l3[C > 5 ? 64 : 1];
+    const int lane = threadIdx.x;
+    const int strip = blockIdx.y & 3, tile_y = blockIdx.y >> 2;
+    const uint32_t strip_bits = 0xFu << (4 * strip);
+    const int tile = tile_y * grid_x + blockIdx.x;
+    const int px = blockIdx.x * GSR_TILE + (lane & 15), py = tile_y * GSR_TILE + 4 * strip + (lane >> 4);
+    const bool inside = px < W && py < H;
+    const float fx = (float)px, fy = (float)py;
+    const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
+    const int to_do = (int)(end - start);
+
+    bool done = !inside;
+    float T = 1.0f;
+    uint32_t last = 0;
+    float color[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) color[c] = 0.0f;
+    float unc = 0.0f;
+
+    for (int base = 0; base < to_do; base += 64) {
+        if (__ballot(!done) == 0ull) break;  // the whole strip has saturated
+        const int jj = base + lane;
+        float4 r2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (jj < to_do) r2 = stream.s2[start + jj];
+        const bool cand = jj < to_do && (__float_as_uint(r2.w) & strip_bits) != 0u;
+        unsigned long long m = __ballot(cand);
+        if (m == 0ull) continue;
+        __builtin_amdgcn_wave_barrier();  // previous batch's LDS reads are done (single wave, in order)
+        if (cand) {
+            l0[lane] = stream.s0[start + jj];
+            l1[lane] = stream.s1[start + jj];
+            l2[lane] = r2;
+            if (C > 5) l3[lane] = stream.s3[start + jj];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        while (m) {
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            const float4 a = l0[j], b = l1[j], c2 = l2[j];
+            const float dx = a.x - fx, dy = a.y - fy;
+            const float sigma = a.w * dx * dy + 0.5f * (a.z * (dx * dx) + b.x * (dy * dy));
+            const float alpha = fminf(0.99f, b.y * __expf(-sigma));
+            const float Tn = T * (1.0f - alpha);
+            bool ok = !done && sigma >= 0.0f && alpha >= (1.0f / 255.0f);
+            const bool stop = ok && Tn < 1e-4f;
+            done = done || stop;
+            ok = ok && !stop;
+            float f[C];
+            unpack_features<C>(b, c2, C > 5 ? l3[j] : c2, f);
+            const float w = ok ? alpha * T : 0.0f;
+#pragma unroll
+            for (int c = 0; c < C; c++) color[c] += f[c] * w;
+            if (AUX) {
+                unc += w;
+                if (covis && ok && T > 0.5f) covis[values_sorted[start + base + j]] = 1;
+            }
+            T = ok ? Tn : T;
+            last = ok ? (uint32_t)(base + j + 1) : last;
+        }
+    }
+    if (inside) {
+        const size_t pi = (size_t)px + (size_t)W * py;
+        final_T[pi] = T;
+        n_contrib[pi] = last;
+#pragma unroll
+        for (int c = 0; c < C; c++) image[(size_t)C * pi + c] = color[c] + T * bg.v[c];
+        if (AUX && uncert) uncert[pi] = unc;
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------
@@ -335,11 +420,17 @@ Bg make_bg(const float* background, int channels) {
 void gsr_launch_composite_fwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start, GsrStream stream,
                               const float* background, float* image, uint32_t* n_contrib, float* final_T,
                               const uint32_t* values_sorted, uint8_t* covis, float* uncert) {
+#ifdef GSR_FWD_TILE_BLOCKS
     dim3 grid(cam.grid_x, cam.grid_y), block(256);
+#define FWD_KERNEL composite_fwd_kernel
+#else
+    dim3 grid(cam.grid_x, cam.grid_y * 4), block(64);
+#define FWD_KERNEL composite_fwd_strip_kernel
+#endif
     Bg bg = make_bg(background, channels);
     const bool aux = covis || uncert;
 #define LAUNCH(CC, AA)                                                                                             \
-    hipLaunchKernelGGL((composite_fwd_kernel<CC, AA>), grid, block, 0, s, cam.width, cam.height, cam.grid_x,       \
+    hipLaunchKernelGGL((FWD_KERNEL<CC, AA>), grid, block, 0, s, cam.width, cam.height, cam.grid_x,                 \
                        tile_start, stream, bg, image, n_contrib, final_T, values_sorted, covis, uncert)
     if (channels == 3) { if (aux) LAUNCH(3, true); else LAUNCH(3, false); }
     else if (channels == 5) { if (aux) LAUNCH(5, true); else LAUNCH(5, false); }

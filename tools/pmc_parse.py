@@ -14,7 +14,7 @@ import sys
 from collections import defaultdict
 
 STAGES = {"preprocess_kernel": "preprocess", "tile_scan_kernel": "tile_scan", "scatter_kernel": "scatter",
-          "tile_sort_kernel": "tile_sort", "composite_fwd_kernel": "composite_fwd",
+          "tile_sort_kernel": "tile_sort", "composite_fwd_": "composite_fwd",
           "composite_bwd_kernel": "composite_bwd", "pergauss_bwd_kernel": "pergauss_bwd",
           "ssim_fwd_kernel": "loss_fwd", "ssim_bwd_kernel": "loss_bwd"}
 CAL_BYTES = 256 * 1024 * 1024 * 4

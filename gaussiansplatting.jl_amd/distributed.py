@@ -44,8 +44,10 @@ def init_from_env(backend: str | None = None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+            # GSR_DIST_BACKEND=gloo lets several ranks share one GPU (logic tests on a 1-GPU box)
+            backend = os.environ.get("GSR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            local = local % max(torch.cuda.device_count(), 1)
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local

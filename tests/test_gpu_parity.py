@@ -92,6 +92,64 @@ def test_forward_backward_vs_oracle(pkg, orc, mode, deg, seed, W, H, n):
     assert rel_l2(run.rast.grad_means_2d.cpu().numpy(), g.vmeans2d) <= 1e-4
 
 
+@pytest.mark.parametrize("case", range(12))
+def test_randomised_sweep_vs_oracle(pkg, orc, case):
+    """Seeded sweep over modes, SH degrees, ragged resolutions, views, footprint sizes and
+    opacity ranges (both list modes): every stage against the oracle."""
+    rng = np.random.default_rng(9000 + case)
+    mode = ["rgb", "rgbd", "rgbdn"][case % 3]
+    deg = int(rng.integers(0, 4))
+    W, H = int(rng.integers(20, 140)), int(rng.integers(20, 110))
+    n = int(rng.integers(1, 1500))
+    s = pkg.synthetic.make_scene(n, W, H, deg, 9100 + case, sigma_px=float(rng.uniform(1.5, 9.0)),
+                                 K=16 if case % 4 == 0 else None)
+    opac = (s.opacities * rng.uniform(0.05, 1.0)).astype(np.float32) if case % 2 else s.opacities
+    R, t = pkg.synthetic.view_pose(int(rng.integers(0, 8)))
+    cam = orc.Camera(W, H, s.focal, R=R, t=t, principal=(float(rng.uniform(0.4, 0.6)), float(rng.uniform(0.4, 0.6))))
+    bg = tuple(float(x) for x in rng.uniform(0, 1, 3))
+    st = orc.forward(s.means, s.shs, opac, s.scales, s.rotations, cam, deg, background=bg, mode=mode)
+    run = HipRun(pkg, s.means, s.shs, opac, s.scales, s.rotations, cam, deg, bg, mode)
+    img = run.forward().clone()
+    _compare_forward(st, run, img)
+    C = st.image.shape[2]
+    vp = rng.standard_normal((H, W, C)).astype(np.float32)
+    g = orc.backward(st, vp, s.means, s.shs, opac, s.scales, s.rotations, cam, deg, background=bg)
+    if st.n_rendered > 0 and np.linalg.norm(g.vmeans) > 0:
+        _compare_backward(g, run.backward(vp), st.radii > 0)
+    cul = HipRun(pkg, s.means, s.shs, opac, s.scales, s.rotations, cam, deg, bg, mode, exact_tile_cull=True)
+    assert torch.equal(cul.forward(), img)
+    if st.n_rendered > 0 and np.linalg.norm(g.vmeans) > 0:
+        _compare_backward(g, cul.backward(vp), st.radii > 0)
+
+
+def test_degenerate_inputs(pkg, orc):
+    """Zero / tiny opacities, Gaussians behind the camera or far off-screen, a zero Gaussian count."""
+    W, H = 64, 48
+    s = pkg.synthetic.make_scene(200, W, H, 1, 17, sigma_px=4.0)
+    cam = orc.Camera(W, H, s.focal)
+    opac = s.opacities.copy()
+    opac[:50] = 0.0
+    opac[50:100] = 1e-4
+    means = s.means.copy()
+    means[100:120, 2] *= -1.0
+    means[120:140, 0] += 500.0
+    st = orc.forward(means, s.shs, opac, s.scales, s.rotations, cam, 1, background=(0.5, 0.5, 0.5))
+    for cull in (False, True):
+        run = HipRun(pkg, means, s.shs, opac, s.scales, s.rotations, cam, 1, (0.5, 0.5, 0.5), exact_tile_cull=cull)
+        img = run.forward()
+        assert frac_bad(img.cpu().numpy(), st.image, 0, 1e-4) <= 1e-4
+        vp = np.random.default_rng(1).standard_normal((H, W, 3)).astype(np.float32)
+        g = orc.backward(st, vp, means, s.shs, opac, s.scales, s.rotations, cam, 1, background=(0.5, 0.5, 0.5))
+        out = run.backward(vp)
+        _compare_backward(g, out, st.radii > 0)
+        assert all(torch.isfinite(o).all() for o in out[:5])
+    # n = 0
+    e = np.zeros((0, 3), np.float32)
+    run0 = HipRun(pkg, e, np.zeros((0, 4, 3), np.float32), np.zeros((0,), np.float32), e, np.zeros((0, 4), np.float32),
+                  cam, 1, (1, 0, 0))
+    assert not run0.forward().cpu().numpy().any() and run0.rast.stats.n_rendered == 0
+
+
 def test_k_padded_sh_storage(pkg, orc):
     """sh_degree below the stored band count (training ramps the degree, training.jl:577-585):
     bands above the active degree are ignored forward and get zero gradient."""

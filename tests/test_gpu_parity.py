@@ -406,6 +406,42 @@ def test_update_stats_vs_oracle(pkg, orc):
     assert np.allclose(d_acc.cpu().numpy(), acc, rtol=1e-6, atol=1e-7)
 
 
+def test_side_stream_two_handles_and_buffer_growth(pkg, orc):
+    """Work is enqueued on the caller's stream (not the null stream); handles are independent;
+    scratch grows when N / D grow between calls."""
+    W, H = 96, 64
+    side = torch.cuda.Stream()
+    scenes_ = [pkg.synthetic.make_scene(n, W, H, 1, 70 + i, sigma_px=sp) for i, (n, sp) in
+               enumerate([(100, 3.0), (900, 6.0), (300, 4.0)])]
+    cam_o = orc.Camera(W, H, scenes_[0].focal)
+    cam = pkg.Camera(W, H, tuple(scenes_[0].focal))
+    ra = pkg.rasterizer.GaussianRasterizer(W, H, mode="rgb")
+    rb = pkg.rasterizer.GaussianRasterizer(W, H, mode="rgb", exact_tile_cull=True)
+    vp = np.random.default_rng(5).standard_normal((H, W, 3)).astype(np.float32)
+    with torch.cuda.stream(side):
+        for s in scenes_:
+            t = [dev(s.means), dev(s.shs), dev(s.opacities.reshape(-1, 1)), dev(s.scales), dev(s.rotations)]
+            ia = ra.forward_raw(*t, cam, 1, (0, 0, 0)).clone()
+            ib = rb.forward_raw(*t, cam, 1, (0, 0, 0)).clone()  # interleaved second handle
+            ga = ra.backward_raw(dev(vp), *t, cam, 1, (0, 0, 0))
+            gb = rb.backward_raw(dev(vp), *t, cam, 1, (0, 0, 0))
+            side.synchronize()
+            st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam_o, 1)
+            g = orc.backward(st, vp, s.means, s.shs, s.opacities, s.scales, s.rotations, cam_o, 1)
+            assert torch.equal(ia, ib)
+            assert frac_bad(ia.cpu().numpy(), st.image, 0, 1e-4) <= 1e-4
+            _compare_backward(g, ga, st.radii > 0)
+            _compare_backward(g, gb, st.radii > 0)
+            assert ra.stats.n_rendered == st.n_rendered
+    ra.profile(True)
+    with torch.cuda.stream(side):
+        ra.forward_raw(*t, cam, 1, (0, 0, 0))
+        ra.backward_raw(dev(vp), *t, cam, 1, (0, 0, 0))
+    prof = ra.profile_read()
+    assert prof["composite_fwd"][1] == 1 and prof["composite_bwd"][1] == 1 and prof["composite_bwd"][0] > 0
+    ra.profile(False)
+
+
 def test_state_errors(pkg):
     """gsr_backward without a matching forward -> GSR_E_STATE; bad shapes -> ValueError."""
     s = pkg.synthetic.make_scene(32, 64, 48, 0, 3)

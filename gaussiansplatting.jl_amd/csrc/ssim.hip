@@ -6,8 +6,8 @@
 // horizontal pass into LDS, vertical pass in registers.  Accumulation order follows the
 // reference (symmetric pairs d = 1..5 with weight GAUSS[5-d], centre tap last) and this
 // file is compiled with -ffp-contract=off, so the maps are bit-reproducible against the
-// CPU oracle.  grid.z enumerates (channel, batch) planes so a 1080p RGB image yields
-// 3 x 8160 workgroups (the reference loops channels inside one workgroup).
+// CPU oracle.  grid.z enumerates (channel, batch) planes for the generic entry points; the
+// loss head loops the three channels inside one workgroup, as the reference does.
 #include "gsr_kernels.h"
 
 namespace {
@@ -57,7 +57,10 @@ __device__ __forceinline__ float block_sum(float v, float* red /*[4]*/) {
 }
 
 // fused_ssim.jl:34-238.  LOSS: additionally reduce Σ|x-y| and Σssim into partial[0..1].
-template <class Src, bool LOSS>
+// NCH = channel planes handled per workgroup (the reference loops channels inside the
+// workgroup, fused_ssim.jl:52; the loss head uses 3 so that the three channels of a pixel —
+// adjacent floats of the (C,W,H) image — are fetched and written by the same workgroup).
+template <class Src, bool LOSS, int NCH>
 __global__ __launch_bounds__(256) void ssim_fwd_kernel(Src src, int W, int H, float C1, float C2, int train,
                                                        float* __restrict__ ssim_map, float* __restrict__ d0,
                                                        float* __restrict__ d1, float* __restrict__ d2,
@@ -66,8 +69,11 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(Src src, int W, int H, fl
     __shared__ float hc[5][SH_DIM][GSR_TILE + 1];
     __shared__ float red[4];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int plane = blockIdx.z;
     const int x0 = blockIdx.x * GSR_TILE, y0 = blockIdx.y * GSR_TILE;
+    float l1 = 0.0f, sv = 0.0f;
+  for (int ch = 0; ch < NCH; ch++) {
+    const int plane = blockIdx.z * NCH + ch;
+    if (ch > 0) __syncthreads();  // previous channel's LDS tiles fully consumed
     for (int f = tid; f < SH_DIM * SH_DIM; f += 256) {
         const int ly = f / SH_DIM, lx = f - ly * SH_DIM;
         const int gx = x0 + lx - HALO, gy = y0 + ly - HALO;
@@ -110,7 +116,6 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(Src src, int W, int H, fl
             o[k] = a;
         }
     }
-    float l1 = 0.0f, sv = 0.0f;
     if (in) {
         const float mu1 = o[0], mu2 = o[2];
         const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2;
@@ -127,10 +132,11 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(Src src, int W, int H, fl
             d2[oi] = (2.0f * Cv) / (A * Bv);
         }
         if (LOSS) {
-            sv = val;
-            l1 = fabsf(sx[ty + HALO][tx + HALO] - sy[ty + HALO][tx + HALO]);
+            sv += val;
+            l1 += fabsf(sx[ty + HALO][tx + HALO] - sy[ty + HALO][tx + HALO]);
         }
     }
+  }
     if (LOSS) {
         // one partial pair per workgroup; 24k workgroups hammering two words with atomics
         // serialise at ~12 ns each (MI355X_MICROARCH.md "fanin")
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(Src src, int W, int H, fl
 
 // fused_ssim.jl:241-371.  LOSS: dL_dmap is the constant -λ/(3P) (pullback of
 // λ·(1-mean(map))), the L1 pullback is added, output goes to the (C,W,H) rasterizer layout.
-template <class Src, bool LOSS>
+template <class Src, bool LOSS, int NCH>
 __global__ __launch_bounds__(256) void ssim_bwd_kernel(Src src, int W, int H, const float* __restrict__ dL_dmap,
                                                        float chain_const, float l1_scale,
                                                        const float* __restrict__ d0, const float* __restrict__ d1,
@@ -154,9 +160,13 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(Src src, int W, int H, co
     __shared__ float sd[3][SH_DIM][SH_DIM + 1];
     __shared__ float hc[3][SH_DIM][GSR_TILE + 1];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int plane = blockIdx.z;
     const int x0 = blockIdx.x * GSR_TILE, y0 = blockIdx.y * GSR_TILE;
     const size_t P = (size_t)W * H;
+    float gout[NCH];
+  for (int ch = 0; ch < NCH; ch++) {
+    const int plane = blockIdx.z * NCH + ch;
+    gout[ch] = 0.0f;
+    if (ch > 0) __syncthreads();
     for (int f = tid; f < SH_DIM * SH_DIM; f += 256) {
         const int ly = f / SH_DIM, lx = f - ly * SH_DIM;
         const int gx = x0 + lx - HALO, gy = y0 + ly - HALO;
@@ -197,9 +207,18 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(Src src, int W, int H, co
         if (LOSS) {
             const float df = p1 - p2;
             g = g + l1_scale * (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f));
-            out[(size_t)outC * ((size_t)px + (size_t)W * py) + plane] = g;
+            gout[ch] = g;
         } else {
             out[(size_t)px + (size_t)W * py + P * plane] = g;
+        }
+    }
+  }
+    if (LOSS) {
+        const int px = x0 + tx, py = y0 + ty;
+        if (px < W && py < H) {
+            float* o = out + (size_t)outC * ((size_t)px + (size_t)W * py) + (size_t)blockIdx.z * NCH;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch++) o[ch] = gout[ch];  // adjacent floats of one pixel
         }
     }
 }
@@ -242,21 +261,21 @@ static dim3 ssim_grid(int W, int H, int planes) {
 void gsr_launch_ssim_fwd(hipStream_t s, int W, int H, int CH, int B, const float* img, const float* ref, float C1,
                          float C2, int train, float* ssim_map, float* d0, float* d1, float* d2) {
     PlanarSrc src{img, ref, W, H};
-    hipLaunchKernelGGL((ssim_fwd_kernel<PlanarSrc, false>), ssim_grid(W, H, CH * B), dim3(256), 0, s, src, W, H, C1,
+    hipLaunchKernelGGL((ssim_fwd_kernel<PlanarSrc, false, 1>), ssim_grid(W, H, CH * B), dim3(256), 0, s, src, W, H, C1,
                        C2, train, ssim_map, d0, d1, d2, (float*)nullptr);
 }
 
 void gsr_launch_ssim_bwd(hipStream_t s, int W, int H, int CH, int B, const float* img, const float* ref,
                          const float* dL_dmap, const float* d0, const float* d1, const float* d2, float* dL_dimg) {
     PlanarSrc src{img, ref, W, H};
-    hipLaunchKernelGGL((ssim_bwd_kernel<PlanarSrc, false>), ssim_grid(W, H, CH * B), dim3(256), 0, s, src, W, H,
+    hipLaunchKernelGGL((ssim_bwd_kernel<PlanarSrc, false, 1>), ssim_grid(W, H, CH * B), dim3(256), 0, s, src, W, H,
                        dL_dmap, 0.0f, 0.0f, d0, d1, d2, dL_dimg, 0);
 }
 
 void gsr_launch_loss_fwd(hipStream_t s, int W, int H, int C, const float* image, const float* target, float C1,
                          float C2, float* d0, float* d1, float* d2, float* partial) {
     RasterSrc src{image, target, W, H, C};
-    hipLaunchKernelGGL((ssim_fwd_kernel<RasterSrc, true>), ssim_grid(W, H, 3), dim3(256), 0, s, src, W, H, C1, C2, 1,
+    hipLaunchKernelGGL((ssim_fwd_kernel<RasterSrc, true, 3>), ssim_grid(W, H, 1), dim3(256), 0, s, src, W, H, C1, C2, 1,
                        (float*)nullptr, d0, d1, d2, partial);
 }
 
@@ -270,10 +289,10 @@ void gsr_launch_loss_bwd(hipStream_t s, int W, int H, int C, const float* image,
         const size_t P = (size_t)W * H;
         hipLaunchKernelGGL(zero_extra_channels_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, vpixels, C, P);
     }
-    hipLaunchKernelGGL((ssim_bwd_kernel<RasterSrc, true>), ssim_grid(W, H, 3), dim3(256), 0, s, src, W, H,
+    hipLaunchKernelGGL((ssim_bwd_kernel<RasterSrc, true, 3>), ssim_grid(W, H, 1), dim3(256), 0, s, src, W, H,
                        (const float*)nullptr, -lambda * inv_count, (1.0f - lambda) * inv_count, d0, d1, d2, vpixels,
                        C);
-    const dim3 g = ssim_grid(W, H, 3);
+    const dim3 g = ssim_grid(W, H, 1);
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, s, partial, (int)(g.x * g.y * g.z), lambda,
                        inv_count, loss_out);
 }

@@ -2,25 +2,25 @@
 // Reference behaviour: src/rasterization/render.jl:1-130 (`render!`) and :132-286
 // (`∇render!`); SURVEY.md A.8 / A.9.
 //
-// One 256-thread workgroup (4 wave64) per 16x16 tile, lane <-> pixel.  The tile's
-// depth-sorted splat list is a contiguous slice of the packed stream written by
-// tile_sort (three coalesced float4 planes), staged through LDS in batches of 256
-// and read back with wave-uniform (broadcast) ds_read_b128.
+// A tile's depth-sorted splat list is a contiguous slice of the packed stream written by
+// tile_sort (three coalesced float4 planes) and carries a 16-bit row mask per instance.
+//
+// Forward (default `composite_fwd_strip_kernel`): one wave64 per 16x4 pixel strip, lane <->
+// pixel.  Per 64 instances one ballot over the row masks gives the strip's work list; only
+// those splats are staged in LDS and read back with wave-uniform (broadcast) ds_read_b128.
+// (`composite_fwd_kernel`: the 4-waves-per-tile form with 256-splat batches, kept for A/B.)
 //
 // Backward: instead of the reference's (C+6) global float atomics per (pixel, splat)
-// (render.jl:242,275-282) every wave reduces its 64 lanes with a transposed DPP /
-// permlane-swap network, the four waves meet in wave-private LDS slabs, and one 64-byte
-// gradient ROW per (tile, splat) instance leaves the workgroup as plain stores; the
-// per-Gaussian kernel sums a Gaussian's rows.  Waves whose 16x4 strip a splat cannot
-// touch never visit it (row masks + ballot worklist).
+// (render.jl:242,275-282) ONE wave64 owns the whole tile (4 pixels per lane), reduces the
+// partials of a splat over its 64 lanes with a transposed permlane-swap / DPP network
+// (wave_reduce.h), and one 64-byte gradient ROW per (tile, splat) instance leaves the
+// workgroup as plain stores; the per-Gaussian kernel sums a Gaussian's rows.
 #include "gsr_kernels.h"
 #include "wave_reduce.h"
 
 namespace {
 
 struct Bg { float v[8]; };
-
-template <int C> struct RecPlanes { static constexpr int N = C > 5 ? 4 : 3; };
 
 // feature c of a staged splat: rgb | depth | 1 | normal  (rasterizer.jl:380-385)
 template <int C>

@@ -382,6 +382,7 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(int n, int K, int cha
     }
     constexpr uint32_t BIG = 48;  // larger footprints are summed by the whole wave
     if (area <= BIG) {
+#pragma unroll 4
         for (uint32_t k = 0; k < area; k++) {  // fixed order -> bit-reproducible gradients
             const float4* row = inst.rows + (size_t)4 * (goff + k);  // contiguous; culled / untouched slots are zero
             const float4 f0 = row[0], f1 = row[1], f2 = row[2];
@@ -674,30 +675,51 @@ __global__ __launch_bounds__(256) void scatter_kernel(int n, int grid_x, int exa
     const int x0 = lo & 0xFFFFu, y0 = lo >> 16, x1 = hi & 0xFFFFu, y1 = hi >> 16;
     const uint64_t key = ((uint64_t)__float_as_uint(q2.z) << 32) | (uint32_t)i;
     const float tau = footprint_tau(q1.y);
-    // the same tests, on the same floats, as the count in preprocess; paired 64-bit atomics return
-    // both tiles' slots at once
+    // The same tests, on the same floats, as the count in preprocess.  Every slot request is a
+    // 64-bit atomic on an aligned pair of 32-bit cursors (one or both halves incremented), and up
+    // to 8 of them are kept in flight before their keys are stored: a returning device-scope
+    // atomic is a ~2 us round trip to the memory side, and issuing them one by one made this
+    // kernel latency-bound (68 % of wave cycles waiting).
+    constexpr int PEND = 8;
+    uint32_t pend_t[PEND];
+    uint32_t pend_c[PEND];
+    int np = 0;
+    auto flush = [&]() {
+        unsigned long long old[PEND];
+#pragma unroll
+        for (int k = 0; k < PEND; k++)
+            if (k < np)
+                old[k] = atomicAdd(reinterpret_cast<unsigned long long*>(cursor + pend_t[k]),
+                                   (unsigned long long)(pend_c[k] & 1u) | ((unsigned long long)(pend_c[k] >> 1) << 32));
+#pragma unroll
+        for (int k = 0; k < PEND; k++)
+            if (k < np) {
+                if (pend_c[k] & 1u) keys[(uint32_t)old[k]] = key;
+                if (pend_c[k] & 2u) keys[(uint32_t)(old[k] >> 32)] = key;
+            }
+        np = 0;
+    };
     for (int y = y0; y < y1; y++) {
         int x = x0;
         while (x < x1) {
             const int t = y * grid_x + x;
-            const bool pair = !(t & 1) && x + 1 < x1;
+            const bool odd = t & 1;
+            const bool pair = !odd && x + 1 < x1;
             const uint32_t c0 = (!exact_cull || tile_may_touch(q0.x, q0.y, q0.z, q0.w, q1.x, tau, x * GSR_TILE,
                                                                y * GSR_TILE)) ? 1u : 0u;
             uint32_t c1 = 0u;
             if (pair)
                 c1 = (!exact_cull || tile_may_touch(q0.x, q0.y, q0.z, q0.w, q1.x, tau, (x + 1) * GSR_TILE,
                                                     y * GSR_TILE)) ? 1u : 0u;
-            if (pair && (c0 | c1)) {
-                const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(cursor + t),
-                                                         (unsigned long long)c0 | ((unsigned long long)c1 << 32));
-                if (c0) keys[(uint32_t)old] = key;
-                if (c1) keys[(uint32_t)(old >> 32)] = key;
-            } else if (c0) {
-                keys[atomicAdd(cursor + t, 1u)] = key;
+            if (c0 | c1) {
+                pend_t[np] = (uint32_t)(t & ~1);                 // aligned pair
+                pend_c[np] = odd ? (c0 << 1) : (c0 | (c1 << 1));  // bit 0: even tile, bit 1: odd tile
+                if (++np == PEND) flush();
             }
             x += pair ? 2 : 1;
         }
     }
+    flush();
 }
 
 // _update_stats! (src/strategy.jl:118-136): densification statistics from the side outputs of

@@ -10,6 +10,9 @@
 // the per-Gaussian floats are bit-reproducible against the CPU oracle.  These
 // kernels are HBM-bound (192 B of SH per Gaussian), the extra VALU ops are free.
 #include "gsr_kernels.h"
+#ifndef GSR_PGB_MINWAVES
+#define GSR_PGB_MINWAVES 1
+#endif
 #include "tile_mask.h"
 #include "wave_reduce.h"
 
@@ -177,9 +180,12 @@ __device__ __forceinline__ void sh_basis(const float d[3], float b[16]) {
 __device__ __forceinline__ void gaussian_normal(const M33& Rw, const M33& Rg, const float s[3], const float mc[3],
                                                 float n[3], int& k, float& sign) {
     k = (s[0] <= s[1] && s[0] <= s[2]) ? 0 : (s[1] <= s[2]) ? 1 : 2;
+    // (arithmetic select: a ?: chain over Rg.m[r][k] is turned back into a dynamically indexed
+    // load by the optimiser, which puts Rg in scratch)
+    const float m0 = k == 0 ? 1.0f : 0.0f, m1 = k == 1 ? 1.0f : 0.0f, m2 = k == 2 ? 1.0f : 0.0f;
     float ax[3];
 #pragma unroll
-    for (int r = 0; r < 3; r++) ax[r] = k == 0 ? Rg.m[r][0] : (k == 1 ? Rg.m[r][1] : Rg.m[r][2]);
+    for (int r = 0; r < 3; r++) ax[r] = m0 * Rg.m[r][0] + m1 * Rg.m[r][1] + m2 * Rg.m[r][2];
     float nc[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) nc[r] = Rw.m[r][0] * ax[0] + Rw.m[r][1] * ax[1] + Rw.m[r][2] * ax[2];
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
 // 59·N-float gradient arena needs no memset.
 // ---------------------------------------------------------------------------------
 template <int DEG>
-__global__ __launch_bounds__(256) void pergauss_bwd_kernel(int n, int K, int channels, const float* __restrict__ means,
+__global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int n, int K, int channels, const float* __restrict__ means,
                                                            const float* __restrict__ scales,
                                                            const float4* __restrict__ rots,
                                                            const float* __restrict__ shs, GsrCam cam, GsrGeom geom,
@@ -546,7 +552,9 @@ __global__ __launch_bounds__(256) void pergauss_bwd_kernel(int n, int K, int cha
                 for (int r = 0; r < 3; r++) {
                     float g = R.m[0][r] * a2.x + R.m[1][r] * a2.y + R.m[2][r] * a2.z;
                     float v = sg * g;
-                    if (k == 0) vRg.m[r][0] = v; else if (k == 1) vRg.m[r][1] = v; else vRg.m[r][2] = v;
+                    vRg.m[r][0] = k == 0 ? v : 0.0f;
+                    vRg.m[r][1] = k == 1 ? v : 0.0f;
+                    vRg.m[r][2] = k == 2 ? v : 0.0f;
                 }
             }
             // ∇quat_scale_to_cov (render.jl:302-320)

@@ -24,7 +24,8 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint
                                                          uint32_t* __restrict__ cursor,
                                                          uint32_t* __restrict__ totals, int n_blocks,
                                                          const uint32_t* __restrict__ bsum,
-                                                         uint32_t* __restrict__ bpre) {
+                                                         uint32_t* __restrict__ bpre,
+                                                         const uint32_t* __restrict__ bvis) {
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t carry_s;
     __shared__ uint32_t wave_max[16];
@@ -109,6 +110,19 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint
         __syncthreads();
     }
     if (tid == 0) totals[5] = carry_s;  // sum of tile-rect areas = number of Gaussian-major instance slots (gradient rows)
+    // visible Gaussians: sum of the per-block counts written by preprocess
+    uint32_t vis = 0;
+    for (int i = tid; i < n_blocks; i += 1024) vis += bvis[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vis += __shfl_xor(vis, off);
+    __syncthreads();
+    if (lane == 0) wave_sums[wave] = vis;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t v = 0;
+        for (int w = 0; w < 16; w++) v += wave_sums[w];
+        totals[4] = v;
+    }
 }
 
 // ---- per-tile sort ----
@@ -201,9 +215,10 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restri
 }  // namespace
 
 void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count, uint32_t* tile_start,
-                          uint32_t* cursor, uint32_t* totals, int n_blocks, const uint32_t* bsum, uint32_t* bpre) {
+                          uint32_t* cursor, uint32_t* totals, int n_blocks, const uint32_t* bsum, uint32_t* bpre,
+                          const uint32_t* bvis) {
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, tile_count, tile_start, cursor, totals,
-                       n_blocks, bsum, bpre);
+                       n_blocks, bsum, bpre, bvis);
 }
 
 void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start, uint64_t* keys,

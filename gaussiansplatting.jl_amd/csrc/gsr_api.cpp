@@ -109,7 +109,7 @@ struct gsr_handle {
     // ImageState (states.jl:99-111) + tile bookkeeping
     DevBuf ranges, n_contrib, final_T, tile_count, tile_start, cursor, totals;
     // GeometryState (states.jl:2-47), repacked as one 64-byte record per Gaussian
-    DevBuf geo, gnormal, radii, bsum, bpre;
+    DevBuf geo, gnormal, radii, bsum, bpre, bvis;
     // BinningState (states.jl:66-85): unsorted keys, sorted ids, sorted splat stream
     DevBuf keys, values_sorted, s0, s1, s2, s3, big_scratch;
     // backward: per-instance gradient rows + instance position map; gstate.∇means_2d
@@ -189,7 +189,7 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
     if (h->grid_x > 65535 || h->grid_y > 65535) { delete h; return fail(GSR_E_INVALID_ARG, "resolution too large"); }
     h->n_tiles = h->grid_x * h->grid_y;
     DevBuf* list[] = {&h->ranges, &h->n_contrib, &h->final_T, &h->tile_count, &h->tile_start, &h->cursor, &h->totals,
-                      &h->geo, &h->gnormal, &h->radii, &h->bsum, &h->bpre, &h->keys, &h->values_sorted, &h->s0,
+                      &h->geo, &h->gnormal, &h->radii, &h->bsum, &h->bpre, &h->bvis, &h->keys, &h->values_sorted, &h->s0,
                       &h->s1, &h->s2, &h->s3, &h->big_scratch, &h->rows, &h->vmean2d, &h->d0, &h->d1,
                       &h->d2, &h->partial};
     for (DevBuf* b : list) h->all[h->n_all++] = b;
@@ -222,7 +222,7 @@ int gsr_destroy(gsr_handle* h) {
 
 int gsr_release_scene_buffers(gsr_handle* h) {
     if (!h) return fail(GSR_E_INVALID_ARG, "null handle");
-    DevBuf* scene[] = {&h->geo, &h->gnormal, &h->radii, &h->bsum, &h->bpre, &h->keys, &h->values_sorted, &h->s0, &h->s1,
+    DevBuf* scene[] = {&h->geo, &h->gnormal, &h->radii, &h->bsum, &h->bpre, &h->bvis, &h->keys, &h->values_sorted, &h->s0, &h->s1,
                        &h->s2, &h->s3, &h->big_scratch, &h->rows, &h->vmean2d};
     for (DevBuf* b : scene) {
         int rc = b->release();
@@ -255,7 +255,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     const size_t nn = n > 0 ? (size_t)n : 1;
     const int n_blocks = (n + 255) / 256;
     if ((rc = h->geo.ensure(nn * 64)) || (rc = h->radii.ensure(nn * 4)) || (rc = h->vmean2d.ensure(nn * 8)) ||
-        (rc = h->bsum.ensure((size_t)(n_blocks + 1) * 4)) || (rc = h->bpre.ensure((size_t)(n_blocks + 1) * 4)) ||
+        (rc = h->bsum.ensure((size_t)(n_blocks + 1) * 4)) || (rc = h->bpre.ensure((size_t)(n_blocks + 1) * 4)) || (rc = h->bvis.ensure((size_t)(n_blocks + 1) * 4)) ||
         (C > 5 && (rc = h->gnormal.ensure(nn * 16))))
         return rc;
 
@@ -265,11 +265,12 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     HIPCHK(hipMemsetAsync(totals, 0, 8 * 4, s));
     h->prof.begin(ST_PREPROCESS, s);
     gsr_launch_preprocess(s, n, in->n_coeffs, in->sh_degree, C, in->means, in->scales, in->rotations, in->opacities,
-                          in->shs, k, geom_of(h), h->tile_count.as<uint32_t>(), totals + 4);
+                          in->shs, k, geom_of(h), h->tile_count.as<uint32_t>(), h->bvis.as<uint32_t>());
     h->prof.end(s);
     h->prof.begin(ST_SCAN, s);
     gsr_launch_tile_scan(s, h->n_tiles, h->tile_count.as<uint32_t>(), h->tile_start.as<uint32_t>(),
-                         h->cursor.as<uint32_t>(), totals, n_blocks, h->bsum.as<uint32_t>(), h->bpre.as<uint32_t>());
+                         h->cursor.as<uint32_t>(), totals, n_blocks, h->bsum.as<uint32_t>(), h->bpre.as<uint32_t>(),
+                         h->bvis.as<uint32_t>());
     h->prof.end(s);
     HIPCHK(hipGetLastError());
     // the one host sync of the path: instance count D (reference: rasterizer.jl:337)

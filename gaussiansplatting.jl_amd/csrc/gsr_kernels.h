@@ -60,7 +60,7 @@ struct GsrInst {
 // ---- pergauss.hip (compiled with -ffp-contract=off: bit-reproducible fp32) ----
 void gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels, const float* means,
                            const float* scales, const float* rots, const float* opac, const float* shs, GsrCam cam,
-                           GsrGeom geom, uint32_t* tile_count, uint32_t* n_visible);
+                           GsrGeom geom, uint32_t* tile_count, uint32_t* n_visible /* per 256-block */);
 void gsr_launch_scatter(hipStream_t s, int n, GsrCam cam, GsrGeom geom, uint32_t* cursor, uint64_t* keys);
 void gsr_launch_pergauss_bwd(hipStream_t s, int n, int K, int degree, int channels, const float* means,
                              const float* scales, const float* rots, const float* shs, GsrCam cam, GsrGeom geom,
@@ -75,7 +75,8 @@ void gsr_launch_update_stats(hipStream_t s, int n, const int32_t* radii, const f
 // rect-area sums bsum[nb] -> bpre[nb];
 // totals[0] = D, totals[1] = max count, totals[2] = #tiles over GSR_SORT_LDS_CAP, totals[3] = slab counter (0)
 void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count, uint32_t* tile_start,
-                          uint32_t* cursor, uint32_t* totals, int n_blocks, const uint32_t* bsum, uint32_t* bpre);
+                          uint32_t* cursor, uint32_t* totals, int n_blocks, const uint32_t* bsum, uint32_t* bpre,
+                          const uint32_t* bvis);
 void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start, uint64_t* keys,
                           uint64_t* big_scratch, uint32_t big_scratch_stride, uint32_t* slab_counter, GsrGeom geom,
                           GsrStream stream, uint32_t* values_sorted, uint32_t* ranges);

@@ -333,12 +333,19 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
             uint32_t y = __shfl_up(x, off);
             if (lane >= off) x += y;
         }
-        if (lane == 63) wsum[wave] = x;
+        __shared__ uint32_t wvis[4];
+        const unsigned long long vm = __ballot(visible);
+        if (lane == 63) { wsum[wave] = x; wvis[wave] = (uint32_t)__popcll(vm); }
         __syncthreads();
         uint32_t woff = 0;
         for (int w = 0; w < wave; w++) woff += wsum[w];
         const uint32_t lpre = woff + x - area;
-        if (threadIdx.x == 255) geom.bsum[blockIdx.x] = lpre + area;
+        if (threadIdx.x == 255) {
+            geom.bsum[blockIdx.x] = lpre + area;
+            // visible count per block, summed by tile_scan (15 k same-address atomics would
+            // serialise at ~12 ns each: 0.19 ms — the "fanin" price of MI355X_MICROARCH.md)
+            n_visible[blockIdx.x] = wvis[0] + wvis[1] + wvis[2] + wvis[3];
+        }
         if (visible) {
             GsrGeoRec rec;
             rec.q0 = make_float4(m2[0], m2[1], conic[0], conic[1]);
@@ -349,8 +356,6 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
             geom.rec[i] = rec;
         }
     }
-    unsigned long long m = __ballot(visible);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_visible, (uint32_t)__popcll(m));
 }
 
 // ---------------------------------------------------------------------------------

@@ -664,13 +664,22 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
             for (int c = 0; c < 3; c++) vmeans[3 * i + c] = vmean[c] + vmsh[c];
         }
     }
-    if (vR_out) {  // projection.jl:243-256: thresholded per Gaussian, then summed (wave sum -> 1 atomic / wave)
+    if (vR_out) {  // projection.jl:243-256: thresholded per Gaussian, then summed
+        // wave sum -> workgroup sum in LDS -> ONE atomic per workgroup and component (the 12
+        // destinations are shared by every workgroup; per-wave atomics would serialise 4x longer)
+        __shared__ float pose_red[4][12];
 #pragma unroll
         for (int k = 0; k < 12; k++) {
             float v = k < 9 ? poseR[k] : poset[k - 9];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-            if ((threadIdx.x & 63) == 0 && v != 0.0f) atomicAdd(k < 9 ? &vR_out[k] : &vt_out[k - 9], v);
+            if ((threadIdx.x & 63) == 0) pose_red[threadIdx.x >> 6][k] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 12) {
+            const int k = threadIdx.x;
+            const float v = pose_red[0][k] + pose_red[1][k] + pose_red[2][k] + pose_red[3][k];
+            if (v != 0.0f) atomicAdd(k < 9 ? &vR_out[k] : &vt_out[k - 9], v);
         }
     }
 }

@@ -177,7 +177,11 @@ __device__ __forceinline__ void sort_and_emit(uint64_t* buf, uint32_t m, uint32_
     }
 }
 
-template <int CH>
+// CAP = LDS key capacity of this launch.  The kernel is launched twice: CAP = 1024 (8 KB of
+// LDS, full wave occupancy — most tiles) handles lists of <= 1024 instances, CAP = 4096 (32 KB)
+// the longer ones (and, through a global slab, lists beyond 4096); a workgroup whose tile
+// belongs to the other launch exits immediately.
+template <int CH, int CAP>
 __global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restrict__ tile_start,
                                                         const uint64_t* __restrict__ keys,
                                                         uint64_t* __restrict__ big_scratch,
@@ -186,11 +190,12 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restri
                                                         GsrGeom geom, GsrStream stream,
                                                         uint32_t* __restrict__ values_sorted,
                                                         uint32_t* __restrict__ ranges) {
-    __shared__ uint64_t skeys[GSR_SORT_LDS_CAP];
+    __shared__ uint64_t skeys[CAP];
     __shared__ uint32_t slab_s;
     const int tile = blockIdx.x, tid = threadIdx.x;
     const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
     const uint32_t n = end - start;
+    if (CAP < GSR_SORT_LDS_CAP ? n > (uint32_t)CAP : n <= 1024u) return;  // the other launch handles this tile
     if (tid == 0) {
         // identify_tile_range! (utils.jl:56-78): empty tiles keep the (0,0) of the prior fill!
         ranges[2 * tile] = n ? start : 0u;
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restri
     const int X0 = (tile % grid_x) * GSR_TILE, Y0 = (tile / grid_x) * GSR_TILE;
     uint32_t m = 1;
     while (m < n) m <<= 1;
-    if (m <= GSR_SORT_LDS_CAP) {
+    if (m <= (uint32_t)CAP) {
         sort_and_emit<CH>(skeys, m, n, start, tid, X0, Y0, keys, geom, stream, values_sorted);
     } else {
         // oversized tile: same network through a global-scratch slab (rare; slabs are sized by
@@ -224,10 +229,10 @@ void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count
 void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start, uint64_t* keys,
                           uint64_t* big_scratch, uint32_t big_scratch_stride, uint32_t* slab_counter, GsrGeom geom,
                           GsrStream stream, uint32_t* values_sorted, uint32_t* ranges) {
-    if (channels > 5)
-        hipLaunchKernelGGL(tile_sort_kernel<8>, dim3(n_tiles), dim3(256), 0, s, tile_start, keys, big_scratch,
-                           big_scratch_stride, slab_counter, grid_x, geom, stream, values_sorted, ranges);
-    else
-        hipLaunchKernelGGL(tile_sort_kernel<3>, dim3(n_tiles), dim3(256), 0, s, tile_start, keys, big_scratch,
-                           big_scratch_stride, slab_counter, grid_x, geom, stream, values_sorted, ranges);
+#define LAUNCH(CC, CAPV)                                                                                          \
+    hipLaunchKernelGGL((tile_sort_kernel<CC, CAPV>), dim3(n_tiles), dim3(256), 0, s, tile_start, keys, big_scratch, \
+                       big_scratch_stride, slab_counter, grid_x, geom, stream, values_sorted, ranges)
+    if (channels > 5) { LAUNCH(8, 1024); LAUNCH(8, GSR_SORT_LDS_CAP); }
+    else { LAUNCH(3, 1024); LAUNCH(3, GSR_SORT_LDS_CAP); }
+#undef LAUNCH
 }

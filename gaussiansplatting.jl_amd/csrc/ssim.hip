@@ -14,6 +14,9 @@ namespace {
 
 constexpr int HALO = 5;
 constexpr int SH_DIM = GSR_TILE + 2 * HALO;  // 26
+// LDS row strides (floats): a ds_read_b32 is served in two groups of 32 lanes = two tile rows of
+// 16 lanes, so a row stride of 16 (mod 32) puts the two rows on disjoint banks.
+constexpr int IN_STRIDE = 48, HC_STRIDE = 16;
 
 __constant__ float GAUSS[11] = {0.001028380123898387f, 0.0075987582094967365f, 0.036000773310661316f,
                                 0.10936068743467331f,  0.21300552785396576f,   0.26601171493530273f,
@@ -65,8 +68,8 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(Src src, int W, int H, fl
                                                        float* __restrict__ ssim_map, float* __restrict__ d0,
                                                        float* __restrict__ d1, float* __restrict__ d2,
                                                        float* __restrict__ partial) {
-    __shared__ float sx[SH_DIM][SH_DIM + 1], sy[SH_DIM][SH_DIM + 1];
-    __shared__ float hc[5][SH_DIM][GSR_TILE + 1];
+    __shared__ float sx[SH_DIM][IN_STRIDE], sy[SH_DIM][IN_STRIDE];
+    __shared__ float hc[5][SH_DIM][HC_STRIDE];
     __shared__ float red[4];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int x0 = blockIdx.x * GSR_TILE, y0 = blockIdx.y * GSR_TILE;
@@ -157,8 +160,8 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(Src src, int W, int H, co
                                                        const float* __restrict__ d0, const float* __restrict__ d1,
                                                        const float* __restrict__ d2, float* __restrict__ out,
                                                        int outC) {
-    __shared__ float sd[3][SH_DIM][SH_DIM + 1];
-    __shared__ float hc[3][SH_DIM][GSR_TILE + 1];
+    __shared__ float sd[3][SH_DIM][IN_STRIDE];
+    __shared__ float hc[3][SH_DIM][HC_STRIDE];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int x0 = blockIdx.x * GSR_TILE, y0 = blockIdx.y * GSR_TILE;
     const size_t P = (size_t)W * H;

@@ -395,10 +395,12 @@ __global__ __launch_bounds__(256 / PPL) void composite_bwd_kernel(int W, int H, 
                     for (int k = 0; k < NA; k++) r[k] += lacc[w][tid * ST + k];
                 }
             }
-            if (any) {
-                // one 64-byte gradient row per instance, plain stores (rows are zero-filled per
-                // backward): the per-Gaussian kernel sums a Gaussian's rows in a fixed order —
-                // no fp32 atomics (35 M per view before), bit-reproducible gradients
+            (void)any;
+            {
+                // one 64-byte gradient row per instance, plain stores, written for EVERY emitted
+                // instance exactly once per backward (zeros when no pixel touched it), so the row
+                // buffer needs no memset; the per-Gaussian kernel sums a Gaussian's rows in a fixed
+                // order — no fp32 atomics (35 M per view before), bit-reproducible gradients
                 float4* row = inst.rows + (size_t)4 * __float_as_uint(l2[tid].y);  // Gaussian-major slot
                 row[0] = make_float4(r[0], r[1], r[2], r[3]);
                 row[1] = make_float4(r[4], r[5], r[6], C > 3 ? r[9 < NA ? 9 : 0] : 0.0f);
@@ -406,6 +408,13 @@ __global__ __launch_bounds__(256 / PPL) void composite_bwd_kernel(int W, int H, 
                 if (C > 5) row[3] = make_float4(r[12 < NA ? 12 : 0], 0.0f, 0.0f, 0.0f);
             }
         }
+    }
+    // instances behind every pixel's last contributor were never staged: their rows are zero
+    for (uint32_t p = start + (uint32_t)tile_last + tid; p < end; p += NT) {
+        float4* row = inst.rows + (size_t)4 * __float_as_uint(stream.s2[p].y);
+        const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        row[0] = z; row[1] = z; row[2] = z;
+        if (C > 5) row[3] = z;
     }
 }
 

@@ -343,8 +343,8 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
     const int C = h->cfg.mode, n = in->n;
     if (n == 0) return GSR_OK;
     h->prof.begin(ST_ZERO_ACC, s);
-    // rows not touched by any pixel must read as zero in the per-Gaussian sum
-    if (h->last_D > 0) HIPCHK(hipMemsetAsync(h->rows.p, 0, (size_t)h->last_slots * 64, s));
+    // (the gradient rows need no memset: composite_bwd writes the row of every emitted instance,
+    // pergauss_bwd skips the slots of culled tiles)
     if (g->vR) {
         HIPCHK(hipMemsetAsync(g->vR, 0, 9 * 4, s));
         HIPCHK(hipMemsetAsync(g->vt, 0, 3 * 4, s));

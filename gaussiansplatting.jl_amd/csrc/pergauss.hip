@@ -381,6 +381,7 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
     // ---- sum this Gaussian's per-instance gradient rows (written by composite_bwd) ----
     // acc: [0..2] v rgb, [3] v opacity, [4..6] v conic, [7] v depth, [8..9] v mean2d, [10..12] v normal
     GsrGeoRec rec;
+    rec.q0 = rec.q1 = rec.q2 = rec.q3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float acc[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) acc[k] = 0.0f;
@@ -392,10 +393,24 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
         goff = geom.bpre[i >> 8] + __float_as_uint(rec.q2.w);
     }
     constexpr uint32_t BIG = 48;  // larger footprints are summed by the whole wave
+    // Slots of tiles the exact footprint test culled at binning were never written by
+    // composite_bwd (no instance exists): they are skipped by repeating the SAME test, on the
+    // same record floats, in the same translation unit as the count / scatter kernels.
+    uint32_t rx0 = 0, ry0 = 0, rw = 1;
+    float tau = 0.0f;
+    if (visible) {
+        const uint32_t lo = __float_as_uint(rec.q3.x), hi = __float_as_uint(rec.q3.y);
+        rx0 = lo & 0xFFFFu; ry0 = lo >> 16; rw = (hi & 0xFFFFu) - rx0;
+        tau = footprint_tau(rec.q1.y);
+    }
     if (area <= BIG) {
-#pragma unroll 4
+        uint32_t tx = rx0, ty = ry0;
         for (uint32_t k = 0; k < area; k++) {  // fixed order -> bit-reproducible gradients
-            const float4* row = inst.rows + (size_t)4 * (goff + k);  // contiguous; culled / untouched slots are zero
+            const bool emitted = !cam.exact_cull || tile_may_touch(rec.q0.x, rec.q0.y, rec.q0.z, rec.q0.w, rec.q1.x,
+                                                                   tau, (int)tx * GSR_TILE, (int)ty * GSR_TILE);
+            if (++tx == rx0 + rw) { tx = rx0; ty++; }
+            if (!emitted) continue;
+            const float4* row = inst.rows + (size_t)4 * (goff + k);
             const float4 f0 = row[0], f1 = row[1], f2 = row[2];
             acc[0] += f0.x; acc[1] += f0.y; acc[2] += f0.z; acc[3] += f0.w;
             acc[4] += f1.x; acc[5] += f1.y; acc[6] += f1.z; acc[7] += f1.w;
@@ -416,10 +431,16 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
             const int src = __builtin_ctzll(big);
             big &= big - 1;
             const uint32_t a = __shfl(area, src), o = __shfl(goff, src);
+            const uint32_t sx0 = __shfl(rx0, src), sy0 = __shfl(ry0, src), sw = __shfl(rw, src);
+            const float smx = __shfl(rec.q0.x, src), smy = __shfl(rec.q0.y, src), sa = __shfl(rec.q0.z, src),
+                        sb = __shfl(rec.q0.w, src), sc = __shfl(rec.q1.x, src), stau = __shfl(tau, src);
             float part[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) part[k] = 0.0f;
             for (uint32_t k = lane; k < a; k += 64) {
+                const uint32_t tx = sx0 + k % sw, ty = sy0 + k / sw;
+                if (cam.exact_cull && !tile_may_touch(smx, smy, sa, sb, sc, stau, (int)tx * GSR_TILE, (int)ty * GSR_TILE))
+                    continue;
                 const float4* row = inst.rows + (size_t)4 * (o + k);
                 const float4 f0 = row[0], f1 = row[1], f2 = row[2];
                 part[0] += f0.x; part[1] += f0.y; part[2] += f0.z; part[3] += f0.w;

@@ -45,7 +45,7 @@ def algorithmic_bytes(stage, N, V, D, P, T, C=3, K=16):
         "composite_fwd": (28 + 4 * C) * D + 8 * T + (4 * C + 8) * P,
         "composite_bwd": (4 * C + 8) * P + 8 * T + (28 + 4 * C) * D + 4 * (C + 6) * D,
         "pergauss_bwd": 4 * N + (87 + 12 * K) * V + (44 + 12 * K) * N,
-        "zero_acc": 4 * (C + 6) * N,
+        "zero_acc": 48,  # pose-gradient accumulators only (when requested)
         "loss_fwd": 72 * P,
         "loss_bwd": 84 * P + 24 * P,
     }[stage]

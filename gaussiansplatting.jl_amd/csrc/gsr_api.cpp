@@ -342,14 +342,14 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
     hipStream_t s = (hipStream_t)stream_v;
     const int C = h->cfg.mode, n = in->n;
     if (n == 0) return GSR_OK;
-    h->prof.begin(ST_ZERO_ACC, s);
     // (the gradient rows need no memset: composite_bwd writes the row of every emitted instance,
-    // pergauss_bwd skips the slots of culled tiles)
+    // pergauss_bwd skips the slots of culled tiles; only the 12 pose-gradient floats are accumulated into)
     if (g->vR) {
+        h->prof.begin(ST_ZERO_ACC, s);
         HIPCHK(hipMemsetAsync(g->vR, 0, 9 * 4, s));
         HIPCHK(hipMemsetAsync(g->vt, 0, 3 * 4, s));
+        h->prof.end(s);
     }
-    h->prof.end(s);
     GsrCam k = make_cam(h, cam);
     h->prof.begin(ST_COMPOSITE_BWD, s);
     if (h->last_D > 0)

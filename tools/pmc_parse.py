@@ -49,7 +49,10 @@ def main(d):
         for k, vs in acc.items():
             for key, stage in STAGES.items():
                 if key in k:
-                    res.setdefault(stage, {})[tag] = factor * sum(vs) / len(vs)
+                    # several kernel variants may belong to one stage (e.g. the two tile_sort launches):
+                    # their per-launch means add up
+                    r = res.setdefault(stage, {})
+                    r[tag] = r.get(tag, 0.0) + factor * sum(vs) / len(vs)
     for stage, v in res.items():
         out[stage] = int(v.get("fetch", 0) + v.get("write", 0))
         out[stage + "_read"] = int(v.get("fetch", 0))

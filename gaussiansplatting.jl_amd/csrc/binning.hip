@@ -13,6 +13,7 @@
 // keys with emit order by Gaussian id: within a tile, ascending depth
 // bits, ties by ascending id.  Unlike a global 64-bit radix sort this moves each instance
 // through HBM twice (8 B key out, 8 B key in) instead of ~8 passes x 12 B.
+#include <cstdlib>
 #include "gsr_kernels.h"
 #include "tile_mask.h"
 
@@ -125,6 +126,46 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint
     }
 }
 
+// ---- launch order of the compositing workgroups ----
+// Tiles in descending order of list length (longest-processing-time-first): the compositing
+// kernels hand the heavy tiles out first and the light ones fill the gaps, so the makespan over
+// the 1024 SIMDs is ~1 % above the mean load instead of 5-8 % (synthetic) or far more (real
+// scenes with a few very deep tiles).  Counting sort over 1024 length classes in one workgroup;
+// the order inside a class is arbitrary — tiles are independent, outputs do not depend on it.
+__global__ __launch_bounds__(1024) void tile_order_kernel(int n_tiles, const uint32_t* __restrict__ tile_count,
+                                                          const uint32_t* __restrict__ totals,
+                                                          uint32_t* __restrict__ order) {
+    constexpr int NB = 1024;
+    __shared__ uint32_t hist[NB];
+    __shared__ uint32_t wave_sums[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    hist[tid] = 0;
+    __syncthreads();
+    const uint64_t maxc = totals[1] > 0u ? totals[1] : 1u;
+    for (int i = tid; i < n_tiles; i += NB) {
+        const uint32_t b = (NB - 1) - (uint32_t)(((uint64_t)tile_count[i] * (NB - 1)) / maxc);
+        atomicAdd(&hist[b], 1u);
+    }
+    __syncthreads();
+    const uint32_t v = hist[tid];
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(x, off);
+        if (lane >= off) x += y;
+    }
+    if (lane == 63) wave_sums[wave] = x;
+    __syncthreads();
+    uint32_t wave_off = 0;
+    for (int w = 0; w < wave; w++) wave_off += wave_sums[w];
+    hist[tid] = wave_off + x - v;
+    __syncthreads();
+    for (int i = tid; i < n_tiles; i += NB) {
+        const uint32_t b = (NB - 1) - (uint32_t)(((uint64_t)tile_count[i] * (NB - 1)) / maxc);
+        order[atomicAdd(&hist[b], 1u)] = (uint32_t)i;
+    }
+}
+
 // ---- per-tile sort ----
 // Bitonic network over `m` (power of two) keys held in `buf` (LDS or global scratch).
 __device__ __forceinline__ void bitonic_sort(uint64_t* buf, uint32_t m, int tid, int nthreads) {
@@ -224,6 +265,21 @@ void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count
                           const uint32_t* bvis) {
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, tile_count, tile_start, cursor, totals,
                        n_blocks, bsum, bpre, bvis);
+}
+
+__global__ void tile_order_identity_kernel(int n_tiles, uint32_t* __restrict__ order) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_tiles) order[i] = (uint32_t)i;
+}
+
+void gsr_launch_tile_order(hipStream_t s, int n_tiles, const uint32_t* tile_count, const uint32_t* totals,
+                           uint32_t* order) {
+    // GSR_TILE_ORDER=raster: row-major launch order (A/B measurements only; outputs are the same)
+    static const bool raster = [] { const char* e = getenv("GSR_TILE_ORDER"); return e && e[0] == 'r'; }();
+    if (raster)
+        hipLaunchKernelGGL(tile_order_identity_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, s, n_tiles, order);
+    else
+        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, n_tiles, tile_count, totals, order);
 }
 
 void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start, uint64_t* keys,

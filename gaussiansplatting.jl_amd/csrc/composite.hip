@@ -8,7 +8,6 @@
 // Forward (default `composite_fwd_strip_kernel`): one wave64 per 16x4 pixel strip, lane <->
 // pixel.  Per 64 instances one ballot over the row masks gives the strip's work list; only
 // those splats are staged in LDS and read back with wave-uniform (broadcast) ds_read_b128.
-// (`composite_fwd_kernel`: the 4-waves-per-tile form with 256-splat batches, kept for A/B.)
 //
 // Backward: instead of the reference's (C+6) global float atomics per (pixel, splat)
 // (render.jl:242,275-282) ONE wave64 owns the whole tile (4 pixels per lane), reduces the
@@ -33,100 +32,13 @@ __device__ __forceinline__ void unpack_features(const float4& s1, const float4& 
 // ---------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------
-template <int C, bool AUX>
-__global__ __launch_bounds__(256) void composite_fwd_kernel(int W, int H, int grid_x,
-                                                            const uint32_t* __restrict__ tile_start,
-                                                            GsrStream stream, Bg bg, float* __restrict__ image,
-                                                            uint32_t* __restrict__ n_contrib,
-                                                            float* __restrict__ final_T,
-                                                            const uint32_t* __restrict__ values_sorted,
-                                                            uint8_t* __restrict__ covis,
-                                                            float* __restrict__ uncert) {
-    __shared__ float4 l0[GSR_BATCH], l1[GSR_BATCH], l2[GSR_BATCH];
-    __shared__ float4 l3[C > 5 ? GSR_BATCH : 1];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t strip_bits = 0xFu << (4 * (tid >> 6));  // this wave's 4 pixel rows
-    const int tile = blockIdx.y * grid_x + blockIdx.x;
-    const int px = blockIdx.x * GSR_TILE + (tid & 15), py = blockIdx.y * GSR_TILE + (tid >> 4);
-    const bool inside = px < W && py < H;
-    const float fx = (float)px, fy = (float)py;
-    const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
-    const int to_do = (int)(end - start);
-
-    bool done = !inside;
-    float T = 1.0f;
-    uint32_t last = 0;
-    float color[C];
-#pragma unroll
-    for (int c = 0; c < C; c++) color[c] = 0.0f;
-    float unc = 0.0f;
-
-    for (int base = 0; base < to_do; base += GSR_BATCH) {
-        // Every pixel of the tile saturated: the reference keeps looping without effect
-        // (render.jl:79-80); leaving here is bit-identical.  Doubles as the WAR barrier.
-        if (__syncthreads_count(!done) == 0) break;
-        const int cnt = min(GSR_BATCH, to_do - base);
-        if (tid < cnt) {
-            const uint32_t idx = start + base + tid;
-            l0[tid] = stream.s0[idx];
-            l1[tid] = stream.s1[idx];
-            l2[tid] = stream.s2[idx];
-            if (C > 5) l3[tid] = stream.s3[idx];
-        }
-        __syncthreads();
-        // Per-wave worklist: lane l looks at splat c0+l's row mask (emitted by tile_sort) and
-        // one ballot yields the splats that can touch this wave's 16x4 pixel strip; the rest
-        // (56 % at the BASELINE configs) are never visited.  Visiting order stays ascending.
-        for (int c0 = 0; c0 < cnt; c0 += 64) {
-            const int jj = c0 + lane;
-            const bool cand = jj < cnt && (__float_as_uint(l2[jj].w) & strip_bits) != 0u;
-            unsigned long long m = __ballot(cand);
-            if (__ballot(!done) == 0ull) m = 0ull;  // the whole strip has saturated
-            while (m) {
-                const int j = c0 + __builtin_ctzll(m);
-                m &= m - 1;
-                // Branch-free body: a lane that is done, or whose pixel this splat does not
-                // touch, blends with weight 0 (what `continue`/`break` leave behind, render.jl:92-101).
-                const float4 a = l0[j], b = l1[j], c2 = l2[j];
-                const float dx = a.x - fx, dy = a.y - fy;
-                const float sigma = a.w * dx * dy + 0.5f * (a.z * (dx * dx) + b.x * (dy * dy));
-                const float alpha = fminf(0.99f, b.y * __expf(-sigma));
-                const float Tn = T * (1.0f - alpha);
-                bool ok = !done && sigma >= 0.0f && alpha >= (1.0f / 255.0f);
-                const bool stop = ok && Tn < 1e-4f;
-                done = done || stop;
-                ok = ok && !stop;
-                float f[C];
-                unpack_features<C>(b, c2, C > 5 ? l3[j] : c2, f);
-                const float w = ok ? alpha * T : 0.0f;
-#pragma unroll
-                for (int c = 0; c < C; c++) color[c] += f[c] * w;
-                if (AUX) {
-                    unc += w;
-                    if (covis && ok && T > 0.5f) covis[values_sorted[start + base + j]] = 1;
-                }
-                T = ok ? Tn : T;
-                last = ok ? (uint32_t)(base + j + 1) : last;
-            }
-        }
-    }
-    if (inside) {
-        const size_t pi = (size_t)px + (size_t)W * py;
-        final_T[pi] = T;
-        n_contrib[pi] = last;
-#pragma unroll
-        for (int c = 0; c < C; c++) image[(size_t)C * pi + c] = color[c] + T * bg.v[c];
-        if (AUX && uncert) uncert[pi] = unc;
-    }
-}
-
-// Strip variant of the forward: one wave64 per 16x4 strip, four independent single-wave
-// workgroups per tile.  No workgroup barriers, a strip stops as soon as ITS pixels have
+// Forward: one wave64 per 16x4 strip, four independent single-wave workgroups per tile.  No workgroup barriers, a strip stops as soon as ITS pixels have
 // saturated, and a wave stages only the splats its row-mask ballot selected (the four strips
 // re-read the tile's stream through L2).  Same per-pixel arithmetic in the same order.
 template <int C, bool AUX>
 __global__ __launch_bounds__(64) void composite_fwd_strip_kernel(int W, int H, int grid_x,
                                                                  const uint32_t* __restrict__ tile_start,
+                                                                 const uint32_t* __restrict__ tile_order,
                                                                  GsrStream stream, Bg bg, float* __restrict__ image,
                                                                  uint32_t* __restrict__ n_contrib,
                                                                  float* __restrict__ final_T,
@@ -136,10 +48,17 @@ __global__ __launch_bounds__(64) void composite_fwd_strip_kernel(int W, int H, i
     __shared__ float4 l0[64], l1[64], l2[64];
     __shared__ float4 l3[C > 5 ? 64 : 1];
     const int lane = threadIdx.x;
-    const int strip = blockIdx.y & 3, tile_y = blockIdx.y >> 2;
+    // 1-D grid, workgroup id -> (launch slot, strip).  Workgroups are dealt round-robin to the 8
+    // XCDs (each with its own L2): the 4 strips of a tile get ids that are equal mod 8, so a tile's
+    // splat stream is fetched into ONE L2; slots follow tile_order (longest lists first).
+    const int id = blockIdx.x, k = id >> 3;
+    const int strip = k & 3;
+    const int slot = ((k >> 2) << 3) | (id & 7);
+    if (slot >= grid_x * ((H + GSR_TILE - 1) / GSR_TILE)) return;
+    const int tile = (int)tile_order[slot];
+    const int tile_x = tile % grid_x, tile_y = tile / grid_x;
     const uint32_t strip_bits = 0xFu << (4 * strip);
-    const int tile = tile_y * grid_x + blockIdx.x;
-    const int px = blockIdx.x * GSR_TILE + (lane & 15), py = tile_y * GSR_TILE + 4 * strip + (lane >> 4);
+    const int px = tile_x * GSR_TILE + (lane & 15), py = tile_y * GSR_TILE + 4 * strip + (lane >> 4);
     const bool inside = px < W && py < H;
     const float fx = (float)px, fy = (float)py;
     const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
@@ -229,6 +148,7 @@ constexpr int BWD_BATCH = GSR_BWD_BATCH;  // splats staged per round (LDS: one a
 template <int C, int PPL>
 __global__ __launch_bounds__(256 / PPL) void composite_bwd_kernel(int W, int H, int grid_x,
                                                                 const uint32_t* __restrict__ tile_start,
+                                                                const uint32_t* __restrict__ tile_order,
                                                                 GsrStream stream, Bg bg,
                                                                 const float* __restrict__ vpixels,
                                                                 const uint32_t* __restrict__ n_contrib,
@@ -249,9 +169,10 @@ __global__ __launch_bounds__(256 / PPL) void composite_bwd_kernel(int W, int H, 
     const gsr::LaneBits lane_bits(lane);
     const int red_slot = gsr::wave_reduce_index<NA>(lane);  // which partial this lane ends up holding
     const bool red_writer = gsr::wave_reduce_writer(lane);
-    const int tile = blockIdx.y * grid_x + blockIdx.x;
-    const int px = blockIdx.x * GSR_TILE + (lane & 15);
-    const int py0 = blockIdx.y * GSR_TILE + ROWS * wave + (lane >> 4);
+    const int tile = (int)tile_order[blockIdx.x];  // 1-D grid in launch order: longest lists first
+    const int tile_x = tile % grid_x, tile_y = tile / grid_x;
+    const int px = tile_x * GSR_TILE + (lane & 15);
+    const int py0 = tile_y * GSR_TILE + ROWS * wave + (lane >> 4);
     const float fx = (float)px;
     const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
     if (end == start) return;
@@ -323,53 +244,67 @@ __global__ __launch_bounds__(256 / PPL) void composite_bwd_kernel(int W, int H, 
             const float o = b.y;
             const float dx = a.x - fx;
             const float hxx = 0.5f * (a.z * (dx * dx)), bdx = a.w * dx;
-            float dy[PPL], G[PPL], alpha[PPL];
-            bool active[PPL], any_active = false;
-#pragma unroll
-            for (int q = 0; q < PPL; q++) {
-                dy[q] = a.y - fy[q];
-                const float sigma = bdx * dy[q] + (hxx + 0.5f * (b.x * (dy[q] * dy[q])));
-                G[q] = __expf(-sigma);
-                alpha[q] = fminf(0.99f, o * G[q]);
-                active[q] = contributor < last_contributor[q] && sigma >= 0.0f && alpha[q] >= (1.0f / 255.0f);
-                any_active = any_active || active[q];
-            }
-            if (__ballot(any_active) == 0ull) continue;  // wave-uniform: none of this wave's pixels is touched
-#pragma unroll
-            for (int w = 0; w < BB / 64; w++)
-                if ((j >> 6) == w) touched[w] |= 1ull << (j & 63);
-
             float f[C];
             unpack_features<C>(b, c2, C > 5 ? l3[j] : c2, f);
-            float part[16];
+            // A lane accumulates only  P = Σ G·vα,  U1 = Σ G·vα·dy,  U2 = Σ G·vα·dy²  and the
+            // feature sums.  The conic / mean2d gradients (render.jl:262-272) are linear in
+            // {dx²·P, dx·U1, U2, dx·P, U1}: those five are what the wave reduces, and the
+            // per-instance flush applies the wave-uniform factors (-o/2, conic) once per row.
+            float P = 0.0f, U1 = 0.0f, U2 = 0.0f, col[C];
 #pragma unroll
-            for (int k = 0; k < 16; k++) part[k] = 0.0f;
+            for (int c = 0; c < C; c++) col[c] = 0.0f;
+            bool any_active = false;
+#ifndef GSR_BWD_NO_ROW_SKIP
+            const uint32_t rowbits = __builtin_amdgcn_readfirstlane(__float_as_uint(c2.w)) >> (ROWS * wave);
+#endif
 #pragma unroll
             for (int q = 0; q < PPL; q++) {
-                if (active[q]) {
+#ifndef GSR_BWD_NO_ROW_SKIP
+                // pixel rows 4q..4q+3 of this wave: untouched by the splat's footprint -> wave-uniform skip
+                if (PPL > 1 && ((rowbits >> (4 * q)) & 0xFu) == 0u) continue;
+#endif
+                const float dy = a.y - fy[q], dy2 = dy * dy;
+                const float sigma = bdx * dy + (hxx + 0.5f * (b.x * dy2));
+                const float G = __expf(-sigma);
+                const float alpha = fminf(0.99f, o * G);
+                const bool active = contributor < last_contributor[q] && sigma >= 0.0f && alpha >= (1.0f / 255.0f);
+                any_active = any_active || active;
+                if (active) {
                     // T /= (1-α) and -T_final/(1-α) (render.jl:237,259) share one hardware reciprocal
-                    const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha[q]);
+                    const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
                     T[q] = T[q] * rinv;
-                    const float fac = alpha[q] * T[q];
+                    const float fac = alpha * T[q];
                     float cv = f[0] * vp[q][0];
 #pragma unroll
                     for (int c = 1; c < C; c++) cv += f[c] * vp[q][c];
                     const float d = cv - A[q];                 // (color - accum_rec)·v
                     const float valpha = d * T[q] + bgT[q] * rinv;
-                    A[q] = A[q] + alpha[q] * d;                // α·cv + (1-α)·A for the next (nearer) splat
-                    const float vsigma = -o * G[q] * valpha;
-                    const float hs = 0.5f * vsigma;
-                    part[0] += fac * vp[q][0]; part[1] += fac * vp[q][1]; part[2] += fac * vp[q][2];
-                    part[3] += G[q] * valpha;
-                    part[4] += hs * (dx * dx);
-                    part[5] += hs * (dx * dy[q]);
-                    part[6] += hs * (dy[q] * dy[q]);
-                    part[7] += vsigma * (a.z * dx + a.w * dy[q]);
-                    part[8] += vsigma * (a.w * dx + b.x * dy[q]);
-                    if (C > 3) part[9] += fac * vp[q][3];  // depth feature; channel 4 (constant 1) is not a parameter
-                    if (C > 5) { part[10] += fac * vp[q][5]; part[11] += fac * vp[q][6]; part[12] += fac * vp[q][7]; }
+                    A[q] = A[q] + alpha * d;                   // α·cv + (1-α)·A for the next (nearer) splat
+                    const float t = G * valpha;
+                    P += t;
+                    U1 += t * dy;
+                    U2 += t * dy2;
+#pragma unroll
+                    for (int c = 0; c < C; c++) col[c] += fac * vp[q][c];
                 }
             }
+            if (__ballot(any_active) == 0ull) continue;  // wave-uniform: none of this wave's pixels is touched
+#pragma unroll
+            for (int w = 0; w < BB / 64; w++)
+                if ((j >> 6) == w) touched[w] |= 1ull << (j & 63);
+            float part[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) part[k] = 0.0f;
+            const float dxp = dx * P;
+            part[0] = col[0]; part[1] = col[1]; part[2] = col[2];
+            part[3] = P;         // Σ G·vα          -> v opacity
+            part[4] = dx * dxp;  // Σ dx²·G·vα      -> v conic.x  (× -o/2 in the flush)
+            part[5] = dx * U1;   // Σ dx·dy·G·vα    -> v conic.y
+            part[6] = U2;        // Σ dy²·G·vα      -> v conic.z
+            part[7] = dxp;       // Σ dx·G·vα   }   -> v mean2d = -o·(conic · these)
+            part[8] = U1;        // Σ dy·G·vα   }
+            if (C > 3) part[9] = col[3];  // depth feature; channel 4 (constant 1) is not a parameter
+            if (C > 5) { part[10] = col[5]; part[11] = col[6]; part[12] = col[7]; }
             // transposed wave64 reduction: ~3·NA/2 + 6 VALU ops, then ONE ds_write for all NA sums
             const float total = gsr::wave_reduce_transposed<NA>(part, lane_bits);
             // (storing the sums straight into the global row when NW == 1 measured 3 % slower than
@@ -401,10 +336,13 @@ __global__ __launch_bounds__(256 / PPL) void composite_bwd_kernel(int W, int H, 
                 // instance exactly once per backward (zeros when no pixel touched it), so the row
                 // buffer needs no memset; the per-Gaussian kernel sums a Gaussian's rows in a fixed
                 // order — no fp32 atomics (35 M per view before), bit-reproducible gradients
+                const float4 a = l0[tid], b = l1[tid];
+                const float mo = -b.y, mh = -0.5f * b.y;  // vσ = -o·G·vα (render.jl:260)
                 float4* row = inst.rows + (size_t)4 * __float_as_uint(l2[tid].y);  // Gaussian-major slot
                 row[0] = make_float4(r[0], r[1], r[2], r[3]);
-                row[1] = make_float4(r[4], r[5], r[6], C > 3 ? r[9 < NA ? 9 : 0] : 0.0f);
-                row[2] = make_float4(r[7], r[8], C > 5 ? r[10 < NA ? 10 : 0] : 0.0f, C > 5 ? r[11 < NA ? 11 : 0] : 0.0f);
+                row[1] = make_float4(mh * r[4], mh * r[5], mh * r[6], C > 3 ? r[9 < NA ? 9 : 0] : 0.0f);
+                row[2] = make_float4(mo * (a.z * r[7] + a.w * r[8]), mo * (a.w * r[7] + b.x * r[8]),
+                                     C > 5 ? r[10 < NA ? 10 : 0] : 0.0f, C > 5 ? r[11 < NA ? 11 : 0] : 0.0f);
                 if (C > 5) row[3] = make_float4(r[12 < NA ? 12 : 0], 0.0f, 0.0f, 0.0f);
             }
         }
@@ -426,35 +364,31 @@ Bg make_bg(const float* background, int channels) {
 
 }  // namespace
 
-void gsr_launch_composite_fwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start, GsrStream stream,
-                              const float* background, float* image, uint32_t* n_contrib, float* final_T,
-                              const uint32_t* values_sorted, uint8_t* covis, float* uncert) {
-#ifdef GSR_FWD_TILE_BLOCKS
-    dim3 grid(cam.grid_x, cam.grid_y), block(256);
-#define FWD_KERNEL composite_fwd_kernel
-#else
-    dim3 grid(cam.grid_x, cam.grid_y * 4), block(64);
-#define FWD_KERNEL composite_fwd_strip_kernel
-#endif
+void gsr_launch_composite_fwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
+                              const uint32_t* tile_order, GsrStream stream, const float* background, float* image,
+                              uint32_t* n_contrib, float* final_T, const uint32_t* values_sorted, uint8_t* covis,
+                              float* uncert) {
+    const int n_tiles = cam.grid_x * cam.grid_y;
+    dim3 grid(32 * ((n_tiles + 7) / 8)), block(64);  // 8 XCD lanes x 4 strips per launch slot
     Bg bg = make_bg(background, channels);
     const bool aux = covis || uncert;
 #define LAUNCH(CC, AA)                                                                                             \
-    hipLaunchKernelGGL((FWD_KERNEL<CC, AA>), grid, block, 0, s, cam.width, cam.height, cam.grid_x,                 \
-                       tile_start, stream, bg, image, n_contrib, final_T, values_sorted, covis, uncert)
+    hipLaunchKernelGGL((composite_fwd_strip_kernel<CC, AA>), grid, block, 0, s, cam.width, cam.height, cam.grid_x, \
+                       tile_start, tile_order, stream, bg, image, n_contrib, final_T, values_sorted, covis, uncert)
     if (channels == 3) { if (aux) LAUNCH(3, true); else LAUNCH(3, false); }
     else if (channels == 5) { if (aux) LAUNCH(5, true); else LAUNCH(5, false); }
     else { if (aux) LAUNCH(8, true); else LAUNCH(8, false); }
 #undef LAUNCH
 }
 
-void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start, GsrStream stream,
-                              const float* background, const float* vpixels, const uint32_t* n_contrib,
-                              const float* final_T, GsrInst inst) {
-    dim3 grid(cam.grid_x, cam.grid_y), block(256 / GSR_BWD_PPL);
+void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
+                              const uint32_t* tile_order, GsrStream stream, const float* background,
+                              const float* vpixels, const uint32_t* n_contrib, const float* final_T, GsrInst inst) {
+    dim3 grid(cam.grid_x * cam.grid_y), block(256 / GSR_BWD_PPL);
     Bg bg = make_bg(background, channels);
 #define LAUNCH(CC)                                                                                                 \
     hipLaunchKernelGGL((composite_bwd_kernel<CC, GSR_BWD_PPL>), grid, block, 0, s, cam.width, cam.height,          \
-                       cam.grid_x, tile_start, stream, bg, vpixels, n_contrib, final_T, inst)
+                       cam.grid_x, tile_start, tile_order, stream, bg, vpixels, n_contrib, final_T, inst)
     if (channels == 3) LAUNCH(3);
     else if (channels == 5) LAUNCH(5);
     else LAUNCH(8);

@@ -107,7 +107,7 @@ struct gsr_handle {
     gsr_config cfg;
     int grid_x, grid_y, n_tiles;
     // ImageState (states.jl:99-111) + tile bookkeeping
-    DevBuf ranges, n_contrib, final_T, tile_count, tile_start, cursor, totals;
+    DevBuf ranges, n_contrib, final_T, tile_count, tile_start, tile_order, cursor, totals;
     // GeometryState (states.jl:2-47), repacked as one 64-byte record per Gaussian
     DevBuf geo, gnormal, radii, bsum, bpre, bvis;
     // BinningState (states.jl:66-85): unsorted keys, sorted ids, sorted splat stream
@@ -116,6 +116,7 @@ struct gsr_handle {
     DevBuf rows, vmean2d;
     // loss-head scratch
     DevBuf d0, d1, d2, partial;
+    hipEvent_t totals_ready = nullptr;  // recorded after the D2H copy of the totals
     uint32_t* host_totals = nullptr;  // pinned: D, max tile count, #oversized tiles, slab ctr, n_visible
     bool fwd_valid = false, bwd_valid = false;
     int last_n = 0;
@@ -188,7 +189,7 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
     h->grid_y = (cfg->height + GSR_TILE - 1) / GSR_TILE;
     if (h->grid_x > 65535 || h->grid_y > 65535) { delete h; return fail(GSR_E_INVALID_ARG, "resolution too large"); }
     h->n_tiles = h->grid_x * h->grid_y;
-    DevBuf* list[] = {&h->ranges, &h->n_contrib, &h->final_T, &h->tile_count, &h->tile_start, &h->cursor, &h->totals,
+    DevBuf* list[] = {&h->ranges, &h->n_contrib, &h->final_T, &h->tile_count, &h->tile_start, &h->tile_order, &h->cursor, &h->totals,
                       &h->geo, &h->gnormal, &h->radii, &h->bsum, &h->bpre, &h->bvis, &h->keys, &h->values_sorted, &h->s0,
                       &h->s1, &h->s2, &h->s3, &h->big_scratch, &h->rows, &h->vmean2d, &h->d0, &h->d1,
                       &h->d2, &h->partial};
@@ -197,11 +198,12 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
     int rc = GSR_OK;
     if ((rc = h->ranges.ensure(2 * T * 4)) || (rc = h->n_contrib.ensure(P * 4)) || (rc = h->final_T.ensure(P * 4)) ||
         (rc = h->tile_count.ensure((T + 2) * 4)) || (rc = h->tile_start.ensure((T + 1) * 4)) ||
-        (rc = h->cursor.ensure((T + 2) * 4)) || (rc = h->totals.ensure(8 * 4))) {
+        (rc = h->cursor.ensure((T + 2) * 4)) || (rc = h->tile_order.ensure((T + 8) * 4)) || (rc = h->totals.ensure(8 * 4))) {
         gsr_destroy(h);
         return rc;
     }
     hipError_t e = hipHostMalloc((void**)&h->host_totals, 8 * sizeof(uint32_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->totals_ready, hipEventDisableTiming);
     if (e != hipSuccess) {
         gsr_destroy(h);
         return fail(GSR_E_HIP, "hipHostMalloc failed: %s", hipGetErrorString(e));
@@ -215,6 +217,7 @@ int gsr_destroy(gsr_handle* h) {
     if (!h) return GSR_OK;
     for (int i = 0; i < h->n_all; i++) h->all[i]->release();
     if (h->host_totals) (void)hipHostFree(h->host_totals);
+    if (h->totals_ready) (void)hipEventDestroy(h->totals_ready);
     h->prof.destroy();
     delete h;
     return GSR_OK;
@@ -275,7 +278,10 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     HIPCHK(hipGetLastError());
     // the one host sync of the path: instance count D (reference: rasterizer.jl:337)
     HIPCHK(hipMemcpyAsync(h->host_totals, totals, 8 * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipEventRecord(h->totals_ready, s));
+    // launch order of the compositing workgroups (longest tile lists first); runs while the host waits
+    gsr_launch_tile_order(s, h->n_tiles, h->tile_count.as<uint32_t>(), totals, h->tile_order.as<uint32_t>());
+    HIPCHK(hipEventSynchronize(h->totals_ready));
     const uint64_t D = h->host_totals[0];
     const uint32_t max_tile = h->host_totals[1], n_big = h->host_totals[2];
     const uint64_t D_slots = h->host_totals[5];  // >= D; == D unless exact culling dropped tiles
@@ -319,7 +325,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
                          h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>());
     h->prof.end(s);
     h->prof.begin(ST_COMPOSITE_FWD, s);
-    gsr_launch_composite_fwd(s, C, k, h->tile_start.as<uint32_t>(), stream_of(h), in->background, image_out,
+    gsr_launch_composite_fwd(s, C, k, h->tile_start.as<uint32_t>(), h->tile_order.as<uint32_t>(), stream_of(h), in->background, image_out,
                              h->n_contrib.as<uint32_t>(), h->final_T.as<float>(), h->values_sorted.as<uint32_t>(),
                              aux ? aux->covisibilities : nullptr, aux ? aux->uncertainties : nullptr);
     h->prof.end(s);
@@ -353,7 +359,7 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
     GsrCam k = make_cam(h, cam);
     h->prof.begin(ST_COMPOSITE_BWD, s);
     if (h->last_D > 0)
-        gsr_launch_composite_bwd(s, C, k, h->tile_start.as<uint32_t>(), stream_of(h), in->background, vpixels,
+        gsr_launch_composite_bwd(s, C, k, h->tile_start.as<uint32_t>(), h->tile_order.as<uint32_t>(), stream_of(h), in->background, vpixels,
                                  h->n_contrib.as<uint32_t>(), h->final_T.as<float>(), inst_of(h));
     h->prof.end(s);
     h->prof.begin(ST_PERGAUSS_BWD, s);

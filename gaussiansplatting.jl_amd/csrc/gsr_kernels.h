@@ -77,15 +77,20 @@ void gsr_launch_update_stats(hipStream_t s, int n, const int32_t* radii, const f
 void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count, uint32_t* tile_start,
                           uint32_t* cursor, uint32_t* totals, int n_blocks, const uint32_t* bsum, uint32_t* bpre,
                           const uint32_t* bvis);
+// order[0..n_tiles) = tile ids by descending list length (launch order of the compositing workgroups)
+void gsr_launch_tile_order(hipStream_t s, int n_tiles, const uint32_t* tile_count, const uint32_t* totals,
+                           uint32_t* order);
 void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start, uint64_t* keys,
                           uint64_t* big_scratch, uint32_t big_scratch_stride, uint32_t* slab_counter, GsrGeom geom,
                           GsrStream stream, uint32_t* values_sorted, uint32_t* ranges);
 
 // ---- composite.hip ----
-void gsr_launch_composite_fwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start, GsrStream stream,
+void gsr_launch_composite_fwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
+                              const uint32_t* tile_order, GsrStream stream,
                               const float* background, float* image, uint32_t* n_contrib, float* final_T,
                               const uint32_t* values_sorted, uint8_t* covis, float* uncert);
-void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start, GsrStream stream,
+void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
+                              const uint32_t* tile_order, GsrStream stream,
                               const float* background, const float* vpixels, const uint32_t* n_contrib,
                               const float* final_T, GsrInst inst);
 

@@ -94,21 +94,22 @@ __device__ __forceinline__ bool wave_reduce_writer(int lane) { return (lane & 6)
 
 // Which input a lane ends up holding (the same network run on indices).
 template <int N>
+__device__ __forceinline__ void index_level(int (&idx)[16], bool bit) {
+    constexpr int H = N / 2;
+#pragma unroll
+    for (int p = 0; p < H; p++) idx[p] = bit ? idx[2 * p + 1] : idx[2 * p];
+    if (N & 1) idx[H] = idx[N - 1];
+}
+template <int N>
 __device__ __forceinline__ int wave_reduce_index(int lane) {
+    constexpr int N1 = (N + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2;
     int idx[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) idx[i] = i;
-    const bool bits[4] = {(lane & 32) != 0, (lane & 16) != 0, (lane & 8) != 0, (lane & 1) != 0};
-    int n = N;
-#pragma unroll
-    for (int lvl = 0; lvl < 4; lvl++) {
-        const int h = n / 2;
-#pragma unroll
-        for (int p = 0; p < 8; p++)
-            if (p < h) idx[p] = bits[lvl] ? idx[2 * p + 1] : idx[2 * p];
-        if (n & 1) idx[h] = idx[n - 1];
-        n = (n + 1) / 2;
-    }
+    index_level<N>(idx, (lane & 32) != 0);
+    index_level<N1>(idx, (lane & 16) != 0);
+    index_level<N2>(idx, (lane & 8) != 0);
+    index_level<N3>(idx, (lane & 1) != 0);
     return idx[0];
 }
 

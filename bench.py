@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--no-loss", action="store_true", help="config 2 style: random cotangent instead of L1/SSIM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--views", type=int, default=8, help="size of the multi-view batch the poses are drawn from")
+    ap.add_argument("--with-optimizer", action="store_true",
+                    help="also run the functor prologue, its pullback and the 6-group Adam step each iteration "
+                         "(SURVEY.md §8f rank 1; NOT part of the headline metric, reported under `trainer_tail`)")
     ap.add_argument("--reference-lists", action="store_true",
                     help="keep the reference's (Gaussian, tile) instance lists instead of exact footprint culling")
     args = ap.parse_args()
@@ -95,7 +98,24 @@ def main():
     arena = torch.empty(D.arena_numel(N, K), device=dev, dtype=torch.float32)
     bg = (0.0, 0.0, 0.0)
 
+    tail = None
+    if args.with_optimizer:
+        # raw parameters the trainer optimises (training.jl:234-239): points, f_dc, f_rest, opacity logits,
+        # log-scales, rotations; one NU.Adam each
+        raw = [params[0].clone(), params[1][:, :1].contiguous(), params[1][:, 1:].contiguous(),
+               to(s.opacities_raw.reshape(-1, 1)), to(s.scales_raw), params[4].clone()]
+        lrs = [1.6e-4, 2.5e-3, 2.5e-3 / 20, 2.5e-2, 5e-3, 1e-3]
+        opts = [pkg.optim.Adam(t, lr, eps=1e-15) for t, lr in zip(raw, lrs)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        tail = {"prologue_fwd": 0.0, "prologue_bwd": 0.0, "adam": 0.0, "n": 0}
+
     def step():
+        if tail is not None:
+            ev[0].record()
+            shs, oa, sa = pkg.rasterizer.prologue_forward(raw[1], raw[2], raw[3], raw[4])
+            ev[1].record()
+            params[1], params[2], params[3] = shs, oa, sa
+            params[0], params[4] = raw[0], raw[5]
         img = rast.forward_raw(*params, cam, deg, bg)
         if args.no_loss:
             vp = vpix_fixed
@@ -103,6 +123,22 @@ def main():
             _, vp = pkg.fused_ssim.l1_ssim_loss(rast, img, target)
         rast.backward_raw(vp, *params, cam, deg, bg, arena=arena)
         D.allreduce_arena(arena)
+        if tail is not None:
+            g = D.split_arena(arena, N, K)
+            ev[2].record()
+            vdc, vrest, vo, vs = pkg.rasterizer.prologue_backward(params[2], params[3], g["vshs"], g["vopacities"].view(-1, 1),
+                                                                  g["vscales"], 3)
+            ev[3].record()
+            pkg.optim.step_all(opts, raw, [g["vmeans"], vdc, vrest, vo, vs, g["vrot"]])
+            e4 = torch.cuda.Event(enable_timing=True); e4.record()
+            tail["_last"] = (ev[0], ev[1], ev[2], ev[3], e4)
+
+    def tail_collect():
+        if tail is not None and "_last" in tail:
+            a, b, c, d, e = tail["_last"]
+            e.synchronize()
+            tail["prologue_fwd"] += a.elapsed_time(b); tail["prologue_bwd"] += c.elapsed_time(d)
+            tail["adam"] += d.elapsed_time(e); tail["n"] += 1
 
     def sync():
         if world > 1:
@@ -118,6 +154,7 @@ def main():
         step()
     sync()
     dt = time.perf_counter() - t0
+    tail_collect()
     prof = rast.profile_read()
     rast.profile(False)
     if world > 1:
@@ -163,6 +200,12 @@ def main():
         "roofline": roofline,
     }
 
+    if tail is not None and tail["n"]:
+        # last iteration's HIP-event times of the three extra stages (they ARE inside ms_per_step here)
+        out["trainer_tail"] = {k: round(tail[k] / tail["n"], 4) for k in ("prologue_fwd", "prologue_bwd", "adam")}
+        out["trainer_tail"]["algorithmic_bytes"] = {"prologue_fwd": 2 * 4 * (3 * K + 4) * N, "prologue_bwd": 2 * 4 * (3 * K + 4) * N + 16 * N,
+                                                    "adam": 7 * 4 * (3 * K + 11) * N}
+        out["config"]["workload"] += " + prologue + Adam (trainer tail, not the headline metric)"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, s, W, H, deg, args)
     if rank == 0:

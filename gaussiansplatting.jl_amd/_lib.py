@@ -56,10 +56,19 @@ class Grads(C.Structure):
                 ("vrotations", C.c_void_p), ("vR", C.c_void_p), ("vt", C.c_void_p)]
 
 
+ADAM_MAX_GROUPS = 8
+
+
+class AdamGroup(C.Structure):
+    _fields_ = [("theta", C.c_void_p), ("grad", C.c_void_p), ("mu", C.c_void_p), ("nu", C.c_void_p),
+                ("count", C.c_int64), ("lr", C.c_float), ("current_step", C.c_uint32)]
+
+
 EXPORTS = ["gsr_create", "gsr_destroy", "gsr_release_scene_buffers", "gsr_memory_usage", "gsr_forward",
            "gsr_backward", "gsr_buffer", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_loss_l1_ssim",
            "gsr_allreduce_grads", "gsr_last_error_string", "gsr_version", "gsr_profile_enable",
-           "gsr_profile_stage_count", "gsr_profile_stage_name", "gsr_profile_read", "gsr_update_stats"]
+           "gsr_profile_stage_count", "gsr_profile_stage_name", "gsr_profile_read", "gsr_update_stats",
+           "gsr_prologue_forward", "gsr_prologue_backward", "gsr_adam_step"]
 
 _lib = None
 
@@ -99,6 +108,9 @@ def load():
     lib.gsr_loss_l1_ssim.argtypes = [vp, vp, vp, f32, vp, vp, vp]
     lib.gsr_allreduce_grads.argtypes = [vp, vp, C.c_size_t, vp]
     lib.gsr_update_stats.argtypes = [vp, vp, vp, vp, vp]
+    lib.gsr_prologue_forward.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_prologue_backward.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_adam_step.argtypes = [C.POINTER(AdamGroup), i32, f32, f32, f32, vp]
     lib.gsr_profile_enable.argtypes = [vp, i32]
     lib.gsr_profile_stage_name.argtypes = [i32]
     lib.gsr_profile_stage_name.restype = C.c_char_p

@@ -6,6 +6,7 @@
 #include "../../include/gsr.h"
 
 #include <dlfcn.h>
+#include <math.h>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -474,6 +475,60 @@ int gsr_profile_read(gsr_handle* h, double* ms_sum, int* launches, int reset) {
         launches[r.stage] += 1;
     }
     if (reset) h->prof.clear();
+    return GSR_OK;
+}
+
+int gsr_prologue_forward(int32_t n, int32_t k_rest, int32_t scale_dims, const float* sh_color,
+                         const float* sh_remainder, const float* opacities, const float* scales, float* shs,
+                         float* opacities_act, float* scales_act, void* stream) {
+    if (n < 0 || k_rest < 0 || (scale_dims != 1 && scale_dims != 3))
+        return fail(GSR_E_INVALID_ARG, "bad sizes: n=%d k_rest=%d scale_dims=%d", n, k_rest, scale_dims);
+    if (n == 0) return GSR_OK;
+    if (!sh_color || (k_rest > 0 && !sh_remainder) || !opacities || !scales || !shs || !opacities_act || !scales_act)
+        return fail(GSR_E_INVALID_ARG, "null array");
+    gsr_launch_prologue_fwd((hipStream_t)stream, n, k_rest, scale_dims, sh_color, sh_remainder, opacities, scales, shs,
+                            opacities_act, scales_act);
+    HIPCHK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_prologue_backward(int32_t n, int32_t k_rest, int32_t scale_dims, const float* opacities_act,
+                          const float* scales_act, const float* vshs, const float* vopacities_act,
+                          const float* vscales_act, float* v_sh_color, float* v_sh_remainder, float* v_opacities,
+                          float* v_scales, void* stream) {
+    if (n < 0 || k_rest < 0 || (scale_dims != 1 && scale_dims != 3))
+        return fail(GSR_E_INVALID_ARG, "bad sizes: n=%d k_rest=%d scale_dims=%d", n, k_rest, scale_dims);
+    if (n == 0) return GSR_OK;
+    if (!opacities_act || !scales_act || !vshs || !vopacities_act || !vscales_act || !v_sh_color ||
+        (k_rest > 0 && !v_sh_remainder) || !v_opacities || !v_scales)
+        return fail(GSR_E_INVALID_ARG, "null array");
+    gsr_launch_prologue_bwd((hipStream_t)stream, n, k_rest, scale_dims, opacities_act, scales_act, vshs, vopacities_act,
+                            vscales_act, v_sh_color, v_sh_remainder, v_opacities, v_scales);
+    HIPCHK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_adam_step(const gsr_adam_group* groups, int32_t n_groups, float beta1, float beta2, float eps, void* stream) {
+    if (n_groups < 0 || n_groups > GSR_ADAM_MAX_GROUPS || (n_groups > 0 && !groups))
+        return fail(GSR_E_INVALID_ARG, "n_groups must be in [0, %d]", GSR_ADAM_MAX_GROUPS);
+    float* theta[GSR_ADAM_MAX_GROUPS]; const float* grad[GSR_ADAM_MAX_GROUPS];
+    float* mu[GSR_ADAM_MAX_GROUPS]; float* nu[GSR_ADAM_MAX_GROUPS];
+    long long count[GSR_ADAM_MAX_GROUPS]; float lr_t[GSR_ADAM_MAX_GROUPS];
+    int m = 0;
+    for (int g = 0; g < n_groups; g++) {
+        const gsr_adam_group& a = groups[g];
+        if (a.count < 0) return fail(GSR_E_INVALID_ARG, "group %d: negative count", g);
+        if (a.count == 0) continue;  // training.jl:770 `isempty(θᵢ) && continue`
+        if (!a.theta || !a.grad || !a.mu || !a.nu) return fail(GSR_E_INVALID_ARG, "group %d: null array", g);
+        if (a.current_step == 0) return fail(GSR_E_INVALID_ARG, "group %d: current_step counts from 1", g);
+        const float t = (float)a.current_step;
+        theta[m] = a.theta; grad[m] = a.grad; mu[m] = a.mu; nu[m] = a.nu; count[m] = a.count;
+        lr_t[m] = a.lr * sqrtf(1.0f - powf(beta2, t)) / (1.0f - powf(beta1, t));  // debiasing, Kingma & Ba §2
+        m++;
+    }
+    if (m == 0) return GSR_OK;
+    gsr_launch_adam((hipStream_t)stream, m, theta, grad, mu, nu, count, lr_t, beta1, beta2, eps);
+    HIPCHK(hipGetLastError());
     return GSR_OK;
 }
 

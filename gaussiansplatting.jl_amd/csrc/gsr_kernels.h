@@ -94,6 +94,18 @@ void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uin
                               const float* background, const float* vpixels, const uint32_t* n_contrib,
                               const float* final_T, GsrInst inst);
 
+// ---- trainer.hip ----
+#define GSR_ADAM_MAX_GROUPS 8
+void gsr_launch_prologue_fwd(hipStream_t s, int n, int k_rest, int scale_dims, const float* sh_color,
+                             const float* sh_remainder, const float* opacities, const float* scales, float* shs,
+                             float* opacities_act, float* scales_act);
+void gsr_launch_prologue_bwd(hipStream_t s, int n, int k_rest, int scale_dims, const float* opacities_act,
+                             const float* scales_act, const float* vshs, const float* vopacities_act,
+                             const float* vscales_act, float* v_sh_color, float* v_sh_remainder, float* v_opacities,
+                             float* v_scales);
+void gsr_launch_adam(hipStream_t s, int n_groups, float* const* theta, const float* const* grad, float* const* mu,
+                     float* const* nu, const long long* count, const float* lr_t, float beta1, float beta2, float eps);
+
 // ---- ssim.hip ----
 void gsr_launch_ssim_fwd(hipStream_t s, int W, int H, int CH, int B, const float* img, const float* ref, float C1,
                          float C2, int train, float* ssim_map, float* d0, float* d1, float* d2);

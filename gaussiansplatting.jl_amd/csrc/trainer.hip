@@ -1,0 +1,171 @@
+// The per-Gaussian streaming passes either side of rasterize(): the functor prologue
+// (rasterizer.jl:200-253: hcat of the SH blocks, sigmoid, exp), its pullback, and the Adam
+// update NU.step! applies to the six parameter arrays (training.jl:234-239,778).
+// All three are pure HBM streams: one thread per element / Gaussian, float4 where the layout
+// allows, no FMA contraction (compiled with -ffp-contract=off) so the update is the same fp32
+// expression tree as the oracle's.
+#include "gsr_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }  // NerfUtils.sigmoid
+
+// shs (3,K,N) <- [sh_color (3,1,N) | sh_remainder (3,K-1,N)]: one thread per output float, coalesced writes
+__global__ __launch_bounds__(256) void prologue_shs_kernel(size_t total, int K3, const float* __restrict__ dc,
+                                                           const float* __restrict__ rest, float* __restrict__ shs) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const size_t i = e / (size_t)K3;
+    const int j = (int)(e - i * (size_t)K3);
+    shs[e] = j < 3 ? dc[3 * i + j] : rest[(size_t)(K3 - 3) * i + (j - 3)];
+}
+__global__ __launch_bounds__(256) void prologue_act_kernel(int n, int scale_dims, const float* __restrict__ opac,
+                                                           const float* __restrict__ scales,
+                                                           float* __restrict__ opac_act, float* __restrict__ scales_act) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    opac_act[i] = sigmoidf_(opac[i]);
+    if (scale_dims == 1) {
+        const float s = expf(scales[i]);  // isotropic: vcat(s, s, s) (rasterizer.jl:235-247)
+        scales_act[3 * (size_t)i] = s; scales_act[3 * (size_t)i + 1] = s; scales_act[3 * (size_t)i + 2] = s;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; c++) scales_act[3 * (size_t)i + c] = expf(scales[3 * (size_t)i + c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void prologue_shs_bwd_kernel(size_t total, int K3, const float* __restrict__ vshs,
+                                                               float* __restrict__ vdc, float* __restrict__ vrest) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const size_t i = e / (size_t)K3;
+    const int j = (int)(e - i * (size_t)K3);
+    const float v = vshs[e];
+    if (j < 3) vdc[3 * i + j] = v;
+    else vrest[(size_t)(K3 - 3) * i + (j - 3)] = v;
+}
+__global__ __launch_bounds__(256) void prologue_act_bwd_kernel(int n, int scale_dims,
+                                                               const float* __restrict__ opac_act,
+                                                               const float* __restrict__ scales_act,
+                                                               const float* __restrict__ vopac_act,
+                                                               const float* __restrict__ vscales_act,
+                                                               float* __restrict__ vopac, float* __restrict__ vscales) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float a = opac_act[i];
+    vopac[i] = vopac_act[i] * (a * (1.0f - a));
+    float g[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) g[c] = vscales_act[3 * (size_t)i + c] * scales_act[3 * (size_t)i + c];
+    if (scale_dims == 1) vscales[i] = (g[0] + g[1]) + g[2];
+    else {
+#pragma unroll
+        for (int c = 0; c < 3; c++) vscales[3 * (size_t)i + c] = g[c];
+    }
+}
+
+struct AdamGroups {
+    float* theta[GSR_ADAM_MAX_GROUPS];
+    const float* grad[GSR_ADAM_MAX_GROUPS];
+    float* mu[GSR_ADAM_MAX_GROUPS];
+    float* nu[GSR_ADAM_MAX_GROUPS];
+    long long count[GSR_ADAM_MAX_GROUPS];
+    float lr_t[GSR_ADAM_MAX_GROUPS];  // lr · sqrt(1-β2^t) / (1-β1^t), evaluated on the host
+    long long block_start[GSR_ADAM_MAX_GROUPS + 1];  // first workgroup of each group
+    int n;
+};
+
+// One launch for all parameter groups: a workgroup belongs to exactly one group (block_start),
+// 4 elements per thread through float4 when the group's pointers are 16-byte aligned.
+__global__ __launch_bounds__(256) void adam_kernel(AdamGroups G, float beta1, float beta2, float eps) {
+    int g = 0;
+#pragma unroll
+    for (int k = 1; k < GSR_ADAM_MAX_GROUPS; k++)
+        if (k < G.n && (long long)blockIdx.x >= G.block_start[k]) g = k;
+    const long long base = (((long long)blockIdx.x - G.block_start[g]) * 256 + threadIdx.x) * 4;
+    const long long count = G.count[g];
+    if (base >= count) return;
+    float* __restrict__ th = G.theta[g];
+    const float* __restrict__ gr = G.grad[g];
+    float* __restrict__ mu = G.mu[g];
+    float* __restrict__ nu = G.nu[g];
+    const float lr_t = G.lr_t[g], omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
+    const bool vec = base + 4 <= count &&
+                     ((((uintptr_t)th | (uintptr_t)gr | (uintptr_t)mu | (uintptr_t)nu) & 15) == 0);
+    float t[4], d[4], m[4], v[4];
+    if (vec) {
+        const float4 t4 = *(const float4*)(th + base), d4 = *(const float4*)(gr + base);
+        const float4 m4 = *(const float4*)(mu + base), v4 = *(const float4*)(nu + base);
+        t[0] = t4.x; t[1] = t4.y; t[2] = t4.z; t[3] = t4.w;
+        d[0] = d4.x; d[1] = d4.y; d[2] = d4.z; d[3] = d4.w;
+        m[0] = m4.x; m[1] = m4.y; m[2] = m4.z; m[3] = m4.w;
+        v[0] = v4.x; v[1] = v4.y; v[2] = v4.z; v[3] = v4.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool ok = base + k < count;
+            t[k] = ok ? th[base + k] : 0.0f; d[k] = ok ? gr[base + k] : 0.0f;
+            m[k] = ok ? mu[base + k] : 0.0f; v[k] = ok ? nu[base + k] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        m[k] = beta1 * m[k] + omb1 * d[k];
+        v[k] = beta2 * v[k] + omb2 * (d[k] * d[k]);
+        t[k] = t[k] - lr_t * m[k] / (sqrtf(v[k]) + eps);
+    }
+    if (vec) {
+        *(float4*)(th + base) = make_float4(t[0], t[1], t[2], t[3]);
+        *(float4*)(mu + base) = make_float4(m[0], m[1], m[2], m[3]);
+        *(float4*)(nu + base) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (base + k < count) { th[base + k] = t[k]; mu[base + k] = m[k]; nu[base + k] = v[k]; }
+    }
+}
+
+}  // namespace
+
+void gsr_launch_prologue_fwd(hipStream_t s, int n, int k_rest, int scale_dims, const float* sh_color,
+                             const float* sh_remainder, const float* opacities, const float* scales, float* shs,
+                             float* opacities_act, float* scales_act) {
+    if (n <= 0) return;
+    const int K3 = 3 * (1 + k_rest);
+    const size_t total = (size_t)n * K3;
+    hipLaunchKernelGGL(prologue_shs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, K3, sh_color,
+                       sh_remainder, shs);
+    hipLaunchKernelGGL(prologue_act_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, scale_dims, opacities, scales,
+                       opacities_act, scales_act);
+}
+
+void gsr_launch_prologue_bwd(hipStream_t s, int n, int k_rest, int scale_dims, const float* opacities_act,
+                             const float* scales_act, const float* vshs, const float* vopacities_act,
+                             const float* vscales_act, float* v_sh_color, float* v_sh_remainder, float* v_opacities,
+                             float* v_scales) {
+    if (n <= 0) return;
+    const int K3 = 3 * (1 + k_rest);
+    const size_t total = (size_t)n * K3;
+    hipLaunchKernelGGL(prologue_shs_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, K3, vshs,
+                       v_sh_color, v_sh_remainder);
+    hipLaunchKernelGGL(prologue_act_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, scale_dims, opacities_act,
+                       scales_act, vopacities_act, vscales_act, v_opacities, v_scales);
+}
+
+void gsr_launch_adam(hipStream_t s, int n_groups, float* const* theta, const float* const* grad, float* const* mu,
+                     float* const* nu, const long long* count, const float* lr_t, float beta1, float beta2, float eps) {
+    AdamGroups G;
+    G.n = n_groups;
+    long long blocks = 0;
+    for (int g = 0; g < GSR_ADAM_MAX_GROUPS; g++) {
+        const bool on = g < n_groups;
+        G.theta[g] = on ? theta[g] : nullptr; G.grad[g] = on ? grad[g] : nullptr;
+        G.mu[g] = on ? mu[g] : nullptr; G.nu[g] = on ? nu[g] : nullptr;
+        G.count[g] = on ? count[g] : 0; G.lr_t[g] = on ? lr_t[g] : 0.0f;
+        G.block_start[g] = blocks;
+        if (on) blocks += (count[g] + 1023) / 1024;
+    }
+    G.block_start[GSR_ADAM_MAX_GROUPS] = blocks;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, G, beta1, beta2, eps);
+}

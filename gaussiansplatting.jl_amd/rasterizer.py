@@ -185,12 +185,8 @@ class GaussianRasterizer:
     def __call__(self, means_3d, opacities, scales, rotations, sh_color, sh_remainder, R_w2c=None, t_w2c=None, *,
                  camera: Camera, sh_degree: int, background=(0.0, 0.0, 0.0), covisibilities=None,
                  uncertainties=None):
-        shs = sh_color if sh_remainder is None or sh_remainder.numel() == 0 else torch.cat([sh_color, sh_remainder], 1)
-        opacities_act = torch.sigmoid(opacities)
-        if scales.shape[-1] == 1:  # isotropic
-            scales = scales.expand(-1, 3)
-        scales_act = torch.exp(scales)
-        return rasterize(means_3d, shs.contiguous(), opacities_act, scales_act.contiguous(), rotations, R_w2c, t_w2c,
+        shs, opacities_act, scales_act = _Prologue.apply(sh_color, sh_remainder, opacities, scales)
+        return rasterize(means_3d, shs, opacities_act, scales_act, rotations, R_w2c, t_w2c,
                          rast=self, camera=camera, sh_degree=sh_degree, background=background,
                          covisibilities=covisibilities, uncertainties=uncertainties)
 
@@ -276,6 +272,64 @@ class GaussianRasterizer:
         with torch.cuda.device(self.device):
             L.check(self._lib.gsr_backward(self._h, C.byref(inp), C.byref(cs), _ptr(vpixels), C.byref(g), _stream()))
         return vmeans, vshs, vopac, vscales, vrot, vR, vt
+
+
+def prologue_forward(sh_color, sh_remainder, opacities, scales):
+    """The functor prologue (rasterizer.jl:218-247) on the device: shs = hcat(sh_color, sh_remainder),
+    σ(opacities), exp(scales) with an isotropic (N,1) scale tiled x3.  Returns (shs, opacities_act, scales_act)."""
+    n = sh_color.shape[0]
+    _chk(sh_color, "sh_color", (n, 1, 3)); _chk(opacities, "opacities"); _chk(scales, "scales")
+    k_rest = 0 if sh_remainder is None or sh_remainder.numel() == 0 else int(sh_remainder.shape[1])
+    if k_rest:
+        _chk(sh_remainder, "sh_remainder", (n, k_rest, 3))
+    if opacities.numel() != n or scales.numel() not in (n, 3 * n):
+        raise ValueError("opacities must be (N,1) and scales (N,3) or (N,1)")
+    sd = 1 if scales.numel() == n and n > 0 and scales.shape[-1] == 1 else 3
+    shs = torch.empty((n, 1 + k_rest, 3), device=sh_color.device, dtype=torch.float32)
+    oa = torch.empty((n, 1), device=sh_color.device, dtype=torch.float32)
+    sa = torch.empty((n, 3), device=sh_color.device, dtype=torch.float32)
+    L.check(L.load().gsr_prologue_forward(n, k_rest, sd, _ptr(sh_color), _ptr(sh_remainder) if k_rest else None,
+                                          _ptr(opacities), _ptr(scales), _ptr(shs), _ptr(oa), _ptr(sa), _stream()))
+    return shs, oa, sa
+
+
+def prologue_backward(opacities_act, scales_act, vshs, vopacities_act, vscales_act, scale_dims=3):
+    """Pullback of the prologue to the raw parameters: (v_sh_color, v_sh_remainder, v_opacities, v_scales)."""
+    n, K = vshs.shape[0], vshs.shape[1]
+    dev = vshs.device
+    vdc = torch.empty((n, 1, 3), device=dev, dtype=torch.float32)
+    vrest = torch.empty((n, K - 1, 3), device=dev, dtype=torch.float32)
+    vo = torch.empty((n, 1), device=dev, dtype=torch.float32)
+    vs = torch.empty((n, scale_dims), device=dev, dtype=torch.float32)
+    for t, nm in ((opacities_act, "opacities_act"), (scales_act, "scales_act"), (vshs, "vshs"),
+                  (vopacities_act, "vopacities_act"), (vscales_act, "vscales_act")):
+        _chk(t, nm)
+    L.check(L.load().gsr_prologue_backward(n, K - 1, scale_dims, _ptr(opacities_act), _ptr(scales_act), _ptr(vshs),
+                                           _ptr(vopacities_act), _ptr(vscales_act), _ptr(vdc),
+                                           _ptr(vrest) if K > 1 else None, _ptr(vo), _ptr(vs), _stream()))
+    return vdc, vrest, vo, vs
+
+
+class _Prologue(torch.autograd.Function):
+    """rasterizer.jl:218-247 under AD: forward and pullback are the library's kernels."""
+
+    @staticmethod
+    def forward(ctx, sh_color, sh_remainder, opacities, scales):
+        shs, oa, sa = prologue_forward(sh_color, sh_remainder, opacities, scales)
+        ctx.save_for_backward(oa, sa)
+        ctx.scale_dims = 1 if scales.shape[-1] == 1 else 3
+        ctx.K = shs.shape[1]
+        return shs, oa, sa
+
+    @staticmethod
+    def backward(ctx, vshs, voa, vsa):
+        oa, sa = ctx.saved_tensors
+        n = oa.shape[0]
+        vshs = torch.zeros((n, ctx.K, 3), device=oa.device) if vshs is None else vshs.contiguous()
+        voa = torch.zeros_like(oa) if voa is None else voa.contiguous()
+        vsa = torch.zeros_like(sa) if vsa is None else vsa.contiguous()
+        vdc, vrest, vo, vs = prologue_backward(oa, sa, vshs, voa, vsa, ctx.scale_dims)
+        return vdc, (vrest if ctx.K > 1 else None), vo, vs
 
 
 class _Rasterize(torch.autograd.Function):

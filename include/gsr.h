@@ -189,6 +189,44 @@ GSR_API int gsr_ssim_backward(int W, int H, int CH, int B, const float* img, con
 GSR_API int gsr_loss_l1_ssim(gsr_handle* h, const float* image, const float* target, float lambda_dssim,
                              float* loss_out, float* vpixels, void* stream);
 
+/* The functor prologue `(rast::GaussianRasterizer)(means_3d, opacities, scales, rotations,
+ * sh_color, sh_remainder, ...)` (rasterizer.jl:200-253) up to its call of rasterize():
+ *   shs = hcat(sh_color (3,1,N), sh_remainder (3,k_rest,N))          (rasterizer.jl:218-228)
+ *   opacities_act = NU.sigmoid.(opacities (1,N))                     (rasterizer.jl:229-234)
+ *   scales_act = exp.(scales), an isotropic (1,N) scale tiled x3     (rasterizer.jl:235-247)
+ * scale_dims is 1 (isotropic) or 3.  k_rest may be 0 (sh_remainder NULL).  All device. */
+GSR_API int gsr_prologue_forward(int32_t n, int32_t k_rest, int32_t scale_dims, const float* sh_color,
+                                 const float* sh_remainder, const float* opacities, const float* scales, float* shs,
+                                 float* opacities_act, float* scales_act, void* stream);
+/* Pullback of the prologue — what Zygote derives around the rrule of rasterize
+ * (rasterizer.jl:552-573) for the raw parameters the trainer optimises
+ * (training.jl:646-656): vshs is split, v_opacities = v_act * a(1-a), v_scales = v_act * exp(s)
+ * (summed over the three tiled rows when isotropic). */
+GSR_API int gsr_prologue_backward(int32_t n, int32_t k_rest, int32_t scale_dims, const float* opacities_act,
+                                  const float* scales_act, const float* vshs, const float* vopacities_act,
+                                  const float* vscales_act, float* v_sh_color, float* v_sh_remainder,
+                                  float* v_opacities, float* v_scales, void* stream);
+
+/* `NU.step!(opt, θ, ∇)` of NerfUtils 0.2's Adam (external dependency, Project.toml:76; call
+ * sites training.jl:234-239,778), for up to GSR_ADAM_MAX_GROUPS parameter arrays in ONE
+ * launch.  Each group is one `NU.Adam` (its own lr; μ, ν of the parameter's length).
+ * `current_step` is the optimizer's counter AFTER its increment (1 on the first step).
+ *   μ = β1 μ + (1-β1) g;  ν = β2 ν + (1-β2) g²;
+ *   θ -= lr · sqrt(1-β2^t)/(1-β1^t) · μ / (sqrt(ν) + ϵ)            (ϵ = 1f-15: training.jl:229)
+ * theta, mu, nu are updated in place; grad is read only.  All device. */
+#define GSR_ADAM_MAX_GROUPS 8
+typedef struct gsr_adam_group {
+    float* theta;
+    const float* grad;
+    float* mu;
+    float* nu;
+    int64_t count; /* elements */
+    float lr;
+    uint32_t current_step;
+} gsr_adam_group;
+GSR_API int gsr_adam_step(const gsr_adam_group* groups, int32_t n_groups, float beta1, float beta2, float eps,
+                          void* stream);
+
 /* New (no reference counterpart): sum the per-view gradient arena over
  * the ranks of an RCCL communicator (ncclComm_t passed as void*).  librccl is resolved
  * lazily with dlopen, so single-GPU users need not have it. */

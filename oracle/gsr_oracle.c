@@ -988,3 +988,73 @@ ORC_API void orc_ssim_backward(int W, int H, int CH, int B, const float *img, co
             }
         }
 }
+
+static inline float scales_dim_pick(const float *scales, int scale_dims, int c, int i) {
+    return scale_dims == 1 ? scales[i] : scales[c + 3 * (size_t)i];
+}
+/* ------------------------------------------------------------------------- */
+/* A.1 functor prologue (rasterizer.jl:200-253) and its pullback              */
+/* shs = hcat(sh_color (3,1,N), sh_remainder (3,KR,N)); σ(opacities);          */
+/* exp(scales), an isotropic (1,N) scale tiled x3 (rasterizer.jl:235-247).     */
+/* NerfUtils.sigmoid (external, NerfUtils 0.2) restated as 1/(1+exp(-x)).      */
+/* ------------------------------------------------------------------------- */
+ORC_API void orc_prologue_forward(int n, int k_rest, int scale_dims, const float *sh_color, const float *sh_remainder,
+                                  const float *opacities, const float *scales, float *shs, float *opacities_act,
+                                  float *scales_act) {
+    const int K = 1 + k_rest;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) {
+        for (int c = 0; c < 3; c++) shs[c + 3 * (size_t)K * i] = sh_color[c + 3 * (size_t)i];
+        for (int j = 0; j < 3 * k_rest; j++) shs[3 + j + 3 * (size_t)K * i] = sh_remainder[j + 3 * (size_t)k_rest * i];
+        opacities_act[i] = 1.0f / (1.0f + expf(-opacities[i]));
+        for (int c = 0; c < 3; c++)
+            scales_act[c + 3 * (size_t)i] = expf(scales_dim_pick(scales, scale_dims, c, i));
+    }
+}
+/* what ChainRules derives for rasterizer.jl:218-247: hcat -> split; σ' = σ(1-σ); exp' = exp;
+ * vcat(s, s, s) -> sum of the three cotangents */
+ORC_API void orc_prologue_backward(int n, int k_rest, int scale_dims, const float *opacities_act,
+                                   const float *scales_act, const float *vshs, const float *vopacities_act,
+                                   const float *vscales_act, float *v_sh_color, float *v_sh_remainder,
+                                   float *v_opacities, float *v_scales) {
+    const int K = 1 + k_rest;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) {
+        for (int c = 0; c < 3; c++) v_sh_color[c + 3 * (size_t)i] = vshs[c + 3 * (size_t)K * i];
+        for (int j = 0; j < 3 * k_rest; j++) v_sh_remainder[j + 3 * (size_t)k_rest * i] = vshs[3 + j + 3 * (size_t)K * i];
+        const float a = opacities_act[i];
+        v_opacities[i] = vopacities_act[i] * (a * (1.0f - a));
+        float g[3];
+        for (int c = 0; c < 3; c++) g[c] = vscales_act[c + 3 * (size_t)i] * scales_act[c + 3 * (size_t)i];
+        if (scale_dims == 1) v_scales[i] = (g[0] + g[1]) + g[2];
+        else for (int c = 0; c < 3; c++) v_scales[c + 3 * (size_t)i] = g[c];
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Adam step of `NU.step!` (call sites training.jl:234-239,778).  NerfUtils    */
+/* 0.2 is an external dependency absent from /root/reference (Project.toml:76) */
+/* — PARITY UNPINNED; restated from Kingma & Ba 2015, Algorithm 1 in the       */
+/* "efficient" ordering of its §2 that NerfUtils uses:                         */
+/*   μ = β1 μ + (1-β1) g;  ν = β2 ν + (1-β2) g²;                               */
+/*   lr_t = lr · sqrt(1-β2^t) / (1-β1^t);  θ -= lr_t · μ / (sqrt(ν) + ϵ)       */
+/* with t the optimizer's step counter after increment (ϵ = 1f-15 at every     */
+/* reference call site).                                                       */
+/* ------------------------------------------------------------------------- */
+ORC_API float orc_adam_lr_t(float lr, float beta1, float beta2, uint32_t step) {
+    const float t = (float)step;
+    return lr * sqrtf(1.0f - powf(beta2, t)) / (1.0f - powf(beta1, t));
+}
+ORC_API void orc_adam_step(int64_t count, float *theta, const float *grad, float *mu, float *nu, uint32_t step,
+                           float lr, float beta1, float beta2, float eps) {
+    const float lr_t = orc_adam_lr_t(lr, beta1, beta2, step);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < count; i++) {
+        const float g = grad[i];
+        const float m = beta1 * mu[i] + (1.0f - beta1) * g;
+        const float v = beta2 * nu[i] + (1.0f - beta2) * (g * g);
+        mu[i] = m;
+        nu[i] = v;
+        theta[i] = theta[i] - lr_t * m / (sqrtf(v) + eps);
+    }
+}

@@ -413,3 +413,50 @@ def update_stats(max_radii, accum, denom, radii, vmeans2d, width, height):
     nrm = np.sqrt(gx * gx + gy * gy, dtype=np.float32)
     accum[vis] += nrm[vis]
     denom[vis] += np.float32(1.0)
+
+
+# ---- functor prologue (rasterizer.jl:200-253) and the optimizer step (training.jl:234-239,778) ----
+def prologue_forward(sh_color, sh_remainder, opacities, scales):
+    """(N,1,3), (N,KR,3) or None, (N,1), (N,3)|(N,1) raw -> shs (N,1+KR,3), σ(opacities) (N,1), exp(scales) (N,3)."""
+    sh_color = _f(sh_color)
+    n = sh_color.shape[0]
+    kr = 0 if sh_remainder is None else int(_f(sh_remainder).shape[1])
+    rem = _f(sh_remainder) if kr else np.zeros(1, np.float32)
+    opacities, scales = _f(opacities), _f(scales)
+    sd = 1 if scales.size == n else 3
+    shs = np.empty((n, 1 + kr, 3), np.float32)
+    oa = np.empty((n, 1), np.float32)
+    sa = np.empty((n, 3), np.float32)
+    lib().orc_prologue_forward(n, kr, sd, _p(sh_color), _p(rem), _p(opacities), _p(scales), _p(shs), _p(oa), _p(sa))
+    return shs, oa, sa
+
+
+def prologue_backward(opacities_act, scales_act, vshs, vopacities_act, vscales_act, scale_dims=3):
+    vshs = _f(vshs)
+    n, K = vshs.shape[0], vshs.shape[1]
+    kr = K - 1
+    vdc = np.empty((n, 1, 3), np.float32)
+    vrest = np.empty((n, max(kr, 1), 3), np.float32)
+    vo = np.empty((n, 1), np.float32)
+    vs = np.empty((n, scale_dims), np.float32)
+    lib().orc_prologue_backward(n, kr, scale_dims, _p(_f(opacities_act)), _p(_f(scales_act)), _p(vshs),
+                                _p(_f(vopacities_act)), _p(_f(vscales_act)), _p(vdc), _p(vrest), _p(vo), _p(vs))
+    return vdc, (vrest if kr else vrest[:, :0]), vo, vs
+
+
+def adam_step(theta, grad, mu, nu, step, lr, beta1=0.9, beta2=0.999, eps=1e-15):
+    """In place on float32 numpy arrays (theta, mu, nu); `step` is the counter AFTER increment."""
+    for a in (theta, mu, nu):
+        assert a.dtype == np.float32 and a.flags.c_contiguous
+    L = lib()
+    L.orc_adam_step.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                C.c_float, C.c_float, C.c_float, C.c_float]
+    L.orc_adam_step(theta.size, theta.ctypes.data, _f(grad).ctypes.data, mu.ctypes.data, nu.ctypes.data,
+                    int(step), float(lr), float(beta1), float(beta2), float(eps))
+
+
+def adam_lr_t(lr, beta1, beta2, step):
+    L = lib()
+    L.orc_adam_lr_t.restype = C.c_float
+    L.orc_adam_lr_t.argtypes = [C.c_float, C.c_float, C.c_float, C.c_uint32]
+    return L.orc_adam_lr_t(float(lr), float(beta1), float(beta2), int(step))

@@ -1,0 +1,117 @@
+"""-m gpu parity of the two streaming passes either side of rasterize(), through the C ABI:
+gsr_prologue_forward/backward (rasterizer.jl:200-253) and gsr_adam_step (NU.step!,
+training.jl:234-239,778) against the oracle on the same inputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from hip_helpers import dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _raw(n, kr, iso, seed):
+    r = np.random.default_rng(seed)
+    return (r.normal(size=(n, 1, 3)).astype(np.float32), r.normal(size=(n, kr, 3)).astype(np.float32) if kr else None,
+            r.normal(size=(n, 1)).astype(np.float32) * 3, r.normal(size=(n, 1 if iso else 3)).astype(np.float32))
+
+
+@pytest.mark.parametrize("n,kr,iso", [(1000, 15, False), (257, 0, False), (4099, 8, True), (1, 3, False)])
+def test_prologue_forward_vs_oracle(pkg, orc, n, kr, iso):
+    dc, rest, o, s = _raw(n, kr, iso, 21)
+    shs, oa, sa = orc.prologue_forward(dc, rest, o, s)
+    R = pkg.rasterizer
+    h = R.prologue_forward(dev(dc), dev(rest) if kr else None, dev(o), dev(s))
+    torch.cuda.synchronize()
+    assert np.array_equal(h[0].cpu().numpy(), shs)                       # hcat: bit-exact
+    # sigmoid / exp: the device expf and glibc expf are each within 1 ulp of the true value
+    np.testing.assert_allclose(h[1].cpu().numpy(), oa, rtol=5e-7, atol=1e-37)
+    np.testing.assert_allclose(h[2].cpu().numpy(), sa, rtol=5e-7, atol=1e-37)
+
+
+@pytest.mark.parametrize("n,kr,iso", [(1000, 15, False), (4099, 8, True), (300, 0, False)])
+def test_prologue_backward_vs_oracle_bit_exact(pkg, orc, n, kr, iso):
+    dc, rest, o, s = _raw(n, kr, iso, 22)
+    shs, oa, sa = orc.prologue_forward(dc, rest, o, s)
+    r = np.random.default_rng(9)
+    vshs, voa, vsa = (r.normal(size=a.shape).astype(np.float32) for a in (shs, oa, sa))
+    want = orc.prologue_backward(oa, sa, vshs, voa, vsa, 1 if iso else 3)
+    got = pkg.rasterizer.prologue_backward(dev(oa), dev(sa), dev(vshs), dev(voa), dev(vsa), 1 if iso else 3)
+    torch.cuda.synchronize()
+    for g, w in zip(got, want):
+        assert np.array_equal(g.cpu().numpy(), w)  # same fp32 expression tree, no contraction
+
+
+def test_prologue_autograd_matches_torch_ops(pkg):
+    """The functor's prologue under autograd == torch.cat / sigmoid / exp under autograd."""
+    n, kr = 500, 15
+    dc, rest, o, s = _raw(n, kr, False, 5)
+    a = [dev(x).requires_grad_(True) for x in (dc, rest, o, s)]
+    b = [dev(x).requires_grad_(True) for x in (dc, rest, o, s)]
+    P = pkg.rasterizer._Prologue
+    ya = P.apply(*a)
+    yb = (torch.cat([b[0], b[1]], 1), torch.sigmoid(b[2]), torch.exp(b[3]))
+    w = [torch.randn_like(y) for y in yb]
+    sum((y * k).sum() for y, k in zip(ya, w)).backward()
+    sum((y * k).sum() for y, k in zip(yb, w)).backward()
+    for x, y in zip(a, b):
+        np.testing.assert_allclose(x.grad.cpu().numpy(), y.grad.cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_adam_vs_oracle_bit_exact_multi_group(pkg, orc):
+    """Six parameter groups (training.jl:234-239) in one launch, odd lengths and an unaligned
+    slice (scalar tail path), 4 steps: θ, μ, ν bit-identical to the oracle."""
+    r = np.random.default_rng(31)
+    n = 1237
+    shapes = [(n, 3), (n, 1, 3), (n, 15, 3), (n, 1), (n, 3), (n, 4)]
+    lrs = [1.6e-4, 2.5e-3, 2.5e-3 / 20, 2.5e-2, 5e-3, 1e-3]
+    th = [r.normal(size=s).astype(np.float32) for s in shapes]
+    O = pkg.optim
+    th_d = [dev(t) for t in th]
+    # group 3 lives at an odd element offset of a larger buffer: not 16-byte aligned
+    big = torch.zeros(n + 1, device="cuda"); big[1:] = th_d[3].reshape(-1); th_d[3] = big[1:].view(n, 1)
+    opts = [O.Adam(t, lr, eps=1e-15) for t, lr in zip(th_d, lrs)]
+    mu = [np.zeros(t.size, np.float32) for t in th]; nu = [np.zeros(t.size, np.float32) for t in th]
+    for step in range(1, 5):
+        gr = [(r.normal(size=s) * 10.0 ** r.uniform(-4, 2)).astype(np.float32) for s in shapes]
+        O.step_all(opts, th_d, [dev(g) for g in gr])
+        for t, g, m, v, lr in zip(th, gr, mu, nu, lrs):
+            orc.adam_step(t.reshape(-1), g.reshape(-1), m, v, step, lr, 0.9, 0.999, 1e-15)
+    torch.cuda.synchronize()
+    for t, td, m, v, o in zip(th, th_d, mu, nu, opts):
+        assert o.current_step == 4
+        assert np.array_equal(td.cpu().numpy(), t)
+        assert np.array_equal(o.mu.cpu().numpy(), m) and np.array_equal(o.nu.cpu().numpy(), v)
+
+
+def test_adam_large_single_group_and_reset(pkg, orc):
+    r = np.random.default_rng(2)
+    n = 3 * 16 * 100_003  # a features_rest-sized array, not a multiple of the 1024-element workgroup
+    th = r.normal(size=n).astype(np.float32); g = r.normal(size=n).astype(np.float32)
+    td = dev(th); opt = pkg.optim.Adam(td, 2.5e-3 / 20, eps=1e-15)
+    opt.step(td, dev(g))
+    mu = np.zeros(n, np.float32); nu = np.zeros(n, np.float32)
+    orc.adam_step(th, g, mu, nu, 1, 2.5e-3 / 20, 0.9, 0.999, 1e-15)
+    assert np.array_equal(td.cpu().numpy(), th)
+    opt.reset()  # NU.reset! (strategy.jl:102)
+    assert opt.current_step == 0 and not opt.mu.any() and not opt.nu.any()
+
+
+def test_adam_errors_and_empty_groups(pkg):
+    L = pkg._lib
+    lib = L.load()
+    t = torch.zeros(8, device="cuda"); g = torch.zeros(8, device="cuda")
+    grp = (L.AdamGroup * 1)(L.AdamGroup(t.data_ptr(), g.data_ptr(), t.data_ptr(), t.data_ptr(), 8, 0.1, 0))
+    assert lib.gsr_adam_step(grp, 1, 0.9, 0.999, 1e-15, None) == L.GSR_E_INVALID_ARG   # step counts from 1
+    assert lib.gsr_adam_step(grp, 9, 0.9, 0.999, 1e-15, None) == L.GSR_E_INVALID_ARG   # too many groups
+    grp[0].count = 0
+    assert lib.gsr_adam_step(grp, 1, 0.9, 0.999, 1e-15, None) == L.GSR_OK              # training.jl:770: empty -> skip
+    empty = torch.zeros((0, 3), device="cuda")
+    o = pkg.optim.Adam(empty, 0.1)
+    o.step(empty, empty.clone())
+    assert o.current_step == 0
+    with pytest.raises(ValueError):
+        pkg.optim.Adam(torch.zeros(4), 0.1)  # CPU tensor: no CPU path
+    assert lib.gsr_prologue_forward(4, 0, 2, None, None, None, None, None, None, None, None) == L.GSR_E_INVALID_ARG

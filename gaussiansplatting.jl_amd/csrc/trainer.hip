@@ -19,6 +19,30 @@ __global__ __launch_bounds__(256) void prologue_shs_kernel(size_t total, int K3,
     const int j = (int)(e - i * (size_t)K3);
     shs[e] = j < 3 ? dc[3 * i + j] : rest[(size_t)(K3 - 3) * i + (j - 3)];
 }
+// K3 % 4 == 0 (SH degree 1 and 3): one float4 of shs per thread — dwordx4 stores, the four source
+// floats are consecutive in (dc | rest) order so the dword loads of a wave stay contiguous
+template <bool BWD>
+__global__ __launch_bounds__(256) void prologue_shs4_kernel(size_t total4, int K3, float* __restrict__ dc,
+                                                            float* __restrict__ rest, float* __restrict__ shs) {
+    const size_t e4 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e4 >= total4) return;
+    const int q = K3 / 4;
+    const size_t i = e4 / (size_t)q;
+    const int j = 4 * (int)(e4 - i * (size_t)q);
+    float* const d = dc + 3 * i;
+    float* const r = rest + (size_t)(K3 - 3) * i - 3;  // r[j] is element j of the Gaussian's row for j >= 3
+    float4* const out = (float4*)shs + e4;
+    if (!BWD) {
+        float4 v;
+        if (j == 0) v = make_float4(d[0], d[1], d[2], r[3]);
+        else v = make_float4(r[j], r[j + 1], r[j + 2], r[j + 3]);
+        *out = v;
+    } else {
+        const float4 v = *out;
+        if (j == 0) { d[0] = v.x; d[1] = v.y; d[2] = v.z; r[3] = v.w; }
+        else { r[j] = v.x; r[j + 1] = v.y; r[j + 2] = v.z; r[j + 3] = v.w; }
+    }
+}
 __global__ __launch_bounds__(256) void prologue_act_kernel(int n, int scale_dims, const float* __restrict__ opac,
                                                            const float* __restrict__ scales,
                                                            float* __restrict__ opac_act, float* __restrict__ scales_act) {
@@ -133,8 +157,12 @@ void gsr_launch_prologue_fwd(hipStream_t s, int n, int k_rest, int scale_dims, c
     if (n <= 0) return;
     const int K3 = 3 * (1 + k_rest);
     const size_t total = (size_t)n * K3;
-    hipLaunchKernelGGL(prologue_shs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, K3, sh_color,
-                       sh_remainder, shs);
+    if (K3 % 4 == 0 && K3 > 4)
+        hipLaunchKernelGGL(prologue_shs4_kernel<false>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s,
+                           total / 4, K3, const_cast<float*>(sh_color), const_cast<float*>(sh_remainder), shs);
+    else
+        hipLaunchKernelGGL(prologue_shs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, K3,
+                           sh_color, sh_remainder, shs);
     hipLaunchKernelGGL(prologue_act_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, scale_dims, opacities, scales,
                        opacities_act, scales_act);
 }
@@ -146,8 +174,12 @@ void gsr_launch_prologue_bwd(hipStream_t s, int n, int k_rest, int scale_dims, c
     if (n <= 0) return;
     const int K3 = 3 * (1 + k_rest);
     const size_t total = (size_t)n * K3;
-    hipLaunchKernelGGL(prologue_shs_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, K3, vshs,
-                       v_sh_color, v_sh_remainder);
+    if (K3 % 4 == 0 && K3 > 4)
+        hipLaunchKernelGGL(prologue_shs4_kernel<true>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s,
+                           total / 4, K3, v_sh_color, v_sh_remainder, const_cast<float*>(vshs));
+    else
+        hipLaunchKernelGGL(prologue_shs_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, K3,
+                           vshs, v_sh_color, v_sh_remainder);
     hipLaunchKernelGGL(prologue_act_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, scale_dims, opacities_act,
                        scales_act, vopacities_act, vscales_act, v_opacities, v_scales);
 }

@@ -179,8 +179,23 @@ def main():
             traffic = json.load(open(tpath)).get(dom)
         except Exception:
             traffic = None
+    # measured HBM ceiling of this device in this run: STREAM triad over 3 x 512 MiB
+    lib = pkg._lib.load()
+    n_tri = 128 * 1024 * 1024
+    ta, tb, tc = (torch.ones(n_tri, device=dev) for _ in range(3))
+    cs = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):
+        pkg._lib.check(lib.gsr_stream_triad(ta.data_ptr(), tb.data_ptr(), tc.data_ptr(), n_tri, 0.5, cs))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        pkg._lib.check(lib.gsr_stream_triad(ta.data_ptr(), tb.data_ptr(), tc.data_ptr(), n_tri, 0.5, cs))
+    e1.record(); e1.synchronize()
+    triad_gbs = 5 * 12.0 * n_tri / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del ta, tb, tc
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "measured_triad_GBps": round(triad_gbs, 1), "frac_of_measured_triad": round(achieved / triad_gbs, 5),
                 "algorithmic_bytes": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
                 "stages_ms": {k: round(v[0], 4) for k, v in stages.items()},
                 "whole_step_algorithmic_GBps": round(

@@ -68,7 +68,7 @@ EXPORTS = ["gsr_create", "gsr_destroy", "gsr_release_scene_buffers", "gsr_memory
            "gsr_backward", "gsr_buffer", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_loss_l1_ssim",
            "gsr_allreduce_grads", "gsr_last_error_string", "gsr_version", "gsr_profile_enable",
            "gsr_profile_stage_count", "gsr_profile_stage_name", "gsr_profile_read", "gsr_update_stats",
-           "gsr_prologue_forward", "gsr_prologue_backward", "gsr_adam_step"]
+           "gsr_prologue_forward", "gsr_prologue_backward", "gsr_adam_step", "gsr_stream_triad"]
 
 _lib = None
 
@@ -111,6 +111,7 @@ def load():
     lib.gsr_prologue_forward.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_prologue_backward.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_adam_step.argtypes = [C.POINTER(AdamGroup), i32, f32, f32, f32, vp]
+    lib.gsr_stream_triad.argtypes = [vp, vp, vp, C.c_size_t, f32, vp]
     lib.gsr_profile_enable.argtypes = [vp, i32]
     lib.gsr_profile_stage_name.argtypes = [i32]
     lib.gsr_profile_stage_name.restype = C.c_char_p

@@ -532,6 +532,15 @@ int gsr_adam_step(const gsr_adam_group* groups, int32_t n_groups, float beta1, f
     return GSR_OK;
 }
 
+int gsr_stream_triad(float* a, const float* b, const float* c, size_t count, float q, void* stream) {
+    if (!a || !b || !c) return fail(GSR_E_INVALID_ARG, "null array");
+    if (count % 4 != 0 || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) != 0)
+        return fail(GSR_E_INVALID_ARG, "count must be a multiple of 4 and the arrays 16-byte aligned");
+    gsr_launch_triad((hipStream_t)stream, count / 4, a, b, c, q);
+    HIPCHK(hipGetLastError());
+    return GSR_OK;
+}
+
 int gsr_allreduce_grads(void* nccl_comm, float* arena, size_t count, void* stream) {
     typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
     static allreduce_fn fn = nullptr;

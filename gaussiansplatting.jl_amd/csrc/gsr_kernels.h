@@ -106,6 +106,8 @@ void gsr_launch_prologue_bwd(hipStream_t s, int n, int k_rest, int scale_dims, c
 void gsr_launch_adam(hipStream_t s, int n_groups, float* const* theta, const float* const* grad, float* const* mu,
                      float* const* nu, const long long* count, const float* lr_t, float beta1, float beta2, float eps);
 
+void gsr_launch_triad(hipStream_t s, size_t n4, float* a, const float* b, const float* c, float q);
+
 // ---- ssim.hip ----
 void gsr_launch_ssim_fwd(hipStream_t s, int W, int H, int CH, int B, const float* img, const float* ref, float C1,
                          float C2, int train, float* ssim_map, float* d0, float* d1, float* d2);

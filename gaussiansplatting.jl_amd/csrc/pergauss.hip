@@ -71,17 +71,16 @@ __device__ __forceinline__ M22 mul22(const M22& a, const M22& b) {
 
 // world->camera rotation as row-major M33, honouring the device override (pose optimisation)
 __device__ __forceinline__ void load_pose(const GsrCam& cam, M33& R, float t[3]) {
-    if (cam.R_dev) {
+    // element-wise selects (a branch over two whole-array initialisations makes the optimiser
+    // keep the pose in scratch memory)
+    const bool dev = cam.R_dev != nullptr;
 #pragma unroll
-        for (int c = 0; c < 3; c++)
+    for (int r = 0; r < 3; r++)
 #pragma unroll
-            for (int r = 0; r < 3; r++) R.m[r][c] = cam.R_dev[c * 3 + r];
-    } else {
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) R.m[r][c] = cam.R[r * 3 + c];
-    }
+        for (int c = 0; c < 3; c++) {
+            const float host = cam.R[r * 3 + c];
+            R.m[r][c] = dev ? cam.R_dev[c * 3 + r] : host;
+        }
 #pragma unroll
     for (int k = 0; k < 3; k++) t[k] = cam.t_dev ? cam.t_dev[k] : cam.t[k];
 }

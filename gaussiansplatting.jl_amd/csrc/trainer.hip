@@ -88,6 +88,16 @@ __global__ __launch_bounds__(256) void prologue_act_bwd_kernel(int n, int scale_
     }
 }
 
+// STREAM triad a = b + q*c over float4: the measured HBM ceiling bench.py quotes next to the
+// 8 TB/s data-sheet figure
+__global__ __launch_bounds__(256) void triad_kernel(size_t n4, float4* __restrict__ a, const float4* __restrict__ b,
+                                                    const float4* __restrict__ c, float q) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 x = b[i], y = c[i];
+        a[i] = make_float4(x.x + q * y.x, x.y + q * y.y, x.z + q * y.z, x.w + q * y.w);
+    }
+}
+
 struct AdamGroups {
     float* theta[GSR_ADAM_MAX_GROUPS];
     const float* grad[GSR_ADAM_MAX_GROUPS];
@@ -200,4 +210,11 @@ void gsr_launch_adam(hipStream_t s, int n_groups, float* const* theta, const flo
     G.block_start[GSR_ADAM_MAX_GROUPS] = blocks;
     if (blocks == 0) return;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, G, beta1, beta2, eps);
+}
+
+void gsr_launch_triad(hipStream_t s, size_t n4, float* a, const float* b, const float* c, float q) {
+    if (n4 == 0) return;
+    const size_t blocks = (n4 + 255) / 256;
+    hipLaunchKernelGGL(triad_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, n4, (float4*)a,
+                       (const float4*)b, (const float4*)c, q);
 }

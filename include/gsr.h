@@ -232,6 +232,11 @@ GSR_API int gsr_adam_step(const gsr_adam_group* groups, int32_t n_groups, float 
  * lazily with dlopen, so single-GPU users need not have it. */
 GSR_API int gsr_allreduce_grads(void* nccl_comm, float* arena, size_t count, void* stream);
 
+/* New (measurement): STREAM triad a = b + q*c over `count` floats — the
+ * device-to-device bandwidth bench.py measures in the same run as the hot path and reports
+ * next to the 8 TB/s data-sheet peak (12 bytes of HBM traffic per element). */
+GSR_API int gsr_stream_triad(float* a, const float* b, const float* c, size_t count, float q, void* stream);
+
 /* New (measurement; the reference has no profiling hooks): per-stage kernel
  * timing with HIP events recorded on the caller's stream around each launch.  While
  * enabled, every gsr_forward / gsr_backward / gsr_loss_l1_ssim appends one event pair per

@@ -38,9 +38,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def algorithmic_bytes(stage, N, V, D, P, T, C=3, K=16):
     """SURVEY.md §8(d) per-stage algorithmic HBM bytes (one launch = one view)."""
     return {
-        "preprocess": 40 * N + 8 * N + 12 * K * V + 39 * V,
+        # preprocess + emit (SURVEY.md §8d rows "preprocess" and "emit": one fused kernel here)
+        "preprocess": 40 * N + 8 * N + 12 * K * V + 39 * V + 8 * N + 12 * V + 12 * D,
         "tile_scan": 8 * T,
-        "scatter": 8 * N + 12 * V + 12 * D,
+        "scatter": 0,  # (stage of earlier builds; now part of preprocess)
         "tile_sort": 12 * D + 12 * D + 8 * D + 8 * T,
         "composite_fwd": (28 + 4 * C) * D + 8 * T + (4 * C + 8) * P,
         "composite_bwd": (4 * C + 8) * P + 8 * T + (28 + 4 * C) * D + 4 * (C + 6) * D,

@@ -1,18 +1,21 @@
 // Tile binning: replaces cumsum! + duplicate_with_keys! + sortperm!/_permute! +
-// identify_tile_range! (reference: rasterizer.jl:333-378, utils.jl:56-120) with a
-// tile-binned counting scatter followed by an independent per-tile LDS sort.
+// identify_tile_range! (reference: rasterizer.jl:333-378, utils.jl:56-120) with
+// fixed-capacity per-tile bins filled by the per-Gaussian kernel and an independent
+// per-tile LDS sort.
 //
-//   preprocess     : per-tile occupancy histogram (atomic, in pergauss.hip)
-//   tile_scan      : exclusive scan over the T tile counts  -> tile ranges, D
-//   scatter        : each visible Gaussian drops (depth_bits<<32 | id) into its tiles' segments (pergauss.hip)
-//   tile_sort      : one workgroup per tile sorts its segment in LDS by (depth, id) and writes
+//   preprocess     : each visible Gaussian drops (depth_bits<<32 | id) into the bins of its
+//                    tiles (returning atomics on the tile counters; pergauss.hip)
+//   tile_scan      : exclusive scan over the T tile counts  -> tile ranges, D, max count
+//   tile_sort      : one workgroup per tile sorts its bin in LDS by (depth, id) and writes
 //                    the sorted ids plus the packed, sorted splat stream the composite
-//                    kernels consume linearly
+//                    kernels consume linearly (compact: tile_start[tile] + rank)
 //
 // The result equals a stable ascending sort of the reference's 64-bit (tile<<32 | depth)
 // keys with emit order by Gaussian id: within a tile, ascending depth
 // bits, ties by ascending id.  Unlike a global 64-bit radix sort this moves each instance
-// through HBM twice (8 B key out, 8 B key in) instead of ~8 passes x 12 B.
+// through HBM twice (8 B key out, 8 B key in) instead of ~8 passes x 12 B.  The bins are
+// sized for the part's 288 GB of HBM: capacity = the longest list seen so far with slack,
+// unused slots are never read.
 #include <cstdlib>
 #include "gsr_kernels.h"
 #include "tile_mask.h"
@@ -22,7 +25,6 @@ namespace {
 // ---- single-workgroup scan over tiles (T = 8160 at 1080p, 32400 at 4K) ----
 __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint32_t* __restrict__ tile_count,
                                                          uint32_t* __restrict__ tile_start,
-                                                         uint32_t* __restrict__ cursor,
                                                          uint32_t* __restrict__ totals, int n_blocks,
                                                          const uint32_t* __restrict__ bsum,
                                                          uint32_t* __restrict__ bpre,
@@ -51,10 +53,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint
         for (int w = 0; w < wave; w++) wave_off += wave_sums[w];
         const uint32_t carry = carry_s;
         const uint32_t excl = carry + wave_off + x - v;
-        if (i < n_tiles) {
-            tile_start[i] = excl;
-            cursor[i] = excl;
-        }
+        if (i < n_tiles) tile_start[i] = excl;
         __syncthreads();
         if (tid == 1023) carry_s = excl + v;
         __syncthreads();
@@ -194,7 +193,7 @@ __device__ __forceinline__ void sort_and_emit(uint64_t* buf, uint32_t m, uint32_
                                               int X0, int Y0,
                                               const uint64_t* __restrict__ keys, const GsrGeom& geom,
                                               const GsrStream& stream, uint32_t* __restrict__ values_sorted) {
-    for (uint32_t i = tid; i < m; i += 256) buf[i] = i < n ? keys[start + i] : ~0ull;
+    for (uint32_t i = tid; i < m; i += 256) buf[i] = i < n ? keys[i] : ~0ull;  // keys = this tile's bin
     __syncthreads();
     if (m > 1) bitonic_sort(buf, m, tid, 256);
     for (uint32_t i = tid; i < n; i += 256) {
@@ -224,7 +223,7 @@ __device__ __forceinline__ void sort_and_emit(uint64_t* buf, uint32_t m, uint32_
 // belongs to the other launch exits immediately.
 template <int CH, int CAP>
 __global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restrict__ tile_start,
-                                                        const uint64_t* __restrict__ keys,
+                                                        const uint64_t* __restrict__ bins, uint32_t bin_cap,
                                                         uint64_t* __restrict__ big_scratch,
                                                         uint32_t big_scratch_stride,
                                                         uint32_t* __restrict__ slab_counter, int grid_x,
@@ -244,6 +243,7 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restri
     }
     if (n == 0) return;
     const int X0 = (tile % grid_x) * GSR_TILE, Y0 = (tile / grid_x) * GSR_TILE;
+    const uint64_t* __restrict__ keys = bins + (size_t)tile * bin_cap;
     uint32_t m = 1;
     while (m < n) m <<= 1;
     if (m <= (uint32_t)CAP) {
@@ -261,9 +261,9 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restri
 }  // namespace
 
 void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count, uint32_t* tile_start,
-                          uint32_t* cursor, uint32_t* totals, int n_blocks, const uint32_t* bsum, uint32_t* bpre,
+                          uint32_t* totals, int n_blocks, const uint32_t* bsum, uint32_t* bpre,
                           const uint32_t* bvis) {
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, tile_count, tile_start, cursor, totals,
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, tile_count, tile_start, totals,
                        n_blocks, bsum, bpre, bvis);
 }
 
@@ -282,11 +282,11 @@ void gsr_launch_tile_order(hipStream_t s, int n_tiles, const uint32_t* tile_coun
         hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, n_tiles, tile_count, totals, order);
 }
 
-void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start, uint64_t* keys,
-                          uint64_t* big_scratch, uint32_t big_scratch_stride, uint32_t* slab_counter, GsrGeom geom,
+void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start,
+                          const uint64_t* bins, uint32_t bin_cap, uint64_t* big_scratch, uint32_t big_scratch_stride, uint32_t* slab_counter, GsrGeom geom,
                           GsrStream stream, uint32_t* values_sorted, uint32_t* ranges) {
 #define LAUNCH(CC, CAPV)                                                                                          \
-    hipLaunchKernelGGL((tile_sort_kernel<CC, CAPV>), dim3(n_tiles), dim3(256), 0, s, tile_start, keys, big_scratch, \
+    hipLaunchKernelGGL((tile_sort_kernel<CC, CAPV>), dim3(n_tiles), dim3(256), 0, s, tile_start, bins, bin_cap, big_scratch, \
                        big_scratch_stride, slab_counter, grid_x, geom, stream, values_sorted, ranges)
     if (channels > 5) { LAUNCH(8, 1024); LAUNCH(8, GSR_SORT_LDS_CAP); }
     else { LAUNCH(3, 1024); LAUNCH(3, GSR_SORT_LDS_CAP); }

@@ -64,9 +64,9 @@ struct DevBuf {
 };
 
 // Optional per-stage timing with HIP events on the caller's stream (gsr_profile_*).
-enum Stage { ST_PREPROCESS, ST_SCAN, ST_SCATTER, ST_SORT, ST_COMPOSITE_FWD, ST_LOSS_FWD, ST_LOSS_BWD, ST_ZERO_ACC,
+enum Stage { ST_PREPROCESS, ST_SCAN, ST_SORT, ST_COMPOSITE_FWD, ST_LOSS_FWD, ST_LOSS_BWD, ST_ZERO_ACC,
              ST_COMPOSITE_BWD, ST_PERGAUSS_BWD, ST_COUNT };
-const char* const kStageNames[ST_COUNT] = {"preprocess", "tile_scan", "scatter", "tile_sort", "composite_fwd",
+const char* const kStageNames[ST_COUNT] = {"preprocess", "tile_scan", "tile_sort", "composite_fwd",
                                            "loss_fwd", "loss_bwd", "zero_acc", "composite_bwd", "pergauss_bwd"};
 struct Profiler {
     bool on = false;
@@ -108,11 +108,12 @@ struct gsr_handle {
     gsr_config cfg;
     int grid_x, grid_y, n_tiles;
     // ImageState (states.jl:99-111) + tile bookkeeping
-    DevBuf ranges, n_contrib, final_T, tile_count, tile_start, tile_order, cursor, totals;
+    DevBuf ranges, n_contrib, final_T, tile_count, tile_start, tile_order, totals;
     // GeometryState (states.jl:2-47), repacked as one 64-byte record per Gaussian
     DevBuf geo, gnormal, radii, bsum, bpre, bvis;
-    // BinningState (states.jl:66-85): unsorted keys, sorted ids, sorted splat stream
-    DevBuf keys, values_sorted, s0, s1, s2, s3, big_scratch;
+    // BinningState (states.jl:66-85): unsorted keys (per-tile bins of bin_cap slots), sorted ids, sorted splat stream
+    uint32_t bin_cap = 0;
+    DevBuf bins, values_sorted, s0, s1, s2, s3, big_scratch;
     // backward: per-instance gradient rows + instance position map; gstate.∇means_2d
     DevBuf rows, vmean2d;
     // loss-head scratch
@@ -190,8 +191,8 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
     h->grid_y = (cfg->height + GSR_TILE - 1) / GSR_TILE;
     if (h->grid_x > 65535 || h->grid_y > 65535) { delete h; return fail(GSR_E_INVALID_ARG, "resolution too large"); }
     h->n_tiles = h->grid_x * h->grid_y;
-    DevBuf* list[] = {&h->ranges, &h->n_contrib, &h->final_T, &h->tile_count, &h->tile_start, &h->tile_order, &h->cursor, &h->totals,
-                      &h->geo, &h->gnormal, &h->radii, &h->bsum, &h->bpre, &h->bvis, &h->keys, &h->values_sorted, &h->s0,
+    DevBuf* list[] = {&h->ranges, &h->n_contrib, &h->final_T, &h->tile_count, &h->tile_start, &h->tile_order, &h->totals,
+                      &h->geo, &h->gnormal, &h->radii, &h->bsum, &h->bpre, &h->bvis, &h->bins, &h->values_sorted, &h->s0,
                       &h->s1, &h->s2, &h->s3, &h->big_scratch, &h->rows, &h->vmean2d, &h->d0, &h->d1,
                       &h->d2, &h->partial};
     for (DevBuf* b : list) h->all[h->n_all++] = b;
@@ -199,7 +200,7 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
     int rc = GSR_OK;
     if ((rc = h->ranges.ensure(2 * T * 4)) || (rc = h->n_contrib.ensure(P * 4)) || (rc = h->final_T.ensure(P * 4)) ||
         (rc = h->tile_count.ensure((T + 2) * 4)) || (rc = h->tile_start.ensure((T + 1) * 4)) ||
-        (rc = h->cursor.ensure((T + 2) * 4)) || (rc = h->tile_order.ensure((T + 8) * 4)) || (rc = h->totals.ensure(8 * 4))) {
+        (rc = h->tile_order.ensure((T + 8) * 4)) || (rc = h->totals.ensure(8 * 4))) {
         gsr_destroy(h);
         return rc;
     }
@@ -226,7 +227,7 @@ int gsr_destroy(gsr_handle* h) {
 
 int gsr_release_scene_buffers(gsr_handle* h) {
     if (!h) return fail(GSR_E_INVALID_ARG, "null handle");
-    DevBuf* scene[] = {&h->geo, &h->gnormal, &h->radii, &h->bsum, &h->bpre, &h->bvis, &h->keys, &h->values_sorted, &h->s0, &h->s1,
+    DevBuf* scene[] = {&h->geo, &h->gnormal, &h->radii, &h->bsum, &h->bpre, &h->bvis, &h->bins, &h->values_sorted, &h->s0, &h->s1,
                        &h->s2, &h->s3, &h->big_scratch, &h->rows, &h->vmean2d};
     for (DevBuf* b : scene) {
         int rc = b->release();
@@ -265,24 +266,38 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
 
     GsrCam k = make_cam(h, cam);
     uint32_t* totals = h->totals.as<uint32_t>();
-    HIPCHK(hipMemsetAsync(h->tile_count.p, 0, T * 4, s));
-    HIPCHK(hipMemsetAsync(totals, 0, 8 * 4, s));
-    h->prof.begin(ST_PREPROCESS, s);
-    gsr_launch_preprocess(s, n, in->n_coeffs, in->sh_degree, C, in->means, in->scales, in->rotations, in->opacities,
-                          in->shs, k, geom_of(h), h->tile_count.as<uint32_t>(), h->bvis.as<uint32_t>());
-    h->prof.end(s);
-    h->prof.begin(ST_SCAN, s);
-    gsr_launch_tile_scan(s, h->n_tiles, h->tile_count.as<uint32_t>(), h->tile_start.as<uint32_t>(),
-                         h->cursor.as<uint32_t>(), totals, n_blocks, h->bsum.as<uint32_t>(), h->bpre.as<uint32_t>(),
-                         h->bvis.as<uint32_t>());
-    h->prof.end(s);
-    HIPCHK(hipGetLastError());
-    // the one host sync of the path: instance count D (reference: rasterizer.jl:337)
-    HIPCHK(hipMemcpyAsync(h->host_totals, totals, 8 * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipEventRecord(h->totals_ready, s));
-    // launch order of the compositing workgroups (longest tile lists first); runs while the host waits
-    gsr_launch_tile_order(s, h->n_tiles, h->tile_count.as<uint32_t>(), totals, h->tile_order.as<uint32_t>());
-    HIPCHK(hipEventSynchronize(h->totals_ready));
+    // Capacity of the per-tile key bins: the longest list seen on this handle with slack; before
+    // the first view an estimate from N / T (6 tiles per Gaussian, x4).  If a view overflows it,
+    // the pass below is repeated once with the capacity the scan reported.
+    if (h->bin_cap == 0) {
+        const uint64_t est = 8ull * (uint64_t)nn / T + 64;  // ~6 tiles per Gaussian, +35 %
+        h->bin_cap = (uint32_t)((est < (1u << 20) ? est : (1u << 20)) + 63) & ~63u;
+    }
+    for (int attempt = 0;; attempt++) {
+        if ((rc = h->bins.ensure((T + 1) * (size_t)h->bin_cap * 8))) return rc;
+        HIPCHK(hipMemsetAsync(h->tile_count.p, 0, (T + 2) * 4, s));
+        HIPCHK(hipMemsetAsync(totals, 0, 8 * 4, s));
+        h->prof.begin(ST_PREPROCESS, s);
+        gsr_launch_preprocess(s, n, in->n_coeffs, in->sh_degree, C, in->means, in->scales, in->rotations, in->opacities,
+                              in->shs, k, geom_of(h), h->tile_count.as<uint32_t>(), h->bvis.as<uint32_t>(),
+                              h->bins.as<uint64_t>(), h->bin_cap);
+        h->prof.end(s);
+        h->prof.begin(ST_SCAN, s);
+        gsr_launch_tile_scan(s, h->n_tiles, h->tile_count.as<uint32_t>(), h->tile_start.as<uint32_t>(), totals,
+                             n_blocks, h->bsum.as<uint32_t>(), h->bpre.as<uint32_t>(), h->bvis.as<uint32_t>());
+        h->prof.end(s);
+        HIPCHK(hipGetLastError());
+        // the one host sync of the path: instance count D (reference: rasterizer.jl:337)
+        HIPCHK(hipMemcpyAsync(h->host_totals, totals, 8 * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(h->totals_ready, s));
+        // launch order of the compositing workgroups (longest tile lists first); runs while the host waits
+        gsr_launch_tile_order(s, h->n_tiles, h->tile_count.as<uint32_t>(), totals, h->tile_order.as<uint32_t>());
+        HIPCHK(hipEventSynchronize(h->totals_ready));
+        if (h->host_totals[1] <= h->bin_cap) break;
+        if (attempt > 0) return fail(GSR_E_STATE, "tile bins overflowed twice (max %u, capacity %u)",
+                                     h->host_totals[1], h->bin_cap);
+        h->bin_cap = (uint32_t)(((uint64_t)h->host_totals[1] + h->host_totals[1] / 4 + 63) & ~63ull);  // +25 %
+    }
     const uint64_t D = h->host_totals[0];
     const uint32_t max_tile = h->host_totals[1], n_big = h->host_totals[2];
     const uint64_t D_slots = h->host_totals[5];  // >= D; == D unless exact culling dropped tiles
@@ -306,7 +321,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
         return GSR_OK;
     }
     const float slack = 1.25f;  // instance count drifts slowly between training steps
-    if ((rc = h->keys.ensure(D * 8, slack)) || (rc = h->values_sorted.ensure(D * 4, slack)) ||
+    if ((rc = h->values_sorted.ensure(D * 4, slack)) ||
         (rc = h->rows.ensure(D_slots * 64, slack)) ||
         (rc = h->s0.ensure(D * 16, slack)) || (rc = h->s1.ensure(D * 16, slack)) ||
         (rc = h->s2.ensure(D * 16, slack)) || (C > 5 && (rc = h->s3.ensure(D * 16, slack))))
@@ -317,11 +332,8 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
         while (big_stride < max_tile) big_stride <<= 1;
         if ((rc = h->big_scratch.ensure((size_t)n_big * big_stride * 8))) return rc;
     }
-    h->prof.begin(ST_SCATTER, s);
-    gsr_launch_scatter(s, n, k, geom_of(h), h->cursor.as<uint32_t>(), h->keys.as<uint64_t>());
-    h->prof.end(s);
     h->prof.begin(ST_SORT, s);
-    gsr_launch_tile_sort(s, h->n_tiles, h->grid_x, C, h->tile_start.as<uint32_t>(), h->keys.as<uint64_t>(),
+    gsr_launch_tile_sort(s, h->n_tiles, h->grid_x, C, h->tile_start.as<uint32_t>(), h->bins.as<uint64_t>(), h->bin_cap,
                          h->big_scratch.as<uint64_t>(), big_stride, totals + 3, geom_of(h), stream_of(h),
                          h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>());
     h->prof.end(s);

@@ -60,8 +60,8 @@ struct GsrInst {
 // ---- pergauss.hip (compiled with -ffp-contract=off: bit-reproducible fp32) ----
 void gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels, const float* means,
                            const float* scales, const float* rots, const float* opac, const float* shs, GsrCam cam,
-                           GsrGeom geom, uint32_t* tile_count, uint32_t* n_visible /* per 256-block */);
-void gsr_launch_scatter(hipStream_t s, int n, GsrCam cam, GsrGeom geom, uint32_t* cursor, uint64_t* keys);
+                           GsrGeom geom, uint32_t* tile_count, uint32_t* n_visible /* per 256-block */,
+                           uint64_t* bins /* (T+1) x bin_cap keys */, uint32_t bin_cap);
 void gsr_launch_pergauss_bwd(hipStream_t s, int n, int K, int degree, int channels, const float* means,
                              const float* scales, const float* rots, const float* shs, GsrCam cam, GsrGeom geom,
                              GsrInst inst, float2* vmean2d, float* vmeans, float* vshs, float* vopac,
@@ -71,17 +71,17 @@ void gsr_launch_update_stats(hipStream_t s, int n, const int32_t* radii, const f
                              int32_t* max_radii, float* accum, float* denom);
 
 // ---- binning.hip ----
-// exclusive scan of tile_count -> tile_start[T+1], cursor[T] = tile_start; and of the per-block
+// exclusive scan of tile_count -> tile_start[T+1]; and of the per-block
 // rect-area sums bsum[nb] -> bpre[nb];
 // totals[0] = D, totals[1] = max count, totals[2] = #tiles over GSR_SORT_LDS_CAP, totals[3] = slab counter (0)
 void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count, uint32_t* tile_start,
-                          uint32_t* cursor, uint32_t* totals, int n_blocks, const uint32_t* bsum, uint32_t* bpre,
+                          uint32_t* totals, int n_blocks, const uint32_t* bsum, uint32_t* bpre,
                           const uint32_t* bvis);
 // order[0..n_tiles) = tile ids by descending list length (launch order of the compositing workgroups)
 void gsr_launch_tile_order(hipStream_t s, int n_tiles, const uint32_t* tile_count, const uint32_t* totals,
                            uint32_t* order);
-void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start, uint64_t* keys,
-                          uint64_t* big_scratch, uint32_t big_scratch_stride, uint32_t* slab_counter, GsrGeom geom,
+void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start,
+                          const uint64_t* bins, uint32_t bin_cap, uint64_t* big_scratch, uint32_t big_scratch_stride, uint32_t* slab_counter, GsrGeom geom,
                           GsrStream stream, uint32_t* values_sorted, uint32_t* ranges);
 
 // ---- composite.hip ----

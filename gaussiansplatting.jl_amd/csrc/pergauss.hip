@@ -206,7 +206,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
                                                          const float* __restrict__ opac,
                                                          const float* __restrict__ shs, GsrCam cam, GsrGeom geom,
                                                          uint32_t* __restrict__ tile_count,
-                                                         uint32_t* __restrict__ n_visible) {
+                                                         uint32_t* __restrict__ n_visible,
+                                                         uint64_t* __restrict__ bins, uint32_t bin_cap) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     bool visible = false;
     uint32_t area = 0, clamp_bits = 0;
@@ -294,30 +295,59 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
             get_rect(m2[0], m2[1], radius, cam.grid_x, cam.grid_y, rmin, rmax);
             area = (uint32_t)((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]));
             const float tau = footprint_tau(opac[i]);
-            // Per-tile occupancy histogram.  Horizontally adjacent tiles are consecutive 32-bit
-            // counters, so an aligned pair is bumped by ONE 64-bit atomic (device-scope atomics
-            // execute memory-side on MI355X and are the bound of this kernel).
+            // duplicate_with_keys! (utils.jl:85-120) restated per tile, fused into this kernel: the
+            // instance takes the next free position of its tile's BIN (a fixed-capacity segment of
+            // `bins`, capacity from the previous view) with a returning atomic on the tile's counter
+            // and stores its (depth bits << 32 | id) key there — the counters end up holding the
+            // reference's per-tile counts, and no separate count / scan / scatter pass over the
+            // instances exists.  Horizontally adjacent tiles are consecutive 32-bit counters, so an
+            // aligned pair is served by ONE 64-bit atomic; up to 8 are kept in flight before their
+            // keys are stored (a returning device-scope atomic is a ~2 us round trip to the memory
+            // side).  A position >= bin_cap is not stored: the host sees max count > capacity in the
+            // scan's totals, grows the bins and repeats the pass (first view / a much denser view).
             // exact-cull mode: a tile none of whose pixels can reach alpha >= 1/255 gets no
             // instance (the reference keeps it and skips it pixel by pixel, render.jl:95).
+            const uint64_t key = ((uint64_t)__float_as_uint(mc_z) << 32) | (uint32_t)i;
+            constexpr int PEND = 8;
+            uint32_t pend_t[PEND], pend_c[PEND];
+            int np = 0;
+            auto flush = [&]() {
+                unsigned long long old[PEND];
+#pragma unroll
+                for (int k = 0; k < PEND; k++)
+                    if (k < np)
+                        old[k] = atomicAdd(reinterpret_cast<unsigned long long*>(tile_count + pend_t[k]),
+                                           (unsigned long long)(pend_c[k] & 1u) | ((unsigned long long)(pend_c[k] >> 1) << 32));
+#pragma unroll
+                for (int k = 0; k < PEND; k++)
+                    if (k < np) {
+                        const uint32_t p0 = (uint32_t)old[k], p1 = (uint32_t)(old[k] >> 32);
+                        if ((pend_c[k] & 1u) && p0 < bin_cap) bins[(size_t)pend_t[k] * bin_cap + p0] = key;
+                        if ((pend_c[k] & 2u) && p1 < bin_cap) bins[(size_t)(pend_t[k] + 1) * bin_cap + p1] = key;
+                    }
+                np = 0;
+            };
             for (int y = rmin[1]; y < rmax[1]; y++) {
                 int x = rmin[0];
                 while (x < rmax[0]) {
                     const int t = y * cam.grid_x + x;
-                    const bool pair = !(t & 1) && x + 1 < rmax[0];
+                    const bool odd = t & 1;
+                    const bool pair = !odd && x + 1 < rmax[0];
                     const uint32_t c0 = (!cam.exact_cull || tile_may_touch(m2[0], m2[1], conic[0], conic[1], conic[2],
                                                                          tau, x * GSR_TILE, y * GSR_TILE)) ? 1u : 0u;
                     uint32_t c1 = 0u;
                     if (pair)
                         c1 = (!cam.exact_cull || tile_may_touch(m2[0], m2[1], conic[0], conic[1], conic[2], tau,
                                                                (x + 1) * GSR_TILE, y * GSR_TILE)) ? 1u : 0u;
-                    if (pair && (c0 | c1))
-                        atomicAdd(reinterpret_cast<unsigned long long*>(tile_count + t),
-                                  (unsigned long long)c0 | ((unsigned long long)c1 << 32));
-                    else if (c0)
-                        atomicAdd(tile_count + t, 1u);
+                    if (c0 | c1) {
+                        pend_t[np] = (uint32_t)(t & ~1);                 // aligned pair
+                        pend_c[np] = odd ? (c0 << 1) : (c0 | (c1 << 1));  // bit 0: even tile, bit 1: odd tile
+                        if (++np == PEND) flush();
+                    }
                     x += pair ? 2 : 1;
                 }
             }
+            flush();
         }
     }
     // Exclusive scan of the tile-rect areas inside the block: with bpre[block] (tile_scan) it
@@ -704,66 +734,6 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
     }
 }
 
-// ---- counting scatter (duplicate_with_keys! restated per tile; utils.jl:96-119) ----
-__global__ __launch_bounds__(256) void scatter_kernel(int n, int grid_x, int exact_cull,
-                                                      const int32_t* __restrict__ radii,
-                                                      const GsrGeoRec* __restrict__ rec,
-                                                      uint32_t* __restrict__ cursor, uint64_t* __restrict__ keys) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    if (!(radii[i] > 0)) return;
-    const float4 q0 = rec[i].q0, q1 = rec[i].q1, q2 = rec[i].q2, q3 = rec[i].q3;
-    const uint32_t lo = __float_as_uint(q3.x), hi = __float_as_uint(q3.y);
-    const int x0 = lo & 0xFFFFu, y0 = lo >> 16, x1 = hi & 0xFFFFu, y1 = hi >> 16;
-    const uint64_t key = ((uint64_t)__float_as_uint(q2.z) << 32) | (uint32_t)i;
-    const float tau = footprint_tau(q1.y);
-    // The same tests, on the same floats, as the count in preprocess.  Every slot request is a
-    // 64-bit atomic on an aligned pair of 32-bit cursors (one or both halves incremented), and up
-    // to 8 of them are kept in flight before their keys are stored: a returning device-scope
-    // atomic is a ~2 us round trip to the memory side, and issuing them one by one made this
-    // kernel latency-bound (68 % of wave cycles waiting).
-    constexpr int PEND = 8;
-    uint32_t pend_t[PEND];
-    uint32_t pend_c[PEND];
-    int np = 0;
-    auto flush = [&]() {
-        unsigned long long old[PEND];
-#pragma unroll
-        for (int k = 0; k < PEND; k++)
-            if (k < np)
-                old[k] = atomicAdd(reinterpret_cast<unsigned long long*>(cursor + pend_t[k]),
-                                   (unsigned long long)(pend_c[k] & 1u) | ((unsigned long long)(pend_c[k] >> 1) << 32));
-#pragma unroll
-        for (int k = 0; k < PEND; k++)
-            if (k < np) {
-                if (pend_c[k] & 1u) keys[(uint32_t)old[k]] = key;
-                if (pend_c[k] & 2u) keys[(uint32_t)(old[k] >> 32)] = key;
-            }
-        np = 0;
-    };
-    for (int y = y0; y < y1; y++) {
-        int x = x0;
-        while (x < x1) {
-            const int t = y * grid_x + x;
-            const bool odd = t & 1;
-            const bool pair = !odd && x + 1 < x1;
-            const uint32_t c0 = (!exact_cull || tile_may_touch(q0.x, q0.y, q0.z, q0.w, q1.x, tau, x * GSR_TILE,
-                                                               y * GSR_TILE)) ? 1u : 0u;
-            uint32_t c1 = 0u;
-            if (pair)
-                c1 = (!exact_cull || tile_may_touch(q0.x, q0.y, q0.z, q0.w, q1.x, tau, (x + 1) * GSR_TILE,
-                                                    y * GSR_TILE)) ? 1u : 0u;
-            if (c0 | c1) {
-                pend_t[np] = (uint32_t)(t & ~1);                 // aligned pair
-                pend_c[np] = odd ? (c0 << 1) : (c0 | (c1 << 1));  // bit 0: even tile, bit 1: odd tile
-                if (++np == PEND) flush();
-            }
-            x += pair ? 2 : 1;
-        }
-    }
-    flush();
-}
-
 // _update_stats! (src/strategy.jl:118-136): densification statistics from the side outputs of
 // the last forward/backward pair (radii, ∇means_2d).
 __global__ __launch_bounds__(256) void update_stats_kernel(int n, const int32_t* __restrict__ radii,
@@ -790,21 +760,16 @@ void gsr_launch_update_stats(hipStream_t s, int n, const int32_t* radii, const f
                        (float)height, max_radii, accum, denom);
 }
 
-void gsr_launch_scatter(hipStream_t s, int n, GsrCam cam, GsrGeom geom, uint32_t* cursor, uint64_t* keys) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, cam.grid_x, cam.exact_cull, geom.radii, geom.rec,
-                       cursor, keys);
-}
 
 void gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels, const float* means,
                            const float* scales, const float* rots, const float* opac, const float* shs, GsrCam cam,
-                           GsrGeom geom, uint32_t* tile_count, uint32_t* n_visible) {
+                           GsrGeom geom, uint32_t* tile_count, uint32_t* n_visible, uint64_t* bins, uint32_t bin_cap) {
     if (n <= 0) return;
     dim3 grid((n + 255) / 256), block(256);
     const float4* r4 = reinterpret_cast<const float4*>(rots);
 #define LAUNCH(D)                                                                                                  \
     hipLaunchKernelGGL(preprocess_kernel<D>, grid, block, 0, s, n, K, channels, means, scales, r4, opac, shs, cam, \
-                       geom, tile_count, n_visible)
+                       geom, tile_count, n_visible, bins, bin_cap)
     switch (degree) {
         case 0: LAUNCH(0); break;
         case 1: LAUNCH(1); break;

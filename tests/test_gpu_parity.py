@@ -215,6 +215,28 @@ def test_oversized_tile_uses_global_sort_path(pkg, orc):
     assert run.rast.stats.max_tile_instances > 4096
 
 
+def test_tile_bin_overflow_regrows_and_repeats(pkg, orc):
+    """The per-tile key bins start at a capacity estimated from N / T.  A view that piles far more
+    instances into one tile than that overflows them: the forward must notice (max count in the
+    scan totals), grow the bins and repeat the pass — lists, ids and image still exact."""
+    W, H, n = 640, 480, 3000   # T = 1200 tiles -> initial capacity 8*3000/1200 + 64 -> 128 keys per tile
+    rng = np.random.default_rng(19)
+    s = pkg.synthetic.make_scene(n, W, H, 1, 19)
+    means = np.stack([rng.uniform(-0.02, 0.02, n), rng.uniform(-0.02, 0.02, n), rng.uniform(2, 8, n)], 1).astype(np.float32)
+    cam = orc.Camera(W, H, s.focal)
+    opac = np.full(n, 0.05, np.float32)
+    st = orc.forward(means, s.shs, opac, s.scales, s.rotations, cam, 1)
+    assert (st.ranges[:, 1] - st.ranges[:, 0]).max() > 1000
+    run = HipRun(pkg, means, s.shs, opac, s.scales, s.rotations, cam, 1)
+    _compare_forward(st, run, run.forward())
+    assert run.rast.stats.max_tile_instances > 1000
+    # and a second, sparse view on the same (grown) handle
+    s2, _ = _scene(pkg, orc, n, W, H, 1, 20)
+    st2 = orc.forward(s2.means, s2.shs, s2.opacities, s2.scales, s2.rotations, cam, 1)
+    run.t = [dev(s2.means), dev(s2.shs), dev(s2.opacities.reshape(-1, 1)), dev(s2.scales), dev(s2.rotations)]
+    _compare_forward(st2, run, run.forward())
+
+
 def test_large_footprints_and_deterministic_gradients(pkg, orc):
     """Splats covering hundreds of tiles take the wave-cooperative row-sum path of the
     per-Gaussian backward; gradients are summed in a fixed order, so two runs agree bit for bit."""

@@ -1,0 +1,13 @@
+set -x
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+R=r01_f
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke_$R.log 2>&1
+python bench.py > gpurun_out/bench_$R.json 2> gpurun_out/bench_$R.err
+python bench.py --no-cpu-baseline --reference-lists > gpurun_out/bench_${R}_reflists.json 2>/dev/null
+python bench.py --no-cpu-baseline --gaussians 100000 --no-loss > gpurun_out/bench_${R}_cfg2.json 2>/dev/null
+python bench.py --no-cpu-baseline --gaussians 5000000 --width 3840 --height 2160 --no-loss --steps 10 > gpurun_out/bench_${R}_cfg5.json 2>/dev/null
+python bench.py --no-cpu-baseline --with-optimizer > gpurun_out/bench_${R}_optimizer.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$R -o bench -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 3 > gpurun_out/prof_$R.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_$R -o fetch -- python3 tools/pmc_workload.py > gpurun_out/pmc_${R}_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_$R -o write -- python3 tools/pmc_workload.py > gpurun_out/pmc_${R}_write.log 2>&1
+tail -2 gpurun_out/smoke_$R.log; cat gpurun_out/bench_$R.json | cut -c1-400

@@ -11,7 +11,7 @@ from .camera import Camera  # noqa: F401
 
 def __getattr__(name):
     # torch-dependent modules are imported lazily
-    if name in ("rasterizer", "fused_ssim", "distributed", "optim"):
+    if name in ("rasterizer", "fused_ssim", "distributed", "optim", "densification"):
         import importlib
         return importlib.import_module(f"{__name__}.{name}")
     if name in ("GaussianRasterizer", "rasterize", "grad_rasterize", "n_color_features"):

@@ -64,11 +64,16 @@ class AdamGroup(C.Structure):
                 ("count", C.c_int64), ("lr", C.c_float), ("current_step", C.c_uint32)]
 
 
+class GatherGroup(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_words", C.c_int32)]
+
+
 EXPORTS = ["gsr_create", "gsr_destroy", "gsr_release_scene_buffers", "gsr_memory_usage", "gsr_forward",
            "gsr_backward", "gsr_buffer", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_loss_l1_ssim",
            "gsr_allreduce_grads", "gsr_last_error_string", "gsr_version", "gsr_profile_enable",
            "gsr_profile_stage_count", "gsr_profile_stage_name", "gsr_profile_read", "gsr_update_stats",
-           "gsr_prologue_forward", "gsr_prologue_backward", "gsr_adam_step", "gsr_stream_triad"]
+           "gsr_prologue_forward", "gsr_prologue_backward", "gsr_adam_step", "gsr_stream_triad",
+           "gsr_mask_findall_scratch_bytes", "gsr_mask_findall", "gsr_gather_rows"]
 
 _lib = None
 
@@ -111,6 +116,10 @@ def load():
     lib.gsr_prologue_forward.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_prologue_backward.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_adam_step.argtypes = [C.POINTER(AdamGroup), i32, f32, f32, f32, vp]
+    lib.gsr_mask_findall_scratch_bytes.argtypes = [C.c_int64]
+    lib.gsr_mask_findall_scratch_bytes.restype = C.c_size_t
+    lib.gsr_mask_findall.argtypes = [vp, C.c_int64, vp, vp, vp, vp]
+    lib.gsr_gather_rows.argtypes = [C.POINTER(GatherGroup), i32, vp, C.c_int64, vp]
     lib.gsr_stream_triad.argtypes = [vp, vp, vp, C.c_size_t, f32, vp]
     lib.gsr_profile_enable.argtypes = [vp, i32]
     lib.gsr_profile_stage_name.argtypes = [i32]

@@ -544,6 +544,38 @@ int gsr_adam_step(const gsr_adam_group* groups, int32_t n_groups, float beta1, f
     return GSR_OK;
 }
 
+size_t gsr_mask_findall_scratch_bytes(int64_t n) { return n > 0 ? gsr_findall_scratch_bytes(n) : sizeof(uint32_t); }
+
+int gsr_mask_findall(const uint8_t* mask, int64_t n, uint32_t* indices, uint32_t* count_out, void* scratch,
+                     void* stream) {
+    if (n < 0 || n > 0xFFFFFFFFll) return fail(GSR_E_INVALID_ARG, "n out of range");
+    if (!count_out || (n > 0 && (!mask || !indices || !scratch))) return fail(GSR_E_INVALID_ARG, "null array");
+    gsr_launch_findall((hipStream_t)stream, n, mask, indices, count_out, (uint32_t*)scratch);
+    HIPCHK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_gather_rows(const gsr_gather_group* groups, int32_t n_groups, const uint32_t* indices, int64_t count,
+                    void* stream) {
+    if (n_groups < 0 || n_groups > GSR_ADAM_MAX_GROUPS || (n_groups > 0 && !groups))
+        return fail(GSR_E_INVALID_ARG, "n_groups must be in [0, %d]", GSR_ADAM_MAX_GROUPS);
+    if (count < 0) return fail(GSR_E_INVALID_ARG, "negative count");
+    if (count == 0 || n_groups == 0) return GSR_OK;
+    if (!indices) return fail(GSR_E_INVALID_ARG, "null indices");
+    const void* src[GSR_ADAM_MAX_GROUPS]; void* dst[GSR_ADAM_MAX_GROUPS]; int rw[GSR_ADAM_MAX_GROUPS];
+    int m = 0;
+    for (int g = 0; g < n_groups; g++) {
+        if (groups[g].row_words < 0) return fail(GSR_E_INVALID_ARG, "group %d: negative row_words", g);
+        if (groups[g].row_words == 0) continue;  // e.g. an empty features_rest (densification.jl:40-41)
+        if (!groups[g].src || !groups[g].dst) return fail(GSR_E_INVALID_ARG, "group %d: null array", g);
+        src[m] = groups[g].src; dst[m] = groups[g].dst; rw[m] = groups[g].row_words; m++;
+    }
+    if (m == 0) return GSR_OK;
+    gsr_launch_gather_rows((hipStream_t)stream, m, src, dst, rw, indices, count);
+    HIPCHK(hipGetLastError());
+    return GSR_OK;
+}
+
 int gsr_stream_triad(float* a, const float* b, const float* c, size_t count, float q, void* stream) {
     if (!a || !b || !c) return fail(GSR_E_INVALID_ARG, "null array");
     if (count % 4 != 0 || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) != 0)

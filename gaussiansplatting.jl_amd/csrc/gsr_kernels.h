@@ -106,6 +106,11 @@ void gsr_launch_prologue_bwd(hipStream_t s, int n, int k_rest, int scale_dims, c
 void gsr_launch_adam(hipStream_t s, int n_groups, float* const* theta, const float* const* grad, float* const* mu,
                      float* const* nu, const long long* count, const float* lr_t, float beta1, float beta2, float eps);
 
+size_t gsr_findall_scratch_bytes(long long n);
+void gsr_launch_findall(hipStream_t s, long long n, const uint8_t* mask, uint32_t* indices, uint32_t* count_dev,
+                        uint32_t* scratch);
+void gsr_launch_gather_rows(hipStream_t s, int n_groups, const void* const* src, void* const* dst, const int* row_words,
+                            const uint32_t* idx, long long count);
 void gsr_launch_triad(hipStream_t s, size_t n4, float* a, const float* b, const float* c, float q);
 
 // ---- ssim.hip ----

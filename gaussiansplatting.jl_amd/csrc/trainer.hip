@@ -159,6 +159,106 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamGroups G, float beta1, fl
     }
 }
 
+// ---- boolean-mask compaction: findall(mask) and x[:, idxs] (densification.jl:138-191,279-288) ----
+// findall in three small passes: per-1024 popcounts, one-workgroup scan of the block counts,
+// per-block ordered emit (ballot + popcount ranks).  Order-preserving, as Julia's logical indexing.
+constexpr int FA_BLOCK = 1024;
+
+__global__ __launch_bounds__(256) void findall_count_kernel(long long n, const uint8_t* __restrict__ mask,
+                                                            uint32_t* __restrict__ block_count) {
+    __shared__ uint32_t wsum[4];
+    const long long base = (long long)blockIdx.x * FA_BLOCK;
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < FA_BLOCK / 256; k++) {
+        const long long i = base + k * 256 + threadIdx.x;
+        c += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(i < n && mask[i] != 0)) ;
+    }
+    // every lane of a wave holds the wave's count
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(1024) void findall_scan_kernel(int nb, uint32_t* __restrict__ block_count /* in: counts, out: exclusive offsets */,
+                                                            uint32_t* __restrict__ total) {
+    __shared__ uint32_t wave_sums[16];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nb; b0 += 1024) {
+        const int i = b0 + tid;
+        const uint32_t v = i < nb ? block_count[i] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(x, off);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) wave_sums[wave] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; w++) woff += wave_sums[w];
+        const uint32_t excl = carry_s + woff + x - v;
+        if (i < nb) block_count[i] = excl;
+        __syncthreads();
+        if (tid == 1023) carry_s = excl + v;
+        __syncthreads();
+    }
+    if (tid == 0) *total = carry_s;
+}
+
+__global__ __launch_bounds__(256) void findall_emit_kernel(long long n, const uint8_t* __restrict__ mask,
+                                                           const uint32_t* __restrict__ block_off,
+                                                           uint32_t* __restrict__ indices) {
+    __shared__ uint32_t wcount[FA_BLOCK / 64];
+    const long long base = (long long)blockIdx.x * FA_BLOCK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool sel[FA_BLOCK / 256];
+    unsigned long long bal[FA_BLOCK / 256];
+#pragma unroll
+    for (int k = 0; k < FA_BLOCK / 256; k++) {
+        const long long i = base + k * 256 + threadIdx.x;
+        sel[k] = i < n && mask[i] != 0;
+        bal[k] = __builtin_amdgcn_ballot_w64(sel[k]);
+        if (lane == 0) wcount[k * 4 + wave] = (uint32_t)__popcll(bal[k]);
+    }
+    __syncthreads();
+    const uint32_t off0 = block_off[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < FA_BLOCK / 256; k++) {
+        uint32_t before = 0;
+        for (int w = 0; w < k * 4 + wave; w++) before += wcount[w];  // chunks of 64 elements in index order
+        if (sel[k]) {
+            const uint32_t rank = (uint32_t)__popcll(bal[k] & ((1ull << lane) - 1ull));
+            indices[off0 + before + rank] = (uint32_t)(base + k * 256 + threadIdx.x);
+        }
+    }
+}
+
+struct GatherGroups {
+    const uint32_t* src[GSR_ADAM_MAX_GROUPS];
+    uint32_t* dst[GSR_ADAM_MAX_GROUPS];
+    int row_words[GSR_ADAM_MAX_GROUPS];
+    long long block_start[GSR_ADAM_MAX_GROUPS + 1];
+    int n;
+};
+// dst[r, :] = src[idx[r], :] for 4-byte words; one thread per output word (coalesced stores, the
+// loads of one row are contiguous)
+__global__ __launch_bounds__(256) void gather_rows_kernel(GatherGroups G, const uint32_t* __restrict__ idx, long long count) {
+    int g = 0;
+#pragma unroll
+    for (int k = 1; k < GSR_ADAM_MAX_GROUPS; k++)
+        if (k < G.n && (long long)blockIdx.x >= G.block_start[k]) g = k;
+    const long long e = ((long long)blockIdx.x - G.block_start[g]) * 256 + threadIdx.x;
+    const int rw = G.row_words[g];
+    if (e >= count * rw) return;
+    const long long r = e / rw;
+    const int j = (int)(e - r * rw);
+    G.dst[g][e] = G.src[g][(long long)idx[r] * rw + j];
+}
+
 }  // namespace
 
 void gsr_launch_prologue_fwd(hipStream_t s, int n, int k_rest, int scale_dims, const float* sh_color,
@@ -217,4 +317,33 @@ void gsr_launch_triad(hipStream_t s, size_t n4, float* a, const float* b, const 
     const size_t blocks = (n4 + 255) / 256;
     hipLaunchKernelGGL(triad_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, n4, (float4*)a,
                        (const float4*)b, (const float4*)c, q);
+}
+
+size_t gsr_findall_scratch_bytes(long long n) { return (size_t)((n + FA_BLOCK - 1) / FA_BLOCK + 1) * sizeof(uint32_t); }
+
+void gsr_launch_findall(hipStream_t s, long long n, const uint8_t* mask, uint32_t* indices, uint32_t* count_dev,
+                        uint32_t* scratch) {
+    const int nb = (int)((n + FA_BLOCK - 1) / FA_BLOCK);
+    if (nb == 0) { (void)hipMemsetAsync(count_dev, 0, 4, s); return; }
+    hipLaunchKernelGGL(findall_count_kernel, dim3(nb), dim3(256), 0, s, n, mask, scratch);
+    hipLaunchKernelGGL(findall_scan_kernel, dim3(1), dim3(1024), 0, s, nb, scratch, count_dev);
+    hipLaunchKernelGGL(findall_emit_kernel, dim3(nb), dim3(256), 0, s, n, mask, scratch, indices);
+}
+
+void gsr_launch_gather_rows(hipStream_t s, int n_groups, const void* const* src, void* const* dst, const int* row_words,
+                            const uint32_t* idx, long long count) {
+    GatherGroups G;
+    G.n = n_groups;
+    long long blocks = 0;
+    for (int g = 0; g < GSR_ADAM_MAX_GROUPS; g++) {
+        const bool on = g < n_groups;
+        G.src[g] = on ? (const uint32_t*)src[g] : nullptr;
+        G.dst[g] = on ? (uint32_t*)dst[g] : nullptr;
+        G.row_words[g] = on ? row_words[g] : 1;
+        G.block_start[g] = blocks;
+        if (on) blocks += (count * row_words[g] + 255) / 256;
+    }
+    G.block_start[GSR_ADAM_MAX_GROUPS] = blocks;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, G, idx, count);
 }

@@ -227,6 +227,27 @@ typedef struct gsr_adam_group {
 GSR_API int gsr_adam_step(const gsr_adam_group* groups, int32_t n_groups, float beta1, float beta2, float eps,
                           void* stream);
 
+/* Boolean-mask compaction of per-Gaussian arrays — the `x[:, mask]` / `x[:, :, mask]` /
+ * `x[mask]` logical indexing that `prune_points!`, `densify_clone!`, `densify_split!` and
+ * `_prune_optimizer!` apply to every parameter, both Adam moments and the densification
+ * statistics (src/densification.jl:29-62,64-121,138-191,279-288).
+ *   gsr_mask_findall : indices (0-based, ascending) of the non-zero bytes of mask[n] — Julia's
+ *                      `findall(mask)`; *count_out (device) receives their number.  `scratch`
+ *                      is gsr_mask_findall_scratch_bytes(n) bytes of device memory.
+ *   gsr_gather_rows  : dst[g][r, :] = src[g][indices[r], :] for up to GSR_ADAM_MAX_GROUPS arrays
+ *                      in one launch; a row is row_words 4-byte words (float / int32 / uint32).
+ * All pointers device; order-preserving, bit-exact. */
+typedef struct gsr_gather_group {
+    const void* src;
+    void* dst;
+    int32_t row_words;
+} gsr_gather_group;
+GSR_API size_t gsr_mask_findall_scratch_bytes(int64_t n);
+GSR_API int gsr_mask_findall(const uint8_t* mask, int64_t n, uint32_t* indices, uint32_t* count_out, void* scratch,
+                             void* stream);
+GSR_API int gsr_gather_rows(const gsr_gather_group* groups, int32_t n_groups, const uint32_t* indices, int64_t count,
+                            void* stream);
+
 /* New (no reference counterpart): sum the per-view gradient arena over
  * the ranks of an RCCL communicator (ncclComm_t passed as void*).  librccl is resolved
  * lazily with dlopen, so single-GPU users need not have it. */

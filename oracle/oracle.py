@@ -460,3 +460,14 @@ def adam_lr_t(lr, beta1, beta2, step):
     L.orc_adam_lr_t.restype = C.c_float
     L.orc_adam_lr_t.argtypes = [C.c_float, C.c_float, C.c_float, C.c_uint32]
     return L.orc_adam_lr_t(float(lr), float(beta1), float(beta2), int(step))
+
+
+# ---- boolean-mask compaction (src/densification.jl:138-191,279-288): x[:, mask] is plain logical indexing ----
+def findall(mask):
+    """`findall(mask)`, 0-based."""
+    return np.flatnonzero(np.asarray(mask)).astype(np.int32)
+
+
+def select_rows(x, idx):
+    """`x[:, idxs]` / `x[:, :, idxs]` for the C-order equivalent array (Gaussian index first)."""
+    return np.ascontiguousarray(np.asarray(x)[np.asarray(idx)])

@@ -115,3 +115,46 @@ def test_adam_errors_and_empty_groups(pkg):
     with pytest.raises(ValueError):
         pkg.optim.Adam(torch.zeros(4), 0.1)  # CPU tensor: no CPU path
     assert lib.gsr_prologue_forward(4, 0, 2, None, None, None, None, None, None, None, None) == L.GSR_E_INVALID_ARG
+
+
+@pytest.mark.parametrize("n,p", [(1, 1.0), (1023, 0.5), (1024, 0.0), (100_003, 0.3), (2_000_001, 0.93)])
+def test_mask_findall_vs_oracle(pkg, orc, n, p):
+    """findall(mask): ascending, exact, any block boundary."""
+    r = np.random.default_rng(n)
+    mask = r.uniform(size=n) < p
+    got = pkg.densification.findall(dev(mask, torch.bool))
+    assert np.array_equal(got.cpu().numpy(), orc.findall(mask))
+
+
+def test_prune_all_parameter_arrays_bit_exact(pkg, orc):
+    """prune_points! (densification.jl:138-191): the same valid_mask applied to the six parameters,
+    their twelve Adam moments, the three densification statistics and the ids — 22 arrays,
+    three launches."""
+    r = np.random.default_rng(77)
+    n = 50_021
+    shapes = [(n, 3), (n, 1, 3), (n, 15, 3), (n, 1), (n, 3), (n, 4)]
+    arrs = [r.normal(size=s).astype(np.float32) for s in shapes]
+    arrs += [r.normal(size=int(np.prod(s))).astype(np.float32).reshape(s) for s in shapes for _ in range(2)]  # mu, nu
+    arrs += [r.integers(0, 50, n).astype(np.int32), r.normal(size=n).astype(np.float32), r.normal(size=n).astype(np.float32)]
+    arrs += [np.arange(n, dtype=np.int32)]
+    mask = r.uniform(size=n) < 0.8
+    out = pkg.densification.prune([dev(a, torch.int32 if a.dtype == np.int32 else torch.float32) for a in arrs],
+                                  dev(mask, torch.bool))
+    idx = orc.findall(mask)
+    for o, a in zip(out, arrs):
+        assert np.array_equal(o.cpu().numpy(), orc.select_rows(a, idx))
+
+
+def test_select_arbitrary_indices_and_errors(pkg, orc):
+    """x[:, idxs] with repeated / unordered indices (MCMC relocation samples with replacement)."""
+    r = np.random.default_rng(5)
+    x = r.normal(size=(1000, 15, 3)).astype(np.float32)
+    idx = r.integers(0, 1000, 4321).astype(np.int32)
+    (y,) = pkg.densification.select([dev(x)], dev(idx, torch.int32))
+    assert np.array_equal(y.cpu().numpy(), orc.select_rows(x, idx))
+    (e,) = pkg.densification.select([dev(x)], torch.empty(0, dtype=torch.int32, device="cuda"))
+    assert e.shape == (0, 15, 3)
+    with pytest.raises(ValueError):
+        pkg.densification.findall(torch.zeros(4, dtype=torch.bool))  # CPU tensor
+    L = pkg._lib
+    assert L.load().gsr_gather_rows(None, 9, None, 1, None) == L.GSR_E_INVALID_ARG

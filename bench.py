@@ -96,7 +96,18 @@ def main():
     target = to(pkg.synthetic.make_target(W, H, args.seed + view))
     vpix_fixed = to(pkg.synthetic.make_vpixels(W, H, 3, args.seed + view))
     rast = pkg.rasterizer.GaussianRasterizer(W, H, mode="rgb", device=dev, exact_tile_cull=not args.reference_lists)
-    arena = torch.empty(D.arena_numel(N, K), device=dev, dtype=torch.float32)
+    # world > 1: factored exchange (distributed.py) unless GSR_DIST_FULL_ARENA=1 asks for the plain
+    # all-reduce of the whole (11+3K)·N arena
+    factored = world > 1 and os.environ.get("GSR_DIST_FULL_ARENA", "0") != "1"
+    arena = torch.empty(D.factored_arena_numel(N) if factored else D.arena_numel(N, K), device=dev, dtype=torch.float32)
+    if factored:
+        centers = []
+        for r in range(world):
+            Rr, tr = pkg.synthetic.view_pose(r % args.views, args.views)
+            centers.append(pkg.Camera(W, H, tuple(s.focal), (0.5, 0.5), Rr, tr).camera_center)
+        centers_d = to(np.stack(centers).astype(np.float32))
+        gathered = torch.empty(world * 3 * N, device=dev, dtype=torch.float32)
+        vshs_sum = torch.empty((N, K, 3), device=dev, dtype=torch.float32)
     bg = (0.0, 0.0, 0.0)
 
     tail = None
@@ -122,10 +133,14 @@ def main():
             vp = vpix_fixed
         else:
             _, vp = pkg.fused_ssim.l1_ssim_loss(rast, img, target)
-        rast.backward_raw(vp, *params, cam, deg, bg, arena=arena)
-        D.allreduce_arena(arena)
+        rast.backward_raw(vp, *params, cam, deg, bg, arena=arena, factored_sh=factored)
+        if factored:
+            vc_all = D.exchange_factored(arena, N, gathered)
+            pkg.rasterizer.sh_grad_from_views(params[0], vc_all, centers_d, K, deg, out=vshs_sum)
+        else:
+            D.allreduce_arena(arena)
         if tail is not None:
-            g = D.split_arena(arena, N, K)
+            g = D.split_arena(arena, N, K) if not factored else dict(D.split_factored_arena(arena, N), vshs=vshs_sum)
             ev[2].record()
             vdc, vrest, vo, vs = pkg.rasterizer.prologue_backward(params[2], params[3], g["vshs"], g["vopacities"].view(-1, 1),
                                                                   g["vscales"], 3)
@@ -212,7 +227,9 @@ def main():
                                 f"N={N} SH{deg} {W}x{H} fwd{'' if args.no_loss else '+loss'}+bwd"),
                    "n_gaussians": N, "visible": V, "tile_instances": Dn, "views_per_gpu": 1,
                    "tile_lists": "reference" if args.reference_lists else "exact footprint cull (same outputs)",
-                   "parallelism": f"view-parallel x{world}, 1 all-reduce of {arena.numel() * 4 / 1e6:.0f} MB"},
+                   "parallelism": (f"view-parallel x{world}, all-reduce of {11 * N * 4 / 1e6:.0f} MB + all-gather of "
+                                   f"{world} x {3 * N * 4 / 1e6:.0f} MB colour cotangents (factored SH gradient)" if factored else
+                                   f"view-parallel x{world}, 1 all-reduce of {arena.numel() * 4 / 1e6:.0f} MB")},
         "roofline": roofline,
     }
 

@@ -53,7 +53,7 @@ class Stats(C.Structure):
 
 class Grads(C.Structure):
     _fields_ = [("vmeans", C.c_void_p), ("vshs", C.c_void_p), ("vopacities", C.c_void_p), ("vscales", C.c_void_p),
-                ("vrotations", C.c_void_p), ("vR", C.c_void_p), ("vt", C.c_void_p)]
+                ("vrotations", C.c_void_p), ("vR", C.c_void_p), ("vt", C.c_void_p), ("vcolors", C.c_void_p)]
 
 
 ADAM_MAX_GROUPS = 8
@@ -73,7 +73,7 @@ EXPORTS = ["gsr_create", "gsr_destroy", "gsr_release_scene_buffers", "gsr_memory
            "gsr_allreduce_grads", "gsr_last_error_string", "gsr_version", "gsr_profile_enable",
            "gsr_profile_stage_count", "gsr_profile_stage_name", "gsr_profile_read", "gsr_update_stats",
            "gsr_prologue_forward", "gsr_prologue_backward", "gsr_adam_step", "gsr_stream_triad",
-           "gsr_mask_findall_scratch_bytes", "gsr_mask_findall", "gsr_gather_rows"]
+           "gsr_mask_findall_scratch_bytes", "gsr_mask_findall", "gsr_gather_rows", "gsr_sh_grad_from_views"]
 
 _lib = None
 
@@ -120,6 +120,7 @@ def load():
     lib.gsr_mask_findall_scratch_bytes.restype = C.c_size_t
     lib.gsr_mask_findall.argtypes = [vp, C.c_int64, vp, vp, vp, vp]
     lib.gsr_gather_rows.argtypes = [C.POINTER(GatherGroup), i32, vp, C.c_int64, vp]
+    lib.gsr_sh_grad_from_views.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.gsr_stream_triad.argtypes = [vp, vp, vp, C.c_size_t, f32, vp]
     lib.gsr_profile_enable.argtypes = [vp, i32]
     lib.gsr_profile_stage_name.argtypes = [i32]

@@ -354,7 +354,7 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
     if (!vpixels || !g) return fail(GSR_E_INVALID_ARG, "null vpixels / grads");
     if (!h->fwd_valid || h->last_n != in->n)
         return fail(GSR_E_STATE, "gsr_backward without a matching gsr_forward on this handle");
-    if (in->n > 0 && (!g->vmeans || !g->vshs || !g->vopacities || !g->vscales || !g->vrotations))
+    if (in->n > 0 && (!g->vmeans || (!g->vshs && !g->vcolors) || !g->vopacities || !g->vscales || !g->vrotations))
         return fail(GSR_E_INVALID_ARG, "null gradient buffer");
     if ((g->vR == nullptr) != (g->vt == nullptr)) return fail(GSR_E_INVALID_ARG, "vR and vt must be given together");
     if (((uintptr_t)g->vrotations & 15) != 0) return fail(GSR_E_INVALID_ARG, "vrotations must be 16-byte aligned");
@@ -378,7 +378,7 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
     h->prof.begin(ST_PERGAUSS_BWD, s);
     gsr_launch_pergauss_bwd(s, n, in->n_coeffs, in->sh_degree, C, in->means, in->scales, in->rotations, in->shs, k,
                             geom_of(h), inst_of(h), h->vmean2d.as<float2>(), g->vmeans, g->vshs, g->vopacities,
-                            g->vscales, g->vrotations, g->vR, g->vt);
+                            g->vscales, g->vrotations, g->vR, g->vt, g->vcolors);
     h->prof.end(s);
     HIPCHK(hipGetLastError());
     h->bwd_valid = true;
@@ -572,6 +572,17 @@ int gsr_gather_rows(const gsr_gather_group* groups, int32_t n_groups, const uint
     }
     if (m == 0) return GSR_OK;
     gsr_launch_gather_rows((hipStream_t)stream, m, src, dst, rw, indices, count);
+    HIPCHK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_sh_grad_from_views(int32_t n, int32_t n_coeffs, int32_t sh_degree, int32_t n_views, const float* camera_centers,
+                           const float* means, const float* vcolors_all, float* vshs, void* stream) {
+    if (n < 0 || n_views < 1 || sh_degree < 0 || sh_degree > 3 || n_coeffs < (sh_degree + 1) * (sh_degree + 1))
+        return fail(GSR_E_INVALID_ARG, "bad sizes: n=%d views=%d degree=%d K=%d", n, n_views, sh_degree, n_coeffs);
+    if (n == 0) return GSR_OK;
+    if (!camera_centers || !means || !vcolors_all || !vshs) return fail(GSR_E_INVALID_ARG, "null array");
+    gsr_launch_sh_grad_views((hipStream_t)stream, n, n_coeffs, sh_degree, n_views, camera_centers, means, vcolors_all, vshs);
     HIPCHK(hipGetLastError());
     return GSR_OK;
 }

@@ -65,7 +65,10 @@ void gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels
 void gsr_launch_pergauss_bwd(hipStream_t s, int n, int K, int degree, int channels, const float* means,
                              const float* scales, const float* rots, const float* shs, GsrCam cam, GsrGeom geom,
                              GsrInst inst, float2* vmean2d, float* vmeans, float* vshs, float* vopac,
-                             float* vscales, float* vrots, float* vR, float* vt);
+                             float* vscales, float* vrots, float* vR, float* vt,
+                             float* vcolors /* (3,N) or NULL: factored SH gradient instead of vshs */);
+void gsr_launch_sh_grad_views(hipStream_t s, int n, int K, int degree, int n_views, const float* centers,
+                              const float* means, const float* vc_all, float* vshs);
 
 void gsr_launch_update_stats(hipStream_t s, int n, const int32_t* radii, const float2* vmean2d, int width, int height,
                              int32_t* max_radii, float* accum, float* denom);

@@ -402,7 +402,8 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
                                                            float* __restrict__ vmeans,
                                                            float* __restrict__ vshs, float* __restrict__ vopac,
                                                            float* __restrict__ vscales, float4* __restrict__ vrots,
-                                                           float* __restrict__ vR_out, float* __restrict__ vt_out) {
+                                                           float* __restrict__ vR_out, float* __restrict__ vt_out,
+                                                           float* __restrict__ vcolors) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     float poseR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, poset[3] = {0, 0, 0};
     const bool visible = i < n && geom.radii[i] > 0;
@@ -499,7 +500,8 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
             vrots[i] = make_float4(0, 0, 0, 0);
             vopac[i] = 0.0f;
             vmean2d_out[i] = make_float2(0.0f, 0.0f);
-            for (int k = 0; k < 3 * K; k++) vsh[k] = 0.0f;
+            if (vcolors) { vcolors[3 * i] = 0.0f; vcolors[3 * i + 1] = 0.0f; vcolors[3 * i + 2] = 0.0f; }
+            else for (int k = 0; k < 3 * K; k++) vsh[k] = 0.0f;
         } else {
             const float4 a0 = make_float4(acc[0], acc[1], acc[2], acc[3]);
             const float4 a1 = make_float4(acc[4], acc[5], acc[6], acc[7]);
@@ -657,11 +659,18 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
             float b[16];
             sh_basis<DEG>(dir, b);
             constexpr int NB = (DEG + 1) * (DEG + 1);
+            if (vcolors) {
+                // factored form for the multi-view exchange: ∇shs of a view is the outer product
+                // basis(dir) x vc, so 3 floats per Gaussian travel instead of 3K (sh_grad_views_kernel
+                // rebuilds Σ_views on every rank)
+                vcolors[3 * i] = vc[0]; vcolors[3 * i + 1] = vc[1]; vcolors[3 * i + 2] = vc[2];
+            } else {
 #pragma unroll
-            for (int k = 0; k < NB; k++)
+                for (int k = 0; k < NB; k++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) vsh[3 * k + c] = b[k] * vc[c];
-            for (int k = 3 * NB; k < 3 * K; k++) vsh[k] = 0.0f;
+                    for (int c = 0; c < 3; c++) vsh[3 * k + c] = b[k] * vc[c];
+                for (int k = 3 * NB; k < 3 * K; k++) vsh[k] = 0.0f;
+            }
             float dcx[3] = {0, 0, 0}, dcy[3] = {0, 0, 0}, dcz[3] = {0, 0, 0};
 #define SHC(k_, c_) sh[3 * (k_) + (c_)]
             if (DEG > 0) {
@@ -734,6 +743,43 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
     }
 }
 
+// ∇shs of a batch of views from the factored per-view colour cotangents:
+//   vshs[i, k, c] = Σ_v basis_k(normalize(mean_i - center_v)) · vc_v[i, c]
+// — exactly the ∇spherical_harmonics! coefficient gradient (spherical_harmonics.jl:32-37) of each
+// view, summed over views in ascending view order on every rank.  The exchange then carries
+// 3 floats per (Gaussian, view) instead of an all-reduce over 3K floats per Gaussian.
+template <int DEG>
+__global__ __launch_bounds__(256) void sh_grad_views_kernel(int n, int K, int n_views, const float* __restrict__ centers,
+                                                            const float* __restrict__ means,
+                                                            const float* __restrict__ vc_all,
+                                                            float* __restrict__ vshs) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    float acc[3 * NB];
+#pragma unroll
+    for (int k = 0; k < 3 * NB; k++) acc[k] = 0.0f;
+    const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+    for (int v = 0; v < n_views; v++) {
+        const float* vcp = vc_all + ((size_t)v * n + i) * 3;
+        const float vc[3] = {vcp[0], vcp[1], vcp[2]};
+        if (vc[0] == 0.0f && vc[1] == 0.0f && vc[2] == 0.0f) continue;  // culled in this view (or zero cotangent)
+        float d0[3] = {p[0] - centers[3 * v], p[1] - centers[3 * v + 1], p[2] - centers[3 * v + 2]};
+        float inv = 1.0f / sqrtf(d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2]);
+        const float dir[3] = {d0[0] * inv, d0[1] * inv, d0[2] * inv};
+        float b[16];
+        sh_basis<DEG>(dir, b);
+#pragma unroll
+        for (int k = 0; k < NB; k++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) acc[3 * k + c] = acc[3 * k + c] + b[k] * vc[c];
+    }
+    float* vsh = vshs + (size_t)3 * K * i;
+#pragma unroll
+    for (int k = 0; k < 3 * NB; k++) vsh[k] = acc[k];
+    for (int k = 3 * NB; k < 3 * K; k++) vsh[k] = 0.0f;
+}
+
 // _update_stats! (src/strategy.jl:118-136): densification statistics from the side outputs of
 // the last forward/backward pair (radii, ∇means_2d).
 __global__ __launch_bounds__(256) void update_stats_kernel(int n, const int32_t* __restrict__ radii,
@@ -782,14 +828,28 @@ void gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels
 void gsr_launch_pergauss_bwd(hipStream_t s, int n, int K, int degree, int channels, const float* means,
                              const float* scales, const float* rots, const float* shs, GsrCam cam, GsrGeom geom,
                              GsrInst inst, float2* vmean2d, float* vmeans, float* vshs, float* vopac,
-                             float* vscales, float* vrots, float* vR, float* vt) {
+                             float* vscales, float* vrots, float* vR, float* vt, float* vcolors) {
     if (n <= 0) return;
     dim3 grid((n + 255) / 256), block(256);
     const float4* r4 = reinterpret_cast<const float4*>(rots);
     float4* vr4 = reinterpret_cast<float4*>(vrots);
 #define LAUNCH(D)                                                                                                 \
     hipLaunchKernelGGL(pergauss_bwd_kernel<D>, grid, block, 0, s, n, K, channels, means, scales, r4, shs, cam,    \
-                       geom, inst, vmean2d, vmeans, vshs, vopac, vscales, vr4, vR, vt)
+                       geom, inst, vmean2d, vmeans, vshs, vopac, vscales, vr4, vR, vt, vcolors)
+    switch (degree) {
+        case 0: LAUNCH(0); break;
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        default: LAUNCH(3); break;
+    }
+#undef LAUNCH
+}
+
+void gsr_launch_sh_grad_views(hipStream_t s, int n, int K, int degree, int n_views, const float* centers,
+                              const float* means, const float* vc_all, float* vshs) {
+    if (n <= 0) return;
+    dim3 grid((n + 255) / 256), block(256);
+#define LAUNCH(D) hipLaunchKernelGGL(sh_grad_views_kernel<D>, grid, block, 0, s, n, K, n_views, centers, means, vc_all, vshs)
     switch (degree) {
         case 0: LAUNCH(0); break;
         case 1: LAUNCH(1); break;

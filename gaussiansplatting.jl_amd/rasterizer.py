@@ -241,16 +241,22 @@ class GaussianRasterizer:
         return img
 
     def backward_raw(self, vpixels, means_3d, shs, opacities, scales, rotations, camera, sh_degree, background,
-                     R_w2c=None, t_w2c=None, arena: Optional[torch.Tensor] = None):
+                     R_w2c=None, t_w2c=None, arena: Optional[torch.Tensor] = None, factored_sh: bool = False):
         """∇rasterize.  Returns (vmeans, vshs, vopacities, vscales, vrot, vR, vt); when `arena`
         (a flat float32 tensor of (11+3K)·N elements, 59·N at K=16) is given the five gradients
         are views into it, laid out [vrot | vmeans | vshs | vopacities | vscales] for one
-        collective (vrot first keeps its 16-byte alignment for any N)."""
+        collective (vrot first keeps its 16-byte alignment for any N).
+
+        factored_sh=True (multi-view exchange): the arena is
+        [vrot | vmeans | vopacities | vscales | vcolors] (14·N floats instead of (11+3K)·N) with
+        (N,3) `vcolors` — the view's colour cotangent after the clamp mask — in place of vshs; the
+        first 11·N floats are summed over ranks, `vcolors` is all-gathered and
+        `sh_grad_from_views` rebuilds ∇shs.  The second return value is then `vcolors`."""
         inp = self._inputs(means_3d, shs, opacities, scales, rotations, sh_degree, background)
         cs = self._camera(camera, R_w2c, t_w2c)
         _chk(vpixels, "vpixels", (self.height, self.width, self.channels))
         n, K = inp.n, inp.n_coeffs
-        sizes = [4 * n, 3 * n, 3 * K * n, n, 3 * n]
+        sizes = [4 * n, 3 * n, n, 3 * n, 3 * n] if factored_sh else [4 * n, 3 * n, 3 * K * n, n, 3 * n]
         if arena is None:
             arena = torch.empty(sum(sizes), device=self.device, dtype=torch.float32)
         elif arena.numel() != sum(sizes):
@@ -258,20 +264,41 @@ class GaussianRasterizer:
         offs = np.cumsum([0] + sizes)
         vrot = arena[offs[0]:offs[1]].view(n, 4)
         vmeans = arena[offs[1]:offs[2]].view(n, 3)
-        vshs = arena[offs[2]:offs[3]].view(n, K, 3)
-        vopac = arena[offs[3]:offs[4]].view(*opacities.shape)
-        vscales = arena[offs[4]:offs[5]].view(n, 3)
+        if factored_sh:
+            vopac = arena[offs[2]:offs[3]].view(*opacities.shape)
+            vscales = arena[offs[3]:offs[4]].view(n, 3)
+            vshs = arena[offs[4]:offs[5]].view(n, 3)  # vcolors
+        else:
+            vshs = arena[offs[2]:offs[3]].view(n, K, 3)
+            vopac = arena[offs[3]:offs[4]].view(*opacities.shape)
+            vscales = arena[offs[4]:offs[5]].view(n, 3)
         if vrot.data_ptr() % 16:
             raise ValueError("arena must be 16-byte aligned")
         vR = vt = None
         if R_w2c is not None:
             vR = torch.empty(3, 3, device=self.device)
             vt = torch.empty(3, device=self.device)
-        g = L.Grads(vmeans.data_ptr(), vshs.data_ptr(), vopac.data_ptr(), vscales.data_ptr(), vrot.data_ptr(),
-                    None if vR is None else vR.data_ptr(), None if vt is None else vt.data_ptr())
+        g = L.Grads(vmeans.data_ptr(), None if factored_sh else vshs.data_ptr(), vopac.data_ptr(), vscales.data_ptr(),
+                    vrot.data_ptr(), None if vR is None else vR.data_ptr(), None if vt is None else vt.data_ptr(),
+                    vshs.data_ptr() if factored_sh else None)
         with torch.cuda.device(self.device):
             L.check(self._lib.gsr_backward(self._h, C.byref(inp), C.byref(cs), _ptr(vpixels), C.byref(g), _stream()))
         return vmeans, vshs, vopac, vscales, vrot, vR, vt
+
+
+def sh_grad_from_views(means_3d, vcolors_all, camera_centers, n_coeffs: int, sh_degree: int, out=None):
+    """∇shs (N,K,3) of a batch of views from their factored colour cotangents `vcolors_all` (V,N,3)
+    and camera centres (V,3) (gsr_sh_grad_from_views); V = 1 reproduces backward_raw's vshs bit for bit."""
+    V, n = vcolors_all.shape[0], vcolors_all.shape[1]
+    _chk(means_3d, "means_3d", (n, 3)); _chk(vcolors_all, "vcolors_all", (V, n, 3))
+    _chk(camera_centers, "camera_centers", (V, 3))
+    if out is None:
+        out = torch.empty((n, n_coeffs, 3), device=means_3d.device, dtype=torch.float32)
+    else:
+        _chk(out, "out", (n, n_coeffs, 3))
+    L.check(L.load().gsr_sh_grad_from_views(n, int(n_coeffs), int(sh_degree), V, _ptr(camera_centers), _ptr(means_3d),
+                                            _ptr(vcolors_all), _ptr(out), _stream()))
+    return out
 
 
 def prologue_forward(sh_color, sh_remainder, opacities, scales):

@@ -118,6 +118,10 @@ typedef struct gsr_grads {
     float* vrotations; /* (4,N) */
     float* vR;         /* (3,3) column-major or NULL */
     float* vt;         /* (3) or NULL */
+    float* vcolors;    /* (3,N) or NULL.  New: when given, vshs is NOT written (may be NULL)
+                        * and the view's SH-coefficient gradient is returned in its factored form — the colour
+                        * cotangent after the clamp mask, vc — from which gsr_sh_grad_from_views rebuilds
+                        * Σ_views basis(dir_view) x vc_view.  3 floats per Gaussian cross the links, not 3K. */
 } gsr_grads;
 
 typedef struct gsr_handle gsr_handle;
@@ -247,6 +251,17 @@ GSR_API int gsr_mask_findall(const uint8_t* mask, int64_t n, uint32_t* indices, 
                              void* stream);
 GSR_API int gsr_gather_rows(const gsr_gather_group* groups, int32_t n_groups, const uint32_t* indices, int64_t count,
                             void* stream);
+
+/* New: the SH-coefficient gradient of a batch of views from the factored
+ * per-view colour cotangents written by gsr_backward (gsr_grads.vcolors):
+ *   vshs[:, k, i] = Σ_v basis_k(normalize(means[:, i] - camera_centers[:, v])) * vcolors_all[:, i, v]
+ * — ∇spherical_harmonics! (spherical_harmonics.jl:32-37) of every view, summed in ascending view
+ * order.  camera_centers: device (3,V); vcolors_all: device (3,N,V) (view slowest), e.g. the output
+ * of an all-gather over the ranks; vshs: device (3,K,N), fully overwritten (bands above
+ * sh_degree get zeros).  With V = 1 the result is bit-identical to gsr_backward's own vshs. */
+GSR_API int gsr_sh_grad_from_views(int32_t n, int32_t n_coeffs, int32_t sh_degree, int32_t n_views,
+                                   const float* camera_centers, const float* means, const float* vcolors_all,
+                                   float* vshs, void* stream);
 
 /* New (no reference counterpart): sum the per-view gradient arena over
  * the ranks of an RCCL communicator (ncclComm_t passed as void*).  librccl is resolved

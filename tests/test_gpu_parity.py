@@ -405,6 +405,45 @@ def test_functor_autograd_end_to_end(pkg, orc):
     assert rel_l2(p[5].grad.cpu().numpy(), g.vshs[:, 1:]) <= 1e-4
 
 
+def test_factored_sh_gradient_exchange_form(pkg, orc):
+    """SURVEY.md §8e: backward_raw(factored_sh=True) returns the colour cotangent vc instead of ∇shs;
+    sh_grad_from_views rebuilds ∇shs — bit-identically for one view, and for a batch of views it
+    equals the sum of the per-view ∇shs (what the all-reduce of the full arena would give)."""
+    W, H, deg, n, V = 96, 64, 3, 800, 3
+    s = pkg.synthetic.make_scene(n, W, H, deg, 77, sigma_px=4.0)
+    K = s.shs.shape[1]
+    rast = pkg.rasterizer.GaussianRasterizer(W, H, mode="rgb")
+    p = [dev(s.means), dev(s.shs), dev(s.opacities.reshape(-1, 1)), dev(s.scales), dev(s.rotations)]
+    full_sum, vcs, centers, small_sum = None, [], [], None
+    for v in range(V):
+        R, t = pkg.synthetic.view_pose(v, V)
+        cam = pkg.Camera(W, H, tuple(s.focal), (0.5, 0.5), R, t)
+        vp = dev(pkg.synthetic.make_vpixels(W, H, 3, 300 + v) * 1e3)
+        rast.forward_raw(*p, cam, deg, (0, 0, 0))
+        full = [x.clone() for x in rast.backward_raw(vp, *p, cam, deg, (0, 0, 0))[:5]]
+        rast.forward_raw(*p, cam, deg, (0, 0, 0))
+        fac = [x.clone() for x in rast.backward_raw(vp, *p, cam, deg, (0, 0, 0), factored_sh=True)[:5]]
+        for k in (0, 2, 3, 4):  # vmeans, vopacities, vscales, vrot: untouched by the form
+            assert torch.equal(full[k], fac[k])
+        assert fac[1].shape == (n, 3)
+        one = pkg.rasterizer.sh_grad_from_views(p[0], fac[1].view(1, n, 3), dev(cam.camera_center.reshape(1, 3)), K, deg)
+        assert torch.equal(one, full[1]), "V = 1 must reproduce the fused ∇shs bit for bit"
+        vcs.append(fac[1]); centers.append(cam.camera_center)
+        full_sum = full[1].double() if full_sum is None else full_sum + full[1].double()
+    got = pkg.rasterizer.sh_grad_from_views(p[0], torch.stack(vcs).contiguous(), dev(np.stack(centers)), K, deg)
+    torch.cuda.synchronize()
+    assert full_sum.abs().max() > 0
+    assert rel_l2(got.cpu().numpy(), full_sum.cpu().numpy()) <= 1e-6
+    # and against the oracle's ∇SH for the first view
+    R, t = pkg.synthetic.view_pose(0, V)
+    ocam = orc.Camera(W, H, s.focal, R=R, t=t)
+    st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, ocam, deg)
+    g = orc.backward(st, pkg.synthetic.make_vpixels(W, H, 3, 300) * 1e3, s.means, s.shs, s.opacities, s.scales,
+                     s.rotations, ocam, deg)
+    vc0 = g.vfeatures[:, :3] * (1.0 - st.clamped.astype(np.float32))
+    assert rel_l2(vcs[0].cpu().numpy(), vc0) <= 1e-4
+
+
 def test_update_stats_vs_oracle(pkg, orc):
     """strategy.jl:107-136 `_update_stats!` on the side outputs of a forward/backward pair."""
     s, cam = _scene(pkg, orc, 500, 96, 64, 1, 61, sigma_px=4.0)

@@ -36,6 +36,7 @@ struct GsrAux; covisibilities::Ptr{UInt8}; uncertainties::Ptr{Float32}; end
 struct GsrGrads
     vmeans::Ptr{Float32}; vshs::Ptr{Float32}; vopacities::Ptr{Float32}
     vscales::Ptr{Float32}; vrotations::Ptr{Float32}; vR::Ptr{Float32}; vt::Ptr{Float32}
+    vcolors::Ptr{Float32}  # C_NULL: classic form (∇shs written); see gsr.h for the factored multi-view form
 end
 
 check(rc) = rc == 0 || error(unsafe_string(ccall((:gsr_last_error_string, LIB), Cstring, ())))
@@ -99,7 +100,7 @@ function ChainRulesCore.rrule(::typeof(GaussianSplatting.rasterize), means_3d::R
         check(ccall((:gsr_backward, LIB), Cint,
             (Ptr{Cvoid}, Ref{GsrInputs}, Ref{GsrCamera}, Ptr{Float32}, Ref{GsrGrads}, Ptr{Cvoid}),
             rast.handle, inp, cam, dptr(vp),
-            GsrGrads(dptr(vmeans), dptr(vshs), dptr(vopac), dptr(vscales), dptr(vrot), dptr(vR), dptr(vt)), hipstream()))
+            GsrGrads(dptr(vmeans), dptr(vshs), dptr(vopac), dptr(vscales), dptr(vrot), dptr(vR), dptr(vt), dptr(nothing)), hipstream()))
         return (NoTangent(), vmeans, vshs, vopac, vscales, vrot, vR, vt)
     end
     return image, _pullback

@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--with-optimizer", action="store_true",
                     help="also run the functor prologue, its pullback and the 6-group Adam step each iteration "
                          "(SURVEY.md §8f rank 1; NOT part of the headline metric, reported under `trainer_tail`)")
+    ap.add_argument("--ply", default=None, help="render a 3DGS .ply scene (gaussians.jl export_ply layout) instead of "
+                                                "the synthetic one; N and the SH degree come from the file")
     ap.add_argument("--reference-lists", action="store_true",
                     help="keep the reference's (Gaussian, tile) instance lists instead of exact footprint culling")
     args = ap.parse_args()
@@ -83,7 +85,13 @@ def main():
     dev = torch.device("cuda", local)
 
     W, H, N, deg = args.width, args.height, args.n, args.sh_degree
-    s = pkg.synthetic.make_scene(N, W, H, deg, args.seed)
+    s = pkg.synthetic.make_scene(N if args.ply is None else 16, W, H, deg, args.seed)
+    if args.ply is not None:
+        gm = pkg.ply.import_ply(args.ply)
+        N, deg = gm.n, gm.max_sh_degree
+        s.means, s.rotations = gm.points, gm.rotations
+        s.shs = np.ascontiguousarray(np.concatenate([gm.features_dc, gm.features_rest], 1))
+        s.scales_raw, s.opacities_raw, s.sh_degree = gm.scales, gm.opacities.reshape(-1), deg
     K = s.shs.shape[1]
     view = rank % args.views
     if world == 1:
@@ -221,9 +229,11 @@ def main():
         "metric": "fwd+bwd Mpixels/s @1920x1080, 1M Gaussians SH=3",
         "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic" if args.ply is None else "ply scene, synthetic camera and target",
         "config": {"workload": ("config3: 1M Gaussians, SH deg 3, 1920x1080, fwd + L1/0.2*DSSIM loss + bwd"
-                                if not args.no_loss and (N, W, H, deg) == (1_000_000, 1920, 1080, 3) else
+                                if not args.no_loss and args.ply is None and (N, W, H, deg) == (1_000_000, 1920, 1080, 3) else
+                                f"ply scene {os.path.basename(args.ply)}: N={N} SH{deg} {W}x{H} fwd{'' if args.no_loss else '+loss'}+bwd"
+                                if args.ply is not None else
                                 f"N={N} SH{deg} {W}x{H} fwd{'' if args.no_loss else '+loss'}+bwd"),
                    "n_gaussians": N, "visible": V, "tile_instances": Dn, "views_per_gpu": 1,
                    "tile_lists": "reference" if args.reference_lists else "exact footprint cull (same outputs)",

@@ -5,6 +5,7 @@ the host-side mirror of the reference's `GaussianRasterizer` / `rasterize` /
 `∇rasterize` / `fused_ssim` interface.  Import via `gsr_pkg.load()`.
 """
 from . import synthetic  # noqa: F401
+from . import ply  # noqa: F401
 from . import _lib  # noqa: F401
 from .camera import Camera  # noqa: F401
 

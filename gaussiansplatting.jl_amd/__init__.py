@@ -6,6 +6,7 @@ the host-side mirror of the reference's `GaussianRasterizer` / `rasterize` /
 """
 from . import synthetic  # noqa: F401
 from . import ply  # noqa: F401
+from . import checkpoint  # noqa: F401
 from . import _lib  # noqa: F401
 from .camera import Camera  # noqa: F401
 

@@ -4,8 +4,8 @@
 These fixtures are produced by the CPU ORACLE (oracle/gsr_oracle.c), not by the
 reference: the reference is GPU-only Julia and cannot run in the build image
 (SURVEY.md §0, §8c), and it ships no golden vectors of its own.  They freeze inputs +
-every intermediate + all gradients of three tiny scenes (one per render mode) and one
-SSIM case, so that (a) the oracle cannot drift silently and (b) the HIP path is checked
+every intermediate + all gradients of three tiny scenes (one per render mode), one
+SSIM case and one trainer-tail case (prologue + Adam), so that (a) the oracle cannot drift silently and (b) the HIP path is checked
 against committed numbers on the GPU box, where /root/reference does not exist.
 
     python tests/golden/make_golden.py
@@ -58,11 +58,33 @@ def ssim_case():
                 loss=loss, vpixels=vp)
 
 
+def trainer_case():
+    """Functor prologue + pullback and three Adam steps (trainer tail)."""
+    rng = np.random.default_rng(205)
+    n, kr = 97, 15
+    dc = rng.normal(size=(n, 1, 3)).astype(np.float32)
+    rest = rng.normal(size=(n, kr, 3)).astype(np.float32)
+    o = (rng.normal(size=(n, 1)) * 3).astype(np.float32)
+    sc = rng.normal(size=(n, 3)).astype(np.float32)
+    shs, oa, sa = orc.prologue_forward(dc, rest, o, sc)
+    vshs, voa, vsa = (rng.normal(size=a.shape).astype(np.float32) for a in (shs, oa, sa))
+    vdc, vrest, vo, vs = orc.prologue_backward(oa, sa, vshs, voa, vsa, 3)
+    theta = rng.normal(size=n * kr * 3).astype(np.float32)
+    th, mu, nu = theta.copy(), np.zeros_like(theta), np.zeros_like(theta)
+    grads = [(rng.normal(size=theta.size) * 10.0 ** rng.uniform(-3, 1)).astype(np.float32) for _ in range(3)]
+    for k, g in enumerate(grads, 1):
+        orc.adam_step(th, g, mu, nu, k, 2.5e-3 / 20, 0.9, 0.999, 1e-15)
+    return dict(sh_color=dc, sh_remainder=rest, opacities=o, scales=sc, shs=shs, opacities_act=oa, scales_act=sa,
+                vshs=vshs, vopacities_act=voa, vscales_act=vsa, v_sh_color=vdc, v_sh_remainder=vrest, v_opacities=vo,
+                v_scales=vs, theta0=theta, grads=np.stack(grads), lr=np.float32(2.5e-3 / 20), theta3=th, mu3=mu, nu3=nu)
+
+
 def main():
     pkg = gsr_pkg.load()
     for mode, deg, seed, W, H, n in CASES:
         np.savez_compressed(os.path.join(HERE, f"scene_{mode}.npz"), **scene_case(pkg, mode, deg, seed, W, H, n))
     np.savez_compressed(os.path.join(HERE, "ssim.npz"), **ssim_case())
+    np.savez_compressed(os.path.join(HERE, "trainer.npz"), **trainer_case())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -76,3 +76,38 @@ def test_hip_matches_golden_ssim(pkg):
     assert np.array_equal(m.cpu().numpy(), f["ssim_map"])
     g = F.fused_ssim_bwd(dev(f["img"]), dev(f["ref"]), dev(f["dL_dmap"]), d0, d1, d2)
     assert np.array_equal(g.cpu().numpy(), f["dL_dimg"])
+
+
+def test_oracle_reproduces_golden_trainer_tail(orc):
+    f = load("trainer.npz")
+    shs, oa, sa = orc.prologue_forward(f["sh_color"], f["sh_remainder"], f["opacities"], f["scales"])
+    assert np.array_equal(shs, f["shs"]) and np.array_equal(oa, f["opacities_act"]) and np.array_equal(sa, f["scales_act"])
+    out = orc.prologue_backward(f["opacities_act"], f["scales_act"], f["vshs"], f["vopacities_act"], f["vscales_act"], 3)
+    for got, k in zip(out, ("v_sh_color", "v_sh_remainder", "v_opacities", "v_scales")):
+        assert np.array_equal(got, f[k]), k
+    th, mu, nu = f["theta0"].copy(), np.zeros_like(f["theta0"]), np.zeros_like(f["theta0"])
+    for k, g in enumerate(f["grads"], 1):
+        orc.adam_step(th, np.ascontiguousarray(g), mu, nu, k, float(f["lr"]), 0.9, 0.999, 1e-15)
+    assert np.array_equal(th, f["theta3"]) and np.array_equal(mu, f["mu3"]) and np.array_equal(nu, f["nu3"])
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden_trainer_tail(pkg):
+    import torch
+    f = load("trainer.npz")
+    d = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    R = pkg.rasterizer
+    shs, oa, sa = R.prologue_forward(d(f["sh_color"]), d(f["sh_remainder"]), d(f["opacities"]), d(f["scales"]))
+    assert np.array_equal(shs.cpu().numpy(), f["shs"])
+    np.testing.assert_allclose(oa.cpu().numpy(), f["opacities_act"], rtol=5e-7)
+    np.testing.assert_allclose(sa.cpu().numpy(), f["scales_act"], rtol=5e-7)
+    out = R.prologue_backward(d(f["opacities_act"]), d(f["scales_act"]), d(f["vshs"]), d(f["vopacities_act"]),
+                              d(f["vscales_act"]), 3)
+    for got, k in zip(out, ("v_sh_color", "v_sh_remainder", "v_opacities", "v_scales")):
+        assert np.array_equal(got.cpu().numpy(), f[k]), k
+    th = d(f["theta0"])
+    opt = pkg.optim.Adam(th, float(f["lr"]), eps=1e-15)
+    for g in f["grads"]:
+        opt.step(th, d(g))
+    assert np.array_equal(th.cpu().numpy(), f["theta3"])
+    assert np.array_equal(opt.mu.cpu().numpy(), f["mu3"]) and np.array_equal(opt.nu.cpu().numpy(), f["nu3"])

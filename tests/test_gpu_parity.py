@@ -237,6 +237,43 @@ def test_tile_bin_overflow_regrows_and_repeats(pkg, orc):
     _compare_forward(st2, run, run.forward())
 
 
+def test_footprint_masks_are_conservative(pkg, orc):
+    """The per-instance row / quadrant masks only ever skip work: every pixel that passes the exact
+    test (sigma >= 0, alpha >= 1/255; render.jl:92-95) must lie in a flagged row AND a flagged
+    quadrant of its instance — for isotropic, elongated and large splats, both list modes."""
+    W, H, n = 160, 96, 2500
+    s = pkg.synthetic.make_scene(n, W, H, 0, 29, sigma_px=5.0)
+    rng = np.random.default_rng(29)
+    scales = (s.scales * np.exp(rng.normal(0, 0.8, (n, 3)))).astype(np.float32)  # strong anisotropy
+    cam = orc.Camera(W, H, s.focal)
+    ys, xs = np.mgrid[0:16, 0:16]
+    gx = (W + 15) // 16
+    for exact in (False, True):
+        run = HipRun(pkg, s.means, s.shs, s.opacities, scales, s.rotations, cam, 0, exact_tile_cull=exact)
+        run.forward()
+        masks = run.rast.instance_masks.cpu().numpy().astype(np.int64)
+        ids = run.rast.values_sorted.cpu().numpy()
+        ranges = run.rast.ranges.cpu().numpy().reshape(-1, 2)
+        geo = {k: v.cpu().numpy() for k, v in run.rast.geometry().items()}
+        m2, con, op = geo["means2d"], geo["conics"], s.opacities
+        checked = active_rows = flagged_rows = 0
+        for t in range(ranges.shape[0]):
+            X0, Y0 = (t % gx) * 16, (t // gx) * 16
+            for p in range(ranges[t, 0], ranges[t, 1]):
+                g, m = ids[p], masks[p]
+                dx, dy = m2[g, 0] - (X0 + xs), m2[g, 1] - (Y0 + ys)
+                sig = 0.5 * (con[g, 0] * dx * dx + con[g, 2] * dy * dy) + con[g, 1] * dx * dy
+                act = (sig >= 0) & (np.minimum(0.99, op[g] * np.exp(-sig)) >= 1.0 / 255.0)
+                rows = act.any(1)
+                assert not (rows & ~((m >> np.arange(16)) & 1).astype(bool)).any(), (t, p, hex(m))
+                for q in range(4):
+                    if act[8 * (q >> 1):8 * (q >> 1) + 8, 8 * (q & 1):8 * (q & 1) + 8].any():
+                        assert (m >> (16 + q)) & 1, (t, p, q, hex(m))
+                checked += 1; active_rows += int(rows.sum()); flagged_rows += bin(m & 0xFFFF).count("1")
+        assert checked > 3000
+        assert flagged_rows <= 1.25 * active_rows + 16  # and they are tight: few rows flagged beyond the active ones
+
+
 def test_large_footprints_and_deterministic_gradients(pkg, orc):
     """Splats covering hundreds of tiles take the wave-cooperative row-sum path of the
     per-Gaussian backward; gradients are summed in a fixed order, so two runs agree bit for bit."""

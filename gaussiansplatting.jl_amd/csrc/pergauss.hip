@@ -18,6 +18,7 @@
 
 namespace {
 
+constexpr uint32_t EMIT_COOP = 48;  // tiles per rect above which the wave emits cooperatively
 constexpr float SH0 = 0.28209479177387814f;
 constexpr float SH1 = 0.4886025119029199f;
 constexpr float SH2C1 = 1.0925484305920792f;
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
     const int i = blockIdx.x * 256 + threadIdx.x;
     bool visible = false;
     uint32_t area = 0, clamp_bits = 0;
-    float m2[2] = {0, 0}, conic[3] = {0, 0, 0}, rgb[3] = {0, 0, 0}, mc_z = 0.0f;
+    float m2[2] = {0, 0}, conic[3] = {0, 0, 0}, rgb[3] = {0, 0, 0}, mc_z = 0.0f, tau = 0.0f;
     int rmin[2] = {0, 0}, rmax[2] = {0, 0};
     if (i < n) {
         M33 R; float t[3];
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
             }
             get_rect(m2[0], m2[1], radius, cam.grid_x, cam.grid_y, rmin, rmax);
             area = (uint32_t)((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]));
-            const float tau = footprint_tau(opac[i]);
+            tau = footprint_tau(opac[i]);
             // duplicate_with_keys! (utils.jl:85-120) restated per tile, fused into this kernel: the
             // instance takes the next free position of its tile's BIN (a fixed-capacity segment of
             // `bins`, capacity from the previous view) with a returning atomic on the tile's counter
@@ -327,7 +328,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
                     }
                 np = 0;
             };
-            for (int y = rmin[1]; y < rmax[1]; y++) {
+            // (rects of more than EMIT_COOP tiles are emitted by the whole wave below)
+            for (int y = rmin[1]; y < rmax[1] && area <= EMIT_COOP; y++) {
                 int x = rmin[0];
                 while (x < rmax[0]) {
                     const int t = y * cam.grid_x + x;
@@ -348,6 +350,35 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
                 }
             }
             flush();
+        }
+    }
+    // Large footprints: one thread walking hundreds of tiles serialises the wave (the reference's
+    // duplicate_with_keys! has exactly this loop, utils.jl:96-119).  Rects of more than EMIT_COOP
+    // tiles are emitted by the whole wave, one tile per lane and round — same tests on the same
+    // (broadcast) floats, so the lists are identical.
+    {
+        const int lane = threadIdx.x & 63;
+        unsigned long long big = __builtin_amdgcn_ballot_w64(visible && area > EMIT_COOP);
+        while (big) {
+            const int src = __builtin_ctzll(big);
+            big &= big - 1;
+            const float bmx = __shfl(m2[0], src), bmy = __shfl(m2[1], src);
+            const float ba = __shfl(conic[0], src), bb = __shfl(conic[1], src), bc = __shfl(conic[2], src);
+            const float btau = __shfl(tau, src);
+            const int bx0 = __shfl(rmin[0], src), by0 = __shfl(rmin[1], src);
+            const int bx1 = __shfl(rmax[0], src), by1 = __shfl(rmax[1], src);
+            const uint32_t bz = __shfl(__float_as_uint(mc_z), src);
+            const uint64_t bkey = ((uint64_t)bz << 32) | (uint32_t)(blockIdx.x * 256 + (threadIdx.x & ~63) + src);
+            const int w = bx1 - bx0, total = w * (by1 - by0);
+            for (int e = lane; e < total; e += 64) {
+                const int ry = e / w, rx = e - ry * w;
+                const int x = bx0 + rx, y = by0 + ry;
+                if (!cam.exact_cull || tile_may_touch(bmx, bmy, ba, bb, bc, btau, x * GSR_TILE, y * GSR_TILE)) {
+                    const uint32_t t = (uint32_t)(y * cam.grid_x + x);
+                    const uint32_t pos = atomicAdd(tile_count + t, 1u);
+                    if (pos < bin_cap) bins[(size_t)t * bin_cap + pos] = bkey;
+                }
+            }
         }
     }
     // Exclusive scan of the tile-rect areas inside the block: with bpre[block] (tile_scan) it

@@ -217,11 +217,12 @@ __device__ __forceinline__ void sort_and_emit(uint64_t* buf, uint32_t m, uint32_
     }
 }
 
-// CAP = LDS key capacity of this launch.  The kernel is launched twice: CAP = 1024 (8 KB of
-// LDS, full wave occupancy — most tiles) handles lists of <= 1024 instances, CAP = 4096 (32 KB)
-// the longer ones (and, through a global slab, lists beyond 4096); a workgroup whose tile
-// belongs to the other launch exits immediately.
-template <int CH, int CAP>
+// CAP = LDS key capacity of this launch, LO = the longest list the smaller launches handle.
+// Up to three launches, chosen by the host from the scan's longest list: CAP = 1024 (8 KB of
+// LDS, full wave occupancy — most tiles), CAP = 4096 (32 KB) only if a list exceeds 1024, and
+// CAP = 8192 (64 KB; beyond that a global slab) only if one exceeds 4096.  A workgroup whose
+// tile belongs to another launch exits immediately.
+template <int CH, int CAP, int LO>
 __global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restrict__ tile_start,
                                                         const uint64_t* __restrict__ bins, uint32_t bin_cap,
                                                         uint64_t* __restrict__ big_scratch,
@@ -231,11 +232,10 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restri
                                                         uint32_t* __restrict__ values_sorted,
                                                         uint32_t* __restrict__ ranges) {
     __shared__ uint64_t skeys[CAP];
-    __shared__ uint32_t slab_s;
     const int tile = blockIdx.x, tid = threadIdx.x;
     const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
     const uint32_t n = end - start;
-    if (CAP < GSR_SORT_LDS_CAP ? n > (uint32_t)CAP : n <= 1024u) return;  // the other launch handles this tile
+    if ((LO >= 0 && n <= (uint32_t)LO) || (CAP < GSR_SORT_LDS_CAP && n > (uint32_t)CAP)) return;  // another launch's tile
     if (tid == 0) {
         // identify_tile_range! (utils.jl:56-78): empty tiles keep the (0,0) of the prior fill!
         ranges[2 * tile] = n ? start : 0u;
@@ -251,9 +251,11 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restri
     } else {
         // oversized tile: same network through a global-scratch slab (rare; slabs are sized by
         // the host from the scan's totals and handed out with one atomic per oversized tile)
-        if (tid == 0) slab_s = atomicAdd(slab_counter, 1u);
+        uint32_t* slab_s = reinterpret_cast<uint32_t*>(skeys);  // the LDS array is idle on this path
+        if (tid == 0) *slab_s = atomicAdd(slab_counter, 1u);
         __syncthreads();
-        uint64_t* slab = big_scratch + (size_t)slab_s * big_scratch_stride;
+        uint64_t* slab = big_scratch + (size_t)(*slab_s) * big_scratch_stride;
+        __syncthreads();
         sort_and_emit<CH>(slab, m, n, start, tid, X0, Y0, keys, geom, stream, values_sorted);
     }
 }
@@ -283,12 +285,20 @@ void gsr_launch_tile_order(hipStream_t s, int n_tiles, const uint32_t* tile_coun
 }
 
 void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start,
-                          const uint64_t* bins, uint32_t bin_cap, uint64_t* big_scratch, uint32_t big_scratch_stride, uint32_t* slab_counter, GsrGeom geom,
-                          GsrStream stream, uint32_t* values_sorted, uint32_t* ranges) {
-#define LAUNCH(CC, CAPV)                                                                                          \
-    hipLaunchKernelGGL((tile_sort_kernel<CC, CAPV>), dim3(n_tiles), dim3(256), 0, s, tile_start, bins, bin_cap, big_scratch, \
-                       big_scratch_stride, slab_counter, grid_x, geom, stream, values_sorted, ranges)
-    if (channels > 5) { LAUNCH(8, 1024); LAUNCH(8, GSR_SORT_LDS_CAP); }
-    else { LAUNCH(3, 1024); LAUNCH(3, GSR_SORT_LDS_CAP); }
+                          uint32_t max_tile, const uint64_t* bins, uint32_t bin_cap, uint64_t* big_scratch,
+                          uint32_t big_scratch_stride, uint32_t* slab_counter, GsrGeom geom, GsrStream stream,
+                          uint32_t* values_sorted, uint32_t* ranges) {
+#define LAUNCH(CC, CAPV, LOV)                                                                                     \
+    hipLaunchKernelGGL((tile_sort_kernel<CC, CAPV, LOV>), dim3(n_tiles), dim3(256), 0, s, tile_start, bins, bin_cap, \
+                       big_scratch, big_scratch_stride, slab_counter, grid_x, geom, stream, values_sorted, ranges)
+    if (channels > 5) {
+        LAUNCH(8, 1024, -1);
+        if (max_tile > 1024u) LAUNCH(8, 4096, 1024);
+        if (max_tile > 4096u) LAUNCH(8, GSR_SORT_LDS_CAP, 4096);
+    } else {
+        LAUNCH(3, 1024, -1);
+        if (max_tile > 1024u) LAUNCH(3, 4096, 1024);
+        if (max_tile > 4096u) LAUNCH(3, GSR_SORT_LDS_CAP, 4096);
+    }
 #undef LAUNCH
 }

@@ -333,7 +333,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
         if ((rc = h->big_scratch.ensure((size_t)n_big * big_stride * 8))) return rc;
     }
     h->prof.begin(ST_SORT, s);
-    gsr_launch_tile_sort(s, h->n_tiles, h->grid_x, C, h->tile_start.as<uint32_t>(), h->bins.as<uint64_t>(), h->bin_cap,
+    gsr_launch_tile_sort(s, h->n_tiles, h->grid_x, C, h->tile_start.as<uint32_t>(), max_tile, h->bins.as<uint64_t>(), h->bin_cap,
                          h->big_scratch.as<uint64_t>(), big_stride, totals + 3, geom_of(h), stream_of(h),
                          h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>());
     h->prof.end(s);

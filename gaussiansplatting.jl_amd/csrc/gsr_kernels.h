@@ -6,7 +6,7 @@
 
 #define GSR_TILE 16         // GaussianSplatting.jl:55 BLOCK
 #define GSR_BATCH 256       // GaussianSplatting.jl:56 BLOCK_SIZE
-#define GSR_SORT_LDS_CAP 4096  // keys per tile sorted in LDS (32 KB); longer lists use the global path
+#define GSR_SORT_LDS_CAP 8192  // keys per tile sorted in LDS (64 KB); longer lists use the global path
 
 // Camera + config constants, passed BY VALUE as a kernel argument (lands in SGPRs).
 struct GsrCam {
@@ -84,7 +84,8 @@ void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count
 void gsr_launch_tile_order(hipStream_t s, int n_tiles, const uint32_t* tile_count, const uint32_t* totals,
                            uint32_t* order);
 void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start,
-                          const uint64_t* bins, uint32_t bin_cap, uint64_t* big_scratch, uint32_t big_scratch_stride, uint32_t* slab_counter, GsrGeom geom,
+                          uint32_t max_tile /* longest list, from the scan */, const uint64_t* bins, uint32_t bin_cap,
+                          uint64_t* big_scratch, uint32_t big_scratch_stride, uint32_t* slab_counter, GsrGeom geom,
                           GsrStream stream, uint32_t* values_sorted, uint32_t* ranges);
 
 // ---- composite.hip ----

@@ -181,6 +181,7 @@ __global__ __launch_bounds__(256 / PPL) void composite_bwd_kernel(int W, int H, 
     const gsr::LaneBits lane_bits(lane);
     const int red_slot = gsr::wave_reduce_index<NA>(lane);  // which partial this lane ends up holding
     const bool red_writer = gsr::wave_reduce_writer(lane);
+    const gsr::RowColConsts rowcol(lane);
     const int tile = (int)tile_order[blockIdx.x];  // 1-D grid in launch order: longest lists first
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
     const int px = tile_x * GSR_TILE + (lane & 15);
@@ -306,24 +307,31 @@ __global__ __launch_bounds__(256 / PPL) void composite_bwd_kernel(int W, int H, 
 #pragma unroll
             for (int w = 0; w < BB / 64; w++)
                 if ((j >> 6) == w) touched[w] |= 1ull << (j & 63);
-            float part[16];
+            if (C == 3) {
+                // :rgb — reduce {P, U1, U2, rgb} over the 4 lanes of each pixel column first, apply the
+                // column's dx weights, then finish over the 16 columns (wave_reduce.h: 5 swaps, not 8)
+                const float total = gsr::wave_reduce_rowcol_rgb(P, U1, U2, col[0], col[1], col[2], dx, lane_bits, rowcol);
+                if (rowcol.slot >= 0) my[j * ST + rowcol.slot] = total;
+            } else {
+                float part[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) part[k] = 0.0f;
-            const float dxp = dx * P;
-            part[0] = col[0]; part[1] = col[1]; part[2] = col[2];
-            part[3] = P;         // Σ G·vα          -> v opacity
-            part[4] = dx * dxp;  // Σ dx²·G·vα      -> v conic.x  (× -o/2 in the flush)
-            part[5] = dx * U1;   // Σ dx·dy·G·vα    -> v conic.y
-            part[6] = U2;        // Σ dy²·G·vα      -> v conic.z
-            part[7] = dxp;       // Σ dx·G·vα   }   -> v mean2d = -o·(conic · these)
-            part[8] = U1;        // Σ dy·G·vα   }
-            if (C > 3) part[9] = col[3];  // depth feature; channel 4 (constant 1) is not a parameter
-            if (C > 5) { part[10] = col[5]; part[11] = col[6]; part[12] = col[7]; }
-            // transposed wave64 reduction: ~3·NA/2 + 6 VALU ops, then ONE ds_write for all NA sums
-            const float total = gsr::wave_reduce_transposed<NA>(part, lane_bits);
-            // (storing the sums straight into the global row when NW == 1 measured 3 % slower than
-            // the LDS slab + coalesced 64-byte row stores below)
-            if (red_writer) my[j * ST + red_slot] = total;
+                for (int k = 0; k < 16; k++) part[k] = 0.0f;
+                const float dxp = dx * P;
+                part[0] = col[0]; part[1] = col[1]; part[2] = col[2];
+                part[3] = P;         // Σ G·vα          -> v opacity
+                part[4] = dx * dxp;  // Σ dx²·G·vα      -> v conic.x  (× -o/2 in the flush)
+                part[5] = dx * U1;   // Σ dx·dy·G·vα    -> v conic.y
+                part[6] = U2;        // Σ dy²·G·vα      -> v conic.z
+                part[7] = dxp;       // Σ dx·G·vα   }   -> v mean2d = -o·(conic · these)
+                part[8] = U1;        // Σ dy·G·vα   }
+                if (C > 3) part[9] = col[3];  // depth feature; channel 4 (constant 1) is not a parameter
+                if (C > 5) { part[10] = col[5]; part[11] = col[6]; part[12] = col[7]; }
+                // transposed wave64 reduction: ~3·NA/2 + 6 VALU ops, then ONE ds_write for all NA sums
+                const float total = gsr::wave_reduce_transposed<NA>(part, lane_bits);
+                // (storing the sums straight into the global row when NW == 1 measured 3 % slower than
+                // the LDS slab + coalesced 64-byte row stores below)
+                if (red_writer) my[j * ST + red_slot] = total;
+            }
           }
         }
         if (lane == 0) {

@@ -92,6 +92,55 @@ __device__ __forceinline__ float wave_reduce_transposed(float (&v)[16], const La
 // Lanes whose result is complete and which are pairwise distinct per input (bit 1 clear, bit 2 set).
 __device__ __forceinline__ bool wave_reduce_writer(int lane) { return (lane & 6) == 4; }
 
+// ---- row-then-column reduction of the backward's partials (mode :rgb) ----
+// The wave is 4 rows of 16 lanes; lanes l, l^16, l^32, l^48 sit in the same pixel COLUMN, and
+// the three geometric moments the gradient row needs are P, dx*P, dx^2*P and U1, dx*U1 with dx a
+// function of the column only.  So the six per-lane sums {P, U1, c0, c1, U2, c2} are first
+// reduced over the 4 rows (two transposed swap levels: 5 swaps instead of 8 for nine values),
+// each row of lanes then expands what it holds with its dx weights into at most 3 outputs, and
+// the 16-lane tail of the network finishes.  Row r (= lane >> 4) ends up with:
+//   r = 0: {P, dx*P, dx^2*P}   r = 1: {c0, U2, -}   r = 2: {U1, dx*U1, c2}   r = 3: {c1, -, -}
+// Output j of a row lands on its lanes with (b3, b0) = (0,0): j = 0, (1,0): j = 1, (0,1): j = 2.
+struct RowColConsts {  // loop-invariant per lane
+    float e1, e3, k2, k4;  // o1 = b0*(dx*e1) + b1*k2;  o2 = b0*(dx*dx*e3) + b1*k4
+    int slot;              // index into the 9-float accumulator row this lane's total goes to, or -1
+    __device__ __forceinline__ explicit RowColConsts(int lane) {
+        const int r = lane >> 4;
+        e1 = (r == 0 || r == 2) ? 1.0f : 0.0f;
+        e3 = r == 0 ? 1.0f : 0.0f;
+        k2 = r == 1 ? 1.0f : 0.0f;
+        k4 = r == 2 ? 1.0f : 0.0f;
+        // accumulator row layout (composite.hip): [0..2] rgb, [3] P, [4] dx^2*P, [5] dx*U1, [6] U2, [7] dx*P, [8] U1
+        const int j = (lane & 1) ? 2 : ((lane & 8) ? 1 : 0);
+        const int table[4][3] = {{3, 7, 4}, {0, 6, -1}, {8, 5, 2}, {1, -1, -1}};
+        int t = -1;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+            for (int jj = 0; jj < 3; jj++)
+                if (rr == r && jj == j) t = table[rr][jj];
+        const bool writer = (lane & 6) == 4 && !((lane & 1) && (lane & 8));  // (b3,b0) = (1,1) duplicates j = 2
+        slot = writer ? t : -1;
+    }
+};
+
+__device__ __forceinline__ float wave_reduce_rowcol_rgb(float P, float U1, float U2, float c0, float c1, float c2,
+                                                        float dx, const LaneBits& L, const RowColConsts& K) {
+    // rows: pairs (P,U1), (c0,c1), (U2,c2) over lane^32, then pair + single over lane^16
+    const float a0 = pair_swap32(P, U1), a1 = pair_swap32(c0, c1), a2 = pair_swap32(U2, c2);
+    const float b0 = pair_swap16(a0, a1), b1 = pair_swap16(a2, a2);
+    // column weights
+    const float o0 = b0;
+    const float o1 = b0 * (dx * K.e1) + b1 * K.k2;
+    const float o2 = b0 * ((dx * dx) * K.e3) + b1 * K.k4;
+    // 16 lanes of the row: pair (o0,o1) by b3, o2 alongside; then pair by b0; then the two plain levels
+    const float x0 = pair_level<2>(o0, o1, L), x1 = single_level<2>(o2, L);
+    float r = pair_level<3>(x0, x1, L);
+    r = r + dpp_xor2(r);
+    r = r + dpp_shr4(r);
+    return r;
+}
+
 // Which input a lane ends up holding (the same network run on indices).
 template <int N>
 __device__ __forceinline__ void index_level(int (&idx)[16], bool bit) {

@@ -68,6 +68,9 @@ def main():
     ap.add_argument("--with-optimizer", action="store_true",
                     help="also run the functor prologue, its pullback and the 6-group Adam step each iteration "
                          "(SURVEY.md §8f rank 1; NOT part of the headline metric, reported under `trainer_tail`)")
+    ap.add_argument("--unfused-tail", action="store_true",
+                    help="with --with-optimizer: run prologue pullback, Adam and prologue as three kernels "
+                         "instead of gsr_trainer_tail_step")
     ap.add_argument("--ply", default=None, help="render a 3DGS .ply scene (gaussians.jl export_ply layout) instead of "
                                                 "the synthetic one; N and the SH degree come from the file")
     ap.add_argument("--reference-lists", action="store_true",
@@ -127,15 +130,20 @@ def main():
         lrs = [1.6e-4, 2.5e-3, 2.5e-3 / 20, 2.5e-2, 5e-3, 1e-3]
         opts = [pkg.optim.Adam(t, lr, eps=1e-15) for t, lr in zip(raw, lrs)]
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        tail = {"prologue_fwd": 0.0, "prologue_bwd": 0.0, "adam": 0.0, "n": 0}
+        tail = {"prologue_fwd": 0.0, "prologue_bwd": 0.0, "adam": 0.0, "n": 0, "n_steps": 0}
+        opt_map = dict(zip(pkg.optim.GROUPS, opts))
+        raw_map = dict(zip(pkg.optim.GROUPS, raw))
 
     def step():
         if tail is not None:
             ev[0].record()
-            shs, oa, sa = pkg.rasterizer.prologue_forward(raw[1], raw[2], raw[3], raw[4])
+            if args.unfused_tail or tail["n_steps"] == 0:
+                shs, oa, sa = pkg.rasterizer.prologue_forward(raw[1], raw[2], raw[3], raw[4])
+                params[1], params[2], params[3] = shs, oa, sa
+            # (fused tail: the previous step's gsr_trainer_tail_step already wrote the activated copies)
             ev[1].record()
-            params[1], params[2], params[3] = shs, oa, sa
             params[0], params[4] = raw[0], raw[5]
+            tail["n_steps"] += 1
         img = rast.forward_raw(*params, cam, deg, bg)
         if args.no_loss:
             vp = vpix_fixed
@@ -150,10 +158,15 @@ def main():
         if tail is not None:
             g = D.split_arena(arena, N, K) if not factored else dict(D.split_factored_arena(arena, N), vshs=vshs_sum)
             ev[2].record()
-            vdc, vrest, vo, vs = pkg.rasterizer.prologue_backward(params[2], params[3], g["vshs"], g["vopacities"].view(-1, 1),
-                                                                  g["vscales"], 3)
-            ev[3].record()
-            pkg.optim.step_all(opts, raw, [g["vmeans"], vdc, vrest, vo, vs, g["vrot"]])
+            if args.unfused_tail:
+                vdc, vrest, vo, vs = pkg.rasterizer.prologue_backward(params[2], params[3], g["vshs"], g["vopacities"].view(-1, 1),
+                                                                      g["vscales"], 3)
+                ev[3].record()
+                pkg.optim.step_all(opts, raw, [g["vmeans"], vdc, vrest, vo, vs, g["vrot"]])
+            else:
+                ev[3].record()
+                pkg.optim.trainer_tail_step(opt_map, raw_map, dict(g, vopacities=g["vopacities"].view(-1, 1)),
+                                            params[1], params[2], params[3])
             e4 = torch.cuda.Event(enable_timing=True); e4.record()
             tail["_last"] = (ev[0], ev[1], ev[2], ev[3], e4)
 
@@ -248,6 +261,7 @@ def main():
         out["trainer_tail"] = {k: round(tail[k] / tail["n"], 4) for k in ("prologue_fwd", "prologue_bwd", "adam")}
         out["trainer_tail"]["algorithmic_bytes"] = {"prologue_fwd": 2 * 4 * (3 * K + 4) * N, "prologue_bwd": 2 * 4 * (3 * K + 4) * N + 16 * N,
                                                     "adam": 7 * 4 * (3 * K + 11) * N}
+        out["trainer_tail"]["form"] = "three kernels" if args.unfused_tail else "fused (gsr_trainer_tail_step: 'adam' is the whole tail)"
         out["config"]["workload"] += " + prologue + Adam (trainer tail, not the headline metric)"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, s, W, H, deg, args)

@@ -64,6 +64,11 @@ class AdamGroup(C.Structure):
                 ("count", C.c_int64), ("lr", C.c_float), ("current_step", C.c_uint32)]
 
 
+class TailGrads(C.Structure):
+    _fields_ = [("vmeans", C.c_void_p), ("vshs", C.c_void_p), ("vopacities", C.c_void_p), ("vscales", C.c_void_p),
+                ("vrotations", C.c_void_p)]
+
+
 class GatherGroup(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_words", C.c_int32)]
 
@@ -73,7 +78,7 @@ EXPORTS = ["gsr_create", "gsr_destroy", "gsr_release_scene_buffers", "gsr_memory
            "gsr_allreduce_grads", "gsr_last_error_string", "gsr_version", "gsr_profile_enable",
            "gsr_profile_stage_count", "gsr_profile_stage_name", "gsr_profile_read", "gsr_update_stats",
            "gsr_prologue_forward", "gsr_prologue_backward", "gsr_adam_step", "gsr_stream_triad",
-           "gsr_mask_findall_scratch_bytes", "gsr_mask_findall", "gsr_gather_rows", "gsr_sh_grad_from_views"]
+           "gsr_mask_findall_scratch_bytes", "gsr_mask_findall", "gsr_gather_rows", "gsr_sh_grad_from_views", "gsr_trainer_tail_step"]
 
 _lib = None
 
@@ -121,6 +126,8 @@ def load():
     lib.gsr_mask_findall.argtypes = [vp, C.c_int64, vp, vp, vp, vp]
     lib.gsr_gather_rows.argtypes = [C.POINTER(GatherGroup), i32, vp, C.c_int64, vp]
     lib.gsr_sh_grad_from_views.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.gsr_trainer_tail_step.argtypes = [i32, i32, i32, C.POINTER(TailGrads), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                          C.POINTER(f32), C.POINTER(C.c_uint32), f32, f32, f32, vp, vp, vp, vp]
     lib.gsr_stream_triad.argtypes = [vp, vp, vp, C.c_size_t, f32, vp]
     lib.gsr_profile_enable.argtypes = [vp, i32]
     lib.gsr_profile_stage_name.argtypes = [i32]

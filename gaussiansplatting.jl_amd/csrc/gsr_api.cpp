@@ -545,6 +545,32 @@ int gsr_adam_step(const gsr_adam_group* groups, int32_t n_groups, float beta1, f
     return GSR_OK;
 }
 
+int gsr_trainer_tail_step(int32_t n, int32_t k_rest, int32_t scale_dims, const gsr_tail_grads* grads,
+                          float* const theta[6], float* const mu[6], float* const nu[6], const float lr[6],
+                          const uint32_t current_step[6], float beta1, float beta2, float eps, float* shs,
+                          float* opacities_act, float* scales_act, void* stream) {
+    if (n < 0 || k_rest < 0 || (scale_dims != 1 && scale_dims != 3))
+        return fail(GSR_E_INVALID_ARG, "bad sizes: n=%d k_rest=%d scale_dims=%d", n, k_rest, scale_dims);
+    if (n == 0) return GSR_OK;
+    if (!grads || !theta || !mu || !nu || !lr || !current_step || !shs || !opacities_act || !scales_act)
+        return fail(GSR_E_INVALID_ARG, "null argument");
+    if (!grads->vmeans || !grads->vshs || !grads->vopacities || !grads->vscales || !grads->vrotations)
+        return fail(GSR_E_INVALID_ARG, "null gradient");
+    float lr_t[6];
+    for (int g = 0; g < 6; g++) {
+        if (g == 2 && k_rest == 0) { lr_t[g] = 0.0f; continue; }  // empty features_rest (training.jl:770)
+        if (!theta[g] || !mu[g] || !nu[g]) return fail(GSR_E_INVALID_ARG, "group %d: null array", g);
+        if (current_step[g] == 0) return fail(GSR_E_INVALID_ARG, "group %d: current_step counts from 1", g);
+        const float t = (float)current_step[g];
+        lr_t[g] = lr[g] * sqrtf(1.0f - powf(beta2, t)) / (1.0f - powf(beta1, t));
+    }
+    const float* gr[5] = {grads->vmeans, grads->vshs, grads->vopacities, grads->vscales, grads->vrotations};
+    gsr_launch_trainer_tail((hipStream_t)stream, n, k_rest, scale_dims, gr, theta, mu, nu, lr_t, beta1, beta2, eps, shs,
+                            opacities_act, scales_act);
+    HIPCHK(hipGetLastError());
+    return GSR_OK;
+}
+
 size_t gsr_mask_findall_scratch_bytes(int64_t n) { return n > 0 ? gsr_findall_scratch_bytes(n) : sizeof(uint32_t); }
 
 int gsr_mask_findall(const uint8_t* mask, int64_t n, uint32_t* indices, uint32_t* count_out, void* scratch,

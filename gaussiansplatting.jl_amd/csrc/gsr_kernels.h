@@ -110,6 +110,9 @@ void gsr_launch_prologue_bwd(hipStream_t s, int n, int k_rest, int scale_dims, c
 void gsr_launch_adam(hipStream_t s, int n_groups, float* const* theta, const float* const* grad, float* const* mu,
                      float* const* nu, const long long* count, const float* lr_t, float beta1, float beta2, float eps);
 
+void gsr_launch_trainer_tail(hipStream_t s, int n, int k_rest, int scale_dims, const float* const* grads,
+                             float* const* theta, float* const* mu, float* const* nu, const float* lr_t, float beta1,
+                             float beta2, float eps, float* shs, float* opac_act, float* scales_act);
 size_t gsr_findall_scratch_bytes(long long n);
 void gsr_launch_findall(hipStream_t s, long long n, const uint8_t* mask, uint32_t* indices, uint32_t* count_dev,
                         uint32_t* scratch);

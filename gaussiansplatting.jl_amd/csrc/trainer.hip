@@ -159,6 +159,99 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamGroups G, float beta1, fl
     }
 }
 
+// ---- fused trainer tail: prologue pullback + Adam + prologue of the next step ----
+// One pass over the parameters instead of three (gsr_prologue_backward, gsr_adam_step,
+// gsr_prologue_forward): the gradients arrive w.r.t. the ACTIVATED values (what gsr_backward
+// writes), the chain rule of the prologue is applied in registers, the six NU.Adam states are
+// advanced, and the activated copies the next rasterize() consumes are written straight away.
+// Same fp32 expression trees as the three separate kernels (bit-identical θ, μ, ν).
+struct AdamHyper { float lr_t, beta1, beta2, omb1, omb2, eps; };
+__device__ __forceinline__ float adam_update(float th, float g, float& m, float& v, const AdamHyper& h) {
+    m = h.beta1 * m + h.omb1 * g;
+    v = h.beta2 * v + h.omb2 * (g * g);
+    return th - h.lr_t * m / (sqrtf(v) + h.eps);
+}
+
+// SH block: one thread per coefficient float of shs (N x 3K); element j of a Gaussian's row
+// belongs to sh_color (j < 3) or sh_remainder — two optimizers, two learning rates.
+__global__ __launch_bounds__(256) void tail_sh_kernel(size_t total, int K3, const float* __restrict__ vshs,
+                                                      float* __restrict__ dc, float* __restrict__ dc_mu,
+                                                      float* __restrict__ dc_nu, float* __restrict__ rest,
+                                                      float* __restrict__ rest_mu, float* __restrict__ rest_nu,
+                                                      AdamHyper h_dc, AdamHyper h_rest, float* __restrict__ shs) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const size_t i = e / (size_t)K3;
+    const int j = (int)(e - i * (size_t)K3);
+    const bool is_dc = j < 3;
+    const size_t k = is_dc ? 3 * i + j : (size_t)(K3 - 3) * i + (j - 3);
+    float* th = is_dc ? dc : rest;
+    float* mu = is_dc ? dc_mu : rest_mu;
+    float* nu = is_dc ? dc_nu : rest_nu;
+    float m = mu[k], v = nu[k];
+    const float t = adam_update(th[k], vshs[e], m, v, is_dc ? h_dc : h_rest);
+    th[k] = t; mu[k] = m; nu[k] = v;
+    shs[e] = t;  // hcat(sh_color, sh_remainder) of the next forward
+}
+
+// per-Gaussian block: points (3), opacity logit (1), log-scales (3 or 1), rotations (4)
+__global__ __launch_bounds__(256) void tail_gauss_kernel(int n, int scale_dims, const float* __restrict__ vmeans,
+                                                         const float* __restrict__ vopac_act,
+                                                         const float* __restrict__ vscales_act,
+                                                         const float* __restrict__ vrot,
+                                                         float* __restrict__ points, float* __restrict__ p_mu, float* __restrict__ p_nu,
+                                                         float* __restrict__ opac, float* __restrict__ o_mu, float* __restrict__ o_nu,
+                                                         float* __restrict__ scales, float* __restrict__ s_mu, float* __restrict__ s_nu,
+                                                         float* __restrict__ rots, float* __restrict__ r_mu, float* __restrict__ r_nu,
+                                                         AdamHyper h_p, AdamHyper h_o, AdamHyper h_s, AdamHyper h_r,
+                                                         float* __restrict__ opac_act, float* __restrict__ scales_act) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const size_t k = 3 * (size_t)i + c;
+        float m = p_mu[k], v = p_nu[k];
+        points[k] = adam_update(points[k], vmeans[k], m, v, h_p);
+        p_mu[k] = m; p_nu[k] = v;
+    }
+    {   // σ' = σ(1-σ) with the σ the forward used (the caller's activated copy)
+        const float a = opac_act[i];
+        const float g = vopac_act[i] * (a * (1.0f - a));
+        float m = o_mu[i], v = o_nu[i];
+        const float t = adam_update(opac[i], g, m, v, h_o);
+        opac[i] = t; o_mu[i] = m; o_nu[i] = v;
+        opac_act[i] = sigmoidf_(t);
+    }
+    {
+        float g[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) g[c] = vscales_act[3 * (size_t)i + c] * scales_act[3 * (size_t)i + c];
+        if (scale_dims == 1) {
+            float m = s_mu[i], v = s_nu[i];
+            const float t = adam_update(scales[i], (g[0] + g[1]) + g[2], m, v, h_s);
+            scales[i] = t; s_mu[i] = m; s_nu[i] = v;
+            const float e = expf(t);
+            scales_act[3 * (size_t)i] = e; scales_act[3 * (size_t)i + 1] = e; scales_act[3 * (size_t)i + 2] = e;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const size_t k = 3 * (size_t)i + c;
+                float m = s_mu[k], v = s_nu[k];
+                const float t = adam_update(scales[k], g[c], m, v, h_s);
+                scales[k] = t; s_mu[k] = m; s_nu[k] = v;
+                scales_act[k] = expf(t);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const size_t k = 4 * (size_t)i + c;
+        float m = r_mu[k], v = r_nu[k];
+        rots[k] = adam_update(rots[k], vrot[k], m, v, h_r);
+        r_mu[k] = m; r_nu[k] = v;
+    }
+}
+
 // ---- boolean-mask compaction: findall(mask) and x[:, idxs] (densification.jl:138-191,279-288) ----
 // findall in three small passes: per-1024 popcounts, one-workgroup scan of the block counts,
 // per-block ordered emit (ballot + popcount ranks).  Order-preserving, as Julia's logical indexing.
@@ -346,4 +439,20 @@ void gsr_launch_gather_rows(hipStream_t s, int n_groups, const void* const* src,
     G.block_start[GSR_ADAM_MAX_GROUPS] = blocks;
     if (blocks == 0) return;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, G, idx, count);
+}
+
+void gsr_launch_trainer_tail(hipStream_t s, int n, int k_rest, int scale_dims, const float* const* grads /* vmeans, vshs, vopac_act, vscales_act, vrot */,
+                             float* const* theta /* points, dc, rest, opac, scales, rots */, float* const* mu,
+                             float* const* nu, const float* lr_t /* [6] */, float beta1, float beta2, float eps,
+                             float* shs, float* opac_act, float* scales_act) {
+    if (n <= 0) return;
+    AdamHyper h[6];
+    for (int g = 0; g < 6; g++) h[g] = AdamHyper{lr_t[g], beta1, beta2, 1.0f - beta1, 1.0f - beta2, eps};
+    const int K3 = 3 * (1 + k_rest);
+    const size_t total = (size_t)n * K3;
+    hipLaunchKernelGGL(tail_sh_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, K3, grads[1],
+                       theta[1], mu[1], nu[1], theta[2], mu[2], nu[2], h[1], h[2], shs);
+    hipLaunchKernelGGL(tail_gauss_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, scale_dims, grads[0], grads[2],
+                       grads[3], grads[4], theta[0], mu[0], nu[0], theta[3], mu[3], nu[3], theta[4], mu[4], nu[4],
+                       theta[5], mu[5], nu[5], h[0], h[3], h[4], h[5], opac_act, scales_act);
 }

@@ -68,3 +68,39 @@ def step_all(opts: Sequence[Adam], thetas: Sequence[torch.Tensor], grads: Sequen
             o.current_step += 1
         groups[i] = o._group(t, g)
     L.check(L.load().gsr_adam_step(groups, len(opts), b1, b2, eps, _stream()))
+
+
+GROUPS = ("points", "features_dc", "features_rest", "opacities", "scales", "rotations")  # training.jl:415-416
+
+
+def trainer_tail_step(opts, raw, grads, shs, opacities_act, scales_act):
+    """Prologue pullback + the six `NU.step!` + the prologue of the next forward in one pass
+    (gsr_trainer_tail_step).  `opts`, `raw`: dicts keyed by GROUPS (Adam objects / raw parameter
+    tensors); `grads`: dict with vmeans, vshs, vopacities, vscales, vrot (as gsr_backward wrote
+    them, w.r.t. the activated values); shs / opacities_act / scales_act are updated in place."""
+    n = raw["points"].shape[0]
+    k_rest = 0 if raw["features_rest"] is None or raw["features_rest"].numel() == 0 else int(raw["features_rest"].shape[1])
+    sd = 1 if raw["scales"].shape[-1] == 1 else 3
+    o0 = opts["points"]
+    vp = C.c_void_p
+    th, mu, nu = (vp * 6)(), (vp * 6)(), (vp * 6)()
+    lr, st = (C.c_float * 6)(), (C.c_uint32 * 6)()
+    for g, name in enumerate(GROUPS):
+        o, t = opts[name], raw[name]
+        if (o.beta1, o.beta2, o.eps) != (o0.beta1, o0.beta2, o0.eps):
+            raise ValueError("the six optimizers must share β1, β2, ϵ")
+        empty = t is None or t.numel() == 0
+        if not empty:
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()) or t.numel() != o.mu.numel():
+                raise ValueError(f"{name}: parameter / optimizer state mismatch")
+            o.current_step += 1
+        th[g] = None if empty else t.data_ptr(); mu[g] = None if empty else o.mu.data_ptr()
+        nu[g] = None if empty else o.nu.data_ptr()
+        lr[g], st[g] = o.lr, o.current_step
+    for k in ("vmeans", "vshs", "vopacities", "vscales", "vrot"):
+        if not (grads[k].is_cuda and grads[k].dtype == torch.float32 and grads[k].is_contiguous()):
+            raise ValueError(f"{k} must be a contiguous float32 HIP device tensor")
+    tg = L.TailGrads(grads["vmeans"].data_ptr(), grads["vshs"].data_ptr(), grads["vopacities"].data_ptr(),
+                     grads["vscales"].data_ptr(), grads["vrot"].data_ptr())
+    L.check(L.load().gsr_trainer_tail_step(n, k_rest, sd, C.byref(tg), th, mu, nu, lr, st, o0.beta1, o0.beta2, o0.eps,
+                                           shs.data_ptr(), opacities_act.data_ptr(), scales_act.data_ptr(), _stream()))

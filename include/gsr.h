@@ -234,6 +234,31 @@ typedef struct gsr_adam_group {
 GSR_API int gsr_adam_step(const gsr_adam_group* groups, int32_t n_groups, float beta1, float beta2, float eps,
                           void* stream);
 
+/* The whole trainer tail of `step!` in one pass over the parameters (SURVEY.md §8f rank 1:
+ * "fusing it removes 3 more round-trips"): pullback of the functor prologue
+ * (rasterizer.jl:218-247) + `NU.step!` on the six optimizers (training.jl:768-779) + the
+ * prologue of the NEXT forward.  Group order everywhere: points, features_dc, features_rest,
+ * opacities, scales, rotations (training.jl:415-416).
+ *   grads: the gradients gsr_backward wrote, w.r.t. the ACTIVATED values
+ *   theta/mu/nu[6], lr[6], current_step[6] (counters AFTER increment): the raw parameters and
+ *          the NU.Adam states, updated in place
+ *   shs (3,K,N), opacities_act (1,N), scales_act (3,N): on entry the activated copies the
+ *          forward of THIS step used (σ' and exp' are taken from them), on exit those of the
+ *          updated parameters, ready for the next gsr_forward.
+ * Bit-identical θ, μ, ν to gsr_prologue_backward + gsr_adam_step; features_rest may be empty
+ * (k_rest = 0). */
+typedef struct gsr_tail_grads {
+    const float* vmeans;        /* (3,N) */
+    const float* vshs;          /* (3,K,N) */
+    const float* vopacities;    /* (1,N)  w.r.t. sigmoid(opacities) */
+    const float* vscales;       /* (3,N)  w.r.t. exp(scales) */
+    const float* vrotations;    /* (4,N) */
+} gsr_tail_grads;
+GSR_API int gsr_trainer_tail_step(int32_t n, int32_t k_rest, int32_t scale_dims, const gsr_tail_grads* grads,
+                                  float* const theta[6], float* const mu[6], float* const nu[6], const float lr[6],
+                                  const uint32_t current_step[6], float beta1, float beta2, float eps, float* shs,
+                                  float* opacities_act, float* scales_act, void* stream);
+
 /* Boolean-mask compaction of per-Gaussian arrays — the `x[:, mask]` / `x[:, :, mask]` /
  * `x[mask]` logical indexing that `prune_points!`, `densify_clone!`, `densify_split!` and
  * `_prune_optimizer!` apply to every parameter, both Adam moments and the densification

@@ -176,3 +176,55 @@ def test_ply_scene_renders_like_the_arrays_it_was_exported_from(pkg, orc, tmp_pa
     img2 = rast(dev(g2.points), dev(g2.opacities), dev(g2.scales), dev(g2.rotations), dev(g2.features_dc),
                 dev(g2.features_rest), camera=cam, sh_degree=g2.max_sh_degree)
     assert img1.abs().max() > 0 and torch.equal(img1, img2)
+
+
+@pytest.mark.parametrize("kr,iso", [(15, False), (0, False), (3, True)])
+def test_fused_trainer_tail_equals_the_three_kernels_and_the_oracle(pkg, orc, kr, iso):
+    """gsr_trainer_tail_step == gsr_prologue_backward + gsr_adam_step (+ gsr_prologue_forward of the
+    updated parameters): θ, μ, ν bit-identical, over 3 steps; and equal to the oracle chain."""
+    r = np.random.default_rng(41)
+    n = 777
+    O, R = pkg.optim, pkg.rasterizer
+    shapes = dict(points=(n, 3), features_dc=(n, 1, 3), features_rest=(n, kr, 3), opacities=(n, 1),
+                  scales=(n, 1 if iso else 3), rotations=(n, 4))
+    lrs = dict(points=1.6e-4, features_dc=2.5e-3, features_rest=2.5e-3 / 20, opacities=2.5e-2, scales=5e-3, rotations=1e-3)
+    host = {k: r.normal(size=s).astype(np.float32) for k, s in shapes.items()}
+    raw_a = {k: dev(v) for k, v in host.items()}          # fused path
+    raw_b = {k: dev(v) for k, v in host.items()}          # three kernels
+    opt_a = {k: O.Adam(raw_a[k], lrs[k], eps=1e-15) for k in O.GROUPS}
+    opt_b = {k: O.Adam(raw_b[k], lrs[k], eps=1e-15) for k in O.GROUPS}
+    th_o = {k: v.copy() for k, v in host.items()}         # oracle
+    mu_o = {k: np.zeros(v.size, np.float32) for k, v in host.items()}
+    nu_o = {k: np.zeros(v.size, np.float32) for k, v in host.items()}
+    rest_or_none = lambda d: d["features_rest"] if kr else None  # noqa: E731
+    shs, oa, sa = R.prologue_forward(raw_a["features_dc"], rest_or_none(raw_a), raw_a["opacities"], raw_a["scales"])
+    for step in range(1, 4):
+        g = dict(vmeans=r.normal(size=(n, 3)), vshs=r.normal(size=(n, 1 + kr, 3)), vopacities=r.normal(size=(n, 1)),
+                 vscales=r.normal(size=(n, 3)), vrot=r.normal(size=(n, 4)))
+        g = {k: v.astype(np.float32) for k, v in g.items()}
+        gd = {k: dev(v) for k, v in g.items()}
+        # --- three kernels (activated copies of THIS step's parameters) ---
+        shs_b, oa_b, sa_b = R.prologue_forward(raw_b["features_dc"], rest_or_none(raw_b), raw_b["opacities"], raw_b["scales"])
+        assert torch.equal(shs_b, shs) and torch.equal(oa_b, oa) and torch.equal(sa_b, sa)  # fused left them ready
+        vdc, vrest, vo, vs = R.prologue_backward(oa_b, sa_b, gd["vshs"], gd["vopacities"], gd["vscales"], 1 if iso else 3)
+        names = [k for k in O.GROUPS if raw_b[k].numel()]
+        gmap = dict(points=gd["vmeans"], features_dc=vdc, features_rest=vrest, opacities=vo, scales=vs, rotations=gd["vrot"])
+        O.step_all([opt_b[k] for k in names], [raw_b[k] for k in names], [gmap[k] for k in names])
+        # --- oracle chain ---
+        oa_h, sa_h = oa_b.cpu().numpy(), sa_b.cpu().numpy()   # same activated values as the device used
+        o_vdc, o_vrest, o_vo, o_vs = orc.prologue_backward(oa_h, sa_h, g["vshs"], g["vopacities"], g["vscales"], 1 if iso else 3)
+        omap = dict(points=g["vmeans"], features_dc=o_vdc, features_rest=o_vrest, opacities=o_vo, scales=o_vs, rotations=g["vrot"])
+        for k in names:
+            orc.adam_step(th_o[k].reshape(-1), np.ascontiguousarray(omap[k]).reshape(-1), mu_o[k], nu_o[k], step, lrs[k],
+                          0.9, 0.999, 1e-15)
+        # --- fused ---
+        O.trainer_tail_step(opt_a, raw_a, gd, shs, oa, sa)
+        torch.cuda.synchronize()
+        for k in names:
+            assert torch.equal(raw_a[k], raw_b[k]), (k, step)
+            assert torch.equal(opt_a[k].mu, opt_b[k].mu) and torch.equal(opt_a[k].nu, opt_b[k].nu), (k, step)
+            assert opt_a[k].current_step == step
+            assert np.array_equal(raw_a[k].cpu().numpy(), th_o[k]), (k, step)
+            assert np.array_equal(opt_a[k].mu.cpu().numpy(), mu_o[k]) and np.array_equal(opt_a[k].nu.cpu().numpy(), nu_o[k])
+    if not kr:
+        assert opt_a["features_rest"].current_step == 0   # empty group skipped (training.jl:770)

@@ -224,6 +224,7 @@ __device__ __forceinline__ void sort_and_emit(uint64_t* buf, uint32_t m, uint32_
 // tile belongs to another launch exits immediately.
 template <int CH, int CAP, int LO>
 __global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restrict__ tile_start,
+                                                        uint32_t* __restrict__ tile_count,
                                                         const uint64_t* __restrict__ bins, uint32_t bin_cap,
                                                         uint64_t* __restrict__ big_scratch,
                                                         uint32_t big_scratch_stride,
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restri
     const int tile = blockIdx.x, tid = threadIdx.x;
     const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
     const uint32_t n = end - start;
+    if (LO < 0 && tid == 0) tile_count[tile] = 0u;  // the first launch covers every tile: counter ready for the next view
     if ((LO >= 0 && n <= (uint32_t)LO) || (CAP < GSR_SORT_LDS_CAP && n > (uint32_t)CAP)) return;  // another launch's tile
     if (tid == 0) {
         // identify_tile_range! (utils.jl:56-78): empty tiles keep the (0,0) of the prior fill!
@@ -285,11 +287,12 @@ void gsr_launch_tile_order(hipStream_t s, int n_tiles, const uint32_t* tile_coun
 }
 
 void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start,
-                          uint32_t max_tile, const uint64_t* bins, uint32_t bin_cap, uint64_t* big_scratch,
+                          uint32_t* tile_count, uint32_t max_tile, const uint64_t* bins, uint32_t bin_cap, uint64_t* big_scratch,
                           uint32_t big_scratch_stride, uint32_t* slab_counter, GsrGeom geom, GsrStream stream,
                           uint32_t* values_sorted, uint32_t* ranges) {
 #define LAUNCH(CC, CAPV, LOV)                                                                                     \
-    hipLaunchKernelGGL((tile_sort_kernel<CC, CAPV, LOV>), dim3(n_tiles), dim3(256), 0, s, tile_start, bins, bin_cap, \
+    hipLaunchKernelGGL((tile_sort_kernel<CC, CAPV, LOV>), dim3(n_tiles), dim3(256), 0, s, tile_start, tile_count, bins, \
+                       bin_cap, \
                        big_scratch, big_scratch_stride, slab_counter, grid_x, geom, stream, values_sorted, ranges)
     if (channels > 5) {
         LAUNCH(8, 1024, -1);

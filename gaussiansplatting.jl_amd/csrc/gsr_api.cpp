@@ -113,6 +113,7 @@ struct gsr_handle {
     DevBuf geo, gnormal, radii, bsum, bpre, bvis;
     // BinningState (states.jl:66-85): unsorted keys (per-tile bins of bin_cap slots), sorted ids, sorted splat stream
     uint32_t bin_cap = 0;
+    bool tile_count_dirty = false;  // counters not yet re-zeroed by the tile sort
     DevBuf bins, values_sorted, s0, s1, s2, s3, big_scratch;
     // backward: per-instance gradient rows + instance position map; gstate.∇means_2d
     DevBuf rows, vmean2d;
@@ -211,6 +212,7 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
         return fail(GSR_E_HIP, "hipHostMalloc failed: %s", hipGetErrorString(e));
     }
     (void)hipMemset(h->ranges.p, 0, 2 * T * 4);
+    (void)hipMemset(h->tile_count.p, 0, (T + 2) * 4);
     *out = h;
     return GSR_OK;
 }
@@ -275,8 +277,11 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     }
     for (int attempt = 0;; attempt++) {
         if ((rc = h->bins.ensure((T + 1) * (size_t)h->bin_cap * 8))) return rc;
-        HIPCHK(hipMemsetAsync(h->tile_count.p, 0, (T + 2) * 4, s));
-        HIPCHK(hipMemsetAsync(totals, 0, 8 * 4, s));
+        // The tile counters are zero on entry: gsr_create clears them and the tile sort re-zeroes each
+        // tile's counter as it consumes it (no memset kernel per view; the scan overwrites every total).
+        // Only a pass that did not reach the sort — an error, or the overflow retry below — leaves them dirty.
+        if (h->tile_count_dirty) HIPCHK(hipMemsetAsync(h->tile_count.p, 0, (T + 2) * 4, s));
+        h->tile_count_dirty = true;
         h->prof.begin(ST_PREPROCESS, s);
         gsr_launch_preprocess(s, n, in->n_coeffs, in->sh_degree, C, in->means, in->scales, in->rotations, in->opacities,
                               in->shs, k, geom_of(h), h->tile_count.as<uint32_t>(), h->bvis.as<uint32_t>(),
@@ -311,6 +316,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
         stats->max_tile_instances = (int32_t)max_tile;
     }
     if (D == 0) {
+        h->tile_count_dirty = false;  // every counter is zero
         // rasterizer.jl:283,338: all-zero image, background not applied
         HIPCHK(hipMemsetAsync(image_out, 0, P * C * 4, s));
         HIPCHK(hipMemsetAsync(h->n_contrib.p, 0, P * 4, s));
@@ -333,10 +339,12 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
         if ((rc = h->big_scratch.ensure((size_t)n_big * big_stride * 8))) return rc;
     }
     h->prof.begin(ST_SORT, s);
-    gsr_launch_tile_sort(s, h->n_tiles, h->grid_x, C, h->tile_start.as<uint32_t>(), max_tile, h->bins.as<uint64_t>(), h->bin_cap,
+    gsr_launch_tile_sort(s, h->n_tiles, h->grid_x, C, h->tile_start.as<uint32_t>(), h->tile_count.as<uint32_t>(), max_tile,
+                         h->bins.as<uint64_t>(), h->bin_cap,
                          h->big_scratch.as<uint64_t>(), big_stride, totals + 3, geom_of(h), stream_of(h),
                          h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>());
     h->prof.end(s);
+    h->tile_count_dirty = false;  // tile_sort zeroed the counters
     h->prof.begin(ST_COMPOSITE_FWD, s);
     gsr_launch_composite_fwd(s, C, k, h->tile_start.as<uint32_t>(), h->tile_order.as<uint32_t>(), stream_of(h), in->background, image_out,
                              h->n_contrib.as<uint32_t>(), h->final_T.as<float>(), h->values_sorted.as<uint32_t>(),

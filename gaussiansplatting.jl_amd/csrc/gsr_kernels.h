@@ -84,7 +84,7 @@ void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count
 void gsr_launch_tile_order(hipStream_t s, int n_tiles, const uint32_t* tile_count, const uint32_t* totals,
                            uint32_t* order);
 void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start,
-                          uint32_t max_tile /* longest list, from the scan */, const uint64_t* bins, uint32_t bin_cap,
+                          uint32_t* tile_count /* re-zeroed for the next view */, uint32_t max_tile /* longest list, from the scan */, const uint64_t* bins, uint32_t bin_cap,
                           uint64_t* big_scratch, uint32_t big_scratch_stride, uint32_t* slab_counter, GsrGeom geom,
                           GsrStream stream, uint32_t* values_sorted, uint32_t* ranges);
 

@@ -22,7 +22,32 @@
 
 namespace {
 
-// ---- single-workgroup scan over tiles (T = 8160 at 1080p, 32400 at 4K) ----
+// ---- single-workgroup scans (T = 8160 tiles at 1080p, 32400 at 4K; N/256 Gaussian blocks) ----
+// Each thread owns a CONTIGUOUS chunk of ceil(n/1024) elements: serial sum, one block-wide
+// exclusive scan of the 1024 chunk sums (wave scan + 16 wave totals), serial write-back — two
+// barriers per array instead of four per 1024 elements (this kernel sits before the host sync).
+__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t* wave_sums, uint32_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(x, off);
+        if (lane >= off) x += y;
+    }
+    __syncthreads();  // wave_sums free for reuse
+    if (lane == 63) wave_sums[wave] = x;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        const uint32_t ws = wave_sums[w];
+        woff += w < wave ? ws : 0u;
+        tot += ws;
+    }
+    total = tot;
+    return woff + x - v;
+}
+
 __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint32_t* __restrict__ tile_count,
                                                          uint32_t* __restrict__ tile_start,
                                                          uint32_t* __restrict__ totals, int n_blocks,
@@ -30,98 +55,82 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint
                                                          uint32_t* __restrict__ bpre,
                                                          const uint32_t* __restrict__ bvis) {
     __shared__ uint32_t wave_sums[16];
-    __shared__ uint32_t carry_s;
-    __shared__ uint32_t wave_max[16];
+    __shared__ uint32_t red[3][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    uint32_t vmax = 0;
-    __syncthreads();
-    for (int base = 0; base < n_tiles; base += 1024) {
-        const int i = base + tid;
-        const uint32_t v = i < n_tiles ? tile_count[i] : 0u;
-        vmax = v > vmax ? v : vmax;
-        // inclusive wave scan
-        uint32_t x = v;
+    // tiles: exclusive scan of the counts, longest list, lists beyond the LDS sort
+    {
+        constexpr int PER = 8;  // a wave reads 2 KB contiguous per round; rounds of 8192 elements carry a running total
+        uint32_t vmax = 0, big = 0, total = 0;
+        for (int base = 0; base < n_tiles; base += 1024 * PER) {
+            const int lo = base + tid * PER, hi = min(lo + PER, n_tiles);
+            uint32_t v[PER], sum = 0;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t y = __shfl_up(x, off);
-            if (lane >= off) x += y;
+            for (int k = 0; k < PER; k++) {
+                v[k] = lo + k < hi ? tile_count[lo + k] : 0u;
+                sum += v[k];
+                vmax = v[k] > vmax ? v[k] : vmax;
+                big += v[k] > GSR_SORT_LDS_CAP ? 1u : 0u;
+            }
+            uint32_t round_total;
+            uint32_t run = total + block_exclusive_scan_1024(sum, wave_sums, round_total);
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                if (lo + k < hi) tile_start[lo + k] = run;
+                run += v[k];
+            }
+            total += round_total;
         }
-        if (lane == 63) wave_sums[wave] = x;
-        __syncthreads();
-        uint32_t wave_off = 0;
-        for (int w = 0; w < wave; w++) wave_off += wave_sums[w];
-        const uint32_t carry = carry_s;
-        const uint32_t excl = carry + wave_off + x - v;
-        if (i < n_tiles) tile_start[i] = excl;
-        __syncthreads();
-        if (tid == 1023) carry_s = excl + v;
-        __syncthreads();
-    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        uint32_t y = __shfl_xor(vmax, off);
-        vmax = y > vmax ? y : vmax;
-    }
-    if (lane == 0) wave_max[wave] = vmax;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t m = 0;
-        for (int w = 0; w < 16; w++) m = wave_max[w] > m ? wave_max[w] : m;
-        tile_start[n_tiles] = carry_s;
-        totals[0] = carry_s;
-        totals[1] = m;
-        totals[3] = 0;  // slab allocator of the oversized-tile path
-    }
-    // number of tiles whose list does not fit the LDS sort (they get a global-scratch slab each)
-    uint32_t big = 0;
-    for (int i = tid; i < n_tiles; i += 1024) big += tile_count[i] > GSR_SORT_LDS_CAP ? 1u : 0u;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) big += __shfl_xor(big, off);
-    __syncthreads();
-    if (lane == 0) wave_sums[wave] = big;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t b = 0;
-        for (int w = 0; w < 16; w++) b += wave_sums[w];
-        totals[2] = b;
-    }
-    // second scan: per-block sums of tile-rect areas -> bpre (Gaussian-major instance-slot offsets)
-    __syncthreads();
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < n_blocks; base += 1024) {
-        const int i = base + tid;
-        const uint32_t v = i < n_blocks ? bsum[i] : 0u;
-        uint32_t x = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t y = __shfl_up(x, off);
-            if (lane >= off) x += y;
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t y = __shfl_xor(vmax, off);
+            vmax = y > vmax ? y : vmax;
+            big += __shfl_xor(big, off);
         }
-        if (lane == 63) wave_sums[wave] = x;
+        if (lane == 0) { red[0][wave] = vmax; red[1][wave] = big; }
         __syncthreads();
-        uint32_t wave_off = 0;
-        for (int w = 0; w < wave; w++) wave_off += wave_sums[w];
-        const uint32_t excl = carry_s + wave_off + x - v;
-        if (i < n_blocks) bpre[i] = excl;
-        __syncthreads();
-        if (tid == 1023) carry_s = excl + v;
-        __syncthreads();
+        if (tid == 0) {
+            uint32_t m = 0, b = 0;
+            for (int w = 0; w < 16; w++) { m = red[0][w] > m ? red[0][w] : m; b += red[1][w]; }
+            tile_start[n_tiles] = total;
+            totals[0] = total;  // D
+            totals[1] = m;      // longest list
+            totals[2] = b;      // #tiles over GSR_SORT_LDS_CAP (they get a global-scratch slab each)
+            totals[3] = 0;      // slab allocator of the oversized-tile path
+        }
     }
-    if (tid == 0) totals[5] = carry_s;  // sum of tile-rect areas = number of Gaussian-major instance slots (gradient rows)
-    // visible Gaussians: sum of the per-block counts written by preprocess
-    uint32_t vis = 0;
-    for (int i = tid; i < n_blocks; i += 1024) vis += bvis[i];
+    // Gaussian blocks: per-block sums of tile-rect areas -> bpre (Gaussian-major instance-slot
+    // offsets), and the visible count (per-block counts written by preprocess)
+    {
+        constexpr int PER = 8;
+        uint32_t vis = 0, total = 0;
+        for (int base = 0; base < n_blocks; base += 1024 * PER) {
+            const int lo = base + tid * PER, hi = min(lo + PER, n_blocks);
+            uint32_t v[PER], sum = 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) vis += __shfl_xor(vis, off);
-    __syncthreads();
-    if (lane == 0) wave_sums[wave] = vis;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t v = 0;
-        for (int w = 0; w < 16; w++) v += wave_sums[w];
-        totals[4] = v;
+            for (int k = 0; k < PER; k++) {
+                v[k] = lo + k < hi ? bsum[lo + k] : 0u;
+                sum += v[k];
+                vis += lo + k < hi ? bvis[lo + k] : 0u;
+            }
+            uint32_t round_total;
+            uint32_t run = total + block_exclusive_scan_1024(sum, wave_sums, round_total);
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                if (lo + k < hi) bpre[lo + k] = run;
+                run += v[k];
+            }
+            total += round_total;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vis += __shfl_xor(vis, off);
+        if (lane == 0) red[2][wave] = vis;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t v = 0;
+            for (int w = 0; w < 16; w++) v += red[2][w];
+            totals[4] = v;      // visible Gaussians
+            totals[5] = total;  // sum of tile-rect areas = number of Gaussian-major instance slots (gradient rows)
+        }
     }
 }
 

@@ -55,6 +55,29 @@ def test_config2_100k_1080p_full_oracle_compare(pkg, orc):
     _tile_lists_sorted(run)
 
 
+@pytest.mark.parametrize("mode", ["rgbd", "rgbdn"])
+def test_depth_and_normal_modes_full_oracle_compare(pkg, orc, mode):
+    """:rgbd is the reference's default training mode (rasterizer.jl:57-58): 30 k Gaussians at 960x540,
+    forward and all gradients (generic C = 5 / 8 reduction path of the backward) against the oracle."""
+    W, H, n, deg, seed = 960, 540, 30_000, 2, 1006
+    s = pkg.synthetic.make_scene(n, W, H, deg, seed)
+    cam = orc.Camera(W, H, s.focal)
+    bg = (0.1, 0.2, 0.3)
+    st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, background=bg, mode=mode)
+    run = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, bg, mode=mode)
+    img = run.forward().cpu().numpy()
+    C = img.shape[2]
+    assert np.array_equal(run.rast.values_sorted.cpu().numpy().astype(np.uint32), st.values_sorted)
+    scale = np.maximum(1.0, np.abs(st.image).reshape(-1, C).max(0))      # depth channel is not in [0,1]
+    assert frac_bad(img / scale, st.image / scale, 0, 1e-4) <= 1e-4
+    vp = (np.random.default_rng(seed).standard_normal((H, W, C)) / (C * W * H)).astype(np.float32)
+    g = orc.backward(st, vp, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, background=bg)
+    out = [o.cpu().numpy() for o in run.backward(vp)[:5]]
+    for o, ref, name in zip(out, (g.vmeans, g.vshs, g.vopacities, g.vscales, g.vrots), "means shs opac scales rots".split()):
+        assert rel_l2(o.reshape(-1), ref.reshape(-1)) <= 1e-4, (mode, name)
+    _tile_lists_sorted(run)
+
+
 def _properties(pkg, orc, n, W, H, seed, with_oracle_fwd):
     deg = 3
     s = pkg.synthetic.make_scene(n, W, H, deg, seed)

@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--unfused-tail", action="store_true",
                     help="with --with-optimizer: run prologue pullback, Adam and prologue as three kernels "
                          "instead of gsr_trainer_tail_step")
+    ap.add_argument("--mode", default="rgb", choices=["rgb", "rgbd", "rgbdn"],
+                    help="render mode (the headline metric is :rgb; :rgbd is the reference's default training mode)")
     ap.add_argument("--ply", default=None, help="render a 3DGS .ply scene (gaussians.jl export_ply layout) instead of "
                                                 "the synthetic one; N and the SH degree come from the file")
     ap.add_argument("--reference-lists", action="store_true",
@@ -105,8 +107,8 @@ def main():
     to = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(dev)  # noqa: E731
     params = [to(s.means), to(s.shs), to(s.opacities.reshape(-1, 1)), to(s.scales), to(s.rotations)]
     target = to(pkg.synthetic.make_target(W, H, args.seed + view))
-    vpix_fixed = to(pkg.synthetic.make_vpixels(W, H, 3, args.seed + view))
-    rast = pkg.rasterizer.GaussianRasterizer(W, H, mode="rgb", device=dev, exact_tile_cull=not args.reference_lists)
+    vpix_fixed = to(pkg.synthetic.make_vpixels(W, H, pkg.rasterizer.n_color_features(args.mode), args.seed + view))
+    rast = pkg.rasterizer.GaussianRasterizer(W, H, mode=args.mode, device=dev, exact_tile_cull=not args.reference_lists)
     # world > 1: factored exchange (distributed.py) unless GSR_DIST_FULL_ARENA=1 asks for the plain
     # all-reduce of the whole (11+3K)·N arena
     factored = world > 1 and os.environ.get("GSR_DIST_FULL_ARENA", "0") != "1"
@@ -207,7 +209,8 @@ def main():
     stages = {k: (ms / max(c, 1), c) for k, (ms, c) in prof.items() if c > 0}
     dom = max(stages, key=lambda k: stages[k][0] * stages[k][1])
     dom_ms = stages[dom][0]
-    dom_bytes = algorithmic_bytes(dom, N, V, Dn, P, T, 3, K)
+    Cn = pkg.rasterizer.n_color_features(args.mode)
+    dom_bytes = algorithmic_bytes(dom, N, V, Dn, P, T, Cn, K)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -236,7 +239,7 @@ def main():
                 "algorithmic_bytes": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
                 "stages_ms": {k: round(v[0], 4) for k, v in stages.items()},
                 "whole_step_algorithmic_GBps": round(
-                    sum(algorithmic_bytes(k, N, V, Dn, P, T, 3, K) for k in stages) / (ms_step * 1e-3) / 1e9, 2)}
+                    sum(algorithmic_bytes(k, N, V, Dn, P, T, Cn, K) for k in stages) / (ms_step * 1e-3) / 1e9, 2)}
 
     out = {
         "metric": "fwd+bwd Mpixels/s @1920x1080, 1M Gaussians SH=3",
@@ -244,10 +247,10 @@ def main():
         "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic" if args.ply is None else "ply scene, synthetic camera and target",
         "config": {"workload": ("config3: 1M Gaussians, SH deg 3, 1920x1080, fwd + L1/0.2*DSSIM loss + bwd"
-                                if not args.no_loss and args.ply is None and (N, W, H, deg) == (1_000_000, 1920, 1080, 3) else
+                                if not args.no_loss and args.ply is None and args.mode == "rgb" and (N, W, H, deg) == (1_000_000, 1920, 1080, 3) else
                                 f"ply scene {os.path.basename(args.ply)}: N={N} SH{deg} {W}x{H} fwd{'' if args.no_loss else '+loss'}+bwd"
                                 if args.ply is not None else
-                                f"N={N} SH{deg} {W}x{H} fwd{'' if args.no_loss else '+loss'}+bwd"),
+                                f"N={N} SH{deg} {W}x{H} :{args.mode} fwd{'' if args.no_loss else '+loss'}+bwd"),
                    "n_gaussians": N, "visible": V, "tile_instances": Dn, "views_per_gpu": 1,
                    "tile_lists": "reference" if args.reference_lists else "exact footprint cull (same outputs)",
                    "parallelism": (f"view-parallel x{world}, all-reduce of {11 * N * 4 / 1e6:.0f} MB + all-gather of "

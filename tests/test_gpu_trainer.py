@@ -228,3 +228,37 @@ def test_fused_trainer_tail_equals_the_three_kernels_and_the_oracle(pkg, orc, kr
             assert np.array_equal(opt_a[k].mu.cpu().numpy(), mu_o[k]) and np.array_equal(opt_a[k].nu.cpu().numpy(), nu_o[k])
     if not kr:
         assert opt_a["features_rest"].current_step == 0   # empty group skipped (training.jl:770)
+
+
+def test_end_to_end_fit_reduces_the_loss(pkg):
+    """The whole chain a trainer step runs — functor prologue, rasterize, L1/DSSIM loss head, ∇rasterize,
+    fused trainer tail — fits a perturbed scene back towards the image it was rendered from."""
+    W, H, deg, n = 96, 64, 1, 600
+    s = pkg.synthetic.make_scene(n, W, H, deg, 123, sigma_px=4.0)
+    cam = pkg.Camera(W, H, tuple(s.focal))
+    R, O = pkg.rasterizer, pkg.optim
+    rast = R.GaussianRasterizer(W, H, mode="rgb")
+    gt = [dev(s.means), dev(s.shs[:, :1].copy()), dev(s.shs[:, 1:].copy()), dev(s.opacities_raw.reshape(-1, 1)),
+          dev(s.scales_raw), dev(s.rotations)]
+    shs, oa, sa = R.prologue_forward(gt[1], gt[2], gt[3], gt[4])
+    target_hwc = rast.forward_raw(gt[0], shs, oa, sa, gt[5], cam, deg, (0, 0, 0)).clone()
+    target = target_hwc.permute(2, 0, 1).contiguous()            # (3,H,W) == Julia (W,H,3)
+    rng = np.random.default_rng(5)
+    raw = dict(points=dev(s.means + rng.normal(0, 0.01, s.means.shape).astype(np.float32)),
+               features_dc=dev(s.shs[:, :1] + rng.normal(0, 0.3, (n, 1, 3)).astype(np.float32)),
+               features_rest=dev(s.shs[:, 1:] * 0.5),
+               opacities=dev(s.opacities_raw.reshape(-1, 1) - 0.5), scales=dev(s.scales_raw + 0.1),
+               rotations=dev(s.rotations))
+    lrs = dict(points=1.6e-4, features_dc=2.5e-2, features_rest=2.5e-3, opacities=5e-2, scales=5e-3, rotations=1e-3)
+    opts = {k: O.Adam(raw[k], lrs[k], eps=1e-15) for k in O.GROUPS}
+    shs, oa, sa = R.prologue_forward(raw["features_dc"], raw["features_rest"], raw["opacities"], raw["scales"])
+    losses = []
+    for it in range(60):
+        img = rast.forward_raw(raw["points"], shs, oa, sa, raw["rotations"], cam, deg, (0, 0, 0))
+        loss, vp = pkg.fused_ssim.l1_ssim_loss(rast, img, target)
+        vm, vsh, vo, vsc, vr, _, _ = rast.backward_raw(vp, raw["points"], shs, oa, sa, raw["rotations"], cam, deg, (0, 0, 0))
+        O.trainer_tail_step(opts, raw, dict(vmeans=vm, vshs=vsh, vopacities=vo, vscales=vsc, vrot=vr), shs, oa, sa)
+        losses.append(float(loss))
+    assert all(np.isfinite(losses))
+    assert losses[-1] < 0.6 * losses[0], (losses[0], losses[-1])
+    assert np.mean(losses[-5:]) < np.mean(losses[:5])

@@ -49,6 +49,19 @@ struct RasterSrc {
     }
 };
 
+// Workgroup id -> tile, XCD-aware: workgroups are dealt round-robin to the 8 XCDs (one L2 each).
+// Tiles that share halo rows and columns should share an L2, so XCD x gets the x-th contiguous
+// eighth of the tiles (raster order) instead of every 8th tile.  Grid: (8 * ceil(tiles / 8), 1, planes).
+__device__ __forceinline__ bool ssim_tile_of_block(int W, int H, int& tx0, int& ty0) {
+    const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
+    const int n = gx * gy, per = (n + 7) / 8;
+    const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || t >= n) return false;
+    tx0 = (t % gx) * GSR_TILE;
+    ty0 = (t / gx) * GSR_TILE;
+    return true;
+}
+
 __device__ __forceinline__ float block_sum(float v, float* red /*[4]*/) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -72,8 +85,13 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(Src src, int W, int H, fl
     __shared__ float hc[5][SH_DIM][HC_STRIDE];
     __shared__ float red[4];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int x0 = blockIdx.x * GSR_TILE, y0 = blockIdx.y * GSR_TILE;
+    int x0, y0;
+    const bool live = ssim_tile_of_block(W, H, x0, y0);
     float l1 = 0.0f, sv = 0.0f;
+    if (!live) {  // padding workgroup of the XCD-aware grid: contributes zero partials
+        if (LOSS && tid == 0) { partial[2 * ((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.z)] = 0.0f; partial[2 * ((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.z) + 1] = 0.0f; }
+        return;
+    }
   for (int ch = 0; ch < NCH; ch++) {
     const int plane = blockIdx.z * NCH + ch;
     if (ch > 0) __syncthreads();  // previous channel's LDS tiles fully consumed
@@ -145,7 +163,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(Src src, int W, int H, fl
         // serialise at ~12 ns each (MI355X_MICROARCH.md "fanin")
         const float a = block_sum(l1, red), b = block_sum(sv, red);
         if (tid == 0) {
-            const size_t blk = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+            const size_t blk = (size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.z;
             partial[2 * blk] = a;
             partial[2 * blk + 1] = b;
         }
@@ -163,7 +181,8 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(Src src, int W, int H, co
     __shared__ float sd[3][SH_DIM][IN_STRIDE];
     __shared__ float hc[3][SH_DIM][HC_STRIDE];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int x0 = blockIdx.x * GSR_TILE, y0 = blockIdx.y * GSR_TILE;
+    int x0, y0;
+    if (!ssim_tile_of_block(W, H, x0, y0)) return;
     const size_t P = (size_t)W * H;
     float gout[NCH];
   for (int ch = 0; ch < NCH; ch++) {
@@ -258,7 +277,8 @@ __global__ void zero_extra_channels_kernel(float* __restrict__ vpixels, int C, s
 }  // namespace
 
 static dim3 ssim_grid(int W, int H, int planes) {
-    return dim3((W + GSR_TILE - 1) / GSR_TILE, (H + GSR_TILE - 1) / GSR_TILE, planes);
+    const int n = ((W + GSR_TILE - 1) / GSR_TILE) * ((H + GSR_TILE - 1) / GSR_TILE);
+    return dim3(8 * ((n + 7) / 8), 1, planes);
 }
 
 void gsr_launch_ssim_fwd(hipStream_t s, int W, int H, int CH, int B, const float* img, const float* ref, float C1,

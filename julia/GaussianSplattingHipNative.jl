@@ -120,4 +120,21 @@ update_stats!(strategy, rast::HipNativeRasterizer) = check(ccall((:gsr_update_st
     (Ptr{Cvoid}, Ptr{Int32}, Ptr{Float32}, Ptr{Float32}, Ptr{Cvoid}), rast.handle,
     Ptr{Int32}(UInt(pointer(strategy.max_radii))), dptr(strategy.accum_∇means_2d), dptr(strategy.denom), hipstream()))
 
+# The tail of `step!` (src/training.jl:768-779 + the prologue of the next `rast(...)` call, rasterizer.jl:218-247)
+# in one pass: `∇` are the cotangents the rrule above returned (w.r.t. the ACTIVATED opacity / scale), `θ` the raw
+# parameter arrays and `opts` the six NU.Adam in OPTIMIZER_NAMES order; shs / opacities_act / scales_act are the
+# activated copies of this step on entry and of the updated parameters on exit.
+struct GsrTailGrads; vmeans::Ptr{Float32}; vshs::Ptr{Float32}; vopacities::Ptr{Float32}; vscales::Ptr{Float32}; vrotations::Ptr{Float32}; end
+function trainer_tail_step!(θ::NTuple{6}, opts::NTuple{6}, ∇, shs, opacities_act, scales_act; β1=0.9f0, β2=0.999f0, ϵ=1f-15)
+    vmeans, vshs, vopac, vscales, vrot = ∇
+    foreach(o -> o.current_step += 0x1, opts)
+    p(xs) = Ptr{Float32}[dptr(x) for x in xs]
+    check(ccall((:gsr_trainer_tail_step, LIB), Cint,
+        (Cint, Cint, Cint, Ref{GsrTailGrads}, Ptr{Ptr{Float32}}, Ptr{Ptr{Float32}}, Ptr{Ptr{Float32}}, Ptr{Cfloat}, Ptr{UInt32},
+         Cfloat, Cfloat, Cfloat, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Cvoid}),
+        size(θ[1], 2), size(θ[3], 2), size(θ[5], 1), GsrTailGrads(dptr(vmeans), dptr(vshs), dptr(vopac), dptr(vscales), dptr(vrot)),
+        p(θ), p(map(o -> o.μ[1], opts)), p(map(o -> o.ν[1], opts)), Float32[o.lr for o in opts],
+        UInt32[o.current_step for o in opts], β1, β2, ϵ, dptr(shs), dptr(opacities_act), dptr(scales_act), hipstream()))
+end
+
 end # module

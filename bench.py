@@ -13,9 +13,15 @@ per-GPU work is fixed, `value` counts the pixels of all views).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline     — dominant kernel: algorithmic HBM bytes per launch / mean launch time
-                 (HIP events on the launch stream, gsr_profile_*), against 8 TB/s;
+                 (HIP events on the launch stream, gsr_profile_*), against 8 TB/s; `traffic` =
+                 PMC-counted HBM bytes per launch of that kernel, ONLY when profiles/pmc_traffic.json
+                 holds a measurement of exactly this configuration (else null); `valu` = the VALU-issue
+                 roofline of the same kernel (SQ_INSTS_VALU x 2 cycles / 1024 SIMDs, the bound that
+                 actually binds the compositing kernels), from the same file;
   cpu_baseline — the oracle (C restatement of the reference algorithm, OpenMP) timed on
                  this host's cores on the same workload (rank 0, N = 1 only).
+`value` / `ms_per_step` follow the driver contract (K steps between two barriers+synchronize, total / K);
+`ms_per_step_median` is the median of the K per-step HIP-event times.
 """
 import argparse
 import json
@@ -33,6 +39,12 @@ import torch.distributed as dist  # noqa: E402
 import gsr_pkg  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_SIMD, CLOCK_HZ, VALU_CYCLES = 1024, 2.4e9, 2.0  # 256 CUs x 4 SIMD-32; a wave64 VALU op issues over 2 cycles
+
+
+def config_key(N, W, H, deg, mode, exact_cull, loss):
+    """Key of a measured configuration in profiles/pmc_traffic.json (tools/pmc_workload.py writes the same)."""
+    return f"N{N}_{W}x{H}_SH{deg}_{mode}_{'cull' if exact_cull else 'reflists'}_{'loss' if loss else 'noloss'}"
 
 
 def algorithmic_bytes(stage, N, V, D, P, T, C=3, K=16):
@@ -76,7 +88,9 @@ def main():
     ap.add_argument("--ply", default=None, help="render a 3DGS .ply scene (gaussians.jl export_ply layout) instead of "
                                                 "the synthetic one; N and the SH degree come from the file")
     ap.add_argument("--reference-lists", action="store_true",
-                    help="keep the reference's (Gaussian, tile) instance lists instead of exact footprint culling")
+                    help="GSR_FLAG_REFERENCE_TILE_LISTS: keep the reference's (Gaussian, tile) instance lists instead of "
+                         "the library default (exact footprint culling)")
+    ap.add_argument("--no-other-lists", action="store_true", help="skip the secondary timing of the other tile-list mode")
     args = ap.parse_args()
 
     pkg = gsr_pkg.load()
@@ -188,11 +202,16 @@ def main():
         step()
     sync()
     rast.profile(True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        marks[k].record()
         step()
+    marks[args.steps].record()
     sync()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+    ms_median = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     tail_collect()
     prof = rast.profile_read()
     rast.profile(False)
@@ -212,13 +231,24 @@ def main():
     Cn = pkg.rasterizer.n_color_features(args.mode)
     dom_bytes = algorithmic_bytes(dom, N, V, Dn, P, T, Cn, K)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-    traffic = None
+    # PMC-counted HBM bytes and VALU instructions per launch: only a measurement of EXACTLY this configuration
+    # (tools/pmc_workload.py + tools/pmc_parse.py under rocprofv3 --pmc, committed per round) is reported
+    key = config_key(N, W, H, deg, args.mode, not args.reference_lists, not args.no_loss) if args.ply is None else None
+    traffic, valu, pmc_src = None, None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
+    if key is not None and os.path.exists(tpath) and not (tail is not None):
         try:
-            traffic = json.load(open(tpath)).get(dom)
+            rec = json.load(open(tpath)).get("configs", {}).get(key)
+            if rec is not None and int(rec.get("tile_instances", -1)) == Dn:
+                traffic = rec.get("hbm_bytes", {}).get(dom)
+                insts = rec.get("sq", {}).get(dom, {}).get("SQ_INSTS_VALU")
+                pmc_src = rec.get("source")
+                if insts:
+                    issue_ms = insts * VALU_CYCLES / N_SIMD / CLOCK_HZ * 1e3
+                    valu = {"kernel": dom, "insts": int(insts), "issue_cycles_peak": int(insts * VALU_CYCLES / N_SIMD),
+                            "peak_ms_at_2.4GHz": round(issue_ms, 4), "frac": round(issue_ms / dom_ms, 4)}
         except Exception:
-            traffic = None
+            traffic, valu = None, None
     # measured HBM ceiling of this device in this run: STREAM triad over 3 x 512 MiB
     lib = pkg._lib.load()
     n_tri = 128 * 1024 * 1024
@@ -234,7 +264,8 @@ def main():
     triad_gbs = 5 * 12.0 * n_tri / (e0.elapsed_time(e1) * 1e-3) / 1e9
     del ta, tb, tc
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "valu": valu, "pmc_source": pmc_src,
+                "pmc_config_key": key,
                 "measured_triad_GBps": round(triad_gbs, 1), "frac_of_measured_triad": round(achieved / triad_gbs, 5),
                 "algorithmic_bytes": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
                 "stages_ms": {k: round(v[0], 4) for k, v in stages.items()},
@@ -244,7 +275,7 @@ def main():
     out = {
         "metric": "fwd+bwd Mpixels/s @1920x1080, 1M Gaussians SH=3",
         "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_step, 4), "ms_per_step_median": round(ms_median, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic" if args.ply is None else "ply scene, synthetic camera and target",
         "config": {"workload": ("config3: 1M Gaussians, SH deg 3, 1920x1080, fwd + L1/0.2*DSSIM loss + bwd"
                                 if not args.no_loss and args.ply is None and args.mode == "rgb" and (N, W, H, deg) == (1_000_000, 1920, 1080, 3) else
@@ -252,7 +283,8 @@ def main():
                                 if args.ply is not None else
                                 f"N={N} SH{deg} {W}x{H} :{args.mode} fwd{'' if args.no_loss else '+loss'}+bwd"),
                    "n_gaussians": N, "visible": V, "tile_instances": Dn, "views_per_gpu": 1,
-                   "tile_lists": "reference" if args.reference_lists else "exact footprint cull (same outputs)",
+                   "tile_lists": ("reference lists (GSR_FLAG_REFERENCE_TILE_LISTS)" if args.reference_lists else
+                                  "library default: exact footprint cull (same image / gradients)"),
                    "parallelism": (f"view-parallel x{world}, all-reduce of {11 * N * 4 / 1e6:.0f} MB + all-gather of "
                                    f"{world} x {3 * N * 4 / 1e6:.0f} MB colour cotangents (factored SH gradient)" if factored else
                                    f"view-parallel x{world}, 1 all-reduce of {arena.numel() * 4 / 1e6:.0f} MB")},
@@ -266,6 +298,23 @@ def main():
                                                     "adam": 7 * 4 * (3 * K + 11) * N}
         out["trainer_tail"]["form"] = "three kernels" if args.unfused_tail else "fused (gsr_trainer_tail_step: 'adam' is the whole tail)"
         out["config"]["workload"] += " + prologue + Adam (trainer tail, not the headline metric)"
+    if world == 1 and tail is None and not args.no_other_lists:
+        # the same step with the OTHER tile-list mode, timed in the same run (headline = the library default)
+        rast2 = pkg.rasterizer.GaussianRasterizer(W, H, mode=args.mode, device=dev, exact_tile_cull=args.reference_lists)
+        rast_main, rast = rast, rast2
+        for _ in range(max(args.warmup, 2)):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        dt2 = (time.perf_counter() - t0) / args.steps
+        out["other_tile_lists"] = {"tile_lists": "exact footprint cull" if args.reference_lists else "reference lists",
+                                   "ms_per_step": round(1e3 * dt2, 4), "value": round(P / dt2 / 1e6, 3),
+                                   "tile_instances": int(rast2.stats.n_rendered)}
+        rast = rast_main
+        rast2.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, s, W, H, deg, args)
     if rank == 0:
@@ -290,7 +339,8 @@ def cpu_baseline(pkg, s, W, H, deg, args):
     orc.backward(st, vp, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, deterministic=False)
     dt = time.perf_counter() - t0
     return {"value": round(W * H / dt / 1e6, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
-            "sample": f"1 full step of the same workload ({dt:.1f} s wall)"}
+            "sample": f"1 full step of the same workload ({dt:.1f} s wall); backward = the reference's atomic-accumulation "
+                      f"form over OpenMP threads (non-deterministic summation order, as render.jl:242,275-282)"}
 
 
 if __name__ == "__main__":

@@ -15,7 +15,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gsr.h")
 
 GSR_OK, GSR_E_INVALID_ARG, GSR_E_OOM, GSR_E_HIP, GSR_E_STATE = 0, -1, -2, -3, -4
 MODES = {"rgb": 3, "rgbd": 5, "rgbdn": 8}
-FLAG_EXACT_TILE_CULL = 1
+FLAG_REFERENCE_TILE_LISTS = 1  # flags = 0: exact footprint culling (the default)
 
 (BUF_RADII, BUF_GRAD_MEANS2D, BUF_N_CONTRIB, BUF_FINAL_T, BUF_TILE_RANGES, BUF_VALUES_SORTED, BUF_GEOM, BUF_NORMALS,
  BUF_GRAD_ROWS, BUF_INSTANCE_AUX) = range(10)
@@ -44,16 +44,18 @@ class CameraS(C.Structure):
 
 
 class Aux(C.Structure):
-    _fields_ = [("covisibilities", C.c_void_p), ("uncertainties", C.c_void_p)]
+    _fields_ = [("covisibilities", C.c_void_p), ("uncertainties", C.c_void_p), ("radii", C.c_void_p)]
 
 
 class Stats(C.Structure):
-    _fields_ = [("n_rendered", C.c_int64), ("n_visible", C.c_int32), ("max_tile_instances", C.c_int32)]
+    _fields_ = [("n_rendered", C.c_int64), ("n_visible", C.c_int32), ("max_tile_instances", C.c_int32),
+                ("generation", C.c_uint64)]
 
 
 class Grads(C.Structure):
     _fields_ = [("vmeans", C.c_void_p), ("vshs", C.c_void_p), ("vopacities", C.c_void_p), ("vscales", C.c_void_p),
-                ("vrotations", C.c_void_p), ("vR", C.c_void_p), ("vt", C.c_void_p), ("vcolors", C.c_void_p)]
+                ("vrotations", C.c_void_p), ("vR", C.c_void_p), ("vt", C.c_void_p), ("vcolors", C.c_void_p),
+                ("vmeans2d", C.c_void_p), ("forward_generation", C.c_uint64)]
 
 
 ADAM_MAX_GROUPS = 8
@@ -74,7 +76,7 @@ class GatherGroup(C.Structure):
 
 
 EXPORTS = ["gsr_create", "gsr_destroy", "gsr_release_scene_buffers", "gsr_memory_usage", "gsr_forward",
-           "gsr_backward", "gsr_buffer", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_loss_l1_ssim",
+           "gsr_backward", "gsr_buffer", "gsr_copy_buffer", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_loss_l1_ssim",
            "gsr_allreduce_grads", "gsr_last_error_string", "gsr_version", "gsr_profile_enable",
            "gsr_profile_stage_count", "gsr_profile_stage_name", "gsr_profile_read", "gsr_update_stats",
            "gsr_prologue_forward", "gsr_prologue_backward", "gsr_adam_step", "gsr_stream_triad",
@@ -113,6 +115,7 @@ def load():
     lib.gsr_forward.argtypes = [vp, C.POINTER(Inputs), C.POINTER(CameraS), vp, C.POINTER(Aux), vp, C.POINTER(Stats)]
     lib.gsr_backward.argtypes = [vp, C.POINTER(Inputs), C.POINTER(CameraS), vp, C.POINTER(Grads), vp]
     lib.gsr_buffer.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.gsr_copy_buffer.argtypes = [vp, i32, vp, C.c_size_t, vp]
     lib.gsr_ssim_forward.argtypes = [i32, i32, i32, i32, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp]
     lib.gsr_ssim_backward.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_loss_l1_ssim.argtypes = [vp, vp, vp, f32, vp, vp, vp]
@@ -142,17 +145,3 @@ def load():
 def check(rc: int):
     if rc != 0:
         raise GsrError(rc, load().gsr_last_error_string().decode())
-
-
-_hip = None
-
-
-def memcpy_d2d_async(dst: int, src: int, nbytes: int, stream: int):
-    """hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, stream) — plumbing for the state views."""
-    global _hip
-    if _hip is None:
-        _hip = C.CDLL("libamdhip64.so")
-        _hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
-    rc = _hip.hipMemcpyAsync(C.c_void_p(dst), C.c_void_p(src), C.c_size_t(nbytes), 3, C.c_void_p(stream))
-    if rc != 0:
-        raise RuntimeError(f"hipMemcpyAsync failed with code {rc}")

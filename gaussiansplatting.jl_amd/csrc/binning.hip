@@ -210,8 +210,9 @@ __device__ __forceinline__ void sort_and_emit(uint64_t* buf, uint32_t m, uint32_
         const uint32_t id = (uint32_t)k;
         values_sorted[start + i] = id;
         const GsrGeoRec rec = geom.rec[id];  // one 64-byte line per gather
-        stream.s0[start + i] = rec.q0;
-        stream.s1[start + i] = rec.q1;
+        // the compositing kernels evaluate sigma = b·dx·dy + (a/2)·dx² + (c/2)·dy²: the stream carries the halves
+        stream.s0[start + i] = make_float4(rec.q0.x, rec.q0.y, 0.5f * rec.q0.z, rec.q0.w);
+        stream.s1[start + i] = make_float4(0.5f * rec.q1.x, rec.q1.y, rec.q1.z, rec.q1.w);
         // Gaussian-major slot of this instance: offset of the Gaussian's rect (cumsum of
         // tiles_touched, rasterizer.jl:333-335) + row-major rank of the tile inside the rect (the
         // emit order of duplicate_with_keys!, utils.jl:112).  The backward writes the instance's

@@ -24,6 +24,20 @@ struct Bg { float v[8]; };
 // wave64 ballot straight from the compare mask (HIP's __ballot goes through v_cndmask + v_cmp_ne)
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
+// The Gaussian exponent  sigma = b·dx·dy + ½(a·dx² + c·dy²)  (render.jl:90-91 and :226-227) — ONE definition, with
+// explicitly rounded operations, used by the forward AND the backward kernel: the backward replays exactly the
+// contributor set the forward blended (`sigma >= 0`, `alpha >= 1/255` and the `T' < 1e-4` stop are decided on
+// bit-identical sigma / alpha in both passes, whatever the compiler's FMA contraction would have done to two
+// differently written expressions).  The sorted stream carries ha = a/2 and hc = c/2 (exact halvings).
+struct SigmaX { float hxx, bdx; };  // the dx-dependent part, shared by the pixels of a column
+__device__ __forceinline__ SigmaX sigma_x(float ha, float b, float dx) {
+    return SigmaX{__fmul_rn(ha, __fmul_rn(dx, dx)), __fmul_rn(b, dx)};
+}
+__device__ __forceinline__ float sigma_of(const SigmaX sx, float hc, float dy, float dy2) {
+    return __fmaf_rn(sx.bdx, dy, __fmaf_rn(hc, dy2, sx.hxx));
+}
+__device__ __forceinline__ float alpha_of(float opacity, float G) { return fminf(0.99f, __fmul_rn(opacity, G)); }
+
 // feature c of a staged splat: rgb | depth | 1 | normal  (rasterizer.jl:380-385)
 template <int C>
 __device__ __forceinline__ void unpack_features(const float4& s1, const float4& s2, const float4& s3, float f[C]) {
@@ -86,8 +100,8 @@ __global__ __launch_bounds__(64) void composite_fwd_strip_kernel(int W, int H, i
         if (m == 0ull) continue;
         auto blend = [&](const float4& a, const float4& b, const float4& c2, const float4& c3, int j) {
             const float dx = a.x - fx, dy = a.y - fy;
-            const float sigma = a.w * dx * dy + 0.5f * (a.z * (dx * dx) + b.x * (dy * dy));
-            const float alpha = fminf(0.99f, b.y * __expf(-sigma));
+            const float sigma = sigma_of(sigma_x(a.z, a.w, dx), b.x, dy, __fmul_rn(dy, dy));
+            const float alpha = alpha_of(b.y, __expf(-sigma));
             // Branch-free body: a lane that is done, or whose pixel this splat does not touch, blends
             // with weight 0 (what `continue`/`break` leave behind, render.jl:92-101).  (Handling the
             // saturating lanes in a wave-uniform rare path instead measured 10 % slower.)
@@ -256,7 +270,7 @@ __global__ __launch_bounds__(256 / PPL) void composite_bwd_kernel(int W, int H, 
             const float4 a = l0[j], b = l1[j], c2 = l2[j];
             const float o = b.y;
             const float dx = a.x - fx;
-            const float hxx = 0.5f * (a.z * (dx * dx)), bdx = a.w * dx;
+            const SigmaX sx = sigma_x(a.z, a.w, dx);
             float f[C];
             unpack_features<C>(b, c2, C > 5 ? l3[j] : c2, f);
             // A lane accumulates only  P = Σ G·vα,  U1 = Σ G·vα·dy,  U2 = Σ G·vα·dy²  and the
@@ -276,10 +290,10 @@ __global__ __launch_bounds__(256 / PPL) void composite_bwd_kernel(int W, int H, 
                 // pixel rows 4q..4q+3 of this wave: untouched by the splat's footprint -> wave-uniform skip
                 if (PPL > 1 && ((rowbits >> (4 * q)) & 0xFu) == 0u) continue;
 #endif
-                const float dy = a.y - fy[q], dy2 = dy * dy;
-                const float sigma = bdx * dy + (hxx + 0.5f * (b.x * dy2));
+                const float dy = a.y - fy[q], dy2 = __fmul_rn(dy, dy);
+                const float sigma = sigma_of(sx, b.x, dy, dy2);
                 const float G = __expf(-sigma);
-                const float alpha = fminf(0.99f, o * G);
+                const float alpha = alpha_of(o, G);
                 const bool c_live = contributor < last_contributor[q], c_sig = sigma >= 0.0f, c_al = alpha >= (1.0f / 255.0f);
                 const bool active = c_live && c_sig && c_al;
                 // ballots of the bare compares are their SGPR masks; the AND/OR runs on the scalar unit
@@ -363,7 +377,8 @@ __global__ __launch_bounds__(256 / PPL) void composite_bwd_kernel(int W, int H, 
                 float4* row = inst.rows + (size_t)4 * __float_as_uint(l2[tid].y);  // Gaussian-major slot
                 row[0] = make_float4(r[0], r[1], r[2], r[3]);
                 row[1] = make_float4(mh * r[4], mh * r[5], mh * r[6], C > 3 ? r[9 < NA ? 9 : 0] : 0.0f);
-                row[2] = make_float4(mo * (a.z * r[7] + a.w * r[8]), mo * (a.w * r[7] + b.x * r[8]),
+                // conic a = 2·ha, c = 2·hc (the stream carries the halves)
+                row[2] = make_float4(mo * (2.0f * a.z * r[7] + a.w * r[8]), mo * (a.w * r[7] + 2.0f * b.x * r[8]),
                                      C > 5 ? r[10 < NA ? 10 : 0] : 0.0f, C > 5 ? r[11 < NA ? 11 : 0] : 0.0f);
                 if (C > 5) row[3] = make_float4(r[12 < NA ? 12 : 0], 0.0f, 0.0f, 0.0f);
             }

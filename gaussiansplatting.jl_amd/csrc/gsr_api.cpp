@@ -11,6 +11,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -68,8 +69,40 @@ enum Stage { ST_PREPROCESS, ST_SCAN, ST_SORT, ST_COMPOSITE_FWD, ST_LOSS_FWD, ST_
              ST_COMPOSITE_BWD, ST_PERGAUSS_BWD, ST_COUNT };
 const char* const kStageNames[ST_COUNT] = {"preprocess", "tile_scan", "tile_sort", "composite_fwd",
                                            "loss_fwd", "loss_bwd", "zero_acc", "composite_bwd", "pergauss_bwd"};
+// roctx ranges per stage: resolved lazily from the ROCm tools library, only when asked for
+// (GSR_ROCTX=1 in the environment, or gsr_profile_enable(h, 2 | ...)); rocprofv3 --marker-trace then
+// slices the kernel trace by stage without kernel-name matching.
+struct Roctx {
+    typedef int (*push_fn)(const char*);
+    typedef int (*pop_fn)(void);
+    push_fn push = nullptr;
+    pop_fn pop = nullptr;
+    bool tried = false;
+    bool load() {
+        if (tried) return push != nullptr;
+        tried = true;
+        const char* names[] = {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"};
+        for (const char* n : names) {
+            void* lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) continue;
+            push = (push_fn)dlsym(lib, "roctxRangePushA");
+            pop = (pop_fn)dlsym(lib, "roctxRangePop");
+            if (push && pop) return true;
+            push = nullptr; pop = nullptr;
+        }
+        return false;
+    }
+};
+Roctx g_roctx;
+bool roctx_env() {
+    static const bool on = [] { const char* e = getenv("GSR_ROCTX"); return e && e[0] == '1'; }();
+    return on;
+}
+
 struct Profiler {
-    bool on = false;
+    bool on = false;      // HIP-event timing per stage
+    bool ranges = false;  // roctx range per stage
+    bool in_range = false;
     struct Rec { int stage; hipEvent_t a, b; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
@@ -79,13 +112,9 @@ struct Profiler {
         (void)hipEventCreate(&e);
         return e;
     }
-    void begin(int stage, hipStream_t s) {
-        if (!on) return;
-        Rec r{stage, get(), get()};
-        (void)hipEventRecord(r.a, s);
-        recs.push_back(r);
-    }
+    void begin(int stage, hipStream_t s);
     void end(hipStream_t s) {
+        if (in_range) { g_roctx.pop(); in_range = false; }
         if (!on || recs.empty()) return;
         (void)hipEventRecord(recs.back().b, s);
     }
@@ -99,6 +128,19 @@ struct Profiler {
         pool.clear();
     }
 };
+
+void Profiler::begin(int stage, hipStream_t s) {
+    if ((ranges || roctx_env()) && g_roctx.load()) {
+        char name[48];
+        snprintf(name, sizeof name, "gsr:%s", kStageNames[stage]);
+        g_roctx.push(name);
+        in_range = true;
+    }
+    if (!on) return;
+    Rec r{stage, get(), get()};
+    (void)hipEventRecord(r.a, s);
+    recs.push_back(r);
+}
 
 bool valid_mode(int m) { return m == GSR_MODE_RGB || m == GSR_MODE_RGBD || m == GSR_MODE_RGBDN; }
 
@@ -122,6 +164,9 @@ struct gsr_handle {
     hipEvent_t totals_ready = nullptr;  // recorded after the D2H copy of the totals
     uint32_t* host_totals = nullptr;  // pinned: D, max tile count, #oversized tiles, slab ctr, n_visible
     bool fwd_valid = false, bwd_valid = false;
+    uint64_t generation = 0;             // ordinal of the last gsr_forward (gsr_stats.generation)
+    int32_t* radii_cur = nullptr;        // gstate.radii of the last forward: caller's (gsr_aux.radii) or h->radii
+    float2* vmean2d_cur = nullptr;       // gstate.∇means_2d of the last backward: caller's (gsr_grads.vmeans2d) or h->vmean2d
     int last_n = 0;
     int64_t last_D = 0;
     uint32_t last_max_tile = 0;
@@ -144,13 +189,13 @@ GsrCam make_cam(const gsr_handle* h, const gsr_camera* c) {
     k.grid_x = h->grid_x; k.grid_y = h->grid_y;
     k.near_plane = h->cfg.near_plane; k.far_plane = h->cfg.far_plane;
     k.radius_clip = h->cfg.radius_clip; k.blur_eps = h->cfg.blur_eps;
-    k.exact_cull = (h->cfg.flags & GSR_FLAG_EXACT_TILE_CULL) ? 1 : 0;
+    k.exact_cull = (h->cfg.flags & GSR_FLAG_REFERENCE_TILE_LISTS) ? 0 : 1;
     k.R_dev = c->R_dev; k.t_dev = c->t_dev;
     return k;
 }
 
 GsrGeom geom_of(const gsr_handle* h) {
-    return GsrGeom{h->geo.as<GsrGeoRec>(), h->gnormal.as<float4>(), h->radii.as<int32_t>(), h->bsum.as<uint32_t>(),
+    return GsrGeom{h->geo.as<GsrGeoRec>(), h->gnormal.as<float4>(), h->radii_cur, h->bsum.as<uint32_t>(),
                    h->bpre.as<uint32_t>()};
 }
 GsrStream stream_of(const gsr_handle* h) {
@@ -184,7 +229,7 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
     if (cfg->width <= 0 || cfg->height <= 0) return fail(GSR_E_INVALID_ARG, "bad resolution %dx%d", cfg->width, cfg->height);
     if (!valid_mode(cfg->mode)) return fail(GSR_E_INVALID_ARG, "Invalid render mode: %d (3=rgb, 5=rgbd, 8=rgbdn)", cfg->mode);
     if (!(cfg->near_plane < cfg->far_plane)) return fail(GSR_E_INVALID_ARG, "near_plane >= far_plane");
-    if (cfg->flags & ~(uint32_t)GSR_FLAG_EXACT_TILE_CULL) return fail(GSR_E_INVALID_ARG, "unknown flags 0x%x", cfg->flags);
+    if (cfg->flags & ~(uint32_t)GSR_FLAG_REFERENCE_TILE_LISTS) return fail(GSR_E_INVALID_ARG, "unknown flags 0x%x", cfg->flags);
     gsr_handle* h = new (std::nothrow) gsr_handle();
     if (!h) return fail(GSR_E_OOM, "host allocation failed");
     h->cfg = *cfg;
@@ -236,6 +281,9 @@ int gsr_release_scene_buffers(gsr_handle* h) {
         if (rc) return rc;
     }
     h->fwd_valid = false;
+    h->bwd_valid = false;
+    h->radii_cur = nullptr;
+    h->vmean2d_cur = nullptr;
     h->last_n = 0;
     h->last_D = 0;
     return GSR_OK;
@@ -261,10 +309,15 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
 
     const size_t nn = n > 0 ? (size_t)n : 1;
     const int n_blocks = (n + 255) / 256;
-    if ((rc = h->geo.ensure(nn * 64)) || (rc = h->radii.ensure(nn * 4)) || (rc = h->vmean2d.ensure(nn * 8)) ||
+    const bool own_radii = !(aux && aux->radii);
+    if ((rc = h->geo.ensure(nn * 64)) || (own_radii && (rc = h->radii.ensure(nn * 4))) ||
         (rc = h->bsum.ensure((size_t)(n_blocks + 1) * 4)) || (rc = h->bpre.ensure((size_t)(n_blocks + 1) * 4)) || (rc = h->bvis.ensure((size_t)(n_blocks + 1) * 4)) ||
         (C > 5 && (rc = h->gnormal.ensure(nn * 16))))
         return rc;
+    h->radii_cur = own_radii ? h->radii.as<int32_t>() : aux->radii;
+    h->vmean2d_cur = nullptr;
+    h->generation++;
+    if (stats) stats->generation = h->generation;
 
     GsrCam k = make_cam(h, cam);
     uint32_t* totals = h->totals.as<uint32_t>();
@@ -362,6 +415,10 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
     if (!vpixels || !g) return fail(GSR_E_INVALID_ARG, "null vpixels / grads");
     if (!h->fwd_valid || h->last_n != in->n)
         return fail(GSR_E_STATE, "gsr_backward without a matching gsr_forward on this handle");
+    if (g->forward_generation != 0 && g->forward_generation != h->generation)
+        return fail(GSR_E_STATE, "gsr_backward for forward #%llu, but the handle's last forward is #%llu (another "
+                    "gsr_forward ran in between)", (unsigned long long)g->forward_generation,
+                    (unsigned long long)h->generation);
     if (in->n > 0 && (!g->vmeans || (!g->vshs && !g->vcolors) || !g->vopacities || !g->vscales || !g->vrotations))
         return fail(GSR_E_INVALID_ARG, "null gradient buffer");
     if ((g->vR == nullptr) != (g->vt == nullptr)) return fail(GSR_E_INVALID_ARG, "vR and vt must be given together");
@@ -369,6 +426,8 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
     hipStream_t s = (hipStream_t)stream_v;
     const int C = h->cfg.mode, n = in->n;
     if (n == 0) return GSR_OK;
+    if (!g->vmeans2d && (rc = h->vmean2d.ensure((size_t)n * 8))) return rc;
+    h->vmean2d_cur = g->vmeans2d ? reinterpret_cast<float2*>(g->vmeans2d) : h->vmean2d.as<float2>();
     // (the gradient rows need no memset: composite_bwd writes the row of every emitted instance,
     // pergauss_bwd skips the slots of culled tiles; only the 12 pose-gradient floats are accumulated into)
     if (g->vR) {
@@ -385,7 +444,7 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
     h->prof.end(s);
     h->prof.begin(ST_PERGAUSS_BWD, s);
     gsr_launch_pergauss_bwd(s, n, in->n_coeffs, in->sh_degree, C, in->means, in->scales, in->rotations, in->shs, k,
-                            geom_of(h), inst_of(h), h->vmean2d.as<float2>(), g->vmeans, g->vshs, g->vopacities,
+                            geom_of(h), inst_of(h), h->vmean2d_cur, g->vmeans, g->vshs, g->vopacities,
                             g->vscales, g->vrotations, g->vR, g->vt, g->vcolors);
     h->prof.end(s);
     HIPCHK(hipGetLastError());
@@ -393,15 +452,20 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
     return GSR_OK;
 }
 
-int gsr_buffer(const gsr_handle* h, int which, const void** dev_ptr, size_t* bytes) {
-    if (!h || !dev_ptr || !bytes) return fail(GSR_E_INVALID_ARG, "null argument");
+static int buffer_lookup(const gsr_handle* h, int which, const void** dev_ptr, size_t* bytes) {
     const size_t n = (size_t)h->last_n, P = (size_t)h->cfg.width * h->cfg.height, T = (size_t)h->n_tiles;
     const size_t D = (size_t)h->last_D;
     const DevBuf* b = nullptr;
     size_t sz = 0;
     switch (which) {
-        case GSR_BUF_RADII: b = &h->radii; sz = n * 4; break;
-        case GSR_BUF_GRAD_MEANS2D: b = &h->vmean2d; sz = n * 8; break;
+        case GSR_BUF_RADII:  // handle-owned, or the caller's gsr_aux.radii of the last forward
+            *dev_ptr = h->fwd_valid && n ? h->radii_cur : nullptr;
+            *bytes = *dev_ptr ? n * 4 : 0;
+            return GSR_OK;
+        case GSR_BUF_GRAD_MEANS2D:
+            *dev_ptr = h->bwd_valid && n ? h->vmean2d_cur : nullptr;
+            *bytes = *dev_ptr ? n * 8 : 0;
+            return GSR_OK;
         case GSR_BUF_N_CONTRIB: b = &h->n_contrib; sz = P * 4; break;
         case GSR_BUF_FINAL_T: b = &h->final_T; sz = P * 4; break;
         case GSR_BUF_TILE_RANGES: b = &h->ranges; sz = 2 * T * 4; break;
@@ -415,6 +479,22 @@ int gsr_buffer(const gsr_handle* h, int which, const void** dev_ptr, size_t* byt
     if (sz > b->cap) sz = 0;  // not produced yet
     *dev_ptr = sz ? b->p : nullptr;
     *bytes = sz;
+    return GSR_OK;
+}
+
+int gsr_buffer(const gsr_handle* h, int which, const void** dev_ptr, size_t* bytes) {
+    if (!h || !dev_ptr || !bytes) return fail(GSR_E_INVALID_ARG, "null argument");
+    return buffer_lookup(h, which, dev_ptr, bytes);
+}
+
+int gsr_copy_buffer(const gsr_handle* h, int which, void* dst, size_t bytes, void* stream) {
+    if (!h || (!dst && bytes)) return fail(GSR_E_INVALID_ARG, "null argument");
+    const void* src = nullptr;
+    size_t have = 0;
+    int rc = buffer_lookup(h, which, &src, &have);
+    if (rc) return rc;
+    if (bytes > have) return fail(GSR_E_STATE, "buffer %d holds %zu bytes, %zu requested (not produced yet?)", which, have, bytes);
+    if (bytes) HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return GSR_OK;
 }
 
@@ -469,7 +549,7 @@ int gsr_loss_l1_ssim(gsr_handle* h, const float* image, const float* target, flo
 int gsr_update_stats(gsr_handle* h, int32_t* max_radii, float* accum_grad_means2d, float* denom, void* stream) {
     if (!h || !max_radii || !accum_grad_means2d || !denom) return fail(GSR_E_INVALID_ARG, "null argument");
     if (!h->fwd_valid || !h->bwd_valid) return fail(GSR_E_STATE, "gsr_update_stats needs a completed forward/backward pair");
-    gsr_launch_update_stats((hipStream_t)stream, h->last_n, h->radii.as<int32_t>(), h->vmean2d.as<float2>(),
+    gsr_launch_update_stats((hipStream_t)stream, h->last_n, h->radii_cur, h->vmean2d_cur,
                             h->cfg.width, h->cfg.height, max_radii, accum_grad_means2d, denom);
     HIPCHK(hipGetLastError());
     return GSR_OK;
@@ -477,8 +557,9 @@ int gsr_update_stats(gsr_handle* h, int32_t* max_radii, float* accum_grad_means2
 
 int gsr_profile_enable(gsr_handle* h, int on) {
     if (!h) return fail(GSR_E_INVALID_ARG, "null handle");
-    h->prof.on = on != 0;
-    if (!on) h->prof.clear();
+    h->prof.on = (on & 1) != 0;      // bit 0: HIP-event stage timing
+    h->prof.ranges = (on & 2) != 0;  // bit 1: roctx range per stage
+    if (!h->prof.on) h->prof.clear();
     return GSR_OK;
 }
 

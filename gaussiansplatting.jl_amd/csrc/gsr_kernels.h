@@ -43,8 +43,8 @@ struct GsrGeom {
 
 // Sorted per-instance splat stream written by tile_sort (planes of float4, coalesced).
 struct GsrStream {
-    float4* s0;  // mean2d.x, mean2d.y, conic.a, conic.b
-    float4* s1;  // conic.c, opacity, r, g
+    float4* s0;  // mean2d.x, mean2d.y, conic.a / 2, conic.b
+    float4* s1;  // conic.c / 2, opacity, r, g
     float4* s2;  // b, slot (uint bits: Gaussian-major instance slot), depth, row mask (uint bits: tile rows touched)
     float4* s3;  // normal (C == 8) or nullptr
 };

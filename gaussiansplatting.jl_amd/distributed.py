@@ -55,7 +55,14 @@ def init_from_env(backend: str | None = None):
             # GSR_DIST_BACKEND=gloo lets several ranks share one GPU (logic tests on a 1-GPU box)
             backend = os.environ.get("GSR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
-            local = local % max(torch.cuda.device_count(), 1)
+            ndev = torch.cuda.device_count()
+            if local >= ndev:
+                # several ranks on one GPU is a logic-test configuration (gloo only); with RCCL it is a
+                # mis-launch and must not be hidden by wrapping the device index
+                if backend != "gloo":
+                    raise RuntimeError(f"LOCAL_RANK={local} but only {ndev} HIP device(s) are visible "
+                                       f"(set GSR_DIST_BACKEND=gloo to share a device in logic tests)")
+                local = local % max(ndev, 1)
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local

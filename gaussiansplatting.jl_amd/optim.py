@@ -35,7 +35,7 @@ class Adam:
         self.nu.zero_()
         self.current_step = 0
 
-    def _group(self, theta, grad) -> L.AdamGroup:
+    def _group(self, theta, grad, step: int) -> L.AdamGroup:
         if theta.numel() != self.mu.numel():
             raise ValueError("parameter length does not match the optimizer state")
         if grad.shape != theta.shape:
@@ -44,7 +44,7 @@ class Adam:
             if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
                 raise ValueError(f"{nm} must be a contiguous float32 HIP device tensor")
         return L.AdamGroup(theta.data_ptr(), grad.data_ptr(), self.mu.data_ptr(), self.nu.data_ptr(), theta.numel(),
-                           self.lr, self.current_step)
+                           self.lr, step)
 
     def step(self, theta: torch.Tensor, grad: torch.Tensor):
         """NU.step!(opt, θ, ∇): in-place update of θ, μ, ν."""
@@ -61,13 +61,18 @@ def step_all(opts: Sequence[Adam], thetas: Sequence[torch.Tensor], grads: Sequen
         return
     b1, b2, eps = opts[0].beta1, opts[0].beta2, opts[0].eps
     groups = (L.AdamGroup * len(opts))()
+    bump = []
     for i, (o, t, g) in enumerate(zip(opts, thetas, grads)):
         if (o.beta1, o.beta2, o.eps) != (b1, b2, eps):
             raise ValueError("optimizers updated in one launch must share β1, β2, ϵ")
+        # the counter the kernel sees is the one AFTER the increment; it is committed only once every
+        # group validated and the launch succeeded, so a rejected call leaves all counters untouched
+        groups[i] = o._group(t, g, o.current_step + (1 if t.numel() else 0))
         if t.numel():
-            o.current_step += 1
-        groups[i] = o._group(t, g)
+            bump.append(o)
     L.check(L.load().gsr_adam_step(groups, len(opts), b1, b2, eps, _stream()))
+    for o in bump:
+        o.current_step += 1
 
 
 GROUPS = ("points", "features_dc", "features_rest", "opacities", "scales", "rotations")  # training.jl:415-416
@@ -85,6 +90,7 @@ def trainer_tail_step(opts, raw, grads, shs, opacities_act, scales_act):
     vp = C.c_void_p
     th, mu, nu = (vp * 6)(), (vp * 6)(), (vp * 6)()
     lr, st = (C.c_float * 6)(), (C.c_uint32 * 6)()
+    bump = []
     for g, name in enumerate(GROUPS):
         o, t = opts[name], raw[name]
         if (o.beta1, o.beta2, o.eps) != (o0.beta1, o0.beta2, o0.eps):
@@ -93,10 +99,10 @@ def trainer_tail_step(opts, raw, grads, shs, opacities_act, scales_act):
         if not empty:
             if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()) or t.numel() != o.mu.numel():
                 raise ValueError(f"{name}: parameter / optimizer state mismatch")
-            o.current_step += 1
+            bump.append(o)
         th[g] = None if empty else t.data_ptr(); mu[g] = None if empty else o.mu.data_ptr()
         nu[g] = None if empty else o.nu.data_ptr()
-        lr[g], st[g] = o.lr, o.current_step
+        lr[g], st[g] = o.lr, o.current_step + (0 if empty else 1)
     for k in ("vmeans", "vshs", "vopacities", "vscales", "vrot"):
         if not (grads[k].is_cuda and grads[k].dtype == torch.float32 and grads[k].is_contiguous()):
             raise ValueError(f"{k} must be a contiguous float32 HIP device tensor")
@@ -104,3 +110,5 @@ def trainer_tail_step(opts, raw, grads, shs, opacities_act, scales_act):
                      grads["vscales"].data_ptr(), grads["vrot"].data_ptr())
     L.check(L.load().gsr_trainer_tail_step(n, k_rest, sd, C.byref(tg), th, mu, nu, lr, st, o0.beta1, o0.beta2, o0.eps,
                                            shs.data_ptr(), opacities_act.data_ptr(), scales_act.data_ptr(), _stream()))
+    for o in bump:  # committed only after validation and a successful launch
+        o.current_step += 1

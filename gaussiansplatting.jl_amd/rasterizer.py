@@ -50,6 +50,40 @@ def _chk(t: torch.Tensor, name: str, shape=None):
     return t
 
 
+class GeometryState:
+    """The two members of `rast.gstate` (states.jl:2-47) that code outside the rasterizer reads —
+    `radii` (Int32, N) and `∇means_2d` (2,N), consumed by the densification strategy right after a
+    training step (strategy.jl:85-86).  As in the reference they are arrays the rasterizer OBJECT
+    owns (grow-only, rasterizer.jl:275-278); the library writes straight into them through
+    gsr_aux.radii / gsr_grads.vmeans2d, so `rast.gstate.radii` is truthful without a copy."""
+
+    def __init__(self, device):
+        self.device = device
+        self._cap = 0
+        self._n = 0
+        self._radii = torch.empty(0, dtype=torch.int32, device=device)
+        self._grad_means_2d = torch.empty((0, 2), dtype=torch.float32, device=device)
+
+    def __len__(self):  # Base.length(::GeometryState), states.jl
+        return self._cap
+
+    def ensure(self, n: int):
+        if self._cap < n:  # rasterizer.jl:275-278: reallocate when the model grew
+            self._radii = torch.zeros(n, dtype=torch.int32, device=self.device)
+            self._grad_means_2d = torch.zeros((n, 2), dtype=torch.float32, device=self.device)
+            self._cap = n
+        self._n = n
+
+    @property
+    def radii(self):
+        return self._radii[:self._n]
+
+    @property
+    def grad_means_2d(self):
+        """gstate.∇means_2d"""
+        return self._grad_means_2d[:self._n]
+
+
 class GaussianRasterizer:
     """GaussianRasterizer(kab; width, height, mode=:rgbd, near_plane=0.2, far_plane=1000)
     — rasterizer.jl:60-90.  Owns the grow-only scratch (gstate/bstate/istate) and the
@@ -57,7 +91,7 @@ class GaussianRasterizer:
 
     def __init__(self, width: int, height: int, mode: str = "rgbd", near_plane: float = 0.2,
                  far_plane: float = 1000.0, device="cuda", radius_clip: int = 3, blur_eps: float = 0.3,
-                 exact_tile_cull: bool = False):
+                 exact_tile_cull: bool = True):
         self.mode = mode
         self.channels = n_color_features(mode)
         self.width, self.height = int(width), int(height)
@@ -67,11 +101,13 @@ class GaussianRasterizer:
         if self.device.type != "cuda":
             raise ValueError("GaussianRasterizer needs a HIP device (no CPU path)")
         self._lib = L.load()
-        # exact_tile_cull: drop (Gaussian, tile) instances that cannot reach alpha >= 1/255 anywhere
-        # in the tile; outputs are unchanged, the internal lists are no longer the reference's
+        # exact_tile_cull (the library's default, flags = 0): (Gaussian, tile) instances that cannot reach
+        # alpha >= 1/255 anywhere in the tile are not emitted; image, gradients, radii and ∇means_2d are
+        # unchanged, only the internal lists (n_rendered, ranges, values_sorted, n_contrib positions) shrink.
+        # False = GSR_FLAG_REFERENCE_TILE_LISTS: exactly the reference's lists (list-level parity checks).
         self.exact_tile_cull = bool(exact_tile_cull)
         cfg = L.Config(self.width, self.height, self.channels, self.near_plane, self.far_plane, int(radius_clip),
-                       float(blur_eps), L.FLAG_EXACT_TILE_CULL if exact_tile_cull else 0)
+                       float(blur_eps), 0 if exact_tile_cull else L.FLAG_REFERENCE_TILE_LISTS)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             L.check(self._lib.gsr_create(C.byref(cfg), C.byref(h)))
@@ -79,6 +115,7 @@ class GaussianRasterizer:
         # rast.image — the returned image aliases rasterizer memory (rasterizer.jl:407)
         self.image = torch.zeros(self.height, self.width, self.channels, device=self.device)
         self.stats = L.Stats()
+        self.gstate = GeometryState(self.device)
         self._n = 0
 
     @classmethod
@@ -101,6 +138,8 @@ class GaussianRasterizer:
     def release_scene_buffers(self):
         """release_scene_buffers!(rast) — rasterizer.jl:111-123"""
         L.check(self._lib.gsr_release_scene_buffers(self._h))
+        self.gstate = GeometryState(self.device)  # rasterizer.jl:116-117
+        self._n = 0
 
     def memory_usage(self) -> int:
         """memory_usage(rast) — rasterizer.jl:127-134"""
@@ -136,20 +175,22 @@ class GaussianRasterizer:
         itemsize = torch.empty((), dtype=dtype).element_size()
         if sz.value < n * itemsize or not p.value:
             raise RuntimeError("buffer not produced yet")
-        # copy out through hipMemcpy on the current stream (torch owns no view of library memory)
+        # copied out by the library itself on the current stream (torch owns no view of library memory,
+        # and a second HIP runtime must not be opened next to torch's)
         out = torch.empty(shape, dtype=dtype, device=self.device)
-        L.memcpy_d2d_async(out.data_ptr(), p.value, n * itemsize, torch.cuda.current_stream().cuda_stream)
+        with torch.cuda.device(self.device):
+            L.check(self._lib.gsr_copy_buffer(self._h, which, out.data_ptr(), n * itemsize, _stream()))
         return out
 
     @property
     def radii(self):
         """gstate.radii (Int32, N) — read by densification (strategy.jl:85-86)"""
-        return self._buffer(L.BUF_RADII, torch.int32, (self._n,))
+        return self.gstate.radii
 
     @property
     def grad_means_2d(self):
         """gstate.∇means_2d (2,N) — valid after the backward"""
-        return self._buffer(L.BUF_GRAD_MEANS2D, torch.float32, (self._n, 2))
+        return self.gstate.grad_means_2d
 
     @property
     def n_contrib(self):
@@ -236,18 +277,19 @@ class GaussianRasterizer:
         inp = self._inputs(means_3d, shs, opacities, scales, rotations, sh_degree, background)
         cs = self._camera(camera, R_w2c, t_w2c)
         img = self.image if image_out is None else _chk(image_out, "image_out", (self.height, self.width, self.channels))
-        aux = None
-        if covisibilities is not None or uncertainties is not None:
-            aux = L.Aux(None if covisibilities is None else covisibilities.data_ptr(),
-                        None if uncertainties is None else uncertainties.data_ptr())
+        self.gstate.ensure(inp.n)  # rasterizer.jl:275-278
+        aux = L.Aux(None if covisibilities is None else covisibilities.data_ptr(),
+                    None if uncertainties is None else uncertainties.data_ptr(),
+                    self.gstate._radii.data_ptr() if inp.n else None)
         with torch.cuda.device(self.device):
-            L.check(self._lib.gsr_forward(self._h, C.byref(inp), C.byref(cs), _ptr(img),
-                                          None if aux is None else C.byref(aux), _stream(), C.byref(self.stats)))
+            L.check(self._lib.gsr_forward(self._h, C.byref(inp), C.byref(cs), _ptr(img), C.byref(aux), _stream(),
+                                          C.byref(self.stats)))
         self._n = inp.n
         return img
 
     def backward_raw(self, vpixels, means_3d, shs, opacities, scales, rotations, camera, sh_degree, background,
-                     R_w2c=None, t_w2c=None, arena: Optional[torch.Tensor] = None, factored_sh: bool = False):
+                     R_w2c=None, t_w2c=None, arena: Optional[torch.Tensor] = None, factored_sh: bool = False,
+                     forward_generation: int = 0):
         """∇rasterize.  Returns (vmeans, vshs, vopacities, vscales, vrot, vR, vt); when `arena`
         (a flat float32 tensor of (11+3K)·N elements, 59·N at K=16) is given the five gradients
         are views into it, laid out [vrot | vmeans | vshs | vopacities | vscales] for one
@@ -286,7 +328,8 @@ class GaussianRasterizer:
             vt = torch.empty(3, device=self.device)
         g = L.Grads(vmeans.data_ptr(), None if factored_sh else vshs.data_ptr(), vopac.data_ptr(), vscales.data_ptr(),
                     vrot.data_ptr(), None if vR is None else vR.data_ptr(), None if vt is None else vt.data_ptr(),
-                    vshs.data_ptr() if factored_sh else None)
+                    vshs.data_ptr() if factored_sh else None,
+                    self.gstate._grad_means_2d.data_ptr() if n else None, int(forward_generation))
         with torch.cuda.device(self.device):
             L.check(self._lib.gsr_backward(self._h, C.byref(inp), C.byref(cs), _ptr(vpixels), C.byref(g), _stream()))
         return vmeans, vshs, vopac, vscales, vrot, vR, vt
@@ -375,6 +418,7 @@ class _Rasterize(torch.autograd.Function):
         Rd = None if R_w2c is None else R_w2c.detach().contiguous()
         td = None if t_w2c is None else t_w2c.detach().contiguous()
         img = rast.forward_raw(*args, camera, sh_degree, background, Rd, td, covisibilities, uncertainties)
+        ctx.generation = int(rast.stats.generation)  # an eval render in between is reported, not silently used
         ctx.rast, ctx.camera, ctx.sh_degree, ctx.background = rast, camera, sh_degree, background
         ctx.pose = (Rd, td)
         ctx.save_for_backward(*args)
@@ -386,7 +430,7 @@ class _Rasterize(torch.autograd.Function):
         Rd, td = ctx.pose
         vm, vs, vo, vsc, vr, vR, vt = ctx.rast.backward_raw(
             vpixels.contiguous(), means_3d, shs, opacities, scales, rotations, ctx.camera, ctx.sh_degree,
-            ctx.background, Rd, td)
+            ctx.background, Rd, td, forward_generation=ctx.generation)
         return vm, vs, vo, vsc, vr, vR, vt, None, None, None, None, None, None
 
 

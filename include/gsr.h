@@ -10,8 +10,11 @@
  *     rotations (4,N) as (w,x,y,z), opacities (1,N), shs (3,K,N), image (C,W,H) channel
  *     fastest, n_contrib / final_T (W,H) x fastest, tile_ranges (2,T);
  *   - all work is enqueued on the `stream` argument (a hipStream_t passed as void*);
- *     the only host synchronisation is the instance-count read-back inside gsr_forward
- *     (the reference has the same one: rasterizer.jl:337);
+ *     the only host synchronisation in steady state is the instance-count read-back inside
+ *     gsr_forward (the reference has the same one: rasterizer.jl:337).  Scratch is grow-only
+ *     (rasterizer.jl:275-278,340-343): a call that has to GROW a scratch buffer (first view, more
+ *     Gaussians, a much denser view) frees and reallocates it with hipFree / hipMalloc, which
+ *     synchronise the device — exactly where the reference reallocates;
  *   - every function returns 0 on success or a negative GSR_E_* code; no C++ exception
  *     crosses this boundary; gsr_last_error_string() describes the last failure on the
  *     calling thread;
@@ -57,12 +60,17 @@ typedef struct gsr_config {
     uint32_t flags;      /* GSR_FLAG_* */
 } gsr_config;
 
-/* Exact footprint culling at binning: a (Gaussian, tile) instance none of whose pixels can
- * reach alpha >= 1/255 is not emitted at all.  The reference emits it and then skips it
- * pixel by pixel (render.jl:95), so image and gradients are unchanged (bit-identical);
- * only the internal lists shrink (n_rendered, ranges, values_sorted, n_contrib count
- * positions in the culled lists).  Off: lists are exactly the reference's. */
-#define GSR_FLAG_EXACT_TILE_CULL 1u
+/* Tile lists.  DEFAULT (flags = 0): exact footprint culling at binning — a (Gaussian, tile)
+ * instance none of whose pixels can reach alpha >= 1/255 is not emitted at all.  The reference
+ * emits it and then skips it pixel by pixel (render.jl:95), so the image, final_T, every
+ * gradient, radii and ∇means_2d are unchanged (image / final_T bit-identical, tested at 1 M
+ * Gaussians); only the INTERNAL lists shrink: gsr_stats.n_rendered, GSR_BUF_TILE_RANGES and
+ * GSR_BUF_VALUES_SORTED describe the culled lists (each an order-preserving subsequence of the
+ * reference's), and GSR_BUF_N_CONTRIB counts positions in them.  No caller of the reference reads
+ * those (bstate / istate are private to rasterize / ∇rasterize).
+ * GSR_FLAG_REFERENCE_TILE_LISTS: keep exactly the reference's lists (duplicate_with_keys!,
+ * utils.jl:85-120) — for list-level parity checks; ~7 % slower at 1 M Gaussians @1080p. */
+#define GSR_FLAG_REFERENCE_TILE_LISTS 1u
 
 /* Positional arguments of `rasterize(means_3d, shs, opacities, scales, rotations, ...)`
  * (rasterizer.jl:255-267).  opacities / scales are the ACTIVATED values, as the
@@ -98,12 +106,19 @@ typedef struct gsr_camera {
 typedef struct gsr_aux {
     uint8_t* covisibilities; /* device (N) Bool, set to 1 where T > 0.5, never cleared; or NULL */
     float* uncertainties;    /* device (W,H); or NULL */
+    /* `rast.gstate.radii` (states.jl:12, Int32 (N)) — read by the densification strategy right after
+     * the step (strategy.jl:85-86).  When non-NULL the forward writes the radii THERE instead of into
+     * handle-owned memory, so the caller's own GeometryState stays truthful; the array must stay valid
+     * until the matching gsr_backward (which re-reads it).  NULL: handle-owned (GSR_BUF_RADII). */
+    int32_t* radii;
 } gsr_aux;
 
 typedef struct gsr_stats {
     int64_t n_rendered;         /* D: tile instances (rasterizer.jl:337) */
     int32_t n_visible;          /* V: count(radii > 0) */
     int32_t max_tile_instances; /* longest per-tile list */
+    uint64_t generation;        /* ordinal of this forward on the handle (1, 2, ...): pass it to
+                                 * gsr_backward (gsr_grads.forward_generation) to have the pairing checked */
 } gsr_stats;
 
 /* Cotangents returned by `∇rasterize` (rasterizer.jl:549): caller-provided device
@@ -122,6 +137,14 @@ typedef struct gsr_grads {
                         * and the view's SH-coefficient gradient is returned in its factored form — the colour
                         * cotangent after the clamp mask, vc — from which gsr_sh_grad_from_views rebuilds
                         * Σ_views basis(dir_view) x vc_view.  3 floats per Gaussian cross the links, not 3K. */
+    float* vmeans2d;   /* (2,N) or NULL: `rast.gstate.∇means_2d` (states.jl:8; rasterizer.jl:440,474) — when given
+                        * the screen-space mean gradient the densification statistics read (strategy.jl:85-86) is
+                        * written THERE (fully overwritten; zeros for culled Gaussians) instead of into
+                        * handle-owned memory (GSR_BUF_GRAD_MEANS2D then returns this pointer). */
+    uint64_t forward_generation; /* 0: unchecked.  Otherwise must equal the gsr_stats.generation of the forward
+                        * this backward belongs to: an intervening forward on the same handle (e.g. an eval
+                        * render between a training forward and its pullback) is reported as GSR_E_STATE instead
+                        * of silently producing the gradients of the wrong view. */
 } gsr_grads;
 
 typedef struct gsr_handle gsr_handle;
@@ -152,8 +175,10 @@ GSR_API int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* 
  * (states.jl:2-111); valid until the next gsr_forward / release on this handle.
  * gsr_buffer() copies nothing: it returns the device address and byte size. */
 enum {
-    GSR_BUF_RADII = 0,         /* int32 (N)        gstate.radii — read by densification (strategy.jl:85-86) */
-    GSR_BUF_GRAD_MEANS2D = 1,  /* float (2,N)      gstate.∇means_2d, valid after gsr_backward */
+    GSR_BUF_RADII = 0,         /* int32 (N)        gstate.radii — read by densification (strategy.jl:85-86); the caller's
+                                *                   own array when the forward was given gsr_aux.radii */
+    GSR_BUF_GRAD_MEANS2D = 1,  /* float (2,N)      gstate.∇means_2d, valid after gsr_backward (the caller's own array when
+                                *                   the backward was given gsr_grads.vmeans2d) */
     GSR_BUF_N_CONTRIB = 2,     /* uint32 (W,H)     istate.n_contrib */
     GSR_BUF_FINAL_T = 3,       /* float (W,H)      istate.accum_α */
     GSR_BUF_TILE_RANGES = 4,   /* uint32 (2,T)     istate.ranges */
@@ -170,6 +195,11 @@ enum {
                                 *   (bits 0..15 tile rows, 16..19 8x8 quadrants the instance can touch) */
 };
 GSR_API int gsr_buffer(const gsr_handle* h, int which, const void** dev_ptr, size_t* bytes);
+/* Copy of one of those buffers into caller memory, enqueued on `stream` by the library's own HIP
+ * runtime (hosts that cannot wrap foreign device pointers — and must not dlopen a second HIP
+ * runtime to copy them — use this).  dst: device, at least `bytes` bytes; bytes must not exceed
+ * what gsr_buffer reports. */
+GSR_API int gsr_copy_buffer(const gsr_handle* h, int which, void* dst, size_t bytes, void* stream);
 
 /* update_stats!(strategy, rast.gstate.radii, rast.gstate.∇means_2d, resolution) —
  * src/strategy.jl:107-136 (`_update_stats!`): for every Gaussian visible in the last
@@ -306,6 +336,9 @@ GSR_API int gsr_stream_triad(float* a, const float* b, const float* c, size_t co
  * enabled, every gsr_forward / gsr_backward / gsr_loss_l1_ssim appends one event pair per
  * stage; gsr_profile_read() waits for them and returns, per stage, the summed
  * milliseconds and the number of launches (arrays of gsr_profile_stage_count() entries). */
+/* `on` is a bit set: 1 = HIP-event stage timing (above), 2 = one roctx range "gsr:<stage>" per stage around its
+ * launches (lets `rocprofv3 --marker-trace --kernel-trace` slice a trace by stage; the roctx library
+ * is resolved lazily with dlopen; GSR_ROCTX=1 in the environment enables the ranges on every handle). */
 GSR_API int gsr_profile_enable(gsr_handle* h, int on);
 GSR_API int gsr_profile_stage_count(void);
 GSR_API const char* gsr_profile_stage_name(int stage);

@@ -79,12 +79,41 @@ def trainer_case():
                 v_scales=vs, theta0=theta, grads=np.stack(grads), lr=np.float32(2.5e-3 / 20), theta3=th, mu3=mu, nu3=nu)
 
 
+def config1_case(pkg):
+    """BASELINE.json configs[0] ("CPU restatement only ... image hash + timings"):
+    10 k Gaussians, SH degree 0, 640x480, forward only, seed 1001.  Frozen: the integer outputs in
+    full (as checksums), every 4th pixel of the image, and the sha256 of the full image bytes (the hash
+    is informational across machines: glibc's expf is IFUNC-dispatched per CPU)."""
+    import hashlib
+    import time
+    W, H, n, deg, seed = 640, 480, 10_000, 0, 1001
+    s = pkg.synthetic.make_scene(n, W, H, deg, seed)
+    cam = orc.Camera(W, H, s.focal)
+    t0 = time.perf_counter()
+    st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg)
+    dt = time.perf_counter() - t0
+    print(f"config 1: oracle forward {dt * 1e3:.1f} ms on {orc.num_threads()} threads, "
+          f"{W * H / dt / 1e6:.2f} Mpixels/s, D = {st.n_rendered}")
+    return dict(image_sub=st.image[::4, ::4].copy(), n_rendered=st.n_rendered, radii_sum=int(st.radii.sum()),
+                n_visible=int((st.radii > 0).sum()), values_sorted_sum=int(st.values_sorted.astype(np.int64).sum()),
+                n_contrib_sum=int(st.n_contrib.astype(np.int64).sum()),
+                image_sha256=hashlib.sha256(st.image.tobytes()).hexdigest())
+
+
 def main():
+    """`make_golden.py [name ...]` regenerates only the named fixtures (config1, scene_rgb, ..., ssim, trainer)."""
     pkg = gsr_pkg.load()
+    only = set(sys.argv[1:])
+    want = lambda name: not only or name in only  # noqa: E731
+    if want("config1"):
+        np.savez_compressed(os.path.join(HERE, "config1.npz"), **config1_case(pkg))
     for mode, deg, seed, W, H, n in CASES:
-        np.savez_compressed(os.path.join(HERE, f"scene_{mode}.npz"), **scene_case(pkg, mode, deg, seed, W, H, n))
-    np.savez_compressed(os.path.join(HERE, "ssim.npz"), **ssim_case())
-    np.savez_compressed(os.path.join(HERE, "trainer.npz"), **trainer_case())
+        if want(f"scene_{mode}"):
+            np.savez_compressed(os.path.join(HERE, f"scene_{mode}.npz"), **scene_case(pkg, mode, deg, seed, W, H, n))
+    if want("ssim"):
+        np.savez_compressed(os.path.join(HERE, "ssim.npz"), **ssim_case())
+    if want("trainer"):
+        np.savez_compressed(os.path.join(HERE, "trainer.npz"), **trainer_case())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -27,8 +27,9 @@ def test_struct_sizes_match_header(pkg):
     assert C.sizeof(L.Config) == 32
     assert C.sizeof(L.Inputs) == 16 + 5 * 8 + 12 + 4
     assert C.sizeof(L.CameraS) == (9 + 3 + 2 + 2 + 3) * 4 + 4 + 16
-    assert C.sizeof(L.Stats) == 16
-    assert C.sizeof(L.Grads) == 64
+    assert C.sizeof(L.Stats) == 24
+    assert C.sizeof(L.Grads) == 80
+    assert C.sizeof(L.Aux) == 24
 
 
 def test_invalid_arguments_fail_before_touching_the_gpu(pkg):

@@ -12,6 +12,8 @@ Tolerances:
   * gradients: ‖Δ‖₂/‖g‖₂ <= 1e-4 per tensor (fp32 atomics / reassociation against the
     oracle's double-precision deterministic accumulation).
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -514,7 +516,7 @@ def test_side_stream_two_handles_and_buffer_growth(pkg, orc):
                enumerate([(100, 3.0), (900, 6.0), (300, 4.0)])]
     cam_o = orc.Camera(W, H, scenes_[0].focal)
     cam = pkg.Camera(W, H, tuple(scenes_[0].focal))
-    ra = pkg.rasterizer.GaussianRasterizer(W, H, mode="rgb")
+    ra = pkg.rasterizer.GaussianRasterizer(W, H, mode="rgb", exact_tile_cull=False)
     rb = pkg.rasterizer.GaussianRasterizer(W, H, mode="rgb", exact_tile_cull=True)
     vp = np.random.default_rng(5).standard_normal((H, W, 3)).astype(np.float32)
     with torch.cuda.stream(side):
@@ -557,3 +559,46 @@ def test_state_errors(pkg):
     assert rast.memory_usage() > 0
     rast.release_scene_buffers()
     rast.forward_raw(*t, cam, 0, (0, 0, 0))
+    # forward generation: a backward that names a superseded forward is refused (an eval render between a
+    # training forward and its pullback must not silently yield the wrong view's gradients)
+    gen = int(rast.stats.generation)
+    rast.forward_raw(*t, cam, 0, (0, 0, 0))
+    assert int(rast.stats.generation) == gen + 1
+    with pytest.raises(pkg._lib.GsrError) as e:
+        rast.backward_raw(torch.zeros(48, 64, 3).cuda(), *t, cam, 0, (0, 0, 0), forward_generation=gen)
+    assert e.value.code == pkg._lib.GSR_E_STATE
+    rast.backward_raw(torch.zeros(48, 64, 3).cuda(), *t, cam, 0, (0, 0, 0), forward_generation=gen + 1)
+
+
+def test_gstate_is_filled_by_the_library(pkg, orc):
+    """The drop-in contract of strategy.jl:85-86: after a step the caller reads `rast.gstate.radii` and
+    `rast.gstate.∇means_2d` — arrays the rasterizer OBJECT owns (rasterizer.jl:275-278), written in place by
+    gsr_forward / gsr_backward through gsr_aux.radii / gsr_grads.vmeans2d (no copies, no accessor calls);
+    they survive growth of the model and feed gsr_update_stats."""
+    W, H = 96, 64
+    rast = pkg.rasterizer.GaussianRasterizer(W, H, mode="rgb")
+    for n, seed in ((200, 5), (700, 6), (300, 7)):  # grows, then shrinks: gstate is grow-only
+        s, cam = _scene(pkg, orc, n, W, H, 1, seed, sigma_px=4.0)
+        camera = pkg.Camera(W, H, tuple(s.focal))
+        t = [dev(s.means), dev(s.shs), dev(s.opacities.reshape(-1, 1)), dev(s.scales), dev(s.rotations)]
+        st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, 1)
+        vp = np.random.default_rng(seed).standard_normal((H, W, 3)).astype(np.float32)
+        g = orc.backward(st, vp, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, 1)
+        rast.forward_raw(*t, camera, 1, (0, 0, 0))
+        p0 = rast.gstate.radii.data_ptr()
+        rast.backward_raw(dev(vp), *t, camera, 1, (0, 0, 0))
+        torch.cuda.synchronize()
+        assert rast.gstate.radii.data_ptr() == p0 and len(rast.gstate) >= n
+        assert rast.gstate.radii.shape == (n,) and rast.gstate.grad_means_2d.shape == (n, 2)
+        assert np.array_equal(rast.gstate.radii.cpu().numpy(), st.radii)
+        assert rel_l2(rast.gstate.grad_means_2d.cpu().numpy(), g.vmeans2d) <= 1e-4
+        # the library reports the caller's arrays as the state buffers, and update_stats reads them
+        ptr, sz = C.c_void_p(), C.c_size_t()
+        pkg._lib.check(rast._lib.gsr_buffer(rast._h, pkg._lib.BUF_RADII, C.byref(ptr), C.byref(sz)))
+        assert ptr.value == p0 and sz.value == 4 * n
+        mr = torch.zeros(n, dtype=torch.int32, device="cuda"); acc = torch.zeros(n, device="cuda"); den = torch.zeros(n, device="cuda")
+        rast.update_stats(mr, acc, den)
+        mo, ao, do = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+        orc.update_stats(mo, ao, do, st.radii, rast.gstate.grad_means_2d.cpu().numpy(), W, H)
+        assert np.array_equal(mr.cpu().numpy(), mo) and np.array_equal(den.cpu().numpy(), do)
+        assert np.allclose(acc.cpu().numpy(), ao, rtol=1e-6, atol=0)

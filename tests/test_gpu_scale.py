@@ -1,7 +1,10 @@
-"""-m gpu tests at BASELINE.json's sizes.  Config 2 (100 k Gaussians, 1080p) is compared
-with the oracle in full; config 3 (1 M) forward vs oracle + size-independent properties;
-config 5 (5 M, 3840x2160) properties only (the oracle would take minutes):
-sortedness of every tile list, Σ ranges = D, background-composite identity, backward
+"""-m gpu tests at BASELINE.json's sizes.  Config 1 (10 k, SH 0, 640x480, forward), config 2
+(100 k Gaussians, 1080p) and config 3 (1 M, 1080p, forward + L1/SSIM loss head + backward, in the
+mode bench.py times: exact footprint culling) are compared with the oracle in full — image, loss,
+the loss pullback, all five gradients and gstate.∇means_2d, with both SURVEY.md §8(c) criteria
+(rel-L2 <= 1e-4 and |Δ| <= 1e-3|g| + 1e-6·max|g| on >= 99.9 % of elements).  Config 5 (5 M,
+3840x2160): oracle forward compare (marked slow-ish: ~30 s of host time) + size-independent
+properties: sortedness of every tile list, Σ ranges = D, background-composite identity, backward
 linearity in the cotangent, run-to-run determinism of the forward."""
 import numpy as np
 import pytest
@@ -140,5 +143,89 @@ def test_config3_1m_1080p(pkg, orc):
     _properties(pkg, orc, 1_000_000, 1920, 1080, 1003, with_oracle_fwd=True)
 
 
+def _full_step_vs_oracle(pkg, orc, n, W, H, deg, seed, exact_tile_cull):
+    """One whole bench.py step — gsr_forward -> gsr_loss_l1_ssim -> gsr_backward — against
+    orc.forward / orc.loss_head / orc.backward(deterministic=True)
+    (rasterizer.jl:255-408,416-550; training.jl:684-694)."""
+    import time
+    s = pkg.synthetic.make_scene(n, W, H, deg, seed)
+    cam = orc.Camera(W, H, s.focal)
+    tgt = pkg.synthetic.make_target(W, H, seed)
+    t0 = time.perf_counter()
+    st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg)
+    loss_o, vp_o = orc.loss_head(st.image, tgt)
+    g = orc.backward(st, vp_o, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, deterministic=True)
+    t_orc = time.perf_counter() - t0
+    run = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, exact_tile_cull=exact_tile_cull)
+    img = run.forward()
+    loss, vpix = pkg.fused_ssim.l1_ssim_loss(run.rast, img, dev(tgt))
+    out = run.rast.backward_raw(vpix, *run.t, run.camera, deg, run.bg)
+    torch.cuda.synchronize()
+    # forward: discrete outputs exact, image within the stated tolerance
+    assert np.array_equal(run.rast.radii.cpu().numpy(), st.radii)
+    if not exact_tile_cull:
+        assert run.rast.stats.n_rendered == st.n_rendered
+        assert np.array_equal(run.rast.values_sorted.cpu().numpy().astype(np.uint32), st.values_sorted)
+    else:
+        assert run.rast.stats.n_rendered <= st.n_rendered
+    assert frac_bad(img.cpu().numpy(), st.image, 0, 1e-4) <= 1e-4
+    assert frac_bad(run.rast.accum_alpha.cpu().numpy(), st.accum_alpha, 0, 1e-4) <= 1e-4
+    # loss head at full size
+    assert abs(float(loss) - float(loss_o)) <= 1e-5 * max(1.0, abs(float(loss_o)))
+    vp_h = vpix.cpu().numpy()
+    assert rel_l2(vp_h.reshape(-1), vp_o.reshape(-1)) <= 1e-4
+    # all five gradients + gstate.∇means_2d, both §8(c) criteria
+    names = "means shs opac scales rots".split()
+    refs = (g.vmeans, g.vshs, g.vopacities, g.vscales, g.vrots)
+    worst = {}
+    for o, ref, name in zip(out[:5], refs, names):
+        o = o.cpu().numpy().reshape(-1); ref = ref.reshape(-1)
+        r = rel_l2(o, ref)
+        fb = frac_bad(o, ref, 1e-3, 1e-6 * np.abs(ref).max())
+        worst[name] = (r, fb)
+        assert r <= 1e-4, (name, r)
+        assert fb <= 1e-3, (name, fb)
+    m2 = run.rast.grad_means_2d.cpu().numpy().reshape(-1)
+    r = rel_l2(m2, g.vmeans2d.reshape(-1))
+    assert r <= 1e-4, ("means2d", r)
+    assert frac_bad(m2, g.vmeans2d.reshape(-1), 1e-3, 1e-6 * np.abs(g.vmeans2d).max()) <= 1e-3
+    print(f"[full step vs oracle] n={n} {W}x{H} exact_cull={exact_tile_cull}: oracle {t_orc:.1f} s on "
+          f"{orc.num_threads()} threads; worst rel-L2 {max(v[0] for v in worst.values()):.2e}, "
+          f"worst outlier fraction {max(v[1] for v in worst.values()):.2e}")
+    return st, img
+
+
+def test_config3_full_step_vs_oracle_in_bench_mode(pkg, orc):
+    """What bench.py times, at the size it times it: config 3 with GSR_FLAG_EXACT_TILE_CULL."""
+    _full_step_vs_oracle(pkg, orc, 1_000_000, 1920, 1080, 3, 1003, exact_tile_cull=True)
+
+
+def test_config3_full_step_vs_oracle_reference_lists(pkg, orc):
+    """Same step with the reference's instance lists (flag off)."""
+    _full_step_vs_oracle(pkg, orc, 1_000_000, 1920, 1080, 3, 1003, exact_tile_cull=False)
+
+
+def test_config1_10k_sh0_640x480_forward(pkg, orc):
+    """BASELINE.json configs[0]: 10 k Gaussians, SH degree 0 (K = 1), 640x480, forward only.
+    The oracle is the CPU path (pinned to the committed fixture tests/golden/config1.npz by
+    tests/test_golden.py); the HIP forward must agree with it in both list modes."""
+    W, H, n, deg, seed = 640, 480, 10_000, 0, 1001
+    s = pkg.synthetic.make_scene(n, W, H, deg, seed)
+    assert s.shs.shape[1] == 1
+    cam = orc.Camera(W, H, s.focal)
+    st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg)
+    for cull in (False, True):
+        run = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, exact_tile_cull=cull)
+        img = run.forward().cpu().numpy()
+        assert np.array_equal(run.rast.radii.cpu().numpy(), st.radii)
+        if not cull:
+            assert run.rast.stats.n_rendered == st.n_rendered
+            assert np.array_equal(run.rast.values_sorted.cpu().numpy().astype(np.uint32), st.values_sorted)
+            assert np.array_equal(run.rast.ranges.cpu().numpy().astype(np.uint32), st.ranges)
+            assert (run.rast.n_contrib.cpu().numpy().astype(np.uint32) != st.n_contrib).mean() <= 1e-4
+        assert frac_bad(img, st.image, 0, 1e-4) <= 1e-4
+        assert frac_bad(run.rast.accum_alpha.cpu().numpy(), st.accum_alpha, 0, 1e-4) <= 1e-4
+
+
 def test_config5_5m_4k(pkg, orc):
-    _properties(pkg, orc, 5_000_000, 3840, 2160, 1005, with_oracle_fwd=False)
+    _properties(pkg, orc, 5_000_000, 3840, 2160, 1005, with_oracle_fwd=True)

@@ -1,67 +1,95 @@
 #!/usr/bin/env python3
-"""Turn the two rocprofv3 --pmc passes of tools/pmc_workload.py into HBM bytes per launch.
+"""Turn the rocprofv3 --pmc passes of tools/pmc_workload.py into per-launch HBM bytes and SQ counters
+of ONE configuration and merge them into profiles/pmc_traffic.json under configs[<key>].
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB-like units that are uncalibrated on gfx950
 (MI355X_MICROARCH.md §HBM: FETCH_SIZE reads exactly 1/2 of a wide coalesced stream), so
-both are calibrated on the 1 GiB copy kernel of the same run: factor = known bytes /
-counter value.  Output: {stage: bytes per launch} with the calibration factors recorded.
+both are calibrated on the 1 GiB copy kernel of the same pass: factor = known bytes /
+counter value.  SQ counters (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_WAVE_CYCLES, ...) are taken as
+reported (per-launch mean).
+
+  tools/pmc_parse.py OUT_DIR profiles/pmc_traffic.json [--meta gpurun_out/pmc_meta.json] [--source r02_a]
 """
+import argparse
 import csv
 import glob
 import json
 import os
-import sys
 from collections import defaultdict
 
-STAGES = {"preprocess_kernel": "preprocess", "tile_scan_kernel": "tile_scan", "scatter_kernel": "scatter",
-          "tile_sort_kernel": "tile_sort", "composite_fwd_": "composite_fwd",
-          "composite_bwd_kernel": "composite_bwd", "pergauss_bwd_kernel": "pergauss_bwd",
-          "ssim_fwd_kernel": "loss_fwd", "ssim_bwd_kernel": "loss_bwd"}
+STAGES = {"preprocess_kernel": "preprocess", "tile_scan_kernel": "tile_scan", "tile_sort_kernel": "tile_sort",
+          "tile_count_kernel": "tile_sort", "tile_scatter_kernel": "tile_sort", "tile_radix": "tile_sort",
+          "composite_fwd_": "composite_fwd", "composite_bwd_kernel": "composite_bwd",
+          "pergauss_bwd_kernel": "pergauss_bwd", "ssim_fwd_kernel": "loss_fwd", "ssim_bwd_kernel": "loss_bwd"}
 CAL_BYTES = 256 * 1024 * 1024 * 4
 
 
-def per_kernel(path, counter):
-    acc = defaultdict(list)
-    with open(path) as f:
+def per_kernel(path):
+    """{counter: {kernel name: [values]}} — streaming parse (kernel names are kilobytes long)."""
+    acc = defaultdict(lambda: defaultdict(list))
+    with open(path, newline="") as f:
         for row in csv.DictReader(f):
-            if row.get("Counter_Name") != counter:
-                continue
-            acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+            acc[row["Counter_Name"]][row["Kernel_Name"]].append(float(row["Counter_Value"]))
     return acc
 
 
-def main(d):
-    out = {"unit": "bytes per launch", "calibration": {}}
-    res = {}
-    for counter, tag in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
-        files = glob.glob(os.path.join(d, "**", f"{tag}*counter_collection.csv"), recursive=True)
-        if not files:
-            print("missing", tag)
-            continue
-        acc = per_kernel(files[0], counter)
-        # torch's Tensor.copy_ of the 1 GiB buffer runs as the runtime's blit kernel
-        cal = [v for k, vs in acc.items() if "copyBuffer" in k for v in vs]
-        cal = [v for v in cal if v > 0.5 * max(cal)] if cal else []
-        if not cal:
-            raise SystemExit(f"no calibration kernel found for {counter}")
-        factor = CAL_BYTES / (sum(cal) / len(cal))
-        out["calibration"][counter] = {"bytes_per_unit": factor, "copy_kernel_value": sum(cal) / len(cal)}
-        for k, vs in acc.items():
-            for key, stage in STAGES.items():
-                if key in k:
-                    # several kernel variants may belong to one stage (e.g. the two tile_sort launches):
-                    # their per-launch means add up
-                    r = res.setdefault(stage, {})
-                    r[tag] = r.get(tag, 0.0) + factor * sum(vs) / len(vs)
-    for stage, v in res.items():
-        out[stage] = int(v.get("fetch", 0) + v.get("write", 0))
-        out[stage + "_read"] = int(v.get("fetch", 0))
-        out[stage + "_write"] = int(v.get("write", 0))
-    print(json.dumps(out, indent=1))
-    return out
+def stage_of(kernel_name):
+    for key, stage in STAGES.items():
+        if key in kernel_name:
+            return stage
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("out_dir")
+    ap.add_argument("json_path")
+    ap.add_argument("--meta", default=None)
+    ap.add_argument("--source", default="")
+    a = ap.parse_args()
+    meta_path = a.meta or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "pmc_meta.json")
+    meta = json.load(open(meta_path))
+    rec = {"source": a.source, "tile_instances": meta["tile_instances"], "n_visible": meta.get("n_visible"),
+           "unit": "per launch (mean over the launches of the pass)", "calibration": {}, "hbm_bytes": {}, "hbm_read": {},
+           "hbm_write": {}, "sq": {}}
+    for f in sorted(glob.glob(os.path.join(a.out_dir, "**", "*counter_collection.csv"), recursive=True)):
+        acc = per_kernel(f)
+        for counter, by_kernel in acc.items():
+            if counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                # torch's Tensor.copy_ of the 1 GiB buffer runs as an elementwise copy kernel
+                cal = [v for k, vs in by_kernel.items() if ("copyBuffer" in k or "direct_copy" in k or "CopyFunctor" in k) for v in vs]
+                cal = [v for v in cal if v > 0.5 * max(cal)] if cal else []
+                if not cal:
+                    raise SystemExit(f"no calibration kernel found for {counter} in {f}")
+                factor = CAL_BYTES / (sum(cal) / len(cal))
+                rec["calibration"][counter] = {"bytes_per_unit": factor, "copy_kernel_value": sum(cal) / len(cal)}
+                dst = rec["hbm_read"] if counter == "FETCH_SIZE" else rec["hbm_write"]
+                for k, vs in by_kernel.items():
+                    st = stage_of(k)
+                    if st:  # several kernel variants may belong to one stage: their per-launch means add up
+                        dst[st] = dst.get(st, 0) + int(factor * sum(vs) / len(vs))
+            else:
+                for k, vs in by_kernel.items():
+                    st = stage_of(k)
+                    if st:
+                        d = rec["sq"].setdefault(st, {})
+                        d[counter] = d.get(counter, 0) + sum(vs) / len(vs)
+    for st in set(rec["hbm_read"]) | set(rec["hbm_write"]):
+        rec["hbm_bytes"][st] = rec["hbm_read"].get(st, 0) + rec["hbm_write"].get(st, 0)
+    doc = {"configs": {}}
+    if os.path.exists(a.json_path):
+        try:
+            old = json.load(open(a.json_path))
+            if "configs" in old:
+                doc = old
+        except Exception:
+            pass
+    doc["configs"][meta["key"]] = rec
+    json.dump(doc, open(a.json_path, "w"), indent=1, sort_keys=True)
+    print(meta["key"], json.dumps({k: rec[k] for k in ("tile_instances", "hbm_bytes")}, indent=1))
+    for st, d in rec["sq"].items():
+        print(st, {k: int(v) for k, v in d.items()})
 
 
 if __name__ == "__main__":
-    o = main(sys.argv[1])
-    if len(sys.argv) > 2:
-        json.dump(o, open(sys.argv[2], "w"), indent=1)
+    main()

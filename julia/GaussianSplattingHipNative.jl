@@ -1,19 +1,32 @@
 # Julia-side binding of libgsr_hip.so for GaussianSplatting.jl (reference @ v2.0.0).
 #
-# This file could not be executed in the build environment (no Julia there); it is kept
-# small and mirrors, field for field, the ctypes binding that IS tested
-# (gaussiansplatting.jl_amd/_lib.py + rasterizer.py).  It adds `rasterize` / `rrule`
-# methods for a `HipNativeRasterizer`, so `Trainer.step!`, `validate`, the GUI worker etc.
-# (callers listed in SURVEY.md §8b) run unchanged once they construct this rasterizer
-# instead of `GaussianRasterizer`.
+# Could not be executed in the build environment (no Julia there); kept small and field-for-field
+# identical to the ctypes binding that IS tested (gaussiansplatting.jl_amd/_lib.py + rasterizer.py).
 #
-# Replaces: src/rasterization/rasterizer.jl:255-408 (rasterize), :416-550 (∇rasterize),
-#           :552-573 (rrule).
+# Design (what makes it a drop-in — every caller of the reference runs unchanged):
+#   * callers keep holding the reference's own `GaussianRasterizer` — `Trainer{R <: GaussianRasterizer}`
+#     (training.jl:185-194,225), the functor `rast(points, opacities, scales, rotations, f_dc, f_rest; ...)`
+#     (rasterizer.jl:200-253, called at training.jl:646 / :501) and `rast.gstate.radii` / `rast.gstate.∇means_2d`
+#     (strategy.jl:85-86) all keep working because nothing about that object changes;
+#   * the native handle lives in a side table keyed by the rasterizer (`enable_hip_native!(rast)`); rasterizers
+#     that were not enabled — e.g. the sky dome's second `GaussianRasterizer` (sky_dome.jl:144,191) unless it is
+#     enabled too — fall through to the reference kernels via `invoke`;
+#   * NO dispatch on keyword arguments (Julia has none): the two methods below are more specific than the
+#     reference's only in their POSITIONAL types (ROCArray instead of AbstractArray), and branch on the side table;
+#   * only `rasterize` and `∇rasterize` are overridden.  The reference's `ChainRulesCore.rrule`
+#     (rasterizer.jl:552-573) calls exactly these two generics, so the rrule, Zygote and the functor prologue are
+#     the reference's own code;
+#   * the library writes `radii` and `∇means_2d` straight into `rast.gstate` (gsr_aux.radii / gsr_grads.vmeans2d) and
+#     the image into `rast.image`, so the reference's state object stays truthful.
+#
+# Replaces: src/rasterization/rasterizer.jl:255-408 (rasterize), :416-550 (∇rasterize).
 module GaussianSplattingHipNative
 
-using AMDGPU, ChainRulesCore, StaticArrays
+using AMDGPU, StaticArrays
+import KernelAbstractions as KA
+import GPUArrays
 import GaussianSplatting
-import GaussianSplatting: Camera, resolution
+import GaussianSplatting: GaussianRasterizer, GeometryState, Camera, resolution, n_color_features, rasterize, ∇rasterize
 
 const LIB = get(ENV, "GSR_HIP_LIB", "libgsr_hip.so")
 
@@ -32,34 +45,51 @@ struct GsrCamera
     principal::NTuple{2, Float32}; camera_center::NTuple{3, Float32}
     R_dev::Ptr{Float32}; t_dev::Ptr{Float32}
 end
-struct GsrAux; covisibilities::Ptr{UInt8}; uncertainties::Ptr{Float32}; end
+struct GsrAux; covisibilities::Ptr{UInt8}; uncertainties::Ptr{Float32}; radii::Ptr{Int32}; end
+struct GsrStats; n_rendered::Int64; n_visible::Int32; max_tile_instances::Int32; generation::UInt64; end
 struct GsrGrads
     vmeans::Ptr{Float32}; vshs::Ptr{Float32}; vopacities::Ptr{Float32}
     vscales::Ptr{Float32}; vrotations::Ptr{Float32}; vR::Ptr{Float32}; vt::Ptr{Float32}
-    vcolors::Ptr{Float32}  # C_NULL: classic form (∇shs written); see gsr.h for the factored multi-view form
+    vcolors::Ptr{Float32}          # C_NULL: classic form (∇shs written); see gsr.h for the factored multi-view form
+    vmeans2d::Ptr{Float32}         # rast.gstate.∇means_2d
+    forward_generation::UInt64     # pairs the pullback with its forward (0 = unchecked)
 end
 
 check(rc) = rc == 0 || error(unsafe_string(ccall((:gsr_last_error_string, LIB), Cstring, ())))
-dptr(x) = x === nothing ? Ptr{Float32}(C_NULL) : Ptr{Float32}(UInt(pointer(x)))
+dptr(::Type{T}, x) where T = x === nothing ? Ptr{T}(C_NULL) : Ptr{T}(UInt(pointer(x)))
+dptr(x) = dptr(Float32, x)
 hipstream() = Ptr{Cvoid}(UInt(AMDGPU.stream().stream))  # the task-local stream (gui/worker.jl:47-51)
 
-mutable struct HipNativeRasterizer
+# ---- side table: reference rasterizer -> native handle ----
+mutable struct NativeState
     handle::Ptr{Cvoid}
-    image::ROCArray{Float32, 3}
-    mode::Symbol
-    width::Int; height::Int
+    generation::UInt64
+end
+const NATIVE = WeakKeyDict{GaussianRasterizer, NativeState}()
+const NATIVE_LOCK = ReentrantLock()
+native(rast::GaussianRasterizer) = lock(() -> get(NATIVE, rast, nothing), NATIVE_LOCK)
+
+"""
+    enable_hip_native!(rast; reference_tile_lists=false)
+
+Route `rasterize` / `∇rasterize` on this rasterizer through libgsr_hip.so.  Width / height / mode / near / far
+are the rasterizer's own (rasterizer.jl:60-90).  Returns `rast`.
+"""
+function enable_hip_native!(rast::GaussianRasterizer; reference_tile_lists::Bool = false)
+    native(rast) === nothing || return rast
+    c, w, h = size(rast.image)
+    href = Ref{Ptr{Cvoid}}()
+    check(ccall((:gsr_create, LIB), Cint, (Ref{GsrConfig}, Ref{Ptr{Cvoid}}),
+        GsrConfig(w, h, c, rast.near_plane, rast.far_plane, 3, 0.3f0, reference_tile_lists ? 0x1 : 0x0), href))
+    st = NativeState(href[], 0)
+    finalizer(s -> ccall((:gsr_destroy, LIB), Cint, (Ptr{Cvoid},), s.handle), st)
+    lock(() -> (NATIVE[rast] = st), NATIVE_LOCK)
+    return rast
 end
 
-function HipNativeRasterizer(; width::Int, height::Int, mode::Symbol = :rgbd,
-                             near_plane::Float32 = 0.2f0, far_plane::Float32 = 1000f0,
-                             exact_tile_cull::Bool = false)
-    c = GaussianSplatting.n_color_features(mode)
-    h = Ref{Ptr{Cvoid}}()
-    check(ccall((:gsr_create, LIB), Cint, (Ref{GsrConfig}, Ref{Ptr{Cvoid}}),
-        GsrConfig(width, height, c, near_plane, far_plane, 3, 0.3f0, exact_tile_cull ? 1 : 0), h))
-    r = HipNativeRasterizer(h[], AMDGPU.zeros(Float32, c, width, height), mode, width, height)
-    finalizer(x -> ccall((:gsr_destroy, LIB), Cint, (Ptr{Cvoid},), x.handle), r)
-    return r
+function disable_hip_native!(rast::GaussianRasterizer)
+    lock(() -> delete!(NATIVE, rast), NATIVE_LOCK)  # the finalizer of the NativeState destroys the handle
+    return rast
 end
 
 function _structs(means_3d, shs, opacities, scales, rotations, R_w2c, t_w2c, camera::Camera, sh_degree, background)
@@ -72,69 +102,89 @@ function _structs(means_3d, shs, opacities, scales, rotations, R_w2c, t_w2c, cam
     return inp, cam
 end
 
-function GaussianSplatting.rasterize(means_3d::ROCArray, shs::ROCArray, opacities::ROCArray, scales::ROCArray,
-        rotations::ROCArray, R_w2c = nothing, t_w2c = nothing;
-        rast::HipNativeRasterizer, camera::Camera, sh_degree::Int, background::SVector{3, Float32},
+const RM = ROCMatrix{Float32}
+const R3 = ROCArray{Float32, 3}
+const REF_FWD_SIG = Tuple{AbstractMatrix{Float32}, AbstractArray{Float32, 3}, AbstractMatrix{Float32},
+                          AbstractMatrix{Float32}, AbstractMatrix{Float32}, Any, Any}
+const REF_BWD_SIG = Tuple{AbstractArray{Float32, 3}, AbstractMatrix{Float32}, AbstractArray{Float32, 3},
+                          AbstractMatrix{Float32}, AbstractMatrix{Float32}, AbstractMatrix{Float32},
+                          AbstractVector{Int32}, Any, Any}
+
+# rasterize(means_3d, shs, opacities, scales, rotations, R_w2c, t_w2c; rast, camera, ...) — rasterizer.jl:255-408
+function GaussianSplatting.rasterize(means_3d::RM, shs::R3, opacities::RM, scales::RM, rotations::RM,
+        R_w2c = nothing, t_w2c = nothing;
+        rast::GaussianRasterizer, camera::Camera, sh_degree::Int, background::SVector{3, Float32},
         covisibilities = nothing, uncertainties = nothing)
-    inp, cam = _structs(means_3d, shs, opacities, scales, rotations, R_w2c, t_w2c, camera, sh_degree, background)
-    aux = GsrAux(covisibilities === nothing ? C_NULL : Ptr{UInt8}(UInt(pointer(covisibilities))), dptr(uncertainties))
-    check(ccall((:gsr_forward, LIB), Cint,
-        (Ptr{Cvoid}, Ref{GsrInputs}, Ref{GsrCamera}, Ptr{Float32}, Ref{GsrAux}, Ptr{Cvoid}, Ptr{Cvoid}),
-        rast.handle, inp, cam, dptr(rast.image), aux, hipstream(), C_NULL))
-    return rast.image
-end
-
-function ChainRulesCore.rrule(::typeof(GaussianSplatting.rasterize), means_3d::ROCArray, shs, opacities, scales,
-        rotations, R_w2c = nothing, t_w2c = nothing; rast::HipNativeRasterizer, camera::Camera, sh_degree::Int,
-        background::SVector{3, Float32}, covisibilities = nothing, uncertainties = nothing)
-    image = GaussianSplatting.rasterize(means_3d, shs, opacities, scales, rotations, R_w2c, t_w2c;
+    st = native(rast)
+    st === nothing && return invoke(rasterize, REF_FWD_SIG, means_3d, shs, opacities, scales, rotations, R_w2c, t_w2c;
         rast, camera, sh_degree, background, covisibilities, uncertainties)
-    function _pullback(vpixels)
-        vp = unthunk(vpixels)
-        n = size(means_3d, 2)
-        vmeans = similar(means_3d); vshs = similar(shs); vopac = similar(opacities)
-        vscales = similar(scales); vrot = similar(rotations)
-        vR = R_w2c === nothing ? nothing : AMDGPU.zeros(Float32, 3, 3)
-        vt = R_w2c === nothing ? nothing : AMDGPU.zeros(Float32, 3)
-        inp, cam = _structs(means_3d, shs, opacities, scales, rotations, R_w2c, t_w2c, camera, sh_degree, background)
-        check(ccall((:gsr_backward, LIB), Cint,
-            (Ptr{Cvoid}, Ref{GsrInputs}, Ref{GsrCamera}, Ptr{Float32}, Ref{GsrGrads}, Ptr{Cvoid}),
-            rast.handle, inp, cam, dptr(vp),
-            GsrGrads(dptr(vmeans), dptr(vshs), dptr(vopac), dptr(vscales), dptr(vrot), dptr(vR), dptr(vt), dptr(nothing)), hipstream()))
-        return (NoTangent(), vmeans, vshs, vopac, vscales, vrot, vR, vt)
+    n = size(means_3d, 2)
+    if length(rast.gstate) < n  # rasterizer.jl:275-278: the reference's own grow-only GeometryState
+        KA.unsafe_free!(rast.gstate)
+        rast.gstate = GPUArrays.@uncached GeometryState(KA.get_backend(rast), n; n_features=n_color_features(rast.mode))
     end
-    return image, _pullback
+    inp, cam = _structs(means_3d, shs, opacities, scales, rotations, R_w2c, t_w2c, camera, sh_degree, background)
+    aux = GsrAux(dptr(UInt8, covisibilities), dptr(uncertainties), dptr(Int32, rast.gstate.radii))
+    stats = Ref(GsrStats(0, 0, 0, 0))
+    check(ccall((:gsr_forward, LIB), Cint,
+        (Ptr{Cvoid}, Ref{GsrInputs}, Ref{GsrCamera}, Ptr{Float32}, Ref{GsrAux}, Ptr{Cvoid}, Ref{GsrStats}),
+        st.handle, inp, cam, dptr(rast.image), aux, hipstream(), stats))
+    st.generation = stats[].generation
+    return rast.image  # aliased, overwritten by the next call (rasterizer.jl:407)
 end
 
-# Side outputs densification reads (src/strategy.jl:85-86): rast.gstate.radii / ∇means_2d
-function state_buffer(rast::HipNativeRasterizer, which::Integer, ::Type{T}, dims) where T
-    p = Ref{Ptr{Cvoid}}(); sz = Ref{Csize_t}()
-    check(ccall((:gsr_buffer, LIB), Cint, (Ptr{Cvoid}, Cint, Ref{Ptr{Cvoid}}, Ref{Csize_t}), rast.handle, which, p, sz))
-    return unsafe_wrap(ROCArray, Ptr{T}(p[]), dims; own=false)
+# ∇rasterize(vpixels, means_3d, shs, scales, rotations, opacities, radii, R_w2c, t_w2c; rast, ...) — rasterizer.jl:416-550
+# (called by the reference's rrule pullback, rasterizer.jl:565-570, with radii = rast.gstate.radii)
+function GaussianSplatting.∇rasterize(vpixels::R3, means_3d::RM, shs::R3, scales::RM, rotations::RM, opacities::RM,
+        radii::ROCVector{Int32}, R_w2c = nothing, t_w2c = nothing;
+        rast::GaussianRasterizer, camera::Camera, sh_degree::Int, background::SVector{3, Float32})
+    st = native(rast)
+    st === nothing && return invoke(∇rasterize, REF_BWD_SIG, vpixels, means_3d, shs, scales, rotations, opacities,
+        radii, R_w2c, t_w2c; rast, camera, sh_degree, background)
+    # fresh gradient arrays per call, as the reference (rasterizer.jl:437-445); the library overwrites every element
+    vmeans = similar(means_3d); vshs = similar(shs); vopac = similar(opacities)
+    vscales = similar(scales); vrot = similar(rotations)
+    vR = R_w2c === nothing ? nothing : AMDGPU.zeros(Float32, 3, 3)
+    vt = R_w2c === nothing ? nothing : AMDGPU.zeros(Float32, 3)
+    inp, cam = _structs(means_3d, shs, opacities, scales, rotations, R_w2c, t_w2c, camera, sh_degree, background)
+    g = GsrGrads(dptr(vmeans), dptr(vshs), dptr(vopac), dptr(vscales), dptr(vrot), dptr(vR), dptr(vt),
+        Ptr{Float32}(C_NULL), Ptr{Float32}(UInt(pointer(rast.gstate.∇means_2d))), st.generation)
+    check(ccall((:gsr_backward, LIB), Cint,
+        (Ptr{Cvoid}, Ref{GsrInputs}, Ref{GsrCamera}, Ptr{Float32}, Ref{GsrGrads}, Ptr{Cvoid}),
+        st.handle, inp, cam, dptr(vpixels), g, hipstream()))
+    return vmeans, vshs, vopac, vscales, vrot, vR, vt
 end
-radii(rast, n) = state_buffer(rast, 0, Int32, (n,))
-grad_means_2d(rast, n) = state_buffer(rast, 1, Float32, (2, n))
 
-# update_stats!(strategy, radii, ∇means_2d, resolution) (src/strategy.jl:107-116) without the copies
-update_stats!(strategy, rast::HipNativeRasterizer) = check(ccall((:gsr_update_stats, LIB), Cint,
-    (Ptr{Cvoid}, Ptr{Int32}, Ptr{Float32}, Ptr{Float32}, Ptr{Cvoid}), rast.handle,
-    Ptr{Int32}(UInt(pointer(strategy.max_radii))), dptr(strategy.accum_∇means_2d), dptr(strategy.denom), hipstream()))
+# release_scene_buffers!(rast) (rasterizer.jl:111-123) also has to drop the library's scene-sized scratch
+function release_native_scene_buffers!(rast::GaussianRasterizer)
+    st = native(rast)
+    st === nothing || check(ccall((:gsr_release_scene_buffers, LIB), Cint, (Ptr{Cvoid},), st.handle))
+    return
+end
 
-# The tail of `step!` (src/training.jl:768-779 + the prologue of the next `rast(...)` call, rasterizer.jl:218-247)
-# in one pass: `∇` are the cotangents the rrule above returned (w.r.t. the ACTIVATED opacity / scale), `θ` the raw
-# parameter arrays and `opts` the six NU.Adam in OPTIMIZER_NAMES order; shs / opacities_act / scales_act are the
-# activated copies of this step on entry and of the updated parameters on exit.
+# ---- optional fused tails (not needed for the drop-in; callers opt in) ----
+
+# update_stats!(strategy, radii, ∇means_2d, resolution) (strategy.jl:107-136) on the library's kernel
+update_stats!(strategy, rast::GaussianRasterizer) = check(ccall((:gsr_update_stats, LIB), Cint,
+    (Ptr{Cvoid}, Ptr{Int32}, Ptr{Float32}, Ptr{Float32}, Ptr{Cvoid}), native(rast).handle,
+    dptr(Int32, strategy.max_radii), dptr(strategy.accum_∇means_2d), dptr(strategy.denom), hipstream()))
+
+# The tail of `step!` (training.jl:768-779 + the prologue of the next `rast(...)` call, rasterizer.jl:218-247) in one
+# pass: `∇` are the cotangents ∇rasterize returned (w.r.t. the ACTIVATED opacity / scale), `θ` the raw parameter
+# arrays and `opts` the six NU.Adam in OPTIMIZER_NAMES order; shs / opacities_act / scales_act are the activated
+# copies of this step on entry and of the updated parameters on exit.
 struct GsrTailGrads; vmeans::Ptr{Float32}; vshs::Ptr{Float32}; vopacities::Ptr{Float32}; vscales::Ptr{Float32}; vrotations::Ptr{Float32}; end
 function trainer_tail_step!(θ::NTuple{6}, opts::NTuple{6}, ∇, shs, opacities_act, scales_act; β1=0.9f0, β2=0.999f0, ϵ=1f-15)
     vmeans, vshs, vopac, vscales, vrot = ∇
-    foreach(o -> o.current_step += 0x1, opts)
     p(xs) = Ptr{Float32}[dptr(x) for x in xs]
+    steps = UInt32[o.current_step + 0x1 for o in opts]  # the counters AFTER their increment, committed below
     check(ccall((:gsr_trainer_tail_step, LIB), Cint,
         (Cint, Cint, Cint, Ref{GsrTailGrads}, Ptr{Ptr{Float32}}, Ptr{Ptr{Float32}}, Ptr{Ptr{Float32}}, Ptr{Cfloat}, Ptr{UInt32},
          Cfloat, Cfloat, Cfloat, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Cvoid}),
         size(θ[1], 2), size(θ[3], 2), size(θ[5], 1), GsrTailGrads(dptr(vmeans), dptr(vshs), dptr(vopac), dptr(vscales), dptr(vrot)),
         p(θ), p(map(o -> o.μ[1], opts)), p(map(o -> o.ν[1], opts)), Float32[o.lr for o in opts],
-        UInt32[o.current_step for o in opts], β1, β2, ϵ, dptr(shs), dptr(opacities_act), dptr(scales_act), hipstream()))
+        steps, β1, β2, ϵ, dptr(shs), dptr(opacities_act), dptr(scales_act), hipstream()))
+    foreach(o -> o.current_step += 0x1, opts)
 end
 
 end # module

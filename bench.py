@@ -126,6 +126,9 @@ def main():
     # world > 1: factored exchange (distributed.py) unless GSR_DIST_FULL_ARENA=1 asks for the plain
     # all-reduce of the whole (11+3K)·N arena
     factored = world > 1 and os.environ.get("GSR_DIST_FULL_ARENA", "0") != "1"
+    overlap = factored and os.environ.get("GSR_DIST_NO_OVERLAP", "0") != "1"
+    if overlap:
+        D.overlap_groups()
     arena = torch.empty(D.factored_arena_numel(N) if factored else D.arena_numel(N, K), device=dev, dtype=torch.float32)
     if factored:
         centers = []
@@ -166,7 +169,11 @@ def main():
         else:
             _, vp = pkg.fused_ssim.l1_ssim_loss(rast, img, target)
         rast.backward_raw(vp, *params, cam, deg, bg, arena=arena, factored_sh=factored)
-        if factored:
+        if factored and overlap:
+            # all-gather(vc) || all-reduce(11·N): the ∇shs rebuild runs while the all-reduce is in flight
+            D.exchange_factored_overlapped(arena, N, gathered, lambda vc_all: pkg.rasterizer.sh_grad_from_views(
+                params[0], vc_all, centers_d, K, deg, out=vshs_sum))
+        elif factored:
             vc_all = D.exchange_factored(arena, N, gathered)
             pkg.rasterizer.sh_grad_from_views(params[0], vc_all, centers_d, K, deg, out=vshs_sum)
         else:
@@ -286,7 +293,9 @@ def main():
                    "tile_lists": ("reference lists (GSR_FLAG_REFERENCE_TILE_LISTS)" if args.reference_lists else
                                   "library default: exact footprint cull (same image / gradients)"),
                    "parallelism": (f"view-parallel x{world}, all-reduce of {11 * N * 4 / 1e6:.0f} MB + all-gather of "
-                                   f"{world} x {3 * N * 4 / 1e6:.0f} MB colour cotangents (factored SH gradient)" if factored else
+                                   f"{world} x {3 * N * 4 / 1e6:.0f} MB colour cotangents (factored SH gradient"
+                                   f"{'; the two collectives overlapped on two communicators' if overlap else ''}); "
+                                   f"GSR_DIST_FULL_ARENA=1 selects the plain all-reduce of the whole arena" if factored else
                                    f"view-parallel x{world}, 1 all-reduce of {arena.numel() * 4 / 1e6:.0f} MB")},
         "roofline": roofline,
     }

@@ -92,6 +92,38 @@ def split_factored_arena(arena, n: int):
                 vscales=arena[o[3]:o[4]].view(n, 3), vcolors=arena[o[4]:o[5]].view(n, 3))
 
 
+_overlap_groups = None
+
+
+def overlap_groups():
+    """Two extra process groups (= two RCCL communicators with their own streams) so that the two collectives
+    of the factored exchange can be in flight at the same time.  Created once, collectively, by every rank."""
+    global _overlap_groups
+    if _overlap_groups is None and dist.is_initialized() and dist.get_world_size() > 1:
+        _overlap_groups = (dist.new_group(), dist.new_group())
+    return _overlap_groups
+
+
+def exchange_factored_overlapped(arena: torch.Tensor, n: int, gathered: torch.Tensor, rebuild):
+    """The factored exchange with its two collectives overlapped (SURVEY.md §8e "overlap"): the all-gather of the
+    colour cotangents and the all-reduce of the 11·N small gradients are issued together on two communicators;
+    `rebuild(vcolors_all)` — the ∇shs reconstruction kernel, which needs only the gathered cotangents — runs on the
+    compute stream as soon as the all-gather lands, WHILE the all-reduce is still crossing the links; the compute
+    stream joins the all-reduce last.  Same results as exchange_factored + rebuild (the collectives are
+    independent); world == 1: no collective."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    vc = arena[11 * n:]
+    if world == 1:
+        return rebuild(vc.view(1, n, 3))
+    ga, gb = overlap_groups()
+    h_gather = dist.all_gather_into_tensor(gathered.view(-1), vc, group=ga, async_op=True)
+    h_reduce = dist.all_reduce(arena[:11 * n], op=dist.ReduceOp.SUM, group=gb, async_op=True)
+    h_gather.wait()  # nccl: the compute stream waits for the gather (no host block); gloo: host wait
+    out = rebuild(gathered.view(world, n, 3))
+    h_reduce.wait()
+    return out
+
+
 def exchange_factored(arena: torch.Tensor, n: int, gathered: torch.Tensor | None = None):
     """The multi-view exchange on a factored arena, in place: all-reduce (sum) of the first 11·N
     floats + all-gather of the (N,3) colour cotangents.  Returns `vcolors_all` (V,N,3), rank-major

@@ -114,7 +114,13 @@ def _worker_factored(rank, world, port, out_dir):
     D.init_from_env("gloo")
     s = pkg.synthetic.make_scene(200, 64, 48, 2, 33, sigma_px=4.0)
     arena, _, _ = _view_factored(pkg, orc, D, s, rank, world)
+    # overlapped form (two communicators, the rebuild between the two waits) == sequential form
+    arena2 = arena.clone()
+    D.overlap_groups()
+    gathered = torch.empty(world * 3 * s.n)
+    vc_ov = D.exchange_factored_overlapped(arena2, s.n, gathered, lambda vc_all: vc_all.clone())
     vc_all = D.exchange_factored(arena, s.n)
+    assert torch.equal(arena2, arena) and torch.equal(vc_ov, vc_all)
     np.save(os.path.join(out_dir, f"farena_{rank}.npy"), arena.numpy())
     np.save(os.path.join(out_dir, f"vcall_{rank}.npy"), vc_all.numpy())
     torch.distributed.destroy_process_group()

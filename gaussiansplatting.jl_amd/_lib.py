@@ -71,6 +71,14 @@ class TailGrads(C.Structure):
                 ("vrotations", C.c_void_p)]
 
 
+class ComposeGroup(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_words", C.c_int32), ("new_zero", C.c_int32)]
+
+
+COMPOSE_MAX_GROUPS = 24
+DENSIFY_CLONE, DENSIFY_SPLIT, DENSIFY_PRUNE = 0, 1, 2
+
+
 class GatherGroup(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_words", C.c_int32)]
 
@@ -80,7 +88,8 @@ EXPORTS = ["gsr_create", "gsr_destroy", "gsr_release_scene_buffers", "gsr_memory
            "gsr_allreduce_grads", "gsr_last_error_string", "gsr_version", "gsr_profile_enable",
            "gsr_profile_stage_count", "gsr_profile_stage_name", "gsr_profile_read", "gsr_update_stats",
            "gsr_prologue_forward", "gsr_prologue_backward", "gsr_adam_step", "gsr_stream_triad",
-           "gsr_mask_findall_scratch_bytes", "gsr_mask_findall", "gsr_gather_rows", "gsr_sh_grad_from_views", "gsr_trainer_tail_step"]
+           "gsr_mask_findall_scratch_bytes", "gsr_mask_findall", "gsr_gather_rows", "gsr_sh_grad_from_views", "gsr_trainer_tail_step",
+           "gsr_densify_grad_mean", "gsr_densify_mask", "gsr_compose_rows", "gsr_split_transform", "gsr_reset_opacity"]
 
 _lib = None
 
@@ -128,6 +137,12 @@ def load():
     lib.gsr_mask_findall_scratch_bytes.restype = C.c_size_t
     lib.gsr_mask_findall.argtypes = [vp, C.c_int64, vp, vp, vp, vp]
     lib.gsr_gather_rows.argtypes = [C.POINTER(GatherGroup), i32, vp, C.c_int64, vp]
+    i64 = C.c_int64
+    lib.gsr_densify_grad_mean.argtypes = [i64, vp, vp, vp, vp]
+    lib.gsr_densify_mask.argtypes = [C.c_int32, i64, i64, vp, vp, C.c_int32, vp, vp, f32, f32, f32, C.c_int32, vp, vp]
+    lib.gsr_compose_rows.argtypes = [C.POINTER(ComposeGroup), C.c_int32, vp, i64, vp, i64, C.c_int32, vp]
+    lib.gsr_split_transform.argtypes = [i64, C.c_int32, vp, vp, vp, C.c_uint32, vp]
+    lib.gsr_reset_opacity.argtypes = [i64, vp, vp]
     lib.gsr_sh_grad_from_views.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.gsr_trainer_tail_step.argtypes = [i32, i32, i32, C.POINTER(TailGrads), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                           C.POINTER(f32), C.POINTER(C.c_uint32), f32, f32, f32, vp, vp, vp, vp]

@@ -1,0 +1,198 @@
+// Adaptive density control on the device: the mask construction, row composition
+// (append / clone / split / prune of every parameter, both Adam moments and the statistics), the split noise and
+// the opacity reset of the reference's DefaultStrategy.
+// Reference behaviour: src/densification.jl:1-136 (densify_and_prune!, densify_clone!, densify_split!,
+// _add_split_noise!), :138-191 (prune_points!), :193-297 (densification_postfix!, append_gaussians!,
+// _append_optimizer!, _prune_optimizer!), src/gaussians.jl:119-137 (_reset_opacity!, inverse_sigmoid).
+// Compiled with -ffp-contract=off (bit-reproducible fp32 against the oracle's restatement for everything
+// except the transcendental calls exp / log / cos / sin, which differ from glibc's by ulps).
+#include "gsr_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + expf(-x)); }  // NU.sigmoid
+
+// maximum(exp.(gs.scales); dims=1) of Gaussian i (densification.jl:36-38,79-80,22)
+__device__ __forceinline__ float max_exp_scale(const float* __restrict__ scales, int scale_dims, long long i) {
+    if (scale_dims == 1) return expf(scales[i]);
+    const float a = expf(scales[3 * i]), b = expf(scales[3 * i + 1]), c = expf(scales[3 * i + 2]);
+    return fmaxf(fmaxf(a, b), c);
+}
+
+// ∇means_2d = accum ./ denom with NaN -> 0 (densification.jl:7-10)
+__global__ __launch_bounds__(256) void grad_mean_kernel(long long n, const float* __restrict__ accum,
+                                                        const float* __restrict__ denom, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float g = accum[i] / denom[i];
+    out[i] = g != g ? 0.0f : g;
+}
+
+// kind 0: clone mask  = grad > thr  && max(exp(scales)) < gamma            (densification.jl:34-38)
+// kind 1: split mask  = padded_grad >= thr && max(exp(scales)) > gamma     (densification.jl:73-80; grad is padded with
+//                       zeros for the rows appended since it was computed)
+// kind 2: valid mask  = sigmoid(opacity) > min_opacity [&& max_radii < max_screen_size && max(exp(scales)) < gamma]
+//                                                                          (densification.jl:18-25)
+__global__ __launch_bounds__(256) void densify_mask_kernel(int kind, long long n, long long n_grad,
+                                                           const float* __restrict__ grad,
+                                                           const float* __restrict__ scales, int scale_dims,
+                                                           const float* __restrict__ opacities,
+                                                           const int32_t* __restrict__ max_radii, float thr, float gamma,
+                                                           float min_opacity, int max_screen_size,
+                                                           uint8_t* __restrict__ mask) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    bool m;
+    if (kind == 0) {
+        m = (i < n_grad ? grad[i] : 0.0f) > thr && max_exp_scale(scales, scale_dims, i) < gamma;
+    } else if (kind == 1) {
+        m = (i < n_grad ? grad[i] : 0.0f) >= thr && max_exp_scale(scales, scale_dims, i) > gamma;
+    } else {
+        m = sigmoid_(opacities[i]) > min_opacity;
+        if (max_screen_size > 0) m = m && max_radii[i] < max_screen_size && max_exp_scale(scales, scale_dims, i) < gamma;
+    }
+    mask[i] = m ? 1 : 0;
+}
+
+// Row composition: for every array g (a parameter, an Adam moment, a statistic; rows of row_words 4-byte words)
+//   dst[r]                      = src[keep_idx[r]]            r <  n_keep      (keep_idx == nullptr: identity)
+//   dst[n_keep + k * n_sel + j] = new_zero ? 0 : src[sel_idx[j]]   j < n_sel, k < reps
+// — `cat(x, x[:, mask])` (clone, reps = 1), `cat(x, repeat(x[:, mask], 1, 2))[:, valid]` (split, reps = 2: the
+// block-repeat order of Julia's `repeat`), `x[:, valid]` (prune, n_sel = 0), with zero rows appended to the
+// moments (_append_optimizer!).  One thread per output word, all arrays in one launch.
+struct ComposeGroups {
+    const uint32_t* src[GSR_COMPOSE_MAX_GROUPS];
+    uint32_t* dst[GSR_COMPOSE_MAX_GROUPS];
+    int row_words[GSR_COMPOSE_MAX_GROUPS];
+    int new_zero[GSR_COMPOSE_MAX_GROUPS];
+    long long block_start[GSR_COMPOSE_MAX_GROUPS + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void compose_rows_kernel(ComposeGroups G, const uint32_t* __restrict__ keep_idx,
+                                                           long long n_keep, const uint32_t* __restrict__ sel_idx,
+                                                           long long n_sel, int reps) {
+    int g = 0;
+    for (int k = 1; k < G.n; k++)
+        if ((long long)blockIdx.x >= G.block_start[k]) g = k;
+    const long long e = ((long long)blockIdx.x - G.block_start[g]) * 256 + threadIdx.x;
+    const int rw = G.row_words[g];
+    const long long rows = n_keep + n_sel * reps;
+    if (e >= rows * rw) return;
+    const long long r = e / rw;
+    const int j = (int)(e - r * rw);
+    uint32_t v;
+    if (r < n_keep) {
+        const long long s = keep_idx ? (long long)keep_idx[r] : r;
+        v = G.src[g][s * rw + j];
+    } else if (G.new_zero[g]) {
+        v = 0u;
+    } else {
+        const long long s = (long long)sel_idx[(r - n_keep) % n_sel];
+        v = G.src[g][s * rw + j];
+    }
+    G.dst[g][e] = v;
+}
+
+// Counter-based generator for the split noise: 32 well-mixed bits from (seed, row, draw) — integer only, so the
+// host restatement reproduces the stream bit for bit; the reference draws from the backend's device RNG
+// (`randn(Float32)`, densification.jl:128), which no implementation can reproduce.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float uniform01(uint32_t seed, uint32_t row, uint32_t draw) {
+    const uint32_t h = mix32(mix32(seed ^ (row * 0x9E3779B9u)) + draw * 0x85EBCA6Bu);
+    return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1)
+}
+
+// The tail of densify_split! on the 2m appended rows (densification.jl:81-104,121-135):
+//   sigma = exp(scale)              (stds = repeat(exp.(gs.scales)[:, mask], 1, 2))
+//   point += R(q) * (sigma .* randn3)   (_add_split_noise!; R = unnorm_quat2rot(q), render.jl:322-333)
+//   scale  = log(sigma / (0.8 * 2))
+__global__ __launch_bounds__(256) void split_transform_kernel(long long n_new, int scale_dims, float* __restrict__ points,
+                                                              const float4* __restrict__ rots, float* __restrict__ scales,
+                                                              uint32_t seed) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_new) return;
+    float sg[3];
+    if (scale_dims == 1) { sg[0] = sg[1] = sg[2] = expf(scales[i]); }
+    else { sg[0] = expf(scales[3 * i]); sg[1] = expf(scales[3 * i + 1]); sg[2] = expf(scales[3 * i + 2]); }
+    // Box-Muller: two pairs of uniforms -> three normals
+    const float u1 = uniform01(seed, (uint32_t)i, 0), u2 = uniform01(seed, (uint32_t)i, 1);
+    const float u3 = uniform01(seed, (uint32_t)i, 2), u4 = uniform01(seed, (uint32_t)i, 3);
+    const float r1 = sqrtf(-2.0f * logf(u1)), r2 = sqrtf(-2.0f * logf(u3));
+    const float two_pi = 6.2831853071795864f;
+    const float xi[3] = {sg[0] * (r1 * cosf(two_pi * u2)), sg[1] * (r1 * sinf(two_pi * u2)), sg[2] * (r2 * cosf(two_pi * u4))};
+    const float4 q4 = rots[i];
+    const float inv = 1.0f / sqrtf(q4.x * q4.x + q4.y * q4.y + q4.z * q4.z + q4.w * q4.w);
+    const float w = q4.x * inv, x = q4.y * inv, y = q4.z * inv, z = q4.w * inv;
+    const float x2 = x * x, y2 = y * y, z2 = z * z, xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+    const float R[3][3] = {{1.0f - 2.0f * (y2 + z2), 2.0f * (xy - wz), 2.0f * (xz + wy)},
+                           {2.0f * (xy + wz), 1.0f - 2.0f * (x2 + z2), 2.0f * (yz - wx)},
+                           {2.0f * (xz - wy), 2.0f * (yz + wx), 1.0f - 2.0f * (x2 + y2)}};
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+        points[3 * i + r] = points[3 * i + r] + (R[r][0] * xi[0] + R[r][1] * xi[1] + R[r][2] * xi[2]);
+    const float div = 0.8f * 2.0f;
+    if (scale_dims == 1) scales[i] = logf(sg[0] / div);
+    else {
+#pragma unroll
+        for (int c = 0; c < 3; c++) scales[3 * i + c] = logf(sg[c] / div);
+    }
+}
+
+// _reset_opacity! (gaussians.jl:119-126): opacity = inverse_sigmoid(min(0.1, sigmoid(opacity)))
+__global__ __launch_bounds__(256) void reset_opacity_kernel(long long n, float* __restrict__ opacities) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float o = fminf(0.1f, sigmoid_(opacities[i]));
+    opacities[i] = logf(o / (1.0f - o));
+}
+
+}  // namespace
+
+void gsr_launch_grad_mean(hipStream_t s, long long n, const float* accum, const float* denom, float* out) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(grad_mean_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, accum, denom, out);
+}
+
+void gsr_launch_densify_mask(hipStream_t s, int kind, long long n, long long n_grad, const float* grad, const float* scales,
+                             int scale_dims, const float* opacities, const int32_t* max_radii, float thr, float gamma,
+                             float min_opacity, int max_screen_size, uint8_t* mask) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(densify_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, kind, n, n_grad, grad, scales,
+                       scale_dims, opacities, max_radii, thr, gamma, min_opacity, max_screen_size, mask);
+}
+
+void gsr_launch_compose_rows(hipStream_t s, int n_groups, const void* const* src, void* const* dst, const int* row_words,
+                             const int* new_zero, const uint32_t* keep_idx, long long n_keep, const uint32_t* sel_idx,
+                             long long n_sel, int reps) {
+    ComposeGroups G;
+    G.n = n_groups;
+    long long blocks = 0;
+    const long long rows = n_keep + n_sel * reps;
+    for (int g = 0; g < GSR_COMPOSE_MAX_GROUPS; g++) {
+        const bool on = g < n_groups;
+        G.src[g] = on ? (const uint32_t*)src[g] : nullptr;
+        G.dst[g] = on ? (uint32_t*)dst[g] : nullptr;
+        G.row_words[g] = on ? row_words[g] : 1;
+        G.new_zero[g] = on ? new_zero[g] : 0;
+        G.block_start[g] = blocks;
+        if (on) blocks += (rows * row_words[g] + 255) / 256;
+    }
+    G.block_start[GSR_COMPOSE_MAX_GROUPS] = blocks;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(compose_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, G, keep_idx, n_keep, sel_idx, n_sel, reps);
+}
+
+void gsr_launch_split_transform(hipStream_t s, long long n_new, int scale_dims, float* points, const float* rots,
+                                float* scales, uint32_t seed) {
+    if (n_new <= 0) return;
+    hipLaunchKernelGGL(split_transform_kernel, dim3((unsigned)((n_new + 255) / 256)), dim3(256), 0, s, n_new, scale_dims,
+                       points, reinterpret_cast<const float4*>(rots), scales, seed);
+}
+
+void gsr_launch_reset_opacity(hipStream_t s, long long n, float* opacities) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(reset_opacity_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, opacities);
+}

@@ -692,6 +692,75 @@ int gsr_gather_rows(const gsr_gather_group* groups, int32_t n_groups, const uint
     return GSR_OK;
 }
 
+int gsr_densify_grad_mean(int64_t n, const float* accum, const float* denom, float* grad_out, void* stream) {
+    if (n < 0) return fail(GSR_E_INVALID_ARG, "negative n");
+    if (n == 0) return GSR_OK;
+    if (!accum || !denom || !grad_out) return fail(GSR_E_INVALID_ARG, "null array");
+    gsr_launch_grad_mean((hipStream_t)stream, n, accum, denom, grad_out);
+    HIPCHK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_densify_mask(int32_t kind, int64_t n, int64_t n_grad, const float* grad, const float* scales, int32_t scale_dims,
+                     const float* opacities, const int32_t* max_radii, float grad_threshold, float gamma, float min_opacity,
+                     int32_t max_screen_size, uint8_t* mask, void* stream) {
+    if (kind < GSR_DENSIFY_CLONE || kind > GSR_DENSIFY_PRUNE) return fail(GSR_E_INVALID_ARG, "unknown mask kind %d", kind);
+    if (n < 0 || n_grad < 0 || n_grad > n) return fail(GSR_E_INVALID_ARG, "bad sizes: n=%lld n_grad=%lld", (long long)n, (long long)n_grad);
+    if (scale_dims != 1 && scale_dims != 3) return fail(GSR_E_INVALID_ARG, "scale_dims must be 1 or 3");
+    if (n == 0) return GSR_OK;
+    if (!mask) return fail(GSR_E_INVALID_ARG, "null mask");
+    if (kind != GSR_DENSIFY_PRUNE && (!scales || (n_grad > 0 && !grad))) return fail(GSR_E_INVALID_ARG, "null array");
+    if (kind == GSR_DENSIFY_PRUNE && (!opacities || (max_screen_size > 0 && (!max_radii || !scales))))
+        return fail(GSR_E_INVALID_ARG, "null array");
+    gsr_launch_densify_mask((hipStream_t)stream, kind, n, n_grad, grad, scales, scale_dims, opacities, max_radii, grad_threshold,
+                            gamma, min_opacity, max_screen_size, mask);
+    HIPCHK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_compose_rows(const gsr_compose_group* groups, int32_t n_groups, const uint32_t* keep_idx, int64_t n_keep,
+                     const uint32_t* sel_idx, int64_t n_sel, int32_t reps, void* stream) {
+    if (n_groups < 0 || n_groups > GSR_COMPOSE_MAX_GROUPS || (n_groups > 0 && !groups))
+        return fail(GSR_E_INVALID_ARG, "n_groups must be in [0, %d]", GSR_COMPOSE_MAX_GROUPS);
+    if (n_keep < 0 || n_sel < 0 || reps < 0) return fail(GSR_E_INVALID_ARG, "negative count");
+    if (n_sel > 0 && reps > 0 && !sel_idx) return fail(GSR_E_INVALID_ARG, "null sel_idx");
+    if (n_keep + n_sel * reps == 0 || n_groups == 0) return GSR_OK;
+    const void* src[GSR_COMPOSE_MAX_GROUPS]; void* dst[GSR_COMPOSE_MAX_GROUPS];
+    int rw[GSR_COMPOSE_MAX_GROUPS], nz[GSR_COMPOSE_MAX_GROUPS];
+    int m = 0;
+    for (int g = 0; g < n_groups; g++) {
+        if (groups[g].row_words < 0) return fail(GSR_E_INVALID_ARG, "group %d: negative row_words", g);
+        if (groups[g].row_words == 0) continue;  // an empty features_rest (densification.jl:40-41,196-201)
+        if (!groups[g].dst || (!groups[g].src && (n_keep > 0 || !groups[g].new_zero)))
+            return fail(GSR_E_INVALID_ARG, "group %d: null array", g);
+        src[m] = groups[g].src; dst[m] = groups[g].dst; rw[m] = groups[g].row_words; nz[m] = groups[g].new_zero ? 1 : 0; m++;
+    }
+    if (m == 0) return GSR_OK;
+    gsr_launch_compose_rows((hipStream_t)stream, m, src, dst, rw, nz, keep_idx, n_keep, sel_idx, reps > 0 ? n_sel : 0, reps > 0 ? reps : 1);
+    HIPCHK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_split_transform(int64_t n_new, int32_t scale_dims, float* points, const float* rotations, float* scales, uint32_t seed,
+                        void* stream) {
+    if (n_new < 0 || (scale_dims != 1 && scale_dims != 3)) return fail(GSR_E_INVALID_ARG, "bad sizes");
+    if (n_new == 0) return GSR_OK;  // densification.jl:94 `if n_new_points > 0`
+    if (!points || !rotations || !scales) return fail(GSR_E_INVALID_ARG, "null array");
+    if (((uintptr_t)rotations & 15) != 0) return fail(GSR_E_INVALID_ARG, "rotations must be 16-byte aligned");
+    gsr_launch_split_transform((hipStream_t)stream, n_new, scale_dims, points, rotations, scales, seed);
+    HIPCHK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_reset_opacity(int64_t n, float* opacities, void* stream) {
+    if (n < 0) return fail(GSR_E_INVALID_ARG, "negative n");
+    if (n == 0) return GSR_OK;
+    if (!opacities) return fail(GSR_E_INVALID_ARG, "null array");
+    gsr_launch_reset_opacity((hipStream_t)stream, n, opacities);
+    HIPCHK(hipGetLastError());
+    return GSR_OK;
+}
+
 int gsr_sh_grad_from_views(int32_t n, int32_t n_coeffs, int32_t sh_degree, int32_t n_views, const float* camera_centers,
                            const float* means, const float* vcolors_all, float* vshs, void* stream) {
     if (n < 0 || n_views < 1 || sh_degree < 0 || sh_degree > 3 || n_coeffs < (sh_degree + 1) * (sh_degree + 1))

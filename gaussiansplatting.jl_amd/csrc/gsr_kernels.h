@@ -120,6 +120,19 @@ void gsr_launch_gather_rows(hipStream_t s, int n_groups, const void* const* src,
                             const uint32_t* idx, long long count);
 void gsr_launch_triad(hipStream_t s, size_t n4, float* a, const float* b, const float* c, float q);
 
+// ---- densify.hip (compiled with -ffp-contract=off) ----
+#define GSR_COMPOSE_MAX_GROUPS 24
+void gsr_launch_grad_mean(hipStream_t s, long long n, const float* accum, const float* denom, float* out);
+void gsr_launch_densify_mask(hipStream_t s, int kind, long long n, long long n_grad, const float* grad, const float* scales,
+                             int scale_dims, const float* opacities, const int32_t* max_radii, float thr, float gamma,
+                             float min_opacity, int max_screen_size, uint8_t* mask);
+void gsr_launch_compose_rows(hipStream_t s, int n_groups, const void* const* src, void* const* dst, const int* row_words,
+                             const int* new_zero, const uint32_t* keep_idx, long long n_keep, const uint32_t* sel_idx,
+                             long long n_sel, int reps);
+void gsr_launch_split_transform(hipStream_t s, long long n_new, int scale_dims, float* points, const float* rots,
+                                float* scales, uint32_t seed);
+void gsr_launch_reset_opacity(hipStream_t s, long long n, float* opacities);
+
 // ---- ssim.hip ----
 void gsr_launch_ssim_fwd(hipStream_t s, int W, int H, int CH, int B, const float* img, const float* ref, float C1,
                          float C2, int train, float* ssim_map, float* d0, float* d1, float* d2);

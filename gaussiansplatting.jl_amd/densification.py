@@ -8,6 +8,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Sequence
 
+import numpy as np
+
 import torch
 
 from . import _lib as L
@@ -62,3 +64,160 @@ def select(arrays: Sequence[torch.Tensor], idx: torch.Tensor):
 def prune(arrays: Sequence[torch.Tensor], valid_mask: torch.Tensor):
     """`x[:, valid_mask]` for every array (prune_points!, densification.jl:138-191)."""
     return select(arrays, findall(valid_mask))
+
+
+# ======================================================================================================
+# DefaultStrategy: the reference's adaptive density control on the device (src/strategy.jl:28-136,
+# src/densification.jl:1-297, src/gaussians.jl:115-126).  The control flow below is the reference's, function
+# for function; every per-Gaussian pass is one library launch (gsr_densify_* / gsr_compose_rows /
+# gsr_split_transform / gsr_reset_opacity / gsr_update_stats).  As in the reference, each logical-indexing step
+# reads one count back to size its result.
+# ======================================================================================================
+PARAMS = ("points", "features_dc", "features_rest", "scales", "rotations", "opacities")  # training.jl:415-416
+
+
+class GaussianModel:
+    """The six parameter arrays of `GaussianModel` (gaussians.jl:2-20) as HIP device tensors, Gaussian index first:
+    points (N,3), features_dc (N,1,3), features_rest (N,K-1,3) (may be empty), scales (N,3) or (N,1), rotations (N,4),
+    opacities (N,1) — all raw (pre-activation)."""
+
+    def __init__(self, points, features_dc, features_rest, scales, rotations, opacities):
+        self.points, self.features_dc, self.features_rest = points, features_dc, features_rest
+        self.scales, self.rotations, self.opacities = scales, rotations, opacities
+        for k in PARAMS:
+            t = getattr(self, k)
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise ValueError(f"{k} must be a contiguous float32 HIP device tensor (no CPU path)")
+
+    def __len__(self):
+        return int(self.points.shape[0])
+
+
+class DefaultStrategy:
+    """DefaultStrategy (strategy.jl:28-66): per-Gaussian statistics + hyper-parameters."""
+
+    def __init__(self, gs: GaussianModel, dense_percent=1e-2, densify_from_iter=500, densify_until_iter=15_000,
+                 densification_interval=100, densify_grad_threshold=2e-4, opacity_reset_interval=3_000, min_opacity=0.005):
+        n, dev = len(gs), gs.points.device
+        self.max_radii = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.accum_grad_means_2d = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.denom = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.dense_percent, self.densify_from_iter, self.densify_until_iter = float(dense_percent), int(densify_from_iter), int(densify_until_iter)
+        self.densification_interval, self.densify_grad_threshold = int(densification_interval), float(densify_grad_threshold)
+        self.opacity_reset_interval, self.min_opacity = int(opacity_reset_interval), float(min_opacity)
+
+
+def _ptr(t):
+    return None if t is None or t.numel() == 0 else C.c_void_p(t.data_ptr())
+
+
+def _mask(kind, gs, n_grad=0, grad=None, max_radii=None, thr=0.0, gamma=0.0, min_opacity=0.0, max_screen_size=0):
+    n = len(gs)
+    mask = torch.empty(n, dtype=torch.uint8, device=gs.points.device)
+    L.check(L.load().gsr_densify_mask(kind, n, n_grad, _ptr(grad), _ptr(gs.scales), int(gs.scales.shape[1]), _ptr(gs.opacities),
+                                      _ptr(max_radii), float(thr), float(gamma), float(min_opacity), int(max_screen_size),
+                                      _ptr(mask), _stream()))
+    return mask
+
+
+def _compose(gs: GaussianModel, optimizers, keep_idx, n_keep, sel_idx, n_sel, reps):
+    """One launch for the six parameters and their twelve moment vectors (append_gaussians! + _append_optimizer!, or
+    prune_points! + _prune_optimizer!, or both at once for a split).  Replaces the arrays in `gs` / `optimizers`."""
+    rows = n_keep + n_sel * reps
+    groups, outs = [], []
+    for k in PARAMS:
+        x = getattr(gs, k)
+        rw = int(np.prod(x.shape[1:]))
+        if rw == 0:  # empty features_rest (densification.jl:40-41,196-201): passed through, tracking N
+            setattr(gs, k, torch.empty((rows,) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype))
+            continue
+        opt = optimizers[k]
+        y = torch.empty((rows,) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
+        mu = torch.empty(rows * rw, device=x.device, dtype=torch.float32)
+        nu = torch.empty(rows * rw, device=x.device, dtype=torch.float32)
+        groups += [L.ComposeGroup(x.data_ptr(), y.data_ptr(), rw, 0), L.ComposeGroup(opt.mu.data_ptr(), mu.data_ptr(), rw, 1),
+                   L.ComposeGroup(opt.nu.data_ptr(), nu.data_ptr(), rw, 1)]
+        outs.append((k, y, mu, nu))
+    arr = (L.ComposeGroup * len(groups))(*groups)
+    L.check(L.load().gsr_compose_rows(arr, len(groups), _ptr(keep_idx), n_keep, _ptr(sel_idx), n_sel, reps, _stream()))
+    for k, y, mu, nu in outs:
+        setattr(gs, k, y)
+        optimizers[k].mu, optimizers[k].nu = mu, nu
+
+
+def _reset_stats(strategy: DefaultStrategy, n, dev):
+    """densification_postfix! (densification.jl:203-209): the statistics restart from zero for the whole model"""
+    strategy.max_radii = torch.zeros(n, dtype=torch.int32, device=dev)
+    strategy.accum_grad_means_2d = torch.zeros(n, dtype=torch.float32, device=dev)
+    strategy.denom = torch.zeros(n, dtype=torch.float32, device=dev)
+
+
+def densify_clone(strategy, gs, optimizers, grad, grad_threshold, extent, dense_percent):
+    """densify_clone! (densification.jl:29-62): clone Gaussians with a high gradient and a small size."""
+    mask = _mask(L.DENSIFY_CLONE, gs, grad.numel(), grad, thr=grad_threshold, gamma=np.float32(extent) * np.float32(dense_percent))
+    sel = findall(mask)
+    _compose(gs, optimizers, None, len(gs), sel, sel.numel(), 1)
+    _reset_stats(strategy, len(gs), gs.points.device)
+    return mask
+
+
+def densify_split(strategy, gs, optimizers, grad, grad_threshold, extent, dense_percent, seed=0):
+    """densify_split! (densification.jl:64-119): replace big Gaussians with a high gradient by two smaller ones
+    sampled inside them; the originals are pruned in the same composition."""
+    n = len(gs)
+    mask = _mask(L.DENSIFY_SPLIT, gs, grad.numel(), grad, thr=grad_threshold, gamma=np.float32(extent) * np.float32(dense_percent))
+    sel = findall(mask)
+    keep = findall(mask ^ 1)
+    m2 = 2 * sel.numel()
+    _compose(gs, optimizers, keep, keep.numel(), sel, sel.numel(), 2)
+    nk = keep.numel()
+    if m2 > 0:  # densification.jl:94
+        L.check(L.load().gsr_split_transform(m2, int(gs.scales.shape[1]), gs.points[nk:].data_ptr(), gs.rotations[nk:].data_ptr(),
+                                             gs.scales[nk:].data_ptr(), int(seed) & 0xFFFFFFFF, _stream()))
+    _reset_stats(strategy, len(gs), gs.points.device)
+    assert len(gs) == n - sel.numel() + m2
+    return mask
+
+
+def prune_points(strategy, gs, optimizers, valid_mask):
+    """prune_points! (densification.jl:138-191)"""
+    keep = findall(valid_mask)
+    _compose(gs, optimizers, keep, keep.numel(), None, 0, 1)
+    strategy.max_radii, strategy.accum_grad_means_2d, strategy.denom = select(
+        [strategy.max_radii, strategy.accum_grad_means_2d, strategy.denom], keep)
+
+
+def densify_and_prune(strategy: DefaultStrategy, gs: GaussianModel, optimizers, extent, pruning_extent, max_screen_size, seed=0):
+    """densify_and_prune! (densification.jl:1-27).  Returns the three masks (clone, split, valid) for inspection."""
+    n = len(gs)
+    grad = torch.empty(n, dtype=torch.float32, device=gs.points.device)
+    L.check(L.load().gsr_densify_grad_mean(n, _ptr(strategy.accum_grad_means_2d), _ptr(strategy.denom), _ptr(grad), _stream()))
+    m_clone = densify_clone(strategy, gs, optimizers, grad, strategy.densify_grad_threshold, extent, strategy.dense_percent)
+    m_split = densify_split(strategy, gs, optimizers, grad, strategy.densify_grad_threshold, extent, strategy.dense_percent, seed)
+    valid = _mask(L.DENSIFY_PRUNE, gs, max_radii=strategy.max_radii, gamma=np.float32(0.1) * np.float32(pruning_extent),
+                  min_opacity=strategy.min_opacity, max_screen_size=max_screen_size)
+    prune_points(strategy, gs, optimizers, valid)
+    return m_clone, m_split, valid
+
+
+def reset_opacity(gs: GaussianModel):
+    """reset_opacity! (gaussians.jl:115-126)"""
+    L.check(L.load().gsr_reset_opacity(gs.opacities.numel(), _ptr(gs.opacities), _stream()))
+
+
+def post_train_step(strategy: DefaultStrategy, gs: GaussianModel, optimizers, rast, step: int, extent: float, seed=0):
+    """post_train_step! (strategy.jl:78-105), called once per train step after the optimizer update: statistics from
+    `rast.gstate.radii` / `rast.gstate.∇means_2d`, densification on its schedule, periodic opacity reset.
+    Returns (densified, reset)."""
+    if step > strategy.densify_until_iter:
+        return False, False
+    rast.update_stats(strategy.max_radii, strategy.accum_grad_means_2d, strategy.denom)
+    densified = step >= strategy.densify_from_iter and step % strategy.densification_interval == 0
+    if densified:
+        mss = 20 if step > strategy.opacity_reset_interval else 0
+        densify_and_prune(strategy, gs, optimizers, extent, extent, mss, seed)
+    reset = step % strategy.opacity_reset_interval == 0
+    if reset:
+        reset_opacity(gs)
+        optimizers["opacities"].reset()  # NU.reset!(optimizers.opacities)
+    return densified, reset

@@ -310,6 +310,47 @@ GSR_API int gsr_mask_findall(const uint8_t* mask, int64_t n, uint32_t* indices, 
 GSR_API int gsr_gather_rows(const gsr_gather_group* groups, int32_t n_groups, const uint32_t* indices, int64_t count,
                             void* stream);
 
+/* Adaptive density control of the reference's DefaultStrategy on the device (SURVEY.md §8f rank 3;
+ * src/densification.jl:1-297, src/gaussians.jl:119-137).  The host keeps the reference's control flow
+ * (densify_and_prune! -> densify_clone! -> densify_split! -> prune_points!, strategy.jl:78-105); every
+ * per-Gaussian pass is one of these launches.  All pointers device, caller-owned.
+ *
+ * gsr_densify_grad_mean : ∇means_2d = accum ./ denom with NaN -> 0                 (densification.jl:7-10)
+ * gsr_densify_mask      : kind GSR_DENSIFY_CLONE  mask = grad >  thr && max(exp(scales)) < gamma   (:34-38)
+ *                              GSR_DENSIFY_SPLIT  mask = grad >= thr && max(exp(scales)) > gamma   (:73-80; `grad`
+ *                                                 holds n_grad <= n entries, rows beyond it count as 0: padded_grad)
+ *                              GSR_DENSIFY_PRUNE  mask = sigmoid(opacity) > min_opacity, and when max_screen_size > 0
+ *                                                 && max_radii < max_screen_size && max(exp(scales)) < gamma  (:18-25)
+ *                         scales are the RAW log-scales (scale_dims = 3, or 1 for an isotropic model).
+ * gsr_compose_rows      : the row surgery of append_gaussians! / _append_optimizer! / prune_points! /
+ *                         _prune_optimizer! (:138-297) for up to GSR_COMPOSE_MAX_GROUPS arrays in one launch:
+ *                           dst[r]                      = src[keep_idx[r]]                 r < n_keep (keep_idx NULL: r)
+ *                           dst[n_keep + k*n_sel + j]   = new_zero ? 0 : src[sel_idx[j]]   j < n_sel, k < reps
+ *                         clone: keep = identity, sel = findall(mask), reps 1; split: keep = findall(!mask),
+ *                         sel = findall(mask), reps 2 (Julia's block `repeat`); prune: keep = findall(valid), n_sel 0.
+ *                         new_zero = 1 for the Adam moments (their new rows are zeros).
+ * gsr_split_transform   : on the 2m rows a split appended: sigma = exp(scale); point += R(q)·(sigma .* randn3);
+ *                         scale = log(sigma / 1.6)   (:81-104, _add_split_noise! :121-135).  The normals come from a
+ *                         counter-based generator keyed by (seed, row) — the reference uses the backend's device RNG.
+ * gsr_reset_opacity     : opacity = inverse_sigmoid(min(0.1, sigmoid(opacity)))  (gaussians.jl:119-126,137). */
+enum { GSR_DENSIFY_CLONE = 0, GSR_DENSIFY_SPLIT = 1, GSR_DENSIFY_PRUNE = 2 };
+#define GSR_COMPOSE_MAX_GROUPS 24
+typedef struct gsr_compose_group {
+    const void* src;
+    void* dst;
+    int32_t row_words; /* 4-byte words per row */
+    int32_t new_zero;  /* appended rows are zeros (Adam moments) instead of copies */
+} gsr_compose_group;
+GSR_API int gsr_densify_grad_mean(int64_t n, const float* accum_grad_means2d, const float* denom, float* grad_out, void* stream);
+GSR_API int gsr_densify_mask(int32_t kind, int64_t n, int64_t n_grad, const float* grad, const float* scales,
+                             int32_t scale_dims, const float* opacities, const int32_t* max_radii, float grad_threshold,
+                             float gamma, float min_opacity, int32_t max_screen_size, uint8_t* mask, void* stream);
+GSR_API int gsr_compose_rows(const gsr_compose_group* groups, int32_t n_groups, const uint32_t* keep_idx, int64_t n_keep,
+                             const uint32_t* sel_idx, int64_t n_sel, int32_t reps, void* stream);
+GSR_API int gsr_split_transform(int64_t n_new, int32_t scale_dims, float* points, const float* rotations, float* scales,
+                                uint32_t seed, void* stream);
+GSR_API int gsr_reset_opacity(int64_t n, float* opacities, void* stream);
+
 /* New: the SH-coefficient gradient of a batch of views from the factored
  * per-view colour cotangents written by gsr_backward (gsr_grads.vcolors):
  *   vshs[:, k, i] = Σ_v basis_k(normalize(means[:, i] - camera_centers[:, v])) * vcolors_all[:, i, v]

@@ -1,0 +1,132 @@
+"""-m gpu parity tests of the device densification (gsr_densify_* / gsr_compose_rows / gsr_split_transform /
+gsr_reset_opacity through the host mirror densification.py) against the CPU restatement oracle/densify.py:
+masks, indices, row order, Adam moments and statistics EXACT; parameters bit-equal except the split children's
+points / scales (device exp / log / cos / sin vs glibc: 1e-6 relative)."""
+import numpy as np
+import pytest
+import torch
+
+from hip_helpers import dev, rel_l2
+from oracle import densify as dz
+from test_oracle_densify import fill_stats, make_model
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def to_device(pkg, m: dz.Model):
+    return pkg.densification.GaussianModel(*[dev(getattr(m, k)) for k in dz.PARAMS])
+
+
+def device_optimizers(pkg, gs_d, opt_o):
+    out = {}
+    for k in dz.PARAMS:
+        a = pkg.optim.Adam(getattr(gs_d, k), 1e-3, eps=1e-15)
+        a.mu, a.nu = dev(opt_o[k]["mu"]), dev(opt_o[k]["nu"])
+        out[k] = a
+    return out
+
+
+@pytest.mark.parametrize("scale_dims,k_rest,mss", [(3, 15, 0), (1, 3, 20), (3, 0, 20)])
+def test_densify_and_prune_matches_oracle(pkg, scale_dims, k_rest, mss):
+    Dz = pkg.densification
+    n, extent, seed = 5000, 5.0, 99
+    gs_o = make_model(n, k_rest, 31, scale_dims)
+    st_o = dz.Strategy.for_model(n)
+    fill_stats(st_o, 32)
+    opt_o = dz.new_optimizers(gs_o)
+    rng = np.random.default_rng(33)
+    for k in dz.PARAMS:
+        opt_o[k]["mu"][:] = rng.normal(size=opt_o[k]["mu"].shape); opt_o[k]["nu"][:] = rng.uniform(size=opt_o[k]["nu"].shape)
+    gs_d = to_device(pkg, gs_o)
+    opt_d = device_optimizers(pkg, gs_d, opt_o)
+    st_d = Dz.DefaultStrategy(gs_d)
+    st_d.max_radii, st_d.accum_grad_means_2d, st_d.denom = dev(st_o.max_radii, torch.int32), dev(st_o.accum_grad_means_2d), dev(st_o.denom)
+    masks_o = dz.densify_and_prune(st_o, gs_o, opt_o, extent, extent, mss, seed=seed)
+    mc, ms, valid = Dz.densify_and_prune(st_d, gs_d, opt_d, extent, extent, mss, seed=seed)
+    torch.cuda.synchronize()
+    assert np.array_equal(mc.cpu().numpy().astype(bool), masks_o["clone"])
+    assert np.array_equal(ms.cpu().numpy().astype(bool), masks_o["split"])
+    assert np.array_equal(valid.cpu().numpy().astype(bool), masks_o["valid"])
+    assert masks_o["clone"].sum() > 50 and masks_o["split"].sum() > 50 and (~masks_o["valid"]).sum() > 50
+    assert len(gs_d) == len(gs_o)
+    # which surviving rows are split children (their points / scales went through device transcendentals)
+    n1 = n + masks_o["clone"].sum()
+    n_keep = n1 - masks_o["split"].sum()
+    child = np.zeros(masks_o["valid"].shape[0], bool); child[n_keep:] = True
+    child = child[masks_o["valid"]]
+    for k in dz.PARAMS:
+        a, b = getattr(gs_d, k).cpu().numpy(), getattr(gs_o, k)
+        assert a.shape == b.shape, k
+        if k in ("points", "scales"):
+            assert np.array_equal(a[~child], b[~child]), k
+            assert np.allclose(a[child], b[child], rtol=2e-6, atol=2e-6), k
+        else:
+            assert np.array_equal(a, b), k
+        assert np.array_equal(opt_d[k].mu.cpu().numpy(), opt_o[k]["mu"]), k
+        assert np.array_equal(opt_d[k].nu.cpu().numpy(), opt_o[k]["nu"]), k
+    assert np.array_equal(st_d.max_radii.cpu().numpy(), st_o.max_radii) and st_d.denom.shape[0] == len(gs_o)
+    assert not st_d.accum_grad_means_2d.any()
+
+
+def test_reset_opacity_matches_oracle(pkg):
+    gs_o = make_model(3000, 0, 41)
+    gs_d = to_device(pkg, gs_o)
+    dz.reset_opacity(gs_o)
+    pkg.densification.reset_opacity(gs_d)
+    assert np.allclose(gs_d.opacities.cpu().numpy(), gs_o.opacities, rtol=2e-6, atol=2e-6)
+
+
+def test_train_densify_train_chain_matches_oracle_chain(pkg, orc):
+    """SURVEY.md §8f rank 3 'done when': steps of forward + loss + backward + Adam + post_train_step! through the C ABI,
+    with a densification and an opacity reset in the middle, against the same chain on the oracle (orc.forward /
+    loss_head / backward / prologue / adam_step + oracle/densify.py)."""
+    R, O, Dz = pkg.rasterizer, pkg.optim, pkg.densification
+    W, H, deg, n0 = 96, 64, 1, 500
+    s = pkg.synthetic.make_scene(n0, W, H, deg, 123, sigma_px=4.0)
+    cam_d, cam_o = pkg.Camera(W, H, tuple(s.focal)), orc.Camera(W, H, s.focal)
+    target = pkg.synthetic.make_target(W, H, 5)
+    gs_o = dz.Model(s.means.copy(), s.shs[:, :1].copy(), s.shs[:, 1:].copy(), s.scales_raw.copy(), s.rotations.copy(),
+                    s.opacities_raw.reshape(-1, 1).copy())
+    gs_d = to_device(pkg, gs_o)
+    lrs = dict(points=1.6e-4, features_dc=2.5e-3, features_rest=2.5e-3 / 20, opacities=2.5e-2, scales=5e-3, rotations=1e-3)
+    opt_o = dz.new_optimizers(gs_o)
+    opt_d = {k: O.Adam(getattr(gs_d, k), lrs[k], eps=1e-15) for k in dz.PARAMS}
+    kw = dict(densify_from_iter=2, densify_until_iter=100, densification_interval=2, opacity_reset_interval=3,
+              densify_grad_threshold=1e-4, dense_percent=0.08)
+    st_o = dz.Strategy.for_model(n0, **kw)
+    st_d = Dz.DefaultStrategy(gs_d, **kw)
+    rast = R.GaussianRasterizer(W, H, mode="rgb")
+    tgt_d = dev(target)
+    extent, sizes = 5.0, []
+    for step in range(1, 5):
+        # ---- oracle chain ----
+        shs, oa, sa = orc.prologue_forward(gs_o.features_dc, gs_o.features_rest, gs_o.opacities, gs_o.scales)
+        st = orc.forward(gs_o.points, shs, oa, sa, gs_o.rotations, cam_o, deg)
+        loss_o, vp = orc.loss_head(st.image, target)
+        g = orc.backward(st, vp, gs_o.points, shs, oa, sa, gs_o.rotations, cam_o, deg)
+        vdc, vrest, vo, vs = orc.prologue_backward(oa, sa, g.vshs, g.vopacities.reshape(-1, 1), g.vscales, 3)
+        grads = dict(points=g.vmeans, features_dc=vdc, features_rest=vrest, opacities=vo, scales=vs, rotations=g.vrots)
+        for k in dz.PARAMS:
+            opt_o[k]["step"] += 1
+            theta = getattr(gs_o, k).reshape(-1)
+            orc.adam_step(theta, np.ascontiguousarray(grads[k]).reshape(-1), opt_o[k]["mu"], opt_o[k]["nu"], opt_o[k]["step"], lrs[k],
+                          0.9, 0.999, 1e-15)
+        dz.post_train_step(st_o, gs_o, opt_o, st.radii, g.vmeans2d, (W, H), step, extent, seed=step)
+        # ---- HIP chain, through the C ABI ----
+        shs_d, oa_d, sa_d = R.prologue_forward(gs_d.features_dc, gs_d.features_rest, gs_d.opacities, gs_d.scales)
+        img = rast.forward_raw(gs_d.points, shs_d, oa_d, sa_d, gs_d.rotations, cam_d, deg, (0, 0, 0))
+        loss_d, vp_d = pkg.fused_ssim.l1_ssim_loss(rast, img, tgt_d)
+        vm, vsh, vo_d, vsc, vr, _, _ = rast.backward_raw(vp_d, gs_d.points, shs_d, oa_d, sa_d, gs_d.rotations, cam_d, deg, (0, 0, 0))
+        raw = {k: getattr(gs_d, k) for k in dz.PARAMS}
+        O.trainer_tail_step(opt_d, raw, dict(vmeans=vm, vshs=vsh, vopacities=vo_d, vscales=vsc, vrot=vr), shs_d, oa_d, sa_d)
+        Dz.post_train_step(st_d, gs_d, opt_d, rast, step, extent, seed=step)
+        torch.cuda.synchronize()
+        assert abs(float(loss_d) - float(loss_o)) < 1e-5
+        assert len(gs_d) == len(gs_o), f"step {step}: {len(gs_d)} vs {len(gs_o)} Gaussians"
+        sizes.append(len(gs_o))
+        for k in dz.PARAMS:
+            assert rel_l2(getattr(gs_d, k).cpu().numpy().reshape(-1), getattr(gs_o, k).reshape(-1)) <= 2e-5, (step, k)
+            assert opt_d[k].mu.numel() == opt_o[k]["mu"].size
+        assert opt_d["opacities"].current_step == opt_o["opacities"]["step"]
+    assert sizes[1] != n0 and sizes[3] != sizes[2], f"densification must have changed the model: {sizes}"

@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--reference-lists", action="store_true",
                     help="GSR_FLAG_REFERENCE_TILE_LISTS: keep the reference's (Gaussian, tile) instance lists instead of "
                          "the library default (exact footprint culling)")
+    ap.add_argument("--skew", default=None, metavar="KIND",
+                    help="skewed variant of the synthetic scene (synthetic.add_skew): 'hot:K' = K extra Gaussians in ONE tile, "
+                         "'dense:P:F' = a fraction P of the tiles at F x the mean density; reports tile_sort time and bins bytes")
     ap.add_argument("--no-other-lists", action="store_true", help="skip the secondary timing of the other tile-list mode")
     args = ap.parse_args()
 
@@ -105,6 +108,9 @@ def main():
 
     W, H, N, deg = args.width, args.height, args.n, args.sh_degree
     s = pkg.synthetic.make_scene(N if args.ply is None else 16, W, H, deg, args.seed)
+    if args.skew:
+        s = pkg.synthetic.add_skew(s, args.skew, args.seed)
+        N = s.n
     if args.ply is not None:
         gm = pkg.ply.import_ply(args.ply)
         N, deg = gm.n, gm.max_sh_degree
@@ -240,7 +246,7 @@ def main():
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
     # PMC-counted HBM bytes and VALU instructions per launch: only a measurement of EXACTLY this configuration
     # (tools/pmc_workload.py + tools/pmc_parse.py under rocprofv3 --pmc, committed per round) is reported
-    key = config_key(N, W, H, deg, args.mode, not args.reference_lists, not args.no_loss) if args.ply is None else None
+    key = config_key(N, W, H, deg, args.mode, not args.reference_lists, not args.no_loss) if args.ply is None and not args.skew else None
     traffic, valu, pmc_src = None, None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if key is not None and os.path.exists(tpath) and not (tail is not None):
@@ -288,8 +294,12 @@ def main():
                                 if not args.no_loss and args.ply is None and args.mode == "rgb" and (N, W, H, deg) == (1_000_000, 1920, 1080, 3) else
                                 f"ply scene {os.path.basename(args.ply)}: N={N} SH{deg} {W}x{H} fwd{'' if args.no_loss else '+loss'}+bwd"
                                 if args.ply is not None else
-                                f"N={N} SH{deg} {W}x{H} :{args.mode} fwd{'' if args.no_loss else '+loss'}+bwd"),
+                                f"N={N} SH{deg} {W}x{H} :{args.mode} fwd{'' if args.no_loss else '+loss'}+bwd"
+                                + (f" skew={args.skew}" if args.skew else "")),
                    "n_gaussians": N, "visible": V, "tile_instances": Dn, "views_per_gpu": 1,
+                   "binning": {"mode": "compact (count -> scan -> scatter)" if rast.stats.compact_binning else "fixed-capacity bins",
+                               "unsorted_key_bytes": int(rast.stats.bins_bytes), "longest_tile_list": int(rast.stats.max_tile_instances),
+                               "handle_bytes": int(rast.memory_usage())},
                    "tile_lists": ("reference lists (GSR_FLAG_REFERENCE_TILE_LISTS)" if args.reference_lists else
                                   "library default: exact footprint cull (same image / gradients)"),
                    "parallelism": (f"view-parallel x{world}, all-reduce of {11 * N * 4 / 1e6:.0f} MB + all-gather of "

@@ -29,7 +29,8 @@ class GsrError(RuntimeError):
 
 class Config(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("mode", C.c_int32), ("near_plane", C.c_float),
-                ("far_plane", C.c_float), ("radius_clip", C.c_int32), ("blur_eps", C.c_float), ("flags", C.c_uint32)]
+                ("far_plane", C.c_float), ("radius_clip", C.c_int32), ("blur_eps", C.c_float), ("flags", C.c_uint32),
+                ("bins_budget_bytes", C.c_uint64)]
 
 
 class Inputs(C.Structure):
@@ -49,7 +50,7 @@ class Aux(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("n_rendered", C.c_int64), ("n_visible", C.c_int32), ("max_tile_instances", C.c_int32),
-                ("generation", C.c_uint64)]
+                ("generation", C.c_uint64), ("bins_bytes", C.c_int64), ("compact_binning", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Grads(C.Structure):

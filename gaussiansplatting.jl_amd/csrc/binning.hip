@@ -53,10 +53,14 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint
                                                          uint32_t* __restrict__ totals, int n_blocks,
                                                          const uint32_t* __restrict__ bsum,
                                                          uint32_t* __restrict__ bpre,
-                                                         const uint32_t* __restrict__ bvis) {
+                                                         const uint32_t* __restrict__ bvis,
+                                                         uint32_t* __restrict__ big_list) {
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t red[3][16];
+    __shared__ uint32_t big_fill;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) big_fill = 0;
+    __syncthreads();
     // tiles: exclusive scan of the counts, longest list, lists beyond the LDS sort
     {
         constexpr int PER = 8;  // a wave reads 2 KB contiguous per round; rounds of 8192 elements carry a running total
@@ -69,7 +73,10 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint
                 v[k] = lo + k < hi ? tile_count[lo + k] : 0u;
                 sum += v[k];
                 vmax = v[k] > vmax ? v[k] : vmax;
-                big += v[k] > GSR_SORT_LDS_CAP ? 1u : 0u;
+                if (v[k] > GSR_SORT_LDS_CAP) {  // rare: the tile goes to the merge-sort kernel (any order: tiles are independent)
+                    big += 1u;
+                    big_list[atomicAdd(&big_fill, 1u)] = (uint32_t)(lo + k);
+                }
             }
             uint32_t round_total;
             uint32_t run = total + block_exclusive_scan_1024(sum, wave_sums, round_total);
@@ -94,8 +101,8 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint
             tile_start[n_tiles] = total;
             totals[0] = total;  // D
             totals[1] = m;      // longest list
-            totals[2] = b;      // #tiles over GSR_SORT_LDS_CAP (they get a global-scratch slab each)
-            totals[3] = 0;      // slab allocator of the oversized-tile path
+            totals[2] = b;      // #tiles over GSR_SORT_LDS_CAP (listed in big_list; they get two global-scratch slabs each)
+            totals[3] = 0;
         }
     }
     // Gaussian blocks: per-block sums of tile-rect areas -> bpre (Gaussian-major instance-slot
@@ -198,15 +205,10 @@ __device__ __forceinline__ void bitonic_sort(uint64_t* buf, uint32_t m, int tid,
 // sorted ids + the packed splat stream.  Instantiated once on the LDS array and once on a
 // global slab so each copy uses ds_* / global_* instructions (no flat addressing).
 template <int CH>
-__device__ __forceinline__ void sort_and_emit(uint64_t* buf, uint32_t m, uint32_t n, uint32_t start, int tid,
-                                              int X0, int Y0,
-                                              const uint64_t* __restrict__ keys, const GsrGeom& geom,
+__device__ __forceinline__ void emit_instance(uint64_t k, uint32_t pos, int X0, int Y0, const GsrGeom& geom,
                                               const GsrStream& stream, uint32_t* __restrict__ values_sorted) {
-    for (uint32_t i = tid; i < m; i += 256) buf[i] = i < n ? keys[i] : ~0ull;  // keys = this tile's bin
-    __syncthreads();
-    if (m > 1) bitonic_sort(buf, m, tid, 256);
-    for (uint32_t i = tid; i < n; i += 256) {
-        const uint64_t k = buf[i];
+    {
+        const uint32_t i = pos, start = 0;
         const uint32_t id = (uint32_t)k;
         values_sorted[start + i] = id;
         const GsrGeoRec rec = geom.rec[id];  // one 64-byte line per gather
@@ -227,18 +229,28 @@ __device__ __forceinline__ void sort_and_emit(uint64_t* buf, uint32_t m, uint32_
     }
 }
 
+template <int CH>
+__device__ __forceinline__ void sort_and_emit(uint64_t* buf, uint32_t m, uint32_t n, uint32_t start, int tid,
+                                              int X0, int Y0,
+                                              const uint64_t* __restrict__ keys, const GsrGeom& geom,
+                                              const GsrStream& stream, uint32_t* __restrict__ values_sorted) {
+    for (uint32_t i = tid; i < m; i += 256) buf[i] = i < n ? keys[i] : ~0ull;  // keys = this tile's bin / compact segment
+    __syncthreads();
+    if (m > 1) bitonic_sort(buf, m, tid, 256);
+    for (uint32_t i = tid; i < n; i += 256) emit_instance<CH>(buf[i], start + i, X0, Y0, geom, stream, values_sorted);
+}
+
 // CAP = LDS key capacity of this launch, LO = the longest list the smaller launches handle.
 // Up to three launches, chosen by the host from the scan's longest list: CAP = 1024 (8 KB of
 // LDS, full wave occupancy — most tiles), CAP = 4096 (32 KB) only if a list exceeds 1024, and
-// CAP = 8192 (64 KB; beyond that a global slab) only if one exceeds 4096.  A workgroup whose
-// tile belongs to another launch exits immediately.
+// CAP = 8192 (64 KB) only if one exceeds 4096; lists beyond 8192 belong to tile_sort_big_kernel.
+// A workgroup whose tile belongs to another launch exits immediately.
+// bin_cap > 0: the tile's unsorted keys are its fixed-capacity bin; bin_cap == 0: compact layout, the keys of
+// tile t sit at keys[tile_start[t] ...) (count -> scan -> scatter; memory O(D) whatever the skew).
 template <int CH, int CAP, int LO>
 __global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restrict__ tile_start,
                                                         uint32_t* __restrict__ tile_count,
-                                                        const uint64_t* __restrict__ bins, uint32_t bin_cap,
-                                                        uint64_t* __restrict__ big_scratch,
-                                                        uint32_t big_scratch_stride,
-                                                        uint32_t* __restrict__ slab_counter, int grid_x,
+                                                        const uint64_t* __restrict__ bins, uint32_t bin_cap, int grid_x,
                                                         GsrGeom geom, GsrStream stream,
                                                         uint32_t* __restrict__ values_sorted,
                                                         uint32_t* __restrict__ ranges) {
@@ -247,38 +259,131 @@ __global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restri
     const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
     const uint32_t n = end - start;
     if (LO < 0 && tid == 0) tile_count[tile] = 0u;  // the first launch covers every tile: counter ready for the next view
-    if ((LO >= 0 && n <= (uint32_t)LO) || (CAP < GSR_SORT_LDS_CAP && n > (uint32_t)CAP)) return;  // another launch's tile
-    if (tid == 0) {
+    if (LO < 0 && tid == 0) {
         // identify_tile_range! (utils.jl:56-78): empty tiles keep the (0,0) of the prior fill!
         ranges[2 * tile] = n ? start : 0u;
         ranges[2 * tile + 1] = n ? end : 0u;
     }
+    if ((LO >= 0 && n <= (uint32_t)LO) || n > (uint32_t)CAP) return;  // another launch's tile
     if (n == 0) return;
     const int X0 = (tile % grid_x) * GSR_TILE, Y0 = (tile / grid_x) * GSR_TILE;
-    const uint64_t* __restrict__ keys = bins + (size_t)tile * bin_cap;
+    const uint64_t* __restrict__ keys = bin_cap ? bins + (size_t)tile * bin_cap : bins + start;
     uint32_t m = 1;
     while (m < n) m <<= 1;
-    if (m <= (uint32_t)CAP) {
-        sort_and_emit<CH>(skeys, m, n, start, tid, X0, Y0, keys, geom, stream, values_sorted);
-    } else {
-        // oversized tile: same network through a global-scratch slab (rare; slabs are sized by
-        // the host from the scan's totals and handed out with one atomic per oversized tile)
-        uint32_t* slab_s = reinterpret_cast<uint32_t*>(skeys);  // the LDS array is idle on this path
-        if (tid == 0) *slab_s = atomicAdd(slab_counter, 1u);
-        __syncthreads();
-        uint64_t* slab = big_scratch + (size_t)(*slab_s) * big_scratch_stride;
-        __syncthreads();
-        sort_and_emit<CH>(slab, m, n, start, tid, X0, Y0, keys, geom, stream, values_sorted);
+    sort_and_emit<CH>(skeys, m, n, start, tid, X0, Y0, keys, geom, stream, values_sorted);
+}
+
+// ---- lists beyond the LDS capacity: chunked LDS sort + merge passes (one 1024-thread workgroup per listed tile) ----
+// Phase 1 sorts runs of GSR_SORT_LDS_CAP keys in LDS (the same bitonic network) into slab A; phase 2 merges runs
+// pairwise, ping-ponging between the tile's two global slabs: the merge-path split of every 4096-key output block is
+// found by a parallel binary search, then each block's two input pieces are staged in LDS (coalesced), every thread
+// merges its 4 outputs from LDS and the block is stored coalesced — ceil(log2(n / 8192)) passes of n keys instead of
+// the log^2(n)/2 (~100-150) global passes of a bitonic network.  Keys are unique (depth bits << 32 | id), so the
+// result is the same total order as every other tier's.
+constexpr int BIG_THREADS = 1024, BIG_OUT = 4096;  // outputs per merge block (4 per thread)
+__device__ __forceinline__ uint32_t merge_path(const uint64_t* a, uint32_t na, const uint64_t* b, uint32_t nb, uint32_t diag) {
+    // number of elements taken from `a` among the first `diag` outputs of merge(a, b)
+    uint32_t lo = diag > nb ? diag - nb : 0u, hi = diag < na ? diag : na;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] < b[diag - 1 - mid]) lo = mid + 1; else hi = mid;
     }
+    return lo;
+}
+template <int CH>
+__global__ __launch_bounds__(BIG_THREADS) void tile_sort_big_kernel(const uint32_t* __restrict__ tile_start,
+                                                                    const uint32_t* __restrict__ big_list,
+                                                                    const uint64_t* __restrict__ bins, uint32_t bin_cap,
+                                                                    uint64_t* __restrict__ scratch, size_t slab_stride,
+                                                                    int grid_x, GsrGeom geom, GsrStream stream,
+                                                                    uint32_t* __restrict__ values_sorted) {
+    __shared__ uint64_t skeys[GSR_SORT_LDS_CAP];  // 64 KB: chunk sort, then the staging area of a merge block
+    __shared__ uint32_t split_a[BIG_THREADS + 1];
+    const int tile = (int)big_list[blockIdx.x], tid = threadIdx.x;
+    const uint32_t start = tile_start[tile], n = tile_start[tile + 1] - start;
+    const uint64_t* __restrict__ keys = bin_cap ? bins + (size_t)tile * bin_cap : bins + start;
+    uint64_t* slab[2] = {scratch + (size_t)(2 * blockIdx.x) * slab_stride, scratch + (size_t)(2 * blockIdx.x + 1) * slab_stride};
+    // phase 1: sorted runs of GSR_SORT_LDS_CAP keys
+    for (uint32_t c0 = 0; c0 < n; c0 += GSR_SORT_LDS_CAP) {
+        const uint32_t cn = min((uint32_t)GSR_SORT_LDS_CAP, n - c0);
+        uint32_t m = 1;
+        while (m < cn) m <<= 1;
+        __syncthreads();
+        for (uint32_t i = tid; i < m; i += BIG_THREADS) skeys[i] = i < cn ? keys[c0 + i] : ~0ull;
+        __syncthreads();
+        if (m > 1) bitonic_sort(skeys, m, tid, BIG_THREADS);
+        for (uint32_t i = tid; i < cn; i += BIG_THREADS) slab[0][c0 + i] = skeys[i];
+    }
+    __threadfence_block();
+    __syncthreads();
+    // phase 2: merge passes
+    int cur = 0;
+    for (uint32_t L = GSR_SORT_LDS_CAP; L < n; L <<= 1, cur ^= 1) {
+        const uint64_t* __restrict__ src = slab[cur];
+        uint64_t* __restrict__ dst = slab[cur ^ 1];
+        const uint32_t n_blocks = (n + BIG_OUT - 1) / BIG_OUT;
+        for (uint32_t blk0 = 0; blk0 < n_blocks; blk0 += BIG_THREADS - 1) {
+            // split of every output block of this round (+ one sentinel: the start of the block after the round), in
+            // parallel; block k starts at output k * BIG_OUT
+            const uint32_t nb_round = min((uint32_t)(BIG_THREADS - 1), n_blocks - blk0);
+            __syncthreads();
+            if ((uint32_t)tid <= nb_round) {
+                const uint32_t o = min((blk0 + tid) * (uint32_t)BIG_OUT, n);          // first output of block blk0 + tid
+                const uint32_t pair = o / (2 * L) * (2 * L);                          // start of its pair of runs
+                const uint32_t na = min(L, n - pair), nbb = min(L, n - pair - na);
+                // a block never straddles a pair: 2L is a multiple of BIG_OUT; the sentinel entry (tid == nb_round)
+                // that falls on a pair boundary is resolved per block below
+                split_a[tid] = o >= n ? 0u : merge_path(src + pair, na, src + pair + na, nbb, o - pair);
+            }
+            __syncthreads();
+            for (uint32_t kb = 0; kb < nb_round; kb++) {
+                const uint32_t o0 = (blk0 + kb) * (uint32_t)BIG_OUT, cnt = min((uint32_t)BIG_OUT, n - o0);
+                const uint32_t pair = o0 / (2 * L) * (2 * L);
+                const uint32_t na = min(L, n - pair), nbb = min(L, n - pair - na);
+                const uint32_t a0 = split_a[kb], b0 = (o0 - pair) - a0;
+                // end of this block inside the same pair
+                const uint32_t o1 = o0 + cnt;
+                uint32_t a1;
+                if (o1 - pair >= na + nbb) a1 = na;                                   // the block ends the pair
+                else a1 = split_a[kb + 1];                                            // next block's split, same pair
+                const uint32_t la = a1 - a0, lb = cnt - la;
+                (void)b0;
+                __syncthreads();
+                for (uint32_t i = tid; i < cnt; i += BIG_THREADS)
+                    skeys[i] = i < la ? src[pair + a0 + i] : src[pair + na + b0 + (i - la)];
+                __syncthreads();
+                // each thread merges 4 consecutive outputs from the staged pieces [0, la) and [la, la + lb)
+                const uint32_t d0 = min((uint32_t)tid * 4u, cnt);
+                if (d0 < cnt) {
+                    uint32_t ia = merge_path(skeys, la, skeys + la, lb, d0), ib = d0 - ia;
+                    uint64_t out[4];
+                    const uint32_t cnt_t = min(4u, cnt - d0);
+                    for (uint32_t k = 0; k < cnt_t; k++) {
+                        const bool take_a = ib >= lb || (ia < la && skeys[ia] < skeys[la + ib]);
+                        out[k] = take_a ? skeys[ia] : skeys[la + ib];
+                        ia += take_a ? 1u : 0u;
+                        ib += take_a ? 0u : 1u;
+                    }
+                    for (uint32_t k = 0; k < cnt_t; k++) dst[o0 + d0 + k] = out[k];
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    // phase 3: emit (the same per-instance work as sort_and_emit)
+    const uint64_t* __restrict__ sorted = slab[cur];
+    const int X0 = (tile % grid_x) * GSR_TILE, Y0 = (tile / grid_x) * GSR_TILE;
+    for (uint32_t i = tid; i < n; i += BIG_THREADS) emit_instance<CH>(sorted[i], start + i, X0, Y0, geom, stream, values_sorted);
 }
 
 }  // namespace
 
 void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count, uint32_t* tile_start,
                           uint32_t* totals, int n_blocks, const uint32_t* bsum, uint32_t* bpre,
-                          const uint32_t* bvis) {
+                          const uint32_t* bvis, uint32_t* big_list) {
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, tile_count, tile_start, totals,
-                       n_blocks, bsum, bpre, bvis);
+                       n_blocks, bsum, bpre, bvis, big_list);
 }
 
 __global__ void tile_order_identity_kernel(int n_tiles, uint32_t* __restrict__ order) {
@@ -297,21 +402,26 @@ void gsr_launch_tile_order(hipStream_t s, int n_tiles, const uint32_t* tile_coun
 }
 
 void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start,
-                          uint32_t* tile_count, uint32_t max_tile, const uint64_t* bins, uint32_t bin_cap, uint64_t* big_scratch,
-                          uint32_t big_scratch_stride, uint32_t* slab_counter, GsrGeom geom, GsrStream stream,
+                          uint32_t* tile_count, uint32_t max_tile, const uint64_t* bins, uint32_t bin_cap, uint32_t n_big,
+                          const uint32_t* big_list, uint64_t* big_scratch, size_t slab_stride, GsrGeom geom, GsrStream stream,
                           uint32_t* values_sorted, uint32_t* ranges) {
 #define LAUNCH(CC, CAPV, LOV)                                                                                     \
     hipLaunchKernelGGL((tile_sort_kernel<CC, CAPV, LOV>), dim3(n_tiles), dim3(256), 0, s, tile_start, tile_count, bins, \
-                       bin_cap, \
-                       big_scratch, big_scratch_stride, slab_counter, grid_x, geom, stream, values_sorted, ranges)
+                       bin_cap, grid_x, geom, stream, values_sorted, ranges)
+#define LAUNCH_BIG(CC)                                                                                            \
+    hipLaunchKernelGGL((tile_sort_big_kernel<CC>), dim3(n_big), dim3(BIG_THREADS), 0, s, tile_start, big_list, bins, \
+                       bin_cap, big_scratch, slab_stride, grid_x, geom, stream, values_sorted)
     if (channels > 5) {
         LAUNCH(8, 1024, -1);
         if (max_tile > 1024u) LAUNCH(8, 4096, 1024);
         if (max_tile > 4096u) LAUNCH(8, GSR_SORT_LDS_CAP, 4096);
+        if (n_big > 0) LAUNCH_BIG(8);
     } else {
         LAUNCH(3, 1024, -1);
         if (max_tile > 1024u) LAUNCH(3, 4096, 1024);
         if (max_tile > 4096u) LAUNCH(3, GSR_SORT_LDS_CAP, 4096);
+        if (n_big > 0) LAUNCH_BIG(3);
     }
 #undef LAUNCH
+#undef LAUNCH_BIG
 }

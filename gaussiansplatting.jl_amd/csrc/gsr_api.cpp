@@ -9,6 +9,7 @@
 #include <math.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -154,9 +155,13 @@ struct gsr_handle {
     // GeometryState (states.jl:2-47), repacked as one 64-byte record per Gaussian
     DevBuf geo, gnormal, radii, bsum, bpre, bvis;
     // BinningState (states.jl:66-85): unsorted keys (per-tile bins of bin_cap slots), sorted ids, sorted splat stream
-    uint32_t bin_cap = 0;
+    uint32_t bin_cap = 0;           // capacity (keys per tile) the NEXT fast-mode view will use; 0 = none chosen yet
+    uint32_t bin_cap_view = 0;      // capacity the bins were filled with in the current view
+    bool compact_sticky = false;    // the last view showed that fixed-capacity bins do not fit the budget
+    bool last_compact = false;
     bool tile_count_dirty = false;  // counters not yet re-zeroed by the tile sort
-    DevBuf bins, values_sorted, s0, s1, s2, s3, big_scratch;
+    DevBuf bins, keys_compact, big_list, values_sorted, s0, s1, s2, s3, big_scratch;
+    uint32_t bin_cap_used(bool use_bins) const { return use_bins ? bin_cap_view : 0u; }
     // backward: per-instance gradient rows + instance position map; gstate.∇means_2d
     DevBuf rows, vmean2d;
     // loss-head scratch
@@ -173,7 +178,7 @@ struct gsr_handle {
     int64_t last_slots = 0;
     Profiler prof;
 
-    DevBuf* all[30];
+    DevBuf* all[36];
     int n_all = 0;
 };
 
@@ -240,13 +245,13 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
     DevBuf* list[] = {&h->ranges, &h->n_contrib, &h->final_T, &h->tile_count, &h->tile_start, &h->tile_order, &h->totals,
                       &h->geo, &h->gnormal, &h->radii, &h->bsum, &h->bpre, &h->bvis, &h->bins, &h->values_sorted, &h->s0,
                       &h->s1, &h->s2, &h->s3, &h->big_scratch, &h->rows, &h->vmean2d, &h->d0, &h->d1,
-                      &h->d2, &h->partial};
+                      &h->d2, &h->partial, &h->keys_compact, &h->big_list};
     for (DevBuf* b : list) h->all[h->n_all++] = b;
     const size_t P = (size_t)cfg->width * cfg->height, T = (size_t)h->n_tiles;
     int rc = GSR_OK;
     if ((rc = h->ranges.ensure(2 * T * 4)) || (rc = h->n_contrib.ensure(P * 4)) || (rc = h->final_T.ensure(P * 4)) ||
         (rc = h->tile_count.ensure((T + 2) * 4)) || (rc = h->tile_start.ensure((T + 1) * 4)) ||
-        (rc = h->tile_order.ensure((T + 8) * 4)) || (rc = h->totals.ensure(8 * 4))) {
+        (rc = h->tile_order.ensure((T + 8) * 4)) || (rc = h->totals.ensure(8 * 4)) || (rc = h->big_list.ensure((T + 1) * 4))) {
         gsr_destroy(h);
         return rc;
     }
@@ -275,7 +280,9 @@ int gsr_destroy(gsr_handle* h) {
 int gsr_release_scene_buffers(gsr_handle* h) {
     if (!h) return fail(GSR_E_INVALID_ARG, "null handle");
     DevBuf* scene[] = {&h->geo, &h->gnormal, &h->radii, &h->bsum, &h->bpre, &h->bvis, &h->bins, &h->values_sorted, &h->s0, &h->s1,
-                       &h->s2, &h->s3, &h->big_scratch, &h->rows, &h->vmean2d};
+                       &h->s2, &h->s3, &h->big_scratch, &h->rows, &h->vmean2d, &h->keys_compact};
+    h->bin_cap = 0;
+    h->compact_sticky = false;
     for (DevBuf* b : scene) {
         int rc = b->release();
         if (rc) return rc;
@@ -321,40 +328,53 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
 
     GsrCam k = make_cam(h, cam);
     uint32_t* totals = h->totals.as<uint32_t>();
-    // Capacity of the per-tile key bins: the longest list seen on this handle with slack; before
-    // the first view an estimate from N / T (6 tiles per Gaussian, x4).  If a view overflows it,
-    // the pass below is repeated once with the capacity the scan reported.
-    if (h->bin_cap == 0) {
+    // Binning (SURVEY.md A.5-A.7 restated per tile).  FAST mode: every tile owns a fixed-capacity key bin
+    // (capacity = the longest list seen on this handle + 25 %; before the first view an estimate from N / T) and
+    // preprocess drops the keys straight into them — no second pass over the instances.  Its memory is
+    // (T+1)·capacity·8 B, i.e. O(T · longest list), so it is only used while that stays within the bins budget
+    // (default max(128 MiB, 48 B x last instance count); gsr_config.bins_budget_bytes overrides).  Otherwise — a
+    // scene with a few very deep tiles, or a view that overflowed its bins — the COMPACT mode runs: preprocess
+    // only counts, the scan turns the counts into offsets, emit_compact scatters the keys to exact offsets
+    // (8 B per instance whatever the skew), and nothing is ever repeated.
+    if (h->bin_cap == 0 && !h->compact_sticky) {
         const uint64_t est = 8ull * (uint64_t)nn / T + 64;  // ~6 tiles per Gaussian, +35 %
         h->bin_cap = (uint32_t)((est < (1u << 20) ? est : (1u << 20)) + 63) & ~63u;
     }
-    for (int attempt = 0;; attempt++) {
-        if ((rc = h->bins.ensure((T + 1) * (size_t)h->bin_cap * 8))) return rc;
-        // The tile counters are zero on entry: gsr_create clears them and the tile sort re-zeroes each
-        // tile's counter as it consumes it (no memset kernel per view; the scan overwrites every total).
-        // Only a pass that did not reach the sort — an error, or the overflow retry below — leaves them dirty.
-        if (h->tile_count_dirty) HIPCHK(hipMemsetAsync(h->tile_count.p, 0, (T + 2) * 4, s));
-        h->tile_count_dirty = true;
-        h->prof.begin(ST_PREPROCESS, s);
-        gsr_launch_preprocess(s, n, in->n_coeffs, in->sh_degree, C, in->means, in->scales, in->rotations, in->opacities,
-                              in->shs, k, geom_of(h), h->tile_count.as<uint32_t>(), h->bvis.as<uint32_t>(),
-                              h->bins.as<uint64_t>(), h->bin_cap);
-        h->prof.end(s);
-        h->prof.begin(ST_SCAN, s);
-        gsr_launch_tile_scan(s, h->n_tiles, h->tile_count.as<uint32_t>(), h->tile_start.as<uint32_t>(), totals,
-                             n_blocks, h->bsum.as<uint32_t>(), h->bpre.as<uint32_t>(), h->bvis.as<uint32_t>());
-        h->prof.end(s);
-        HIPCHK(hipGetLastError());
-        // the one host sync of the path: instance count D (reference: rasterizer.jl:337)
-        HIPCHK(hipMemcpyAsync(h->host_totals, totals, 8 * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipEventRecord(h->totals_ready, s));
-        // launch order of the compositing workgroups (longest tile lists first); runs while the host waits
-        gsr_launch_tile_order(s, h->n_tiles, h->tile_count.as<uint32_t>(), totals, h->tile_order.as<uint32_t>());
-        HIPCHK(hipEventSynchronize(h->totals_ready));
-        if (h->host_totals[1] <= h->bin_cap) break;
-        if (attempt > 0) return fail(GSR_E_STATE, "tile bins overflowed twice (max %u, capacity %u)",
-                                     h->host_totals[1], h->bin_cap);
-        h->bin_cap = (uint32_t)(((uint64_t)h->host_totals[1] + h->host_totals[1] / 4 + 63) & ~63ull);  // +25 %
+    const uint64_t budget = h->cfg.bins_budget_bytes ? h->cfg.bins_budget_bytes
+                                                     : std::max<uint64_t>(128ull << 20, 48ull * (uint64_t)h->last_D);
+    bool use_bins = h->bin_cap > 0 && (uint64_t)(T + 1) * h->bin_cap * 8ull <= budget;
+    h->bin_cap_view = use_bins ? h->bin_cap : 0u;
+    if (use_bins && (rc = h->bins.ensure((T + 1) * (size_t)h->bin_cap * 8))) return rc;
+    // The tile counters are zero on entry: gsr_create clears them and the tile sort re-zeroes each
+    // tile's counter as it consumes it (no memset kernel per view; the scan overwrites every total).
+    // Only a pass that did not reach the sort (an error) leaves them dirty.
+    if (h->tile_count_dirty) HIPCHK(hipMemsetAsync(h->tile_count.p, 0, (T + 2) * 4, s));
+    h->tile_count_dirty = true;
+    h->prof.begin(ST_PREPROCESS, s);
+    gsr_launch_preprocess(s, n, in->n_coeffs, in->sh_degree, C, in->means, in->scales, in->rotations, in->opacities,
+                          in->shs, k, geom_of(h), h->tile_count.as<uint32_t>(), h->bvis.as<uint32_t>(),
+                          h->bins.as<uint64_t>(), h->bin_cap_view /* 0: count only */);
+    h->prof.end(s);
+    h->prof.begin(ST_SCAN, s);
+    gsr_launch_tile_scan(s, h->n_tiles, h->tile_count.as<uint32_t>(), h->tile_start.as<uint32_t>(), totals,
+                         n_blocks, h->bsum.as<uint32_t>(), h->bpre.as<uint32_t>(), h->bvis.as<uint32_t>(),
+                         h->big_list.as<uint32_t>());
+    h->prof.end(s);
+    HIPCHK(hipGetLastError());
+    // the one host sync of the path: instance count D (reference: rasterizer.jl:337)
+    HIPCHK(hipMemcpyAsync(h->host_totals, totals, 8 * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(h->totals_ready, s));
+    // launch order of the compositing workgroups (longest tile lists first); runs while the host waits
+    gsr_launch_tile_order(s, h->n_tiles, h->tile_count.as<uint32_t>(), totals, h->tile_order.as<uint32_t>());
+    HIPCHK(hipEventSynchronize(h->totals_ready));
+    const bool overflow = use_bins && h->host_totals[1] > h->bin_cap_view;
+    const bool compact = !use_bins || overflow;
+    {   // capacity for the NEXT view: longest list + 25 %, if that fits the budget of a scene of this size
+        const uint64_t want = ((uint64_t)h->host_totals[1] + h->host_totals[1] / 4 + 63) & ~63ull;
+        const uint64_t next_budget = h->cfg.bins_budget_bytes ? h->cfg.bins_budget_bytes
+                                                              : std::max<uint64_t>(128ull << 20, 48ull * (uint64_t)h->host_totals[0]);
+        if ((uint64_t)(T + 1) * want * 8ull > next_budget) { h->bin_cap = 0; h->compact_sticky = true; }
+        else if (want > h->bin_cap || !use_bins) { h->bin_cap = (uint32_t)want; h->compact_sticky = false; }
     }
     const uint64_t D = h->host_totals[0];
     const uint32_t max_tile = h->host_totals[1], n_big = h->host_totals[2];
@@ -367,6 +387,11 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
         stats->n_rendered = (int64_t)D;
         stats->n_visible = (int32_t)h->host_totals[4];
         stats->max_tile_instances = (int32_t)max_tile;
+    }
+    h->last_compact = compact;
+    if (stats) {
+        stats->compact_binning = compact ? 1 : 0;
+        stats->bins_bytes = (int64_t)(compact ? D * 8 : (uint64_t)(T + 1) * h->bin_cap_used(use_bins) * 8ull);
     }
     if (D == 0) {
         h->tile_count_dirty = false;  // every counter is zero
@@ -385,17 +410,26 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
         (rc = h->s0.ensure(D * 16, slack)) || (rc = h->s1.ensure(D * 16, slack)) ||
         (rc = h->s2.ensure(D * 16, slack)) || (C > 5 && (rc = h->s3.ensure(D * 16, slack))))
         return rc;
-    uint32_t big_stride = 0;
-    if (n_big > 0) {
-        big_stride = 1;
-        while (big_stride < max_tile) big_stride <<= 1;
-        if ((rc = h->big_scratch.ensure((size_t)n_big * big_stride * 8))) return rc;
+    size_t slab_stride = 0;
+    if (n_big > 0) {  // lists beyond the LDS sort: two merge slabs per listed tile
+        slab_stride = ((size_t)max_tile + 63) & ~(size_t)63;
+        if ((rc = h->big_scratch.ensure((size_t)n_big * 2 * slab_stride * 8))) return rc;
     }
     h->prof.begin(ST_SORT, s);
+    const uint64_t* keys = h->bins.as<uint64_t>();
+    uint32_t key_cap = h->bin_cap_used(use_bins);
+    if (compact) {
+        // count -> scan -> scatter: the counters become the fill cursors of the scatter pass
+        if ((rc = h->keys_compact.ensure(D * 8, slack))) return rc;
+        HIPCHK(hipMemsetAsync(h->tile_count.p, 0, (T + 2) * 4, s));
+        gsr_launch_emit_compact(s, n, k, geom_of(h), h->tile_start.as<uint32_t>(), h->tile_count.as<uint32_t>(),
+                                h->keys_compact.as<uint64_t>());
+        keys = h->keys_compact.as<uint64_t>();
+        key_cap = 0;
+    }
     gsr_launch_tile_sort(s, h->n_tiles, h->grid_x, C, h->tile_start.as<uint32_t>(), h->tile_count.as<uint32_t>(), max_tile,
-                         h->bins.as<uint64_t>(), h->bin_cap,
-                         h->big_scratch.as<uint64_t>(), big_stride, totals + 3, geom_of(h), stream_of(h),
-                         h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>());
+                         keys, key_cap, n_big, h->big_list.as<uint32_t>(), h->big_scratch.as<uint64_t>(), slab_stride,
+                         geom_of(h), stream_of(h), h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>());
     h->prof.end(s);
     h->tile_count_dirty = false;  // tile_sort zeroed the counters
     h->prof.begin(ST_COMPOSITE_FWD, s);

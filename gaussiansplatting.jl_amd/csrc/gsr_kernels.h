@@ -62,6 +62,9 @@ void gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels
                            const float* scales, const float* rots, const float* opac, const float* shs, GsrCam cam,
                            GsrGeom geom, uint32_t* tile_count, uint32_t* n_visible /* per 256-block */,
                            uint64_t* bins /* (T+1) x bin_cap keys */, uint32_t bin_cap);
+// compact binning mode: scatter the keys to tile_start[t] + arrival rank (tile_fill zeroed by the caller)
+void gsr_launch_emit_compact(hipStream_t s, int n, GsrCam cam, GsrGeom geom, const uint32_t* tile_start, uint32_t* tile_fill,
+                             uint64_t* keys);
 void gsr_launch_pergauss_bwd(hipStream_t s, int n, int K, int degree, int channels, const float* means,
                              const float* scales, const float* rots, const float* shs, GsrCam cam, GsrGeom geom,
                              GsrInst inst, float2* vmean2d, float* vmeans, float* vshs, float* vopac,
@@ -79,13 +82,15 @@ void gsr_launch_update_stats(hipStream_t s, int n, const int32_t* radii, const f
 // totals[0] = D, totals[1] = max count, totals[2] = #tiles over GSR_SORT_LDS_CAP, totals[3] = slab counter (0)
 void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count, uint32_t* tile_start,
                           uint32_t* totals, int n_blocks, const uint32_t* bsum, uint32_t* bpre,
-                          const uint32_t* bvis);
+                          const uint32_t* bvis, uint32_t* big_list /* [n_tiles]: ids of the tiles over GSR_SORT_LDS_CAP */);
 // order[0..n_tiles) = tile ids by descending list length (launch order of the compositing workgroups)
 void gsr_launch_tile_order(hipStream_t s, int n_tiles, const uint32_t* tile_count, const uint32_t* totals,
                            uint32_t* order);
+// bin_cap > 0: keys of tile t at bins + t * bin_cap; bin_cap == 0: compact layout, keys of tile t at bins + tile_start[t]
 void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start,
-                          uint32_t* tile_count /* re-zeroed for the next view */, uint32_t max_tile /* longest list, from the scan */, const uint64_t* bins, uint32_t bin_cap,
-                          uint64_t* big_scratch, uint32_t big_scratch_stride, uint32_t* slab_counter, GsrGeom geom,
+                          uint32_t* tile_count /* re-zeroed for the next view */, uint32_t max_tile /* longest list, from the scan */,
+                          const uint64_t* bins, uint32_t bin_cap, uint32_t n_big, const uint32_t* big_list,
+                          uint64_t* big_scratch /* 2 slabs of slab_stride keys per listed tile */, size_t slab_stride, GsrGeom geom,
                           GsrStream stream, uint32_t* values_sorted, uint32_t* ranges);
 
 // ---- composite.hip ----

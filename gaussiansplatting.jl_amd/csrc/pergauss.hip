@@ -419,6 +419,62 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
 }
 
 // ---------------------------------------------------------------------------------
+// duplicate_with_keys! (utils.jl:85-120) as a separate pass — the compact binning mode (count -> scan -> scatter):
+// used when fixed-capacity bins would cost more memory than the budget allows (a few very deep tiles: capacity is
+// the LONGEST list, times all tiles) or when a view overflowed its bins.  preprocess_kernel has already counted the
+// instances per tile (same tests, same floats, same translation unit) and tile_scan turned the counts into
+// tile_start; here every visible Gaussian re-walks its rect and drops its key at tile_start[t] + (arrival rank in
+// t) — memory 8 B per instance whatever the skew.  Order inside a tile is arbitrary; the tile sort fixes it.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void emit_compact_kernel(int n, GsrCam cam, GsrGeom geom,
+                                                           const uint32_t* __restrict__ tile_start,
+                                                           uint32_t* __restrict__ tile_fill,
+                                                           uint64_t* __restrict__ keys) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool visible = i < n && geom.radii[i] > 0;
+    float mx = 0, my = 0, ca = 0, cb = 0, cc = 0, tau = 0;
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    uint32_t zbits = 0, area = 0;
+    if (visible) {
+        const GsrGeoRec rec = geom.rec[i];
+        mx = rec.q0.x; my = rec.q0.y; ca = rec.q0.z; cb = rec.q0.w; cc = rec.q1.x;
+        tau = footprint_tau(rec.q1.y);
+        zbits = __float_as_uint(rec.q2.z);
+        const uint32_t lo = __float_as_uint(rec.q3.x), hi = __float_as_uint(rec.q3.y);
+        x0 = (int)(lo & 0xFFFFu); y0 = (int)(lo >> 16); x1 = (int)(hi & 0xFFFFu); y1 = (int)(hi >> 16);
+        area = (uint32_t)((x1 - x0) * (y1 - y0));
+        if (area <= EMIT_COOP) {
+            const uint64_t key = ((uint64_t)zbits << 32) | (uint32_t)i;
+            for (int y = y0; y < y1; y++)
+                for (int x = x0; x < x1; x++)
+                    if (!cam.exact_cull || tile_may_touch(mx, my, ca, cb, cc, tau, x * GSR_TILE, y * GSR_TILE)) {
+                        const uint32_t t = (uint32_t)(y * cam.grid_x + x);
+                        keys[tile_start[t] + atomicAdd(tile_fill + t, 1u)] = key;
+                    }
+        }
+    }
+    const int lane = threadIdx.x & 63;
+    unsigned long long big = __builtin_amdgcn_ballot_w64(visible && area > EMIT_COOP);
+    while (big) {  // large footprints: the whole wave, one tile per lane and round (as preprocess_kernel)
+        const int src = __builtin_ctzll(big);
+        big &= big - 1;
+        const float bmx = __shfl(mx, src), bmy = __shfl(my, src), ba = __shfl(ca, src), bb = __shfl(cb, src), bc = __shfl(cc, src);
+        const float btau = __shfl(tau, src);
+        const int bx0 = __shfl(x0, src), by0 = __shfl(y0, src), bx1 = __shfl(x1, src), by1 = __shfl(y1, src);
+        const uint64_t bkey = ((uint64_t)__shfl(zbits, src) << 32) | (uint32_t)(blockIdx.x * 256 + (threadIdx.x & ~63) + src);
+        const int w = bx1 - bx0, total = w * (by1 - by0);
+        for (int e = lane; e < total; e += 64) {
+            const int ry = e / w, rx = e - ry * w;
+            const int x = bx0 + rx, y = by0 + ry;
+            if (!cam.exact_cull || tile_may_touch(bmx, bmy, ba, bb, bc, btau, x * GSR_TILE, y * GSR_TILE)) {
+                const uint32_t t = (uint32_t)(y * cam.grid_x + x);
+                keys[tile_start[t] + atomicAdd(tile_fill + t, 1u)] = bkey;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // fused ∇project! (projection.jl:170-256) + ∇spherical_harmonics!
 // (spherical_harmonics.jl:32-37,76-181).  Every output element is written exactly
 // once (zeros for culled Gaussians and for SH bands above the active degree), so the
@@ -854,6 +910,12 @@ void gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels
         default: LAUNCH(3); break;
     }
 #undef LAUNCH
+}
+
+void gsr_launch_emit_compact(hipStream_t s, int n, GsrCam cam, GsrGeom geom, const uint32_t* tile_start, uint32_t* tile_fill,
+                             uint64_t* keys) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(emit_compact_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, cam, geom, tile_start, tile_fill, keys);
 }
 
 void gsr_launch_pergauss_bwd(hipStream_t s, int n, int K, int degree, int channels, const float* means,

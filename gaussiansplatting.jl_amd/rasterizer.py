@@ -91,7 +91,7 @@ class GaussianRasterizer:
 
     def __init__(self, width: int, height: int, mode: str = "rgbd", near_plane: float = 0.2,
                  far_plane: float = 1000.0, device="cuda", radius_clip: int = 3, blur_eps: float = 0.3,
-                 exact_tile_cull: bool = True):
+                 exact_tile_cull: bool = True, bins_budget_bytes: int = 0):
         self.mode = mode
         self.channels = n_color_features(mode)
         self.width, self.height = int(width), int(height)
@@ -107,7 +107,7 @@ class GaussianRasterizer:
         # False = GSR_FLAG_REFERENCE_TILE_LISTS: exactly the reference's lists (list-level parity checks).
         self.exact_tile_cull = bool(exact_tile_cull)
         cfg = L.Config(self.width, self.height, self.channels, self.near_plane, self.far_plane, int(radius_clip),
-                       float(blur_eps), 0 if exact_tile_cull else L.FLAG_REFERENCE_TILE_LISTS)
+                       float(blur_eps), 0 if exact_tile_cull else L.FLAG_REFERENCE_TILE_LISTS, int(bins_budget_bytes))
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             L.check(self._lib.gsr_create(C.byref(cfg), C.byref(h)))

@@ -86,3 +86,39 @@ def make_vpixels(width: int, height: int, channels: int, seed: int) -> np.ndarra
     p = width * height
     g = np.random.default_rng(seed + 104729).standard_normal((height, width, channels))
     return (g / (channels * p)).astype(np.float32)
+
+
+def add_skew(scene: Scene, kind: str, seed: int = 7) -> Scene:
+    """Skewed variants of the synthetic scene (tile-list length far from uniform), for the skew bench / tests:
+      "hot:K"      K extra Gaussians whose means project into ONE tile (the central one): a list of ~K instances
+      "dense:P:F"  a fraction P of the tiles (random) gets F x the mean density (extra Gaussians centred in them)
+    Extra Gaussians share the distribution of everything else (scales for sigma_px = 3, random rotations, ...)."""
+    rng = np.random.default_rng(seed)
+    W, H = scene.width, scene.height
+    fx, fy = float(scene.focal[0]), float(scene.focal[1])
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    parts = kind.split(":")
+    if parts[0] == "hot":
+        k = int(parts[1])
+        tiles = np.full(k, (gy // 2) * gx + gx // 2)
+    elif parts[0] == "dense":
+        frac, factor = float(parts[1]), float(parts[2])
+        hot = rng.choice(gx * gy, max(1, int(frac * gx * gy)), replace=False)
+        per_tile = int(factor * scene.n * 4.5 / (gx * gy) / 4.5)  # factor x the mean number of Gaussian centres per tile
+        tiles = np.repeat(hot, per_tile)
+        k = tiles.shape[0]
+    else:
+        raise ValueError(f"unknown skew kind {kind!r}")
+    tx, ty = tiles % gx, tiles // gx
+    px = tx * 16 + rng.uniform(0.0, 16.0, k)
+    py = ty * 16 + rng.uniform(0.0, 16.0, k)
+    z = rng.uniform(2.0, 12.0, k)
+    x = (px - 0.5 * W) * z / fx
+    y = (py - 0.5 * H) * z / fy
+    extra = make_scene(k, W, H, scene.sh_degree, seed + 1, K=scene.shs.shape[1])
+    means = np.stack([x, y, z], 1).astype(np.float32)
+    log_s = (np.log(3.0 * z / fx)[:, None] + (extra.scales_raw - np.log(3.0 * extra.means[:, 2:3] / fx))).astype(np.float32)
+    cat = lambda a, b: np.ascontiguousarray(np.concatenate([a, b], 0))  # noqa: E731
+    return Scene(cat(scene.means, means), cat(scene.scales_raw, log_s), cat(scene.rotations, extra.rotations),
+                 cat(scene.opacities_raw, extra.opacities_raw), cat(scene.shs, extra.shs), scene.sh_degree, W, H, scene.focal,
+                 scene.principal)

@@ -58,6 +58,10 @@ typedef struct gsr_config {
     int32_t radius_clip; /* 3 px */
     float blur_eps;      /* 0.3  */
     uint32_t flags;      /* GSR_FLAG_* */
+    uint64_t bins_budget_bytes; /* 0 = default.  Cap on the fixed-capacity per-tile key bins of the fast binning mode
+                          * ((tiles+1) x longest list x 8 B); default max(128 MiB, 48 B x instance count of the last view).
+                          * A view whose bins would exceed it — a few very deep tiles — is binned in compact mode
+                          * (count -> scan -> scatter, 8 B per instance) instead: same lists, same results. */
 } gsr_config;
 
 /* Tile lists.  DEFAULT (flags = 0): exact footprint culling at binning — a (Gaussian, tile)
@@ -119,6 +123,9 @@ typedef struct gsr_stats {
     int32_t max_tile_instances; /* longest per-tile list */
     uint64_t generation;        /* ordinal of this forward on the handle (1, 2, ...): pass it to
                                  * gsr_backward (gsr_grads.forward_generation) to have the pairing checked */
+    int64_t bins_bytes;         /* bytes of unsorted-key storage this view used (fast: (T+1) x capacity x 8; compact: 8 D) */
+    int32_t compact_binning;    /* 1: this view was binned count -> scan -> scatter (budget exceeded or bins overflowed) */
+    int32_t reserved;
 } gsr_stats;
 
 /* Cotangents returned by `∇rasterize` (rasterizer.jl:549): caller-provided device

@@ -33,6 +33,7 @@ const LIB = get(ENV, "GSR_HIP_LIB", "libgsr_hip.so")
 struct GsrConfig
     width::Int32; height::Int32; mode::Int32
     near_plane::Float32; far_plane::Float32; radius_clip::Int32; blur_eps::Float32; flags::UInt32
+    bins_budget_bytes::UInt64  # 0 = default
 end
 struct GsrInputs
     n::Int32; n_coeffs::Int32; sh_degree::Int32
@@ -46,7 +47,10 @@ struct GsrCamera
     R_dev::Ptr{Float32}; t_dev::Ptr{Float32}
 end
 struct GsrAux; covisibilities::Ptr{UInt8}; uncertainties::Ptr{Float32}; radii::Ptr{Int32}; end
-struct GsrStats; n_rendered::Int64; n_visible::Int32; max_tile_instances::Int32; generation::UInt64; end
+struct GsrStats
+    n_rendered::Int64; n_visible::Int32; max_tile_instances::Int32; generation::UInt64
+    bins_bytes::Int64; compact_binning::Int32; reserved::Int32
+end
 struct GsrGrads
     vmeans::Ptr{Float32}; vshs::Ptr{Float32}; vopacities::Ptr{Float32}
     vscales::Ptr{Float32}; vrotations::Ptr{Float32}; vR::Ptr{Float32}; vt::Ptr{Float32}
@@ -80,7 +84,7 @@ function enable_hip_native!(rast::GaussianRasterizer; reference_tile_lists::Bool
     c, w, h = size(rast.image)
     href = Ref{Ptr{Cvoid}}()
     check(ccall((:gsr_create, LIB), Cint, (Ref{GsrConfig}, Ref{Ptr{Cvoid}}),
-        GsrConfig(w, h, c, rast.near_plane, rast.far_plane, 3, 0.3f0, reference_tile_lists ? 0x1 : 0x0), href))
+        GsrConfig(w, h, c, rast.near_plane, rast.far_plane, 3, 0.3f0, reference_tile_lists ? 0x1 : 0x0, 0), href))
     st = NativeState(href[], 0)
     finalizer(s -> ccall((:gsr_destroy, LIB), Cint, (Ptr{Cvoid},), s.handle), st)
     lock(() -> (NATIVE[rast] = st), NATIVE_LOCK)
@@ -125,7 +129,7 @@ function GaussianSplatting.rasterize(means_3d::RM, shs::R3, opacities::RM, scale
     end
     inp, cam = _structs(means_3d, shs, opacities, scales, rotations, R_w2c, t_w2c, camera, sh_degree, background)
     aux = GsrAux(dptr(UInt8, covisibilities), dptr(uncertainties), dptr(Int32, rast.gstate.radii))
-    stats = Ref(GsrStats(0, 0, 0, 0))
+    stats = Ref(GsrStats(0, 0, 0, 0, 0, 0, 0))
     check(ccall((:gsr_forward, LIB), Cint,
         (Ptr{Cvoid}, Ref{GsrInputs}, Ref{GsrCamera}, Ptr{Float32}, Ref{GsrAux}, Ptr{Cvoid}, Ref{GsrStats}),
         st.handle, inp, cam, dptr(rast.image), aux, hipstream(), stats))

@@ -24,10 +24,10 @@ def test_library_exports_every_declared_symbol(pkg):
 def test_struct_sizes_match_header(pkg):
     L = pkg._lib
     # include/gsr.h layouts (x86-64 SysV): catches a drifting binding
-    assert C.sizeof(L.Config) == 32
+    assert C.sizeof(L.Config) == 40
     assert C.sizeof(L.Inputs) == 16 + 5 * 8 + 12 + 4
     assert C.sizeof(L.CameraS) == (9 + 3 + 2 + 2 + 3) * 4 + 4 + 16
-    assert C.sizeof(L.Stats) == 24
+    assert C.sizeof(L.Stats) == 40
     assert C.sizeof(L.Grads) == 80
     assert C.sizeof(L.Aux) == 24
 
@@ -37,10 +37,10 @@ def test_invalid_arguments_fail_before_touching_the_gpu(pkg):
     L = pkg._lib
     lib = L.load()
     h = C.c_void_p()
-    cfg = L.Config(64, 48, 4, 0.2, 1000.0, 3, 0.3, 0)  # mode 4 does not exist
+    cfg = L.Config(64, 48, 4, 0.2, 1000.0, 3, 0.3, 0, 0)  # mode 4 does not exist
     assert lib.gsr_create(C.byref(cfg), C.byref(h)) == L.GSR_E_INVALID_ARG
     assert b"Invalid render mode" in lib.gsr_last_error_string()
-    cfg = L.Config(0, 48, 3, 0.2, 1000.0, 3, 0.3, 0)
+    cfg = L.Config(0, 48, 3, 0.2, 1000.0, 3, 0.3, 0, 0)
     assert lib.gsr_create(C.byref(cfg), C.byref(h)) == L.GSR_E_INVALID_ARG
     assert lib.gsr_forward(None, None, None, None, None, None, None) == L.GSR_E_INVALID_ARG
     assert lib.gsr_backward(None, None, None, None, None, None) == L.GSR_E_INVALID_ARG

@@ -202,10 +202,11 @@ def test_empty_scene(pkg, orc):
     assert all(not o.cpu().numpy().any() for o in out[:5])
 
 
-@pytest.mark.parametrize("n,floor", [(2500, 1024), (6000, 4096), (10000, 8192)])
+@pytest.mark.parametrize("n,floor", [(2500, 1024), (6000, 4096), (10000, 8192), (21000, 16384), (70000, 65536)])
 def test_long_tile_lists_take_the_larger_sort_tiers(pkg, orc, n, floor):
     """Lists beyond 1024 / 4096 / 8192 instances in one tile: the 32 KB and 64 KB LDS sorts and, past
-    8192, the global-scratch slab — sorted ids must stay exactly the oracle's."""
+    8192, the chunked LDS sort + merge passes (1, 2 and 4 merge passes here) — sorted ids must stay exactly
+    the oracle's."""
     rng = np.random.default_rng(9)
     s = pkg.synthetic.make_scene(n, 32, 32, 0, 9)
     means = np.stack([rng.uniform(-0.05, 0.05, n), rng.uniform(-0.05, 0.05, n), rng.uniform(2, 8, n)], 1).astype(np.float32)
@@ -233,11 +234,61 @@ def test_tile_bin_overflow_regrows_and_repeats(pkg, orc):
     run = HipRun(pkg, means, s.shs, opac, s.scales, s.rotations, cam, 1)
     _compare_forward(st, run, run.forward())
     assert run.rast.stats.max_tile_instances > 1000
+    assert run.rast.stats.compact_binning == 1, "an overflowing view is finished in compact mode, nothing is repeated"
+    _compare_forward(st, run, run.forward())
+    assert run.rast.stats.compact_binning == 0, "the next view has bins of the right capacity"
     # and a second, sparse view on the same (grown) handle
     s2, _ = _scene(pkg, orc, n, W, H, 1, 20)
     st2 = orc.forward(s2.means, s2.shs, s2.opacities, s2.scales, s2.rotations, cam, 1)
     run.t = [dev(s2.means), dev(s2.shs), dev(s2.opacities.reshape(-1, 1)), dev(s2.scales), dev(s2.rotations)]
     _compare_forward(st2, run, run.forward())
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_compact_binning_mode_is_bit_identical_to_the_bins(pkg, orc, exact):
+    """gsr_config.bins_budget_bytes: with a budget the fixed-capacity bins cannot meet, every view is binned
+    count -> scan -> scatter (compact mode).  Lists, ids, image and gradients must be bit-identical to the fast
+    mode's (the per-tile sort erases the arrival order), and equal to the oracle's lists in reference-list mode."""
+    W, H, n, deg = 320, 208, 12000, 1
+    s, cam = _scene(pkg, orc, n, W, H, deg, 61, sigma_px=4.0)
+    fast = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, exact_tile_cull=exact)
+    comp = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, exact_tile_cull=exact)
+    comp.rast.close()
+    comp.rast = pkg.rasterizer.GaussianRasterizer(W, H, mode="rgb", exact_tile_cull=exact, bins_budget_bytes=1)
+    vp = np.random.default_rng(3).standard_normal((H, W, 3)).astype(np.float32)
+    for _ in range(2):  # second view: steady state of both modes
+        ia, ib = fast.forward().clone(), comp.forward().clone()
+        assert fast.rast.stats.compact_binning == 0 and comp.rast.stats.compact_binning == 1
+        assert comp.rast.stats.bins_bytes == 8 * comp.rast.stats.n_rendered
+        assert torch.equal(ia, ib)
+        assert torch.equal(fast.rast.values_sorted, comp.rast.values_sorted) and torch.equal(fast.rast.ranges, comp.rast.ranges)
+        ga, gb = fast.backward(vp), comp.backward(vp)
+        assert all(torch.equal(x, y) for x, y in zip(ga[:5], gb[:5]))
+    if not exact:
+        st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg)
+        assert np.array_equal(comp.rast.values_sorted.cpu().numpy().astype(np.uint32), st.values_sorted)
+
+
+def test_hot_tile_scene_stays_within_the_bins_budget(pkg, orc):
+    """A skewed scene — one tile 100x deeper than the rest — must not cost O(tiles x longest list) memory: the
+    library switches to compact binning (8 B per instance) and its scratch stays bounded by the instance count."""
+    W, H, deg = 1920, 1080, 0
+    base = pkg.synthetic.make_scene(100_000, W, H, deg, 71)
+    s = pkg.synthetic.add_skew(base, "hot:40000", seed=72)
+    cam = orc.Camera(W, H, s.focal)
+    run = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg)
+    for _ in range(2):
+        img = run.forward()
+    st_ = run.rast.stats
+    T = 120 * 68
+    assert st_.max_tile_instances > 20000 and st_.compact_binning == 1
+    would_be = (T + 1) * int(st_.max_tile_instances * 1.25) * 8
+    assert would_be > 2 * 2 ** 30, "fixed-capacity bins would need gigabytes here"
+    assert st_.bins_bytes == 8 * st_.n_rendered
+    assert run.rast.memory_usage() < 400 * 2 ** 20 + 300 * st_.n_rendered, run.rast.memory_usage()
+    ref = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg)
+    assert frac_bad(img.cpu().numpy(), ref.image, 0, 1e-4) <= 1e-4
+    assert np.array_equal(run.rast.radii.cpu().numpy(), ref.radii)
 
 
 def test_footprint_masks_are_conservative(pkg, orc):

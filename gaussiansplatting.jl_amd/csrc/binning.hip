@@ -57,9 +57,9 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint
                                                          uint32_t* __restrict__ big_list) {
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t red[3][16];
-    __shared__ uint32_t big_fill;
+    __shared__ uint32_t big_fill, mid8_fill, mid4_fill;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) big_fill = 0;
+    if (tid == 0) { big_fill = 0; mid8_fill = 0; mid4_fill = 0; }
     __syncthreads();
     // tiles: exclusive scan of the counts, longest list, lists beyond the LDS sort
     {
@@ -73,9 +73,16 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint
                 v[k] = lo + k < hi ? tile_count[lo + k] : 0u;
                 sum += v[k];
                 vmax = v[k] > vmax ? v[k] : vmax;
-                if (v[k] > GSR_SORT_LDS_CAP) {  // rare: the tile goes to the merge-sort kernel (any order: tiles are independent)
+                // rare: tiles whose list exceeds the 1024-key LDS sort are listed per tier (any order: tiles are
+                // independent), so the larger sorts launch one workgroup per LISTED tile, sized for their capacity:
+                // big_list[0, T) lists > 8192 (merge sort), [T, 2T) lists in (4096, 8192], [2T, 3T) lists in (1024, 4096]
+                if (v[k] > GSR_SORT_LDS_CAP) {
                     big += 1u;
                     big_list[atomicAdd(&big_fill, 1u)] = (uint32_t)(lo + k);
+                } else if (v[k] > 4096u) {
+                    big_list[n_tiles + atomicAdd(&mid8_fill, 1u)] = (uint32_t)(lo + k);
+                } else if (v[k] > 1024u) {
+                    big_list[2 * n_tiles + atomicAdd(&mid4_fill, 1u)] = (uint32_t)(lo + k);
                 }
             }
             uint32_t round_total;
@@ -102,7 +109,8 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint
             totals[0] = total;  // D
             totals[1] = m;      // longest list
             totals[2] = b;      // #tiles over GSR_SORT_LDS_CAP (listed in big_list; they get two global-scratch slabs each)
-            totals[3] = 0;
+            totals[3] = mid4_fill;  // #tiles with a list in (1024, 4096]
+            totals[6] = mid8_fill;  // #tiles with a list in (4096, 8192]
         }
     }
     // Gaussian blocks: per-block sums of tile-rect areas -> bpre (Gaussian-major instance-slot
@@ -229,48 +237,48 @@ __device__ __forceinline__ void emit_instance(uint64_t k, uint32_t pos, int X0, 
     }
 }
 
-template <int CH>
+template <int CH, int NT>
 __device__ __forceinline__ void sort_and_emit(uint64_t* buf, uint32_t m, uint32_t n, uint32_t start, int tid,
                                               int X0, int Y0,
                                               const uint64_t* __restrict__ keys, const GsrGeom& geom,
                                               const GsrStream& stream, uint32_t* __restrict__ values_sorted) {
-    for (uint32_t i = tid; i < m; i += 256) buf[i] = i < n ? keys[i] : ~0ull;  // keys = this tile's bin / compact segment
+    for (uint32_t i = tid; i < m; i += NT) buf[i] = i < n ? keys[i] : ~0ull;  // keys = this tile's bin / compact segment
     __syncthreads();
-    if (m > 1) bitonic_sort(buf, m, tid, 256);
-    for (uint32_t i = tid; i < n; i += 256) emit_instance<CH>(buf[i], start + i, X0, Y0, geom, stream, values_sorted);
+    if (m > 1) bitonic_sort(buf, m, tid, NT);
+    for (uint32_t i = tid; i < n; i += NT) emit_instance<CH>(buf[i], start + i, X0, Y0, geom, stream, values_sorted);
 }
 
-// CAP = LDS key capacity of this launch, LO = the longest list the smaller launches handle.
-// Up to three launches, chosen by the host from the scan's longest list: CAP = 1024 (8 KB of
-// LDS, full wave occupancy — most tiles), CAP = 4096 (32 KB) only if a list exceeds 1024, and
-// CAP = 8192 (64 KB) only if one exceeds 4096; lists beyond 8192 belong to tile_sort_big_kernel.
-// A workgroup whose tile belongs to another launch exits immediately.
+// CAP = LDS key capacity of this launch.  The first launch (LISTED = false, CAP = 1024: 8 KB of LDS, full wave
+// occupancy) has one 256-thread workgroup per tile: it writes every tile's range, re-zeroes its counter and sorts the
+// lists of up to 1024 keys — nearly all of them.  Longer lists are sorted by launches over the tier lists the scan
+// wrote (LISTED = true): CAP = 4096 with 512 threads (32 KB), CAP = 8192 with 1024 threads (64 KB); lists beyond
+// 8192 belong to tile_sort_big_kernel.  Tiers that are empty (the host knows the counts) are not launched.
 // bin_cap > 0: the tile's unsorted keys are its fixed-capacity bin; bin_cap == 0: compact layout, the keys of
 // tile t sit at keys[tile_start[t] ...) (count -> scan -> scatter; memory O(D) whatever the skew).
-template <int CH, int CAP, int LO>
-__global__ __launch_bounds__(256) void tile_sort_kernel(const uint32_t* __restrict__ tile_start,
-                                                        uint32_t* __restrict__ tile_count,
-                                                        const uint64_t* __restrict__ bins, uint32_t bin_cap, int grid_x,
-                                                        GsrGeom geom, GsrStream stream,
-                                                        uint32_t* __restrict__ values_sorted,
-                                                        uint32_t* __restrict__ ranges) {
+template <int CH, int CAP, bool LISTED, int NT>
+__global__ __launch_bounds__(NT) void tile_sort_kernel(const uint32_t* __restrict__ tile_start,
+                                                       uint32_t* __restrict__ tile_count,
+                                                       const uint32_t* __restrict__ tier_list,
+                                                       const uint64_t* __restrict__ bins, uint32_t bin_cap, int grid_x,
+                                                       GsrGeom geom, GsrStream stream,
+                                                       uint32_t* __restrict__ values_sorted,
+                                                       uint32_t* __restrict__ ranges) {
     __shared__ uint64_t skeys[CAP];
-    const int tile = blockIdx.x, tid = threadIdx.x;
+    const int tile = LISTED ? (int)tier_list[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;
     const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
     const uint32_t n = end - start;
-    if (LO < 0 && tid == 0) tile_count[tile] = 0u;  // the first launch covers every tile: counter ready for the next view
-    if (LO < 0 && tid == 0) {
+    if (!LISTED && tid == 0) {
+        tile_count[tile] = 0u;  // counter ready for the next view
         // identify_tile_range! (utils.jl:56-78): empty tiles keep the (0,0) of the prior fill!
         ranges[2 * tile] = n ? start : 0u;
         ranges[2 * tile + 1] = n ? end : 0u;
     }
-    if ((LO >= 0 && n <= (uint32_t)LO) || n > (uint32_t)CAP) return;  // another launch's tile
-    if (n == 0) return;
+    if (n == 0 || n > (uint32_t)CAP) return;  // a longer list: another launch's tile
     const int X0 = (tile % grid_x) * GSR_TILE, Y0 = (tile / grid_x) * GSR_TILE;
     const uint64_t* __restrict__ keys = bin_cap ? bins + (size_t)tile * bin_cap : bins + start;
     uint32_t m = 1;
     while (m < n) m <<= 1;
-    sort_and_emit<CH>(skeys, m, n, start, tid, X0, Y0, keys, geom, stream, values_sorted);
+    sort_and_emit<CH, NT>(skeys, m, n, start, tid, X0, Y0, keys, geom, stream, values_sorted);
 }
 
 // ---- lists beyond the LDS capacity: chunked LDS sort + merge passes (one 1024-thread workgroup per listed tile) ----
@@ -402,26 +410,22 @@ void gsr_launch_tile_order(hipStream_t s, int n_tiles, const uint32_t* tile_coun
 }
 
 void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start,
-                          uint32_t* tile_count, uint32_t max_tile, const uint64_t* bins, uint32_t bin_cap, uint32_t n_big,
-                          const uint32_t* big_list, uint64_t* big_scratch, size_t slab_stride, GsrGeom geom, GsrStream stream,
-                          uint32_t* values_sorted, uint32_t* ranges) {
-#define LAUNCH(CC, CAPV, LOV)                                                                                     \
-    hipLaunchKernelGGL((tile_sort_kernel<CC, CAPV, LOV>), dim3(n_tiles), dim3(256), 0, s, tile_start, tile_count, bins, \
-                       bin_cap, grid_x, geom, stream, values_sorted, ranges)
+                          uint32_t* tile_count, const uint64_t* bins, uint32_t bin_cap, uint32_t n_mid4, uint32_t n_mid8,
+                          uint32_t n_big, const uint32_t* tier_lists, uint64_t* big_scratch, size_t slab_stride, GsrGeom geom,
+                          GsrStream stream, uint32_t* values_sorted, uint32_t* ranges) {
+#define LAUNCH(CC, CAPV, LISTEDV, NTV, GRID, LIST)                                                                 \
+    hipLaunchKernelGGL((tile_sort_kernel<CC, CAPV, LISTEDV, NTV>), dim3(GRID), dim3(NTV), 0, s, tile_start, tile_count, \
+                       LIST, bins, bin_cap, grid_x, geom, stream, values_sorted, ranges)
 #define LAUNCH_BIG(CC)                                                                                            \
-    hipLaunchKernelGGL((tile_sort_big_kernel<CC>), dim3(n_big), dim3(BIG_THREADS), 0, s, tile_start, big_list, bins, \
+    hipLaunchKernelGGL((tile_sort_big_kernel<CC>), dim3(n_big), dim3(BIG_THREADS), 0, s, tile_start, tier_lists, bins, \
                        bin_cap, big_scratch, slab_stride, grid_x, geom, stream, values_sorted)
-    if (channels > 5) {
-        LAUNCH(8, 1024, -1);
-        if (max_tile > 1024u) LAUNCH(8, 4096, 1024);
-        if (max_tile > 4096u) LAUNCH(8, GSR_SORT_LDS_CAP, 4096);
-        if (n_big > 0) LAUNCH_BIG(8);
-    } else {
-        LAUNCH(3, 1024, -1);
-        if (max_tile > 1024u) LAUNCH(3, 4096, 1024);
-        if (max_tile > 4096u) LAUNCH(3, GSR_SORT_LDS_CAP, 4096);
-        if (n_big > 0) LAUNCH_BIG(3);
-    }
+#define ALL(CC)                                                                                                   \
+    LAUNCH(CC, 1024, false, 256, n_tiles, tier_lists);                                                            \
+    if (n_mid4 > 0) LAUNCH(CC, 4096, true, 512, n_mid4, tier_lists + 2 * (size_t)n_tiles);                        \
+    if (n_mid8 > 0) LAUNCH(CC, GSR_SORT_LDS_CAP, true, 1024, n_mid8, tier_lists + (size_t)n_tiles);                \
+    if (n_big > 0) LAUNCH_BIG(CC)
+    if (channels > 5) { ALL(8); } else { ALL(3); }
+#undef ALL
 #undef LAUNCH
 #undef LAUNCH_BIG
 }

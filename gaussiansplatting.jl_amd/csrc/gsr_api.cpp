@@ -251,7 +251,7 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
     int rc = GSR_OK;
     if ((rc = h->ranges.ensure(2 * T * 4)) || (rc = h->n_contrib.ensure(P * 4)) || (rc = h->final_T.ensure(P * 4)) ||
         (rc = h->tile_count.ensure((T + 2) * 4)) || (rc = h->tile_start.ensure((T + 1) * 4)) ||
-        (rc = h->tile_order.ensure((T + 8) * 4)) || (rc = h->totals.ensure(8 * 4)) || (rc = h->big_list.ensure((T + 1) * 4))) {
+        (rc = h->tile_order.ensure((T + 8) * 4)) || (rc = h->totals.ensure(8 * 4)) || (rc = h->big_list.ensure((3 * T + 1) * 4))) {
         gsr_destroy(h);
         return rc;
     }
@@ -427,9 +427,9 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
         keys = h->keys_compact.as<uint64_t>();
         key_cap = 0;
     }
-    gsr_launch_tile_sort(s, h->n_tiles, h->grid_x, C, h->tile_start.as<uint32_t>(), h->tile_count.as<uint32_t>(), max_tile,
-                         keys, key_cap, n_big, h->big_list.as<uint32_t>(), h->big_scratch.as<uint64_t>(), slab_stride,
-                         geom_of(h), stream_of(h), h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>());
+    gsr_launch_tile_sort(s, h->n_tiles, h->grid_x, C, h->tile_start.as<uint32_t>(), h->tile_count.as<uint32_t>(), keys, key_cap,
+                         h->host_totals[3], h->host_totals[6], n_big, h->big_list.as<uint32_t>(), h->big_scratch.as<uint64_t>(),
+                         slab_stride, geom_of(h), stream_of(h), h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>());
     h->prof.end(s);
     h->tile_count_dirty = false;  // tile_sort zeroed the counters
     h->prof.begin(ST_COMPOSITE_FWD, s);

@@ -82,15 +82,16 @@ void gsr_launch_update_stats(hipStream_t s, int n, const int32_t* radii, const f
 // totals[0] = D, totals[1] = max count, totals[2] = #tiles over GSR_SORT_LDS_CAP, totals[3] = slab counter (0)
 void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count, uint32_t* tile_start,
                           uint32_t* totals, int n_blocks, const uint32_t* bsum, uint32_t* bpre,
-                          const uint32_t* bvis, uint32_t* big_list /* [n_tiles]: ids of the tiles over GSR_SORT_LDS_CAP */);
+                          const uint32_t* bvis, uint32_t* tier_lists /* [3 * n_tiles], see gsr_launch_tile_sort */);
 // order[0..n_tiles) = tile ids by descending list length (launch order of the compositing workgroups)
 void gsr_launch_tile_order(hipStream_t s, int n_tiles, const uint32_t* tile_count, const uint32_t* totals,
                            uint32_t* order);
-// bin_cap > 0: keys of tile t at bins + t * bin_cap; bin_cap == 0: compact layout, keys of tile t at bins + tile_start[t]
+// bin_cap > 0: keys of tile t at bins + t * bin_cap; bin_cap == 0: compact layout, keys of tile t at bins + tile_start[t].
+// tier_lists (written by tile_scan): [0, T) tiles with lists > 8192, [T, 2T) lists in (4096, 8192], [2T, 3T) in (1024, 4096]
 void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start,
-                          uint32_t* tile_count /* re-zeroed for the next view */, uint32_t max_tile /* longest list, from the scan */,
-                          const uint64_t* bins, uint32_t bin_cap, uint32_t n_big, const uint32_t* big_list,
-                          uint64_t* big_scratch /* 2 slabs of slab_stride keys per listed tile */, size_t slab_stride, GsrGeom geom,
+                          uint32_t* tile_count /* re-zeroed for the next view */, const uint64_t* bins, uint32_t bin_cap,
+                          uint32_t n_mid4, uint32_t n_mid8, uint32_t n_big, const uint32_t* tier_lists,
+                          uint64_t* big_scratch /* 2 slabs of slab_stride keys per tile over 8192 */, size_t slab_stride, GsrGeom geom,
                           GsrStream stream, uint32_t* values_sorted, uint32_t* ranges);
 
 // ---- composite.hip ----

@@ -50,3 +50,73 @@ def test_foreign_safetensors_is_rejected(pkg, tmp_path):
     save_file({"x": np.zeros(3, np.float32)}, path, metadata={"format": "pt"})
     with pytest.raises(ValueError, match="not a GaussianSplatting.jl checkpoint"):
         pkg.checkpoint.load_checkpoint(path)
+
+
+def test_on_disk_layout_is_the_references(pkg, tmp_path):
+    """checkpoint.jl:30-33 + the safetensors spec: a Julia (3,N) array is stored with header shape [3,N] and row-major
+    bytes of that logical array.  (a) what we write has those shapes; (b) a file built BY HAND the way the reference
+    writes it — no code of this package involved — loads into the (N,3)-style in-memory arrays; (c) moments are accepted
+    shaped or flat and mis-shaped files are rejected instead of being silently reinterpreted."""
+    import json
+    import struct
+    from safetensors import safe_open
+    ck = pkg.checkpoint
+    g = _model(pkg, n=5, kr=3)
+    sizes = dict(points=15, features_dc=15, features_rest=45, opacities=5, scales=15, rotations=20)
+    opts = {k: _Opt(v, i) for i, (k, v) in enumerate(sizes.items())}
+    path = str(tmp_path / "ours.safetensors")
+    ck.save_state(path, g, opts, step=3)
+    with safe_open(path, framework="numpy") as f:
+        assert f.get_tensor("gaussians.points").shape == (3, 5)
+        assert f.get_tensor("gaussians.features_rest").shape == (3, 3, 5)
+        assert f.get_tensor("gaussians.rotations").shape == (4, 5) and f.get_tensor("gaussians.opacities").shape == (1, 5)
+        assert f.get_tensor("optimizers.features_rest.mu.1").shape == (3, 3, 5)
+        assert np.array_equal(f.get_tensor("gaussians.points")[1], g.points[:, 1])       # A[d, i] = points[i, d]
+
+    # (b) a reference-style file, byte by byte
+    n, kr = 4, 2
+    julia = dict(points=(3, n), features_dc=(3, 1, n), features_rest=(3, kr, n), scales=(3, n), rotations=(4, n), opacities=(1, n))
+    rng = np.random.default_rng(9)
+    logical = {k: rng.normal(size=shp).astype(np.float32) for k, shp in julia.items()}      # A[d, (k,) i] as Julia indexes it
+    tensors = {f"gaussians.{k}": v for k, v in logical.items()}
+    flat_moment = rng.normal(size=3 * n).astype(np.float32)                                 # after a densification: flat, vec(A)
+    for name in ck.OPTIMIZER_NAMES:
+        shp = julia[name]
+        col_major_vec = lambda a: np.ascontiguousarray(a.transpose(tuple(reversed(range(a.ndim))))).reshape(-1)  # noqa: E731
+        if name == "points":
+            tensors[f"optimizers.{name}.mu.1"] = flat_moment
+            tensors[f"optimizers.{name}.nu.1"] = flat_moment * 2
+        else:
+            tensors[f"optimizers.{name}.mu.1"] = rng.normal(size=shp).astype(np.float32)
+            tensors[f"optimizers.{name}.nu.1"] = rng.uniform(size=shp).astype(np.float32)
+    meta = {"format": ck.CHECKPOINT_FORMAT, "step": "42", "gaussians.sh_degree": "1", "gaussians.max_sh_degree": "1"}
+    for name in ck.OPTIMIZER_NAMES:
+        meta[f"optimizers.{name}.n_moments"] = "1"; meta[f"optimizers.{name}.current_step"] = "17"
+    header, blob = {"__metadata__": meta}, b""
+    for k, v in tensors.items():
+        data = np.ascontiguousarray(v).tobytes()                                              # row-major bytes of the logical shape
+        header[k] = {"dtype": "F32", "shape": list(v.shape), "data_offsets": [len(blob), len(blob) + len(data)]}
+        blob += data
+    hj = json.dumps(header).encode()
+    hj += b" " * (-len(hj) % 8)
+    ref_path = str(tmp_path / "reference_style.safetensors")
+    with open(ref_path, "wb") as f:
+        f.write(struct.pack("<Q", len(hj)) + hj + blob)
+    fresh = {k: _Opt(1, 0) for k in ck.OPTIMIZER_NAMES}
+    g2, step = ck.load_state(ref_path, fresh)
+    assert step == 42 and g2.points.shape == (n, 3) and g2.features_rest.shape == (n, kr, 3) and g2.rotations.shape == (n, 4)
+    for i in range(n):
+        assert np.array_equal(g2.points[i], logical["points"][:, i])
+        assert np.array_equal(g2.features_rest[i], logical["features_rest"][:, :, i].T)
+    # moments: vec() of the Julia array == flat C-order of the in-memory (N,...) array, shaped or already flat
+    assert np.array_equal(fresh["points"].mu.numpy(), flat_moment)
+    want = np.ascontiguousarray(tensors["optimizers.rotations.mu.1"].T).reshape(-1)
+    assert np.array_equal(fresh["rotations"].mu.numpy(), want) and fresh["rotations"].current_step == 17
+
+    # (c) a file in the old C-order-shape convention ((N,3) in the header) is rejected, not reinterpreted
+    from safetensors.numpy import save_file
+    bad = {k: np.ascontiguousarray(np.asarray(v).transpose(tuple(reversed(range(np.asarray(v).ndim))))) for k, v in tensors.items()}
+    bad_path = str(tmp_path / "bad.safetensors")
+    save_file(bad, bad_path, metadata=meta)
+    with pytest.raises(ValueError, match="not the reference's layout"):
+        ck.load_state(bad_path, {k: _Opt(1, 0) for k in ck.OPTIMIZER_NAMES})

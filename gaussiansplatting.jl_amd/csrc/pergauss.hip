@@ -212,12 +212,18 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
     const int i = blockIdx.x * 256 + threadIdx.x;
     bool visible = false;
     uint32_t area = 0, clamp_bits = 0;
-    float m2[2] = {0, 0}, conic[3] = {0, 0, 0}, rgb[3] = {0, 0, 0}, mc_z = 0.0f, tau = 0.0f;
+    float m2[2] = {0, 0}, conic[3] = {0, 0, 0}, rgb[3] = {0, 0, 0}, mc_z = 0.0f, tau = 0.0f, opac_v = 0.0f;
     int rmin[2] = {0, 0}, rmax[2] = {0, 0};
     if (i < n) {
         M33 R; float t[3];
         load_pose(cam, R, t);
+        // the small inputs of this Gaussian are requested up front (one round trip instead of three dependent ones:
+        // means -> rotation/scale -> opacity); 14 % of them turn out culled and waste 28 bytes each
         const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+        const float4 q_in = rots[i];
+        const float s_in[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+        const float opac_in = opac[i];
+        opac_v = opac_in;
         float mc[3];
 #pragma unroll
         for (int r = 0; r < 3; r++) mc[r] = (R.m[r][0] * p[0] + R.m[r][1] * p[1] + R.m[r][2] * p[2]) + t[r];
@@ -226,8 +232,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
         M33 Rg; float s[3];
         if (cam.near_plane < mc[2] && mc[2] < cam.far_plane) {
             float qn[4], inv_norm;
-            Rg = quat2rot(rots[i], qn, inv_norm);
-            s[0] = scales[3 * i]; s[1] = scales[3 * i + 1]; s[2] = scales[3 * i + 2];
+            Rg = quat2rot(q_in, qn, inv_norm);
+            s[0] = s_in[0]; s[1] = s_in[1]; s[2] = s_in[2];
             M33 M;
             M33 Sigma = cov3d(Rg, s, M);
             M33 Sc = mul33(mul33(R, Sigma), tr33(R));
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
             }
             get_rect(m2[0], m2[1], radius, cam.grid_x, cam.grid_y, rmin, rmax);
             area = (uint32_t)((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]));
-            tau = footprint_tau(opac[i]);
+            tau = footprint_tau(opac_in);
             // duplicate_with_keys! (utils.jl:85-120) restated per tile, fused into this kernel: the
             // instance takes the next free position of its tile's BIN (a fixed-capacity segment of
             // `bins`, capacity from the previous view) with a returning atomic on the tile's counter
@@ -409,7 +415,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
         if (visible) {
             GsrGeoRec rec;
             rec.q0 = make_float4(m2[0], m2[1], conic[0], conic[1]);
-            rec.q1 = make_float4(conic[2], opac[i], rgb[0], rgb[1]);
+            rec.q1 = make_float4(conic[2], opac_v, rgb[0], rgb[1]);
             rec.q2 = make_float4(rgb[2], __uint_as_float(clamp_bits), mc_z, __uint_as_float(lpre));
             rec.q3 = make_float4(__uint_as_float((uint32_t)rmin[0] | ((uint32_t)rmin[1] << 16)),
                                  __uint_as_float((uint32_t)rmax[0] | ((uint32_t)rmax[1] << 16)), 0.0f, 0.0f);
@@ -493,18 +499,29 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
                                                            float* __restrict__ vcolors) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     float poseR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, poset[3] = {0, 0, 0};
-    const bool visible = i < n && geom.radii[i] > 0;
-
     // ---- sum this Gaussian's per-instance gradient rows (written by composite_bwd) ----
     // acc: [0..2] v rgb, [3] v opacity, [4..6] v conic, [7] v depth, [8..9] v mean2d, [10..12] v normal
+    // The radius, the geometry record and the Gaussian's own inputs are all requested at once (the record and the
+    // inputs of a culled Gaussian are fetched for nothing: 104 bytes x 14 %); fetched one after the other — radius ->
+    // record -> rows -> inputs -> SH — they would be five dependent round trips at 3 waves per SIMD.
     GsrGeoRec rec;
     rec.q0 = rec.q1 = rec.q2 = rec.q3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float p_in[3] = {0, 0, 0}, s_in[3] = {0, 0, 0};
+    float4 q_in = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+    int radius_in = 0;
+    if (i < n) {
+        radius_in = geom.radii[i];
+        rec = geom.rec[i];
+        p_in[0] = means[3 * i]; p_in[1] = means[3 * i + 1]; p_in[2] = means[3 * i + 2];
+        s_in[0] = scales[3 * i]; s_in[1] = scales[3 * i + 1]; s_in[2] = scales[3 * i + 2];
+        q_in = rots[i];
+    }
+    const bool visible = radius_in > 0;
     float acc[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) acc[k] = 0.0f;
     uint32_t area = 0, goff = 0;
     if (visible) {
-        rec = geom.rec[i];
         const uint32_t lo = __float_as_uint(rec.q3.x), hi = __float_as_uint(rec.q3.y);
         area = ((hi & 0xFFFFu) - (lo & 0xFFFFu)) * ((hi >> 16) - (lo >> 16));
         goff = geom.bpre[i >> 8] + __float_as_uint(rec.q2.w);
@@ -521,21 +538,46 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
         tau = footprint_tau(rec.q1.y);
     }
     if (area <= BIG) {
-        uint32_t tx = rx0, ty = ry0;
-        for (uint32_t k = 0; k < area; k++) {  // fixed order -> bit-reproducible gradients
-            const bool emitted = !cam.exact_cull || tile_may_touch(rec.q0.x, rec.q0.y, rec.q0.z, rec.q0.w, rec.q1.x,
-                                                                   tau, (int)tx * GSR_TILE, (int)ty * GSR_TILE);
-            if (++tx == rx0 + rw) { tx = rx0; ty++; }
-            if (!emitted) continue;
-            const float4* row = inst.rows + (size_t)4 * (goff + k);
-            const float4 f0 = row[0], f1 = row[1], f2 = row[2];
-            acc[0] += f0.x; acc[1] += f0.y; acc[2] += f0.z; acc[3] += f0.w;
-            acc[4] += f1.x; acc[5] += f1.y; acc[6] += f1.z; acc[7] += f1.w;
-            acc[8] += f2.x; acc[9] += f2.y;
-            if (channels > 5) {
-                const float4 f3 = row[3];
-                acc[10] += f2.z; acc[11] += f2.w; acc[12] += f3.x;
+        // Which of the rect's tiles hold an instance (pure ALU), then the row loads in batches of ROWS_IN_FLIGHT:
+        // a thread that waits for each 64-byte row before asking for the next one spends its life in memory
+        // latency (3 waves per SIMD cannot hide it).  The sums run in ascending slot order whatever the batching
+        // (fixed order -> bit-reproducible gradients).
+        unsigned long long emask = 0ull;
+        {
+            uint32_t tx = rx0, ty = ry0;
+            for (uint32_t k = 0; k < area; k++) {
+                const bool emitted = !cam.exact_cull || tile_may_touch(rec.q0.x, rec.q0.y, rec.q0.z, rec.q0.w, rec.q1.x,
+                                                                       tau, (int)tx * GSR_TILE, (int)ty * GSR_TILE);
+                if (++tx == rx0 + rw) { tx = rx0; ty++; }
+                emask |= emitted ? (1ull << k) : 0ull;
             }
+        }
+        while (emask) {
+            // up to four rows in flight (explicitly unrolled: arrays indexed by the batch slot end up in scratch)
+            const uint32_t k0 = (uint32_t)__builtin_ctzll(emask); emask &= emask - 1ull;
+            const bool h1 = emask != 0ull; const uint32_t k1 = h1 ? (uint32_t)__builtin_ctzll(emask) : k0; emask &= emask - 1ull;
+            const bool h2 = emask != 0ull; const uint32_t k2 = h2 ? (uint32_t)__builtin_ctzll(emask) : k0; emask &= emask - 1ull;
+            const bool h3 = emask != 0ull; const uint32_t k3 = h3 ? (uint32_t)__builtin_ctzll(emask) : k0; emask &= emask - 1ull;
+            const float4* r0 = inst.rows + (size_t)4 * (goff + k0);
+            const float4* r1 = inst.rows + (size_t)4 * (goff + k1);
+            const float4* r2 = inst.rows + (size_t)4 * (goff + k2);
+            const float4* r3 = inst.rows + (size_t)4 * (goff + k3);
+            const float4 a0 = r0[0], a1 = r0[1], a2 = r0[2];
+            const float4 b0 = r1[0], b1 = r1[1], b2 = r1[2];
+            const float4 c0 = r2[0], c1 = r2[1], c2 = r2[2];
+            const float4 d0 = r3[0], d1 = r3[1], d2 = r3[2];
+            float4 a3 = a2, b3 = a2, c3 = a2, d3 = a2;
+            if (channels > 5) { a3 = r0[3]; b3 = r1[3]; c3 = r2[3]; d3 = r3[3]; }
+#define GSR_ADD_ROW(F0, F1, F2, F3)                                                                      \
+            acc[0] += F0.x; acc[1] += F0.y; acc[2] += F0.z; acc[3] += F0.w;                              \
+            acc[4] += F1.x; acc[5] += F1.y; acc[6] += F1.z; acc[7] += F1.w;                              \
+            acc[8] += F2.x; acc[9] += F2.y;                                                              \
+            if (channels > 5) { acc[10] += F2.z; acc[11] += F2.w; acc[12] += F3.x; }
+            GSR_ADD_ROW(a0, a1, a2, a3)
+            if (h1) { GSR_ADD_ROW(b0, b1, b2, b3) }  // (a duplicate load stands in for a missing row; it is not added)
+            if (h2) { GSR_ADD_ROW(c0, c1, c2, c3) }
+            if (h3) { GSR_ADD_ROW(d0, d1, d2, d3) }
+#undef GSR_ADD_ROW
         }
     }
     {
@@ -608,14 +650,14 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
 #pragma unroll
                 for (int b = 0; b < 2; b++) nC.m[a][b] = -Ci.m[a][b];
             M22 vS2 = mul22(mul22(nC, vCi), Ci);  // ∇inverse (render.jl:383-385)
-            const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+            const float p[3] = {p_in[0], p_in[1], p_in[2]};
             float mc[3];
 #pragma unroll
             for (int r = 0; r < 3; r++) mc[r] = (R.m[r][0] * p[0] + R.m[r][1] * p[1] + R.m[r][2] * p[2]) + t[r];
-            const float4 q4 = rots[i];
+            const float4 q4 = q_in;
             float qn[4], inv_norm;
             M33 Rg = quat2rot(q4, qn, inv_norm);
-            const float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+            const float s[3] = {s_in[0], s_in[1], s_in[2]};
             M33 M;
             M33 Sigma = cov3d(Rg, s, M);
             M33 Sc = mul33(mul33(R, Sigma), tr33(R));

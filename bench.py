@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--no-other-lists", action="store_true", help="skip the secondary timing of the other tile-list mode")
     args = ap.parse_args()
 
+    if os.environ.get("GSR_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["GSR_BENCH_WATCHDOG"]), exit=True)
     pkg = gsr_pkg.load()
     D = pkg.distributed
     rank, world, local = D.init_from_env()
@@ -131,7 +134,8 @@ def main():
     rast = pkg.rasterizer.GaussianRasterizer(W, H, mode=args.mode, device=dev, exact_tile_cull=not args.reference_lists)
     # world > 1: factored exchange (distributed.py) unless GSR_DIST_FULL_ARENA=1 asks for the plain
     # all-reduce of the whole (11+3K)·N arena
-    factored = world > 1 and os.environ.get("GSR_DIST_FULL_ARENA", "0") != "1"
+    dist_on = world > 1 or D.forced()  # GSR_DIST_FORCE=1: the collectives run on a 1-rank RCCL communicator
+    factored = dist_on and os.environ.get("GSR_DIST_FULL_ARENA", "0") != "1"
     overlap = factored and os.environ.get("GSR_DIST_NO_OVERLAP", "0") != "1"
     if overlap:
         D.overlap_groups()
@@ -139,7 +143,7 @@ def main():
     if factored:
         centers = []
         for r in range(world):
-            Rr, tr = pkg.synthetic.view_pose(r % args.views, args.views)
+            Rr, tr = pkg.synthetic.view_pose(r % args.views, args.views) if world > 1 else (R, t)
             centers.append(pkg.Camera(W, H, tuple(s.focal), (0.5, 0.5), Rr, tr).camera_center)
         centers_d = to(np.stack(centers).astype(np.float32))
         gathered = torch.empty(world * 3 * N, device=dev, dtype=torch.float32)
@@ -207,7 +211,7 @@ def main():
             tail["adam"] += d.elapsed_time(e); tail["n"] += 1
 
     def sync():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -228,7 +232,7 @@ def main():
     tail_collect()
     prof = rast.profile_read()
     rast.profile(False)
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -317,7 +321,7 @@ def main():
                                                     "adam": 7 * 4 * (3 * K + 11) * N}
         out["trainer_tail"]["form"] = "three kernels" if args.unfused_tail else "fused (gsr_trainer_tail_step: 'adam' is the whole tail)"
         out["config"]["workload"] += " + prologue + Adam (trainer tail, not the headline metric)"
-    if world == 1 and tail is None and not args.no_other_lists:
+    if world == 1 and not dist_on and tail is None and not args.no_other_lists:
         # the same step with the OTHER tile-list mode, timed in the same run (headline = the library default)
         rast2 = pkg.rasterizer.GaussianRasterizer(W, H, mode=args.mode, device=dev, exact_tile_cull=args.reference_lists)
         rast_main, rast = rast, rast2
@@ -338,7 +342,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(pkg, s, W, H, deg, args)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256 / PPL) void composite_bwd_kernel(int W, int H, 
                 // order — no fp32 atomics (35 M per view before), bit-reproducible gradients
                 const float4 a = l0[tid], b = l1[tid];
                 const float mo = -b.y, mh = -0.5f * b.y;  // vσ = -o·G·vα (render.jl:260)
-                float4* row = inst.rows + (size_t)4 * __float_as_uint(l2[tid].y);  // Gaussian-major slot
+                float4* row = inst.rows + (size_t)GSR_ROW_F4(C) * __float_as_uint(l2[tid].y);  // Gaussian-major slot
                 row[0] = make_float4(r[0], r[1], r[2], r[3]);
                 row[1] = make_float4(mh * r[4], mh * r[5], mh * r[6], C > 3 ? r[9 < NA ? 9 : 0] : 0.0f);
                 // conic a = 2·ha, c = 2·hc (the stream carries the halves)
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256 / PPL) void composite_bwd_kernel(int W, int H, 
     }
     // instances behind every pixel's last contributor were never staged: their rows are zero
     for (uint32_t p = start + (uint32_t)tile_last + tid; p < end; p += NT) {
-        float4* row = inst.rows + (size_t)4 * __float_as_uint(stream.s2[p].y);
+        float4* row = inst.rows + (size_t)GSR_ROW_F4(C) * __float_as_uint(stream.s2[p].y);
         const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         row[0] = z; row[1] = z; row[2] = z;
         if (C > 5) row[3] = z;

@@ -506,7 +506,7 @@ static int buffer_lookup(const gsr_handle* h, int which, const void** dev_ptr, s
         case GSR_BUF_VALUES_SORTED: b = &h->values_sorted; sz = D * 4; break;
         case GSR_BUF_GEOM: b = &h->geo; sz = n * 64; break;
         case GSR_BUF_NORMALS: b = &h->gnormal; sz = h->cfg.mode > 5 ? n * 16 : 0; break;
-        case GSR_BUF_GRAD_ROWS: b = &h->rows; sz = (size_t)h->last_slots * 64; break;
+        case GSR_BUF_GRAD_ROWS: b = &h->rows; sz = (size_t)h->last_slots * 16 * GSR_ROW_F4(h->cfg.mode); break;
         case GSR_BUF_INSTANCE_AUX: b = &h->s2; sz = D * 16; break;
         default: return fail(GSR_E_INVALID_ARG, "unknown buffer id %d", which);
     }

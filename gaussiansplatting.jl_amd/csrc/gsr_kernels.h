@@ -53,6 +53,9 @@ struct GsrStream {
 // Gaussian-major instance slot, so the rows of one Gaussian are contiguous and the
 // per-Gaussian kernel sums them in a fixed order (deterministic gradients).
 //   row = 4 x float4: {v r, v g, v b, v opacity}, {v conic a,b,c, v depth}, {v mean2d x,y, v normal x,y}, {v normal z,-,-,-}
+#ifndef GSR_ROW_F4
+#define GSR_ROW_F4(C) ((C) > 3 ? 4 : 3)  // float4s per gradient row: 48 bytes in :rgb mode (9 floats used), 64 otherwise
+#endif
 struct GsrInst {
     float4* rows;  // D_slots x 4 float4, zero-filled per backward
 };

@@ -558,10 +558,10 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
             const bool h1 = emask != 0ull; const uint32_t k1 = h1 ? (uint32_t)__builtin_ctzll(emask) : k0; emask &= emask - 1ull;
             const bool h2 = emask != 0ull; const uint32_t k2 = h2 ? (uint32_t)__builtin_ctzll(emask) : k0; emask &= emask - 1ull;
             const bool h3 = emask != 0ull; const uint32_t k3 = h3 ? (uint32_t)__builtin_ctzll(emask) : k0; emask &= emask - 1ull;
-            const float4* r0 = inst.rows + (size_t)4 * (goff + k0);
-            const float4* r1 = inst.rows + (size_t)4 * (goff + k1);
-            const float4* r2 = inst.rows + (size_t)4 * (goff + k2);
-            const float4* r3 = inst.rows + (size_t)4 * (goff + k3);
+            const float4* r0 = inst.rows + (size_t)GSR_ROW_F4(channels) * (goff + k0);
+            const float4* r1 = inst.rows + (size_t)GSR_ROW_F4(channels) * (goff + k1);
+            const float4* r2 = inst.rows + (size_t)GSR_ROW_F4(channels) * (goff + k2);
+            const float4* r3 = inst.rows + (size_t)GSR_ROW_F4(channels) * (goff + k3);
             const float4 a0 = r0[0], a1 = r0[1], a2 = r0[2];
             const float4 b0 = r1[0], b1 = r1[1], b2 = r1[2];
             const float4 c0 = r2[0], c1 = r2[1], c2 = r2[2];
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
                 const uint32_t tx = sx0 + k % sw, ty = sy0 + k / sw;
                 if (cam.exact_cull && !tile_may_touch(smx, smy, sa, sb, sc, stau, (int)tx * GSR_TILE, (int)ty * GSR_TILE))
                     continue;
-                const float4* row = inst.rows + (size_t)4 * (o + k);
+                const float4* row = inst.rows + (size_t)GSR_ROW_F4(channels) * (o + k);
                 const float4 f0 = row[0], f1 = row[1], f2 = row[2];
                 part[0] += f0.x; part[1] += f0.y; part[2] += f0.z; part[3] += f0.w;
                 part[4] += f1.x; part[5] += f1.y; part[6] += f1.z; part[7] += f1.w;

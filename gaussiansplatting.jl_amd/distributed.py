@@ -48,7 +48,9 @@ def init_from_env(backend: str | None = None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # GSR_DIST_FORCE=1: run the collectives even with ONE rank (a 1-rank RCCL communicator): the only way to push the
+    # real "nccl" code path — communicator creation, the two extra groups, async work handles — through a 1-GPU box
+    if (world > 1 or forced()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
@@ -68,6 +70,15 @@ def init_from_env(backend: str | None = None):
     return rank, world, local
 
 
+def forced() -> bool:
+    return os.environ.get("GSR_DIST_FORCE", "0") == "1"
+
+
+def active() -> bool:
+    """Collectives are issued: more than one rank, or a forced 1-rank communicator."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or forced())
+
+
 def views_of_rank(rank: int, world: int, n_views: int):
     """Views rendered by `rank`: round-robin, one view per GPU when n_views == world."""
     return list(range(rank, n_views, world))
@@ -75,7 +86,7 @@ def views_of_rank(rank: int, world: int, n_views: int):
 
 def allreduce_arena(arena: torch.Tensor, op=dist.ReduceOp.SUM):
     """The path's single collective: sum the gradient arena over all ranks, in place."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if active():
         dist.all_reduce(arena, op=op)
     return arena
 
@@ -99,7 +110,7 @@ def overlap_groups():
     """Two extra process groups (= two RCCL communicators with their own streams) so that the two collectives
     of the factored exchange can be in flight at the same time.  Created once, collectively, by every rank."""
     global _overlap_groups
-    if _overlap_groups is None and dist.is_initialized() and dist.get_world_size() > 1:
+    if _overlap_groups is None and active() and (dist.get_backend() == "nccl" or not torch.cuda.is_available()):
         _overlap_groups = (dist.new_group(), dist.new_group())
     return _overlap_groups
 
@@ -113,8 +124,12 @@ def exchange_factored_overlapped(arena: torch.Tensor, n: int, gathered: torch.Te
     independent); world == 1: no collective."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     vc = arena[11 * n:]
-    if world == 1:
+    if not active():
         return rebuild(vc.view(1, n, 3))
+    if arena.is_cuda and dist.get_backend() != "nccl":
+        # gloo moving device tensors through the host (several ranks sharing one GPU in logic tests): two
+        # communicators in flight at once deadlock there after a few steps — same results from the sequential form
+        return rebuild(exchange_factored(arena, n, gathered))
     ga, gb = overlap_groups()
     h_gather = dist.all_gather_into_tensor(gathered.view(-1), vc, group=ga, async_op=True)
     h_reduce = dist.all_reduce(arena[:11 * n], op=dist.ReduceOp.SUM, group=gb, async_op=True)
@@ -130,7 +145,7 @@ def exchange_factored(arena: torch.Tensor, n: int, gathered: torch.Tensor | None
     (= view-major when rank r renders view r).  world == 1: no collective, V = 1."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     vc = arena[11 * n:]
-    if world == 1:
+    if not active():
         return vc.view(1, n, 3)
     if gathered is None:
         gathered = torch.empty(world * 3 * n, device=arena.device, dtype=arena.dtype)

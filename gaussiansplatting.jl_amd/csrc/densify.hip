@@ -149,7 +149,45 @@ __global__ __launch_bounds__(256) void reset_opacity_kernel(long long n, float* 
     opacities[i] = logf(o / (1.0f - o));
 }
 
+// The 3DGS .ply vertex rows (src/gaussians.jl:140-203 `export_ply`, :205-247 `import_ply`): per Gaussian
+//   x y z | nx ny nz (zeros) | f_dc_0..2 | f_rest_0..3kr-1 (CHANNEL-major: all of R, then G, then B) | opacity |
+//   scale_0..2 | rot_0..3                                                     — 17 + 3·kr floats, raw parameters.
+// PACK gathers the model's SoA arrays into that AoS row matrix in one pass (one thread per row word: coalesced
+// stores), UNPACK scatters a row matrix back; the file header and the disk I/O stay on the host.
+template <bool PACK>
+__global__ __launch_bounds__(256) void ply_rows_kernel(long long n, int kr, float* __restrict__ points, float* __restrict__ dc,
+                                                       float* __restrict__ rest, float* __restrict__ opac,
+                                                       float* __restrict__ scales, float* __restrict__ rots,
+                                                       float* __restrict__ rows) {
+    const int w = 17 + 3 * kr;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * w) return;
+    const long long i = e / w;
+    const int j = (int)(e - i * w);
+    float* p;
+    if (j < 3) p = points + 3 * i + j;
+    else if (j < 6) p = nullptr;  // normals: zeros on export, ignored on import
+    else if (j < 9) p = dc + 3 * i + (j - 6);
+    else if (j < 9 + 3 * kr) {
+        const int q = j - 9, c = q / kr, k = q - c * kr;  // file: channel-major; model: (gaussian, coefficient, channel)
+        p = rest + ((size_t)i * kr + k) * 3 + c;
+    } else if (j == 9 + 3 * kr) p = opac + i;
+    else if (j < 13 + 3 * kr) p = scales + 3 * i + (j - 10 - 3 * kr);
+    else p = rots + 4 * i + (j - 13 - 3 * kr);
+    if (PACK) rows[e] = p ? *p : 0.0f;
+    else if (p) *p = rows[e];
+}
+
 }  // namespace
+
+void gsr_launch_ply_rows(hipStream_t s, bool pack, long long n, int kr, float* points, float* dc, float* rest, float* opac,
+                         float* scales, float* rots, float* rows) {
+    if (n <= 0) return;
+    const long long total = n * (17 + 3 * kr);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (pack) hipLaunchKernelGGL(ply_rows_kernel<true>, dim3(blocks), dim3(256), 0, s, n, kr, points, dc, rest, opac, scales, rots, rows);
+    else hipLaunchKernelGGL(ply_rows_kernel<false>, dim3(blocks), dim3(256), 0, s, n, kr, points, dc, rest, opac, scales, rots, rows);
+}
 
 void gsr_launch_grad_mean(hipStream_t s, long long n, const float* accum, const float* denom, float* out) {
     if (n <= 0) return;

@@ -795,6 +795,28 @@ int gsr_reset_opacity(int64_t n, float* opacities, void* stream) {
     return GSR_OK;
 }
 
+static int ply_rows(bool pack, int64_t n, int32_t k_rest, const float* points, const float* dc, const float* rest,
+                    const float* opac, const float* scales, const float* rots, const float* rows, void* stream) {
+    if (n < 0 || k_rest < 0) return fail(GSR_E_INVALID_ARG, "bad sizes: n=%lld k_rest=%d", (long long)n, k_rest);
+    if (n == 0) return GSR_OK;
+    if (!points || !dc || (k_rest > 0 && !rest) || !opac || !scales || !rots || !rows) return fail(GSR_E_INVALID_ARG, "null array");
+    gsr_launch_ply_rows((hipStream_t)stream, pack, n, k_rest, const_cast<float*>(points), const_cast<float*>(dc),
+                        const_cast<float*>(rest), const_cast<float*>(opac), const_cast<float*>(scales), const_cast<float*>(rots),
+                        const_cast<float*>(rows));
+    HIPCHK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_ply_pack_rows(int64_t n, int32_t k_rest, const float* points, const float* features_dc, const float* features_rest,
+                      const float* opacities, const float* scales, const float* rotations, float* rows, void* stream) {
+    return ply_rows(true, n, k_rest, points, features_dc, features_rest, opacities, scales, rotations, rows, stream);
+}
+
+int gsr_ply_unpack_rows(int64_t n, int32_t k_rest, const float* rows, float* points, float* features_dc, float* features_rest,
+                        float* opacities, float* scales, float* rotations, void* stream) {
+    return ply_rows(false, n, k_rest, points, features_dc, features_rest, opacities, scales, rotations, rows, stream);
+}
+
 int gsr_sh_grad_from_views(int32_t n, int32_t n_coeffs, int32_t sh_degree, int32_t n_views, const float* camera_centers,
                            const float* means, const float* vcolors_all, float* vshs, void* stream) {
     if (n < 0 || n_views < 1 || sh_degree < 0 || sh_degree > 3 || n_coeffs < (sh_degree + 1) * (sh_degree + 1))

@@ -1,6 +1,8 @@
 """3DGS `.ply` scenes: host mirror of `export_ply` / `import_ply`
 (src/gaussians.jl:157-247) so that trained scenes can be fed to the
-rasterizer and the benchmark.  Pure host I/O (numpy); no device code.
+rasterizer and the benchmark.  `export_ply` / `import_ply` are the host (numpy) forms; `export_ply_device` /
+`import_ply_device` keep the model in HBM and build / take apart the AoS vertex rows with one library launch
+(gsr_ply_pack_rows / gsr_ply_unpack_rows) — only the header and the byte stream touch the host.
 
 Layout (gaussians.jl:140-156): one `vertex` element, every property `float`, in the order
 x y z | nx ny nz (zeros) | f_dc_0..2 | f_rest_0..3(K-1)-1 | opacity | scale_0..2 | rot_0..3.
@@ -147,3 +149,82 @@ def import_ply(filename: str) -> GaussianModel:
         raise ValueError(f"`{filename}`: {kr + 1} SH coefficients per channel is not a square number")
     return GaussianModel(np.ascontiguousarray(xyz), dc, rest, np.ascontiguousarray(scales),
                          np.ascontiguousarray(rots), opac, deg, deg)
+
+
+# ---- device forms: the model lives in HBM (densification.GaussianModel-style objects with torch tensors) ----
+def _header(n: int, kr: int) -> bytes:
+    fmt = "binary_little_endian" if sys.byteorder == "little" else "binary_big_endian"
+    lines = ["ply", f"format {fmt} 1.0", f"element vertex {n}"] + [f"property float {nm}" for nm in property_names(kr)] + ["end_header"]
+    return ("\n".join(lines) + "\n").encode("ascii")
+
+
+def export_ply_device(gs, filename: str) -> None:
+    """export_ply (gaussians.jl:157-203) of a device-resident model: the N x (17+3kr) row matrix is packed on the device
+    (gsr_ply_pack_rows) and streamed to the file; byte-identical to `export_ply` of the same arrays."""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib as L
+    n = int(gs.points.shape[0])
+    kr = int(gs.features_rest.shape[1]) if gs.features_rest.numel() else 0
+    rows = torch.empty((n, 17 + 3 * kr), device=gs.points.device, dtype=torch.float32)
+    ptr = lambda t: None if t.numel() == 0 else C.c_void_p(t.data_ptr())  # noqa: E731
+    for t in (gs.points, gs.features_dc, gs.features_rest, gs.opacities, gs.scales, gs.rotations):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError("export_ply_device needs contiguous float32 HIP device tensors (use export_ply for host arrays)")
+    if gs.scales.shape[1] != 3:
+        raise ValueError("the .ply layout holds three scales per Gaussian")
+    L.check(L.load().gsr_ply_pack_rows(n, kr, ptr(gs.points), ptr(gs.features_dc), ptr(gs.features_rest), ptr(gs.opacities),
+                                       ptr(gs.scales), ptr(gs.rotations), ptr(rows), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    with open(filename, "wb") as io:
+        io.write(_header(n, kr))
+        io.write(rows.cpu().numpy().tobytes())
+
+
+def import_ply_device(filename: str, device="cuda"):
+    """import_ply (gaussians.jl:205-247) into HBM.  A file in the canonical export layout (all-float little-endian rows in
+    `property_names` order — what the reference and this package write) is uploaded as one block and taken apart on the
+    device (gsr_ply_unpack_rows); any other property order / precision / ascii goes through the host parser first.
+    Returns (points, features_dc, features_rest, scales, rotations, opacities, sh_degree) as device tensors."""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib as L
+    with open(filename, "rb") as io:
+        head = b""
+        while not head.endswith(b"end_header\n"):
+            line = io.readline()
+            if not line:
+                raise ValueError(f"`{filename}`: unterminated PLY header")
+            head += line
+        text = head.decode("ascii", "replace").split("\n")
+        props = [ln.split() for ln in text if ln.startswith("property")]
+        names = [p[2] for p in props if len(p) == 3]
+        nverts = [int(ln.split()[2]) for ln in text if ln.startswith("element vertex")]
+        n_frest = sum(1 for nm in names if nm.startswith("f_rest_"))
+        canonical = (len(nverts) == 1 and sum(ln.startswith("element") for ln in text) == 1 and n_frest % 3 == 0 and
+                     f"format binary_{sys.byteorder}_endian 1.0" in [ln.strip() for ln in text] and
+                     all(len(p) == 3 and p[1] in ("float", "float32") for p in props) and names == property_names(n_frest // 3))
+        if canonical:
+            n, kr = nverts[0], n_frest // 3
+            raw = np.frombuffer(io.read(4 * n * (17 + 3 * kr)), dtype=np.float32)
+            if raw.size != n * (17 + 3 * kr):
+                raise ValueError(f"`{filename}`: truncated vertex data")
+    if not canonical:
+        g = import_ply(filename)
+        to = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(device)  # noqa: E731
+        return (to(g.points), to(g.features_dc), to(g.features_rest), to(g.scales), to(g.rotations), to(g.opacities), g.sh_degree)
+    deg = int(round(np.sqrt(kr + 1))) - 1
+    if (deg + 1) ** 2 != kr + 1:
+        raise ValueError(f"`{filename}`: {kr + 1} SH coefficients per channel is not a square number")
+    dev = torch.device(device)
+    rows = torch.from_numpy(raw.copy()).to(dev)
+    mk = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)  # noqa: E731
+    pts, dc, rest, sc, rot, op = mk(n, 3), mk(n, 1, 3), mk(n, kr, 3), mk(n, 3), mk(n, 4), mk(n, 1)
+    ptr = lambda t: None if t.numel() == 0 else C.c_void_p(t.data_ptr())  # noqa: E731
+    with torch.cuda.device(dev):
+        L.check(L.load().gsr_ply_unpack_rows(n, kr, ptr(rows), ptr(pts), ptr(dc), ptr(rest), ptr(op), ptr(sc), ptr(rot),
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return pts, dc, rest, sc, rot, op, deg

@@ -358,6 +358,18 @@ GSR_API int gsr_split_transform(int64_t n_new, int32_t scale_dims, float* points
                                 uint32_t seed, void* stream);
 GSR_API int gsr_reset_opacity(int64_t n, float* opacities, void* stream);
 
+/* The vertex rows of a 3DGS .ply scene (`export_ply` / `import_ply`, src/gaussians.jl:140-247):
+ * per Gaussian  x y z | nx ny nz (0) | f_dc_0..2 | f_rest_0..3·k_rest-1 (channel-major) | opacity | scale_0..2 | rot_0..3,
+ * i.e. 17 + 3·k_rest floats of RAW parameters.  gsr_ply_pack_rows gathers the model's arrays (device, the reference's
+ * layouts: points (3,N), features_dc (3,1,N), features_rest (3,k_rest,N), opacities (1,N), scales (3,N), rotations (4,N))
+ * into the row matrix `rows` (device, N x (17 + 3·k_rest)); gsr_ply_unpack_rows scatters a row matrix back (normals are
+ * ignored).  Header and disk I/O stay with the host. */
+GSR_API int gsr_ply_pack_rows(int64_t n, int32_t k_rest, const float* points, const float* features_dc,
+                              const float* features_rest, const float* opacities, const float* scales, const float* rotations,
+                              float* rows, void* stream);
+GSR_API int gsr_ply_unpack_rows(int64_t n, int32_t k_rest, const float* rows, float* points, float* features_dc,
+                                float* features_rest, float* opacities, float* scales, float* rotations, void* stream);
+
 /* New: the SH-coefficient gradient of a batch of views from the factored
  * per-view colour cotangents written by gsr_backward (gsr_grads.vcolors):
  *   vshs[:, k, i] = Σ_v basis_k(normalize(means[:, i] - camera_centers[:, v])) * vcolors_all[:, i, v]

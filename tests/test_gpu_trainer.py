@@ -262,3 +262,23 @@ def test_end_to_end_fit_reduces_the_loss(pkg):
     assert all(np.isfinite(losses))
     assert losses[-1] < 0.6 * losses[0], (losses[0], losses[-1])
     assert np.mean(losses[-5:]) < np.mean(losses[:5])
+
+
+def test_ply_device_pack_unpack_matches_host_io(pkg, tmp_path):
+    """SURVEY.md §8f rank 4 on the device: gsr_ply_pack_rows / gsr_ply_unpack_rows against the host (numpy) forms of
+    export_ply / import_ply (gaussians.jl:157-247) — byte-identical files, bit-identical arrays, degree 0 and 3."""
+    for n, kr in ((1000, 15), (257, 0)):
+        rng = np.random.default_rng(n)
+        f = lambda *s: rng.normal(size=s).astype(np.float32)  # noqa: E731
+        deg = int(round(np.sqrt(kr + 1))) - 1
+        g = pkg.ply.GaussianModel(f(n, 3), f(n, 1, 3), f(n, kr, 3), f(n, 3), f(n, 4), f(n, 1), deg, deg)
+        gd = pkg.densification.GaussianModel(dev(g.points), dev(g.features_dc), dev(g.features_rest), dev(g.scales), dev(g.rotations),
+                                             dev(g.opacities))
+        a, b = str(tmp_path / f"host_{n}.ply"), str(tmp_path / f"dev_{n}.ply")
+        pkg.ply.export_ply(g, a)
+        pkg.ply.export_ply_device(gd, b)
+        assert open(a, "rb").read() == open(b, "rb").read()
+        pts, dc, rest, sc, rot, op, d = pkg.ply.import_ply_device(a)
+        assert d == deg
+        for t, ref in ((pts, g.points), (dc, g.features_dc), (rest, g.features_rest), (sc, g.scales), (rot, g.rotations), (op, g.opacities)):
+            assert np.array_equal(t.cpu().numpy(), ref)

@@ -63,7 +63,9 @@ def main():
     np.save(os.path.join(out_dir, f"fact_vshs_{rank}.npy"), vshs.cpu().numpy())
     # per-view side outputs stay local (they feed per-view densification statistics)
     np.save(os.path.join(out_dir, f"radii_{rank}.npy"), rast.gstate.radii.cpu().numpy())
-    torch.distributed.destroy_process_group()
+    if torch.distributed.is_initialized():
+        print(f"backend {torch.distributed.get_backend()}, overlap groups {'on' if D._overlap_groups else 'off'}")
+        torch.distributed.destroy_process_group()
     print(f"rank {rank}/{world} ok on {dev}")
 
 

@@ -25,11 +25,22 @@ def _free_port():
 
 
 def test_two_ranks_hip_backward_then_exchange_equals_sum_of_views(tmp_path, pkg, launch_ranks):
+    """Two ranks share the one GPU of the box; gloo carries the collectives (RCCL refuses two ranks on one device)."""
+    _ranks_vs_sequential(tmp_path, pkg, launch_ranks, 2, {"GSR_DIST_BACKEND": "gloo"})
+
+
+def test_one_rank_rccl_communicator_runs_both_exchange_forms(tmp_path, pkg, launch_ranks):
+    """GSR_DIST_FORCE=1: the SAME worker on a one-rank "nccl" (= RCCL) process group — communicator creation, the two
+    extra communicators of the overlapped factored exchange, async work handles and stream joins all execute for real;
+    a sum over one rank must reproduce the single-view HIP gradients."""
+    _ranks_vs_sequential(tmp_path, pkg, launch_ranks, 1, {"GSR_DIST_FORCE": "1"})
+
+
+def _ranks_vs_sequential(tmp_path, pkg, launch_ranks, world, extra_env):
     import dist_gpu_worker as Wk
-    world = 2
-    rc, out = launch_ranks([sys.executable, os.path.join(HERE, "dist_gpu_worker.py"), str(tmp_path)], world,
-                           env={"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()), "GSR_DIST_BACKEND": "gloo"},
-                           timeout=600)
+    env = {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())}
+    env.update(extra_env)
+    rc, out = launch_ranks([sys.executable, os.path.join(HERE, "dist_gpu_worker.py"), str(tmp_path)], world, env=env, timeout=300)
     assert rc == [0] * world, "\n".join(out)
     # sequential single-process reference: the same HIP kernels, view after view
     D = pkg.distributed

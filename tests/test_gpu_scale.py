@@ -229,3 +229,48 @@ def test_config1_10k_sh0_640x480_forward(pkg, orc):
 
 def test_config5_5m_4k(pkg, orc):
     _properties(pkg, orc, 5_000_000, 3840, 2160, 1005, with_oracle_fwd=True)
+
+
+def test_config4_eight_views_on_one_gpu(pkg, orc):
+    """BASELINE.json configs[3] as far as one GPU allows: the 8 poses of the multi-view batch (R_y(5°(j-3.5))) at
+    1 M Gaussians, rendered one after the other.  (a) The factored exchange form — per-view colour cotangents + one rebuild of
+    Σ_v basis(dir_v) ⊗ vc_v — equals the sum of the 8 per-view ∇shs that the plain all-reduce would produce, and the 11·N small
+    gradients are the same numbers in both arenas; (b) one NON-identity pose is compared with the oracle in full (image + all
+    gradients), since every other full-size oracle compare uses R = I."""
+    n, W, H, deg, seed, V = 1_000_000, 1920, 1080, 3, 1004, 8
+    s = pkg.synthetic.make_scene(n, W, H, deg, seed)
+    K = s.shs.shape[1]
+    D = pkg.distributed
+    p = [dev(s.means), dev(s.shs), dev(s.opacities.reshape(-1, 1)), dev(s.scales), dev(s.rotations)]
+    rast = pkg.rasterizer.GaussianRasterizer(W, H, mode="rgb")
+    plain_sum = torch.zeros(D.arena_numel(n, K), device="cuda")
+    small_sum = torch.zeros(11 * n, device="cuda")
+    vcs, centers = [], []
+    arena, farena = torch.empty_like(plain_sum), torch.empty(D.factored_arena_numel(n), device="cuda")
+    for v in range(V):
+        R, t = pkg.synthetic.view_pose(v, V)
+        cam = pkg.Camera(W, H, tuple(s.focal), (0.5, 0.5), R, t)
+        vp = dev(pkg.synthetic.make_vpixels(W, H, 3, seed + v))
+        rast.forward_raw(*p, cam, deg, (0, 0, 0))
+        rast.backward_raw(vp, *p, cam, deg, (0, 0, 0), arena=arena)
+        plain_sum += arena
+        rast.forward_raw(*p, cam, deg, (0, 0, 0))
+        rast.backward_raw(vp, *p, cam, deg, (0, 0, 0), arena=farena, factored_sh=True)
+        small_sum += farena[:11 * n]
+        vcs.append(farena[11 * n:].clone().view(n, 3))
+        centers.append(cam.camera_center)
+        if v == 6:
+            cam_o = orc.Camera(W, H, s.focal, R=R, t=t)
+            st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam_o, deg)
+            g = orc.backward(st, vp.cpu().numpy(), s.means, s.shs, s.opacities, s.scales, s.rotations, cam_o, deg)
+            assert np.array_equal(rast.gstate.radii.cpu().numpy(), st.radii)
+            assert frac_bad(rast.image.cpu().numpy(), st.image, 0, 1e-4) <= 1e-4
+            got = D.split_arena(arena, n, K)
+            for name, ref in (("vmeans", g.vmeans), ("vshs", g.vshs), ("vopacities", g.vopacities), ("vscales", g.vscales), ("vrot", g.vrots)):
+                assert rel_l2(got[name].cpu().numpy().reshape(-1), ref.reshape(-1)) <= 1e-4, name
+    ref = D.split_arena(plain_sum, n, K)
+    o = np.cumsum([0, 4 * n, 3 * n, n, 3 * n])
+    for k, (a, b) in zip(("vrot", "vmeans", "vopacities", "vscales"), zip(o[:-1], o[1:])):
+        assert torch.equal(small_sum[a:b], ref[k].reshape(-1)), k
+    rebuilt = pkg.rasterizer.sh_grad_from_views(p[0], torch.stack(vcs), dev(np.stack(centers).astype(np.float32)), K, deg)
+    assert float((rebuilt - ref["vshs"]).norm() / ref["vshs"].norm()) <= 1e-6

@@ -104,6 +104,8 @@ struct Profiler {
     bool on = false;      // HIP-event timing per stage
     bool ranges = false;  // roctx range per stage
     bool in_range = false;
+    bool rec_open = false;
+    uint32_t mask = ~0u;  // stages that get an event pair (gsr_profile_stages)
     struct Rec { int stage; hipEvent_t a, b; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
@@ -116,7 +118,8 @@ struct Profiler {
     void begin(int stage, hipStream_t s);
     void end(hipStream_t s) {
         if (in_range) { g_roctx.pop(); in_range = false; }
-        if (!on || recs.empty()) return;
+        if (!rec_open) return;
+        rec_open = false;
         (void)hipEventRecord(recs.back().b, s);
     }
     void clear() {
@@ -137,10 +140,11 @@ void Profiler::begin(int stage, hipStream_t s) {
         g_roctx.push(name);
         in_range = true;
     }
-    if (!on) return;
+    if (!on || !((mask >> stage) & 1u)) return;
     Rec r{stage, get(), get()};
     (void)hipEventRecord(r.a, s);
     recs.push_back(r);
+    rec_open = true;
 }
 
 bool valid_mode(int m) { return m == GSR_MODE_RGB || m == GSR_MODE_RGBD || m == GSR_MODE_RGBDN; }
@@ -594,6 +598,12 @@ int gsr_profile_enable(gsr_handle* h, int on) {
     h->prof.on = (on & 1) != 0;      // bit 0: HIP-event stage timing
     h->prof.ranges = (on & 2) != 0;  // bit 1: roctx range per stage
     if (!h->prof.on) h->prof.clear();
+    return GSR_OK;
+}
+
+int gsr_profile_stages(gsr_handle* h, uint32_t stage_mask) {
+    if (!h) return fail(GSR_E_INVALID_ARG, "null handle");
+    h->prof.mask = stage_mask;
     return GSR_OK;
 }
 

@@ -157,7 +157,15 @@ class GaussianRasterizer:
                                                denom.data_ptr(), _stream()))
 
     # ---- per-stage kernel timing (HIP events on the launch stream) ----
-    def profile(self, on: bool = True):
+    def profile(self, on: bool = True, stages=None):
+        """Per-stage HIP-event timing on/off; `stages`: iterable of stage names to restrict the event pairs to (None = all)."""
+        mask = 0xFFFFFFFF
+        if stages is not None:
+            names = [self._lib.gsr_profile_stage_name(i).decode() for i in range(self._lib.gsr_profile_stage_count())]
+            mask = 0
+            for st in stages:
+                mask |= 1 << names.index(st)
+        L.check(self._lib.gsr_profile_stages(self._h, mask))
         L.check(self._lib.gsr_profile_enable(self._h, 1 if on else 0))
 
     def profile_read(self, reset: bool = True) -> dict:

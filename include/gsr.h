@@ -400,6 +400,10 @@ GSR_API int gsr_stream_triad(float* a, const float* b, const float* c, size_t co
  * launches (lets `rocprofv3 --marker-trace --kernel-trace` slice a trace by stage; the roctx library
  * is resolved lazily with dlopen; GSR_ROCTX=1 in the environment enables the ranges on every handle). */
 GSR_API int gsr_profile_enable(gsr_handle* h, int on);
+/* Restrict the event pairs to the stages whose bit is set (bit i = stage i of gsr_profile_stage_name; default all).
+ * An event record is a marker packet between two kernels: eight pairs per step cost ≈ 0.06 ms of a 1.8 ms step on
+ * MI355X, so a benchmark times its dominant stage alone inside the timed region and surveys the rest outside it. */
+GSR_API int gsr_profile_stages(gsr_handle* h, uint32_t stage_mask);
 GSR_API int gsr_profile_stage_count(void);
 GSR_API const char* gsr_profile_stage_name(int stage);
 GSR_API int gsr_profile_read(gsr_handle* h, double* ms_sum, int* launches, int reset);

@@ -196,6 +196,7 @@ __global__ __launch_bounds__(256 / PPL) void composite_bwd_kernel(int W, int H, 
     const int red_slot = gsr::wave_reduce_index<NA>(lane);  // which partial this lane ends up holding
     const bool red_writer = gsr::wave_reduce_writer(lane);
     const gsr::RowColConsts rowcol(lane);
+    const gsr::RowColConstsD rowcol_d(lane);
     const int tile = (int)tile_order[blockIdx.x];  // 1-D grid in launch order: longest lists first
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
     const int px = tile_x * GSR_TILE + (lane & 15);
@@ -326,6 +327,11 @@ __global__ __launch_bounds__(256 / PPL) void composite_bwd_kernel(int W, int H, 
                 // column's dx weights, then finish over the 16 columns (wave_reduce.h: 5 swaps, not 8)
                 const float total = gsr::wave_reduce_rowcol_rgb(P, U1, U2, col[0], col[1], col[2], dx, lane_bits, rowcol);
                 if (rowcol.slot >= 0) my[j * ST + rowcol.slot] = total;
+            } else if (C == 5) {
+                // :rgbd (the reference's default training mode): the same row-then-column scheme with the depth sum
+                // riding along — six swaps instead of the generic network's eight; feature 4 (constant 1) is not a parameter
+                const float total = gsr::wave_reduce_rowcol_rgbd(P, U1, U2, col[0], col[1], col[2], col[C > 3 ? 3 : 0], dx, lane_bits, rowcol_d);
+                if (rowcol_d.slot >= 0) my[j * ST + rowcol_d.slot] = total;
             } else {
                 float part[16];
 #pragma unroll

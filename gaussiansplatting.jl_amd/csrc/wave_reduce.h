@@ -141,6 +141,48 @@ __device__ __forceinline__ float wave_reduce_rowcol_rgb(float P, float U1, float
     return r;
 }
 
+// ---- the same for mode :rgbd (seven per-lane sums: P, U1, U2, r, g, b, depth -> ten outputs) ----
+// swap32 pairs (P,r) (U1,g) (U2,b) (depth,depth), swap16 pairs (a0,a1) and (a3,a2): six swaps instead of the eight the
+// generic ten-value network needs.  Row r (= lane >> 4) ends up with b0 / b1 =
+//   r = 0: P / depth (unused)   r = 1: U1 / U2   r = 2: r / depth   r = 3: g / b
+// and outputs  r = 0: {P, dx*P, dx^2*P}   r = 1: {U1, dx*U1, U2}   r = 2: {r, depth, -}   r = 3: {g, b, -}.
+struct RowColConstsD {
+    float e1, e3, k2, k4;
+    int slot;
+    __device__ __forceinline__ explicit RowColConstsD(int lane) {
+        const int r = lane >> 4;
+        e1 = r < 2 ? 1.0f : 0.0f;        // o1 = dx * b0 on rows 0, 1
+        e3 = r == 0 ? 1.0f : 0.0f;       // o2 = dx^2 * b0 on row 0
+        k2 = r >= 2 ? 1.0f : 0.0f;       // o1 = b1 on rows 2, 3
+        k4 = r == 1 ? 1.0f : 0.0f;       // o2 = b1 on row 1
+        // accumulator row layout (composite.hip, NA = 10): [0..2] rgb, [3] P, [4] dx^2*P, [5] dx*U1, [6] U2, [7] dx*P, [8] U1, [9] depth
+        const int j = (lane & 1) ? 2 : ((lane & 8) ? 1 : 0);
+        const int table[4][3] = {{3, 7, 4}, {8, 5, 6}, {0, 9, -1}, {1, 2, -1}};
+        int t = -1;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+            for (int jj = 0; jj < 3; jj++)
+                if (rr == r && jj == j) t = table[rr][jj];
+        const bool writer = (lane & 6) == 4 && !((lane & 1) && (lane & 8));
+        slot = writer ? t : -1;
+    }
+};
+
+__device__ __forceinline__ float wave_reduce_rowcol_rgbd(float P, float U1, float U2, float c0, float c1, float c2, float c3,
+                                                         float dx, const LaneBits& L, const RowColConstsD& K) {
+    const float a0 = pair_swap32(P, c0), a1 = pair_swap32(U1, c1), a2 = pair_swap32(U2, c2), a3 = pair_swap32(c3, c3);
+    const float b0 = pair_swap16(a0, a1), b1 = pair_swap16(a3, a2);
+    const float o0 = b0;
+    const float o1 = b0 * (dx * K.e1) + b1 * K.k2;
+    const float o2 = b0 * ((dx * dx) * K.e3) + b1 * K.k4;
+    const float x0 = pair_level<2>(o0, o1, L), x1 = single_level<2>(o2, L);
+    float r = pair_level<3>(x0, x1, L);
+    r = r + dpp_xor2(r);
+    r = r + dpp_shr4(r);
+    return r;
+}
+
 // Which input a lane ends up holding (the same network run on indices).
 template <int N>
 __device__ __forceinline__ void index_level(int (&idx)[16], bool bit) {

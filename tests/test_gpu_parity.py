@@ -244,21 +244,24 @@ def test_tile_bin_overflow_regrows_and_repeats(pkg, orc):
     _compare_forward(st2, run, run.forward())
 
 
+@pytest.mark.parametrize("sigma_px", [4.0, 45.0])
 @pytest.mark.parametrize("exact", [False, True])
-def test_compact_binning_mode_is_bit_identical_to_the_bins(pkg, orc, exact):
+def test_compact_binning_mode_is_bit_identical_to_the_bins(pkg, orc, exact, sigma_px):
     """gsr_config.bins_budget_bytes: with a budget the fixed-capacity bins cannot meet, every view is binned
     count -> scan -> scatter (compact mode).  Lists, ids, image and gradients must be bit-identical to the fast
     mode's (the per-tile sort erases the arrival order), and equal to the oracle's lists in reference-list mode."""
-    W, H, n, deg = 320, 208, 12000, 1
-    s, cam = _scene(pkg, orc, n, W, H, deg, 61, sigma_px=4.0)
+    # sigma_px = 45: footprints of well over 48 tiles — the wave-cooperative emit path of both binning modes
+    W, H, n, deg = 320, 208, (12000 if sigma_px < 10 else 1500), 1
+    s, cam = _scene(pkg, orc, n, W, H, deg, 61, sigma_px=sigma_px)
     fast = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, exact_tile_cull=exact)
     comp = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, exact_tile_cull=exact)
     comp.rast.close()
     comp.rast = pkg.rasterizer.GaussianRasterizer(W, H, mode="rgb", exact_tile_cull=exact, bins_budget_bytes=1)
     vp = np.random.default_rng(3).standard_normal((H, W, 3)).astype(np.float32)
-    for _ in range(2):  # second view: steady state of both modes
+    for it in range(2):  # second view: steady state of both modes
         ia, ib = fast.forward().clone(), comp.forward().clone()
-        assert fast.rast.stats.compact_binning == 0 and comp.rast.stats.compact_binning == 1
+        # (a first view that overflows the initial capacity estimate is finished in compact mode, by design)
+        assert (it == 0 or fast.rast.stats.compact_binning == 0) and comp.rast.stats.compact_binning == 1
         assert comp.rast.stats.bins_bytes == 8 * comp.rast.stats.n_rendered
         assert torch.equal(ia, ib)
         assert torch.equal(fast.rast.values_sorted, comp.rast.values_sorted) and torch.equal(fast.rast.ranges, comp.rast.ranges)

@@ -178,7 +178,57 @@ __global__ __launch_bounds__(256) void ply_rows_kernel(long long n, int kr, floa
     else if (p) *p = rows[e];
 }
 
+// The GSP_DEBUG gradient guard of `step!` (src/training.jl:772-777) and the per-parameter count of
+// `nonfinite_gradient_report` (:534-552): for each gradient array (rows of row_words floats, one row per Gaussian) the
+// number of Gaussians with a non-finite entry — one pass over all arrays, one counter per array; `first_bad[g]`
+// receives the smallest offending Gaussian index (0xFFFFFFFF if none), the handle for the report's per-Gaussian dump.
+struct ScanGroups {
+    const float* src[GSR_ADAM_MAX_GROUPS];
+    int row_words[GSR_ADAM_MAX_GROUPS];
+    long long block_start[GSR_ADAM_MAX_GROUPS + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void nonfinite_scan_kernel(ScanGroups G, long long n_rows, uint32_t* __restrict__ counts,
+                                                             uint32_t* __restrict__ first_bad) {
+    int g = 0;
+    for (int k = 1; k < G.n; k++)
+        if ((long long)blockIdx.x >= G.block_start[k]) g = k;
+    const long long r = ((long long)blockIdx.x - G.block_start[g]) * 256 + threadIdx.x;
+    bool bad = false;
+    if (r < n_rows) {
+        const float* row = G.src[g] + r * G.row_words[g];
+        for (int j = 0; j < G.row_words[g]; j++) {
+            const float v = row[j];
+            bad = bad || !(fabsf(v) <= 3.4028234664e38f);  // NaN or ±Inf
+        }
+    }
+    const unsigned long long m = __ballot(bad);
+    if (m != 0ull && (threadIdx.x & 63) == 0) {
+        atomicAdd(&counts[g], (uint32_t)__popcll(m));
+        atomicMin(&first_bad[g], (uint32_t)(r + __builtin_ctzll(m)));
+    }
+}
+
 }  // namespace
+
+void gsr_launch_nonfinite_scan(hipStream_t s, int n_groups, const float* const* src, const int* row_words, long long n_rows,
+                               uint32_t* counts, uint32_t* first_bad) {
+    ScanGroups G;
+    G.n = n_groups;
+    long long blocks = 0;
+    for (int g = 0; g < GSR_ADAM_MAX_GROUPS; g++) {
+        const bool on = g < n_groups;
+        G.src[g] = on ? src[g] : nullptr;
+        G.row_words[g] = on ? row_words[g] : 1;
+        G.block_start[g] = blocks;
+        if (on) blocks += (n_rows + 255) / 256;
+    }
+    G.block_start[GSR_ADAM_MAX_GROUPS] = blocks;
+    (void)hipMemsetAsync(counts, 0, sizeof(uint32_t) * n_groups, s);
+    (void)hipMemsetAsync(first_bad, 0xFF, sizeof(uint32_t) * n_groups, s);
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(nonfinite_scan_kernel, dim3((unsigned)blocks), dim3(256), 0, s, G, n_rows, counts, first_bad);
+}
 
 void gsr_launch_ply_rows(hipStream_t s, bool pack, long long n, int kr, float* points, float* dc, float* rest, float* opac,
                          float* scales, float* rots, float* rows) {

@@ -805,6 +805,24 @@ int gsr_reset_opacity(int64_t n, float* opacities, void* stream) {
     return GSR_OK;
 }
 
+int gsr_count_nonfinite(const float* const* arrays, const int32_t* row_words, int32_t n_groups, int64_t n_rows, uint32_t* counts,
+                        uint32_t* first_bad, void* stream) {
+    if (n_groups < 0 || n_groups > GSR_ADAM_MAX_GROUPS || (n_groups > 0 && (!arrays || !row_words)))
+        return fail(GSR_E_INVALID_ARG, "n_groups must be in [0, %d]", GSR_ADAM_MAX_GROUPS);
+    if (n_rows < 0) return fail(GSR_E_INVALID_ARG, "negative n_rows");
+    if (n_groups == 0) return GSR_OK;
+    if (!counts || !first_bad) return fail(GSR_E_INVALID_ARG, "null output");
+    const float* src[GSR_ADAM_MAX_GROUPS]; int rw[GSR_ADAM_MAX_GROUPS];
+    for (int g = 0; g < n_groups; g++) {
+        if (row_words[g] < 0) return fail(GSR_E_INVALID_ARG, "group %d: negative row_words", g);
+        if (row_words[g] > 0 && n_rows > 0 && !arrays[g]) return fail(GSR_E_INVALID_ARG, "group %d: null array", g);
+        src[g] = arrays[g]; rw[g] = row_words[g];
+    }
+    gsr_launch_nonfinite_scan((hipStream_t)stream, n_groups, src, rw, n_rows, counts, first_bad);
+    HIPCHK(hipGetLastError());
+    return GSR_OK;
+}
+
 static int ply_rows(bool pack, int64_t n, int32_t k_rest, const float* points, const float* dc, const float* rest,
                     const float* opac, const float* scales, const float* rots, const float* rows, void* stream) {
     if (n < 0 || k_rest < 0) return fail(GSR_E_INVALID_ARG, "bad sizes: n=%lld k_rest=%d", (long long)n, k_rest);

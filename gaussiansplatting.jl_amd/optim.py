@@ -112,3 +112,28 @@ def trainer_tail_step(opts, raw, grads, shs, opacities_act, scales_act):
                                            shs.data_ptr(), opacities_act.data_ptr(), scales_act.data_ptr(), _stream()))
     for o in bump:  # committed only after validation and a successful launch
         o.current_step += 1
+
+
+def nonfinite_gradient_report(names, grads, n: int):
+    """The GSP_DEBUG guard of `step!` + the per-parameter part of `nonfinite_gradient_report` (training.jl:534-552,772-777):
+    for gradient arrays `grads` (each with the Gaussian index first, n rows; empty ones are skipped) returns
+    {name: (n_bad_gaussians, first_bad_index)} for the parameters that hold a NaN / Inf — empty dict = all finite.
+    One launch (gsr_count_nonfinite) and one 8-byte-per-parameter read-back."""
+    if len(grads) > L.ADAM_MAX_GROUPS:
+        raise ValueError(f"at most {L.ADAM_MAX_GROUPS} arrays per launch")
+    k = len(grads)
+    arr, rw = (C.c_void_p * k)(), (C.c_int32 * k)()
+    dev = None
+    for i, g in enumerate(grads):
+        empty = g is None or g.numel() == 0
+        if not empty and not (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and g.shape[0] == n):
+            raise ValueError(f"{names[i]}: gradients must be contiguous float32 HIP device tensors with {n} rows")
+        arr[i] = None if empty else g.data_ptr()
+        rw[i] = 0 if empty else g.numel() // n
+        dev = dev if empty else g.device
+    if dev is None:
+        return {}
+    out = torch.empty((2, k), dtype=torch.int32, device=dev)
+    L.check(L.load().gsr_count_nonfinite(arr, rw, k, n, out[0].data_ptr(), out[1].data_ptr(), _stream()))
+    host = out.cpu().numpy().astype("uint32")
+    return {names[i]: (int(host[0, i]), int(host[1, i])) for i in range(k) if host[0, i] > 0}

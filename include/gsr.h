@@ -358,6 +358,14 @@ GSR_API int gsr_split_transform(int64_t n_new, int32_t scale_dims, float* points
                                 uint32_t seed, void* stream);
 GSR_API int gsr_reset_opacity(int64_t n, float* opacities, void* stream);
 
+/* The non-finite gradient guard of `step!` under GSP_DEBUG (src/training.jl:772-777: `isfinite(sum(∇ᵢ))` per parameter)
+ * and the per-parameter counts of `nonfinite_gradient_report` (:534-552), in one pass over up to GSR_ADAM_MAX_GROUPS
+ * gradient arrays of n_rows Gaussians each (rows of row_words floats; row_words = 0 skips an empty array):
+ *   counts[g]    = number of Gaussians whose row holds a NaN or ±Inf          (device, n_groups)
+ *   first_bad[g] = smallest such Gaussian index, 0xFFFFFFFF if none           (device, n_groups) */
+GSR_API int gsr_count_nonfinite(const float* const* arrays, const int32_t* row_words, int32_t n_groups, int64_t n_rows,
+                                uint32_t* counts, uint32_t* first_bad, void* stream);
+
 /* The vertex rows of a 3DGS .ply scene (`export_ply` / `import_ply`, src/gaussians.jl:140-247):
  * per Gaussian  x y z | nx ny nz (0) | f_dc_0..2 | f_rest_0..3·k_rest-1 (channel-major) | opacity | scale_0..2 | rot_0..3,
  * i.e. 17 + 3·k_rest floats of RAW parameters.  gsr_ply_pack_rows gathers the model's arrays (device, the reference's

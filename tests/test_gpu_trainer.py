@@ -282,3 +282,23 @@ def test_ply_device_pack_unpack_matches_host_io(pkg, tmp_path):
         assert d == deg
         for t, ref in ((pts, g.points), (dc, g.features_dc), (rest, g.features_rest), (sc, g.scales), (rot, g.rotations), (op, g.opacities)):
             assert np.array_equal(t.cpu().numpy(), ref)
+
+
+def test_nonfinite_gradient_report(pkg):
+    """gsr_count_nonfinite against torch: the GSP_DEBUG guard of step! (training.jl:772-777) and the per-parameter counts of
+    nonfinite_gradient_report (:534-552)."""
+    n = 5000
+    g = torch.Generator(device="cuda").manual_seed(3)
+    names = ["points", "features_dc", "features_rest", "opacities", "scales", "rotations"]
+    grads = [torch.randn((n, 3), device="cuda", generator=g), torch.randn((n, 1, 3), device="cuda", generator=g),
+             torch.randn((n, 15, 3), device="cuda", generator=g), torch.randn((n, 1), device="cuda", generator=g),
+             torch.randn((n, 3), device="cuda", generator=g), torch.randn((n, 4), device="cuda", generator=g)]
+    assert pkg.optim.nonfinite_gradient_report(names, grads, n) == {}
+    grads[2][[17, 4000, 4000, 4999], [3, 0, 14, 7], [1, 2, 0, 2]] = torch.tensor([float("nan"), float("inf"), float("nan"), float("-inf")], device="cuda")
+    grads[5][123, 3] = float("inf")
+    grads.append(torch.empty((n, 0, 3), device="cuda"))  # an empty features_rest-like array is skipped (training.jl:770)
+    rep = pkg.optim.nonfinite_gradient_report(names + ["empty"], grads, n)
+    assert rep == {"features_rest": (3, 17), "rotations": (1, 123)}
+    for nm, t in zip(names, grads):
+        bad = (~torch.isfinite(t.reshape(n, -1))).any(1)
+        assert int(bad.sum()) == rep.get(nm, (0, 0))[0]

@@ -157,6 +157,9 @@ __global__ __launch_bounds__(64) void composite_fwd_strip_kernel(int W, int H, i
 // [7..8] v mean2d, [9] v depth (C>=5), [10..12] v normal (C==8)
 template <int C> struct AccRow { static constexpr int N = C == 3 ? 9 : (C == 5 ? 10 : 13); static constexpr int STRIDE = N | 1; };
 
+#ifndef GSR_BWD_MINWAVES
+#define GSR_BWD_MINWAVES 1
+#endif
 #ifndef GSR_BWD_BATCH
 #define GSR_BWD_BATCH 64
 #endif
@@ -172,7 +175,7 @@ constexpr int BWD_BATCH = GSR_BWD_BATCH;  // splats staged per round (LDS: one a
 // visited (strip, splat) pair — are paid once for 2x / 4x the pixels (measured at config 3:
 // 1.115 / 0.975 / 0.917 ms for PPL = 1 / 2 / 4).
 template <int C, int PPL>
-__global__ __launch_bounds__(256 / PPL) void composite_bwd_kernel(int W, int H, int grid_x,
+__global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_kernel(int W, int H, int grid_x,
                                                                 const uint32_t* __restrict__ tile_start,
                                                                 const uint32_t* __restrict__ tile_order,
                                                                 GsrStream stream, Bg bg,

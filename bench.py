@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--unfused-tail", action="store_true",
                     help="with --with-optimizer: run prologue pullback, Adam and prologue as three kernels "
                          "instead of gsr_trainer_tail_step")
+    ap.add_argument("--tail-in-backward", action="store_true",
+                    help="with --with-optimizer on one GPU: gsr_backward_trainer_tail — the tail applied in the epilogue of "
+                         "the per-Gaussian backward, the gradients never written")
     ap.add_argument("--mode", default="rgb", choices=["rgb", "rgbd", "rgbdn"],
                     help="render mode (the headline metric is :rgb; :rgbd is the reference's default training mode)")
     ap.add_argument("--ply", default=None, help="render a 3DGS .ply scene (gaussians.jl export_ply layout) instead of "
@@ -135,6 +138,8 @@ def main():
     # world > 1: factored exchange (distributed.py) unless GSR_DIST_FULL_ARENA=1 asks for the plain
     # all-reduce of the whole (11+3K)·N arena
     dist_on = world > 1 or D.forced()  # GSR_DIST_FORCE=1: the collectives run on a 1-rank RCCL communicator
+    if args.tail_in_backward and (dist_on or not args.with_optimizer):
+        raise SystemExit("--tail-in-backward is the single-GPU trainer step: it needs --with-optimizer and no gradient exchange")
     factored = dist_on and os.environ.get("GSR_DIST_FULL_ARENA", "0") != "1"
     overlap = factored and os.environ.get("GSR_DIST_NO_OVERLAP", "0") != "1"
     if overlap:
@@ -178,6 +183,12 @@ def main():
             vp = vpix_fixed
         else:
             _, vp = pkg.fused_ssim.l1_ssim_loss(rast, img, target)
+        if tail is not None and args.tail_in_backward:
+            ev[2].record(); ev[3].record()
+            pkg.optim.fused_backward_tail_step(rast, vp, opt_map, raw_map, params[1], params[2], params[3], cam, deg, bg)
+            e4 = torch.cuda.Event(enable_timing=True); e4.record()
+            tail["_last"] = (ev[0], ev[1], ev[2], ev[3], e4)
+            return
         rast.backward_raw(vp, *params, cam, deg, bg, arena=arena, factored_sh=factored)
         if factored and overlap:
             # all-gather(vc) || all-reduce(11·N): the ∇shs rebuild runs while the all-reduce is in flight
@@ -332,7 +343,9 @@ def main():
         out["trainer_tail"] = {k: round(tail[k] / tail["n"], 4) for k in ("prologue_fwd", "prologue_bwd", "adam")}
         out["trainer_tail"]["algorithmic_bytes"] = {"prologue_fwd": 2 * 4 * (3 * K + 4) * N, "prologue_bwd": 2 * 4 * (3 * K + 4) * N + 16 * N,
                                                     "adam": 7 * 4 * (3 * K + 11) * N}
-        out["trainer_tail"]["form"] = "three kernels" if args.unfused_tail else "fused (gsr_trainer_tail_step: 'adam' is the whole tail)"
+        out["trainer_tail"]["form"] = ("three kernels" if args.unfused_tail else
+                                       "inside the backward (gsr_backward_trainer_tail: 'adam' = composite_bwd + per-Gaussian backward + tail)"
+                                       if args.tail_in_backward else "fused (gsr_trainer_tail_step: 'adam' is the whole tail)")
         out["config"]["workload"] += " + prologue + Adam (trainer tail, not the headline metric)"
     if world == 1 and not dist_on and tail is None and not args.no_other_lists:
         # the same step with the OTHER tile-list mode, timed in the same run (headline = the library default)

@@ -72,6 +72,13 @@ class TailGrads(C.Structure):
                 ("vrotations", C.c_void_p)]
 
 
+class TailState(C.Structure):  # gsr_tail_state
+    _fields_ = [("theta", C.c_void_p * 6), ("mu", C.c_void_p * 6), ("nu", C.c_void_p * 6), ("lr", C.c_float * 6),
+                ("current_step", C.c_uint32 * 6), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("scale_dims", C.c_int32), ("shs", C.c_void_p), ("opacities_act", C.c_void_p),
+                ("scales_act", C.c_void_p), ("vmeans2d", C.c_void_p), ("forward_generation", C.c_uint64)]
+
+
 class ComposeGroup(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_words", C.c_int32), ("new_zero", C.c_int32)]
 
@@ -90,6 +97,7 @@ EXPORTS = ["gsr_create", "gsr_destroy", "gsr_release_scene_buffers", "gsr_memory
            "gsr_profile_stage_count", "gsr_profile_stages", "gsr_profile_stage_name", "gsr_profile_read", "gsr_update_stats",
            "gsr_prologue_forward", "gsr_prologue_backward", "gsr_adam_step", "gsr_stream_triad",
            "gsr_mask_findall_scratch_bytes", "gsr_mask_findall", "gsr_gather_rows", "gsr_sh_grad_from_views", "gsr_trainer_tail_step",
+           "gsr_backward_trainer_tail",
            "gsr_densify_grad_mean", "gsr_densify_mask", "gsr_compose_rows", "gsr_split_transform", "gsr_reset_opacity",
            "gsr_ply_pack_rows", "gsr_ply_unpack_rows", "gsr_count_nonfinite"]
 
@@ -151,6 +159,7 @@ def load():
     lib.gsr_sh_grad_from_views.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.gsr_trainer_tail_step.argtypes = [i32, i32, i32, C.POINTER(TailGrads), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                           C.POINTER(f32), C.POINTER(C.c_uint32), f32, f32, f32, vp, vp, vp, vp]
+    lib.gsr_backward_trainer_tail.argtypes = [vp, C.POINTER(Inputs), C.POINTER(CameraS), vp, C.POINTER(TailState), vp]
     lib.gsr_stream_triad.argtypes = [vp, vp, vp, C.c_size_t, f32, vp]
     lib.gsr_profile_enable.argtypes = [vp, i32]
     lib.gsr_profile_stages.argtypes = [vp, C.c_uint32]

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "gsr_kernels.h"
+#include "adam_math.h"
 
 namespace {
 
@@ -173,6 +174,7 @@ struct gsr_handle {
     hipEvent_t totals_ready = nullptr;  // recorded after the D2H copy of the totals
     uint32_t* host_totals = nullptr;  // pinned: D, max tile count, #oversized tiles, slab ctr, n_visible
     bool fwd_valid = false, bwd_valid = false;
+    bool inputs_consumed = false;  // gsr_backward_trainer_tail updated the forward's inputs in place
     uint64_t generation = 0;             // ordinal of the last gsr_forward (gsr_stats.generation)
     int32_t* radii_cur = nullptr;        // gstate.radii of the last forward: caller's (gsr_aux.radii) or h->radii
     float2* vmean2d_cur = nullptr;       // gstate.∇means_2d of the last backward: caller's (gsr_grads.vmeans2d) or h->vmean2d
@@ -317,6 +319,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     const size_t P = (size_t)h->cfg.width * h->cfg.height, T = (size_t)h->n_tiles;
     h->fwd_valid = false;
     h->bwd_valid = false;
+    h->inputs_consumed = false;
 
     const size_t nn = n > 0 ? (size_t)n : 1;
     const int n_blocks = (n + 255) / 256;
@@ -453,6 +456,9 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
     if (!vpixels || !g) return fail(GSR_E_INVALID_ARG, "null vpixels / grads");
     if (!h->fwd_valid || h->last_n != in->n)
         return fail(GSR_E_STATE, "gsr_backward without a matching gsr_forward on this handle");
+    if (h->inputs_consumed)
+        return fail(GSR_E_STATE, "the inputs of the handle's last forward were updated in place by "
+                    "gsr_backward_trainer_tail; run gsr_forward again");
     if (g->forward_generation != 0 && g->forward_generation != h->generation)
         return fail(GSR_E_STATE, "gsr_backward for forward #%llu, but the handle's last forward is #%llu (another "
                     "gsr_forward ran in between)", (unsigned long long)g->forward_generation,
@@ -701,6 +707,59 @@ int gsr_trainer_tail_step(int32_t n, int32_t k_rest, int32_t scale_dims, const g
     gsr_launch_trainer_tail((hipStream_t)stream, n, k_rest, scale_dims, gr, theta, mu, nu, lr_t, beta1, beta2, eps, shs,
                             opacities_act, scales_act);
     HIPCHK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_backward_trainer_tail(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, const float* vpixels,
+                              const gsr_tail_state* st, void* stream_v) {
+    int rc = check_inputs(h, in, cam);
+    if (rc) return rc;
+    if (!vpixels || !st) return fail(GSR_E_INVALID_ARG, "null vpixels / tail state");
+    if (!h->fwd_valid || h->last_n != in->n)
+        return fail(GSR_E_STATE, "gsr_backward_trainer_tail without a matching gsr_forward on this handle");
+    if (h->inputs_consumed)
+        return fail(GSR_E_STATE, "the inputs of the handle's last forward were updated in place by "
+                    "gsr_backward_trainer_tail; run gsr_forward again");
+    if (st->forward_generation != 0 && st->forward_generation != h->generation)
+        return fail(GSR_E_STATE, "gsr_backward_trainer_tail for forward #%llu, but the handle's last forward is #%llu",
+                    (unsigned long long)st->forward_generation, (unsigned long long)h->generation);
+    if (st->scale_dims != 1 && st->scale_dims != 3) return fail(GSR_E_INVALID_ARG, "scale_dims must be 1 or 3");
+    const int n = in->n, K = in->n_coeffs;
+    if (n == 0) return GSR_OK;
+    float lr_t[6];
+    for (int g = 0; g < 6; g++) {
+        if (g == 2 && K == 1) { lr_t[g] = 0.0f; continue; }  // empty features_rest (training.jl:770)
+        if (!st->theta[g] || !st->mu[g] || !st->nu[g]) return fail(GSR_E_INVALID_ARG, "group %d: null array", g);
+        if (st->current_step[g] == 0) return fail(GSR_E_INVALID_ARG, "group %d: current_step counts from 1", g);
+        const float t = (float)st->current_step[g];
+        lr_t[g] = st->lr[g] * sqrtf(1.0f - powf(st->beta2, t)) / (1.0f - powf(st->beta1, t));
+    }
+    // the kernel reads its inputs through the trainer's arrays and updates them in place
+    if (in->means != st->theta[0] || in->rotations != st->theta[5] || in->shs != st->shs ||
+        in->opacities != st->opacities_act || in->scales != st->scales_act)
+        return fail(GSR_E_INVALID_ARG, "the inputs of the fused step must be the trainer's own arrays (means == theta[0], "
+                    "rotations == theta[5], shs / opacities / scales == the activated copies)");
+    if (((uintptr_t)st->theta[5] & 15) != 0) return fail(GSR_E_INVALID_ARG, "rotations must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream_v;
+    const int C = h->cfg.mode;
+    if (!st->vmeans2d && (rc = h->vmean2d.ensure((size_t)n * 8))) return rc;
+    h->vmean2d_cur = st->vmeans2d ? reinterpret_cast<float2*>(st->vmeans2d) : h->vmean2d.as<float2>();
+    GsrCam k = make_cam(h, cam);
+    h->prof.begin(ST_COMPOSITE_BWD, s);
+    if (h->last_D > 0)
+        gsr_launch_composite_bwd(s, C, k, h->tile_start.as<uint32_t>(), h->tile_order.as<uint32_t>(), stream_of(h), in->background, vpixels,
+                                 h->n_contrib.as<uint32_t>(), h->final_T.as<float>(), inst_of(h));
+    h->prof.end(s);
+    h->prof.begin(ST_PERGAUSS_BWD, s);
+    const gsr::TailState S = gsr_make_tail_state(st->theta, st->mu, st->nu, lr_t, st->beta1, st->beta2, st->eps,
+                                                 st->scale_dims, st->shs, st->opacities_act, st->scales_act);
+    gsr_launch_pergauss_bwd_tail(s, n, K, in->sh_degree, C, k, geom_of(h), inst_of(h), h->vmean2d_cur, S);
+    h->prof.end(s);
+    HIPCHK(hipGetLastError());
+    h->bwd_valid = true;
+    // the forward's inputs no longer exist (updated in place): a second backward on this forward would differentiate
+    // the wrong parameters (the forward's own outputs — radii, tile lists, image — stay readable)
+    h->inputs_consumed = true;
     return GSR_OK;
 }
 

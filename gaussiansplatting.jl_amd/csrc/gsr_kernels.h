@@ -73,6 +73,11 @@ void gsr_launch_pergauss_bwd(hipStream_t s, int n, int K, int degree, int channe
                              GsrInst inst, float2* vmean2d, float* vmeans, float* vshs, float* vopac,
                              float* vscales, float* vrots, float* vR, float* vt,
                              float* vcolors /* (3,N) or NULL: factored SH gradient instead of vshs */);
+// backward epilogue = trainer tail (single-GPU step): no gradient arrays, the parameters / Adam states in S are
+// updated in place and the activated copies of the next forward written (adam_math.h)
+namespace gsr { struct TailState; }
+void gsr_launch_pergauss_bwd_tail(hipStream_t s, int n, int K, int degree, int channels, GsrCam cam, GsrGeom geom,
+                                  GsrInst inst, float2* vmean2d, const gsr::TailState& S);
 void gsr_launch_sh_grad_views(hipStream_t s, int n, int K, int degree, int n_views, const float* centers,
                               const float* means, const float* vc_all, float* vshs);
 

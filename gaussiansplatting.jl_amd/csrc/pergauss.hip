@@ -15,6 +15,7 @@
 #endif
 #include "tile_mask.h"
 #include "wave_reduce.h"
+#include "adam_math.h"
 
 namespace {
 
@@ -485,8 +486,18 @@ __global__ __launch_bounds__(256) void emit_compact_kernel(int n, GsrCam cam, Gs
 // (spherical_harmonics.jl:32-37,76-181).  Every output element is written exactly
 // once (zeros for culled Gaussians and for SH bands above the active degree), so the
 // 59·N-float gradient arena needs no memset.
+//
+// FUSED: the single-GPU trainer step.  The 59 gradient floats of a Gaussian never reach HBM: the
+// trainer tail (pullback of the sigmoid / exp prologue + the six NU.Adam updates + the activated
+// copies of the next forward; trainer.hip, training.jl:768-779) is applied in the epilogue.  The
+// per-Gaussian groups are updated by the owning thread; the SH groups (48 of the 59 floats) by the
+// whole workgroup, element-major over the workgroup's contiguous slice of features_dc /
+// features_rest so that θ, μ, ν stream as full cache lines — the per-Gaussian factors of the SH
+// gradient (basis x colour cotangent) wait in LDS.  `means` / `rots` ARE the raw points / rotations,
+// `scales` the activated copy; the SH coefficients are read from features_rest (the hcat copy `shs`
+// is only written).  Same expression trees as the unfused chain (adam_math.h): identical bits.
 // ---------------------------------------------------------------------------------
-template <int DEG>
+template <int DEG, bool FUSED>
 __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int n, int K, int channels, const float* __restrict__ means,
                                                            const float* __restrict__ scales,
                                                            const float4* __restrict__ rots,
@@ -496,7 +507,7 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
                                                            float* __restrict__ vshs, float* __restrict__ vopac,
                                                            float* __restrict__ vscales, float4* __restrict__ vrots,
                                                            float* __restrict__ vR_out, float* __restrict__ vt_out,
-                                                           float* __restrict__ vcolors) {
+                                                           float* __restrict__ vcolors, gsr::TailState TS) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     float poseR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, poset[3] = {0, 0, 0};
     // ---- sum this Gaussian's per-instance gradient rows (written by composite_bwd) ----
@@ -512,9 +523,13 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
     if (i < n) {
         radius_in = geom.radii[i];
         rec = geom.rec[i];
-        p_in[0] = means[3 * i]; p_in[1] = means[3 * i + 1]; p_in[2] = means[3 * i + 2];
-        s_in[0] = scales[3 * i]; s_in[1] = scales[3 * i + 1]; s_in[2] = scales[3 * i + 2];
-        q_in = rots[i];
+        // (FUSED: these arrays are updated in place by the epilogue — read through the same non-restrict pointers)
+        const float* mp = FUSED ? TS.points : means;
+        const float* sp = FUSED ? TS.scales_act : scales;
+        const float4* qp = FUSED ? reinterpret_cast<const float4*>(TS.rots) : rots;
+        p_in[0] = mp[3 * i]; p_in[1] = mp[3 * i + 1]; p_in[2] = mp[3 * i + 2];
+        s_in[0] = sp[3 * i]; s_in[1] = sp[3 * i + 1]; s_in[2] = sp[3 * i + 2];
+        q_in = qp[i];
     }
     const bool visible = radius_in > 0;
     float acc[16];
@@ -621,23 +636,31 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
         }
     }
 
-    if (i < n) {
-        float* vsh = vshs + (size_t)3 * K * i;
-        if (!visible) {
+    // FUSED: the gradients of this Gaussian stay here (zeros for a culled one)
+    float f_vmean[3] = {0, 0, 0}, f_vs[3] = {0, 0, 0}, f_vq[4] = {0, 0, 0, 0}, f_vopac = 0.0f;
+    float f_vc[3] = {0, 0, 0}, f_b[16];
+    int f_nb = 0;  // SH bands carrying a gradient: 0 for a culled Gaussian
 #pragma unroll
-            for (int c = 0; c < 3; c++) { vmeans[3 * i + c] = 0.0f; vscales[3 * i + c] = 0.0f; }
-            vrots[i] = make_float4(0, 0, 0, 0);
-            vopac[i] = 0.0f;
+    for (int k = 0; k < 16; k++) f_b[k] = 0.0f;
+    if (i < n) {
+        float* vsh = FUSED ? nullptr : vshs + (size_t)3 * K * i;
+        if (!visible) {
             vmean2d_out[i] = make_float2(0.0f, 0.0f);
-            if (vcolors) { vcolors[3 * i] = 0.0f; vcolors[3 * i + 1] = 0.0f; vcolors[3 * i + 2] = 0.0f; }
-            else for (int k = 0; k < 3 * K; k++) vsh[k] = 0.0f;
+            if constexpr (!FUSED) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) { vmeans[3 * i + c] = 0.0f; vscales[3 * i + c] = 0.0f; }
+                vrots[i] = make_float4(0, 0, 0, 0);
+                vopac[i] = 0.0f;
+                if (vcolors) { vcolors[3 * i] = 0.0f; vcolors[3 * i + 1] = 0.0f; vcolors[3 * i + 2] = 0.0f; }
+                else for (int k = 0; k < 3 * K; k++) vsh[k] = 0.0f;
+            }
         } else {
             const float4 a0 = make_float4(acc[0], acc[1], acc[2], acc[3]);
             const float4 a1 = make_float4(acc[4], acc[5], acc[6], acc[7]);
             const float2 vm2 = make_float2(acc[8], acc[9]);
             vmean2d_out[i] = vm2;  // gstate.∇means_2d, read by densification (strategy.jl:85-86)
             const float4 g0 = rec.q0, g1 = rec.q1, g2 = rec.q2;
-            vopac[i] = a0.w;
+            if constexpr (FUSED) f_vopac = a0.w; else vopac[i] = a0.w;
             M33 R; float t[3];
             load_pose(cam, R, t);
             // ---- ∇project ----
@@ -772,12 +795,20 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
             float vq[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) vq[k] = (vqn[k] - dq * qn[k]) * inv_norm;
-            vrots[i] = make_float4(vq[0], vq[1], vq[2], vq[3]);
+            if constexpr (FUSED) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) vscales[3 * i + c] = vs[c];
+                for (int k = 0; k < 4; k++) f_vq[k] = vq[k];
+#pragma unroll
+                for (int c = 0; c < 3; c++) f_vs[c] = vs[c];
+            } else {
+                vrots[i] = make_float4(vq[0], vq[1], vq[2], vq[3]);
+#pragma unroll
+                for (int c = 0; c < 3; c++) vscales[3 * i + c] = vs[c];
+            }
 
             // ---- ∇SH ----
-            const float* sh = shs + (size_t)3 * K * i;
+            // coefficients of band k >= 1 (band 0 has no directional gradient)
+            const float* sh = FUSED ? TS.rest + (size_t)3 * (K - 1) * i : shs + (size_t)3 * K * i + 3;
             const uint32_t clamp_bits = __float_as_uint(g2.y);
             float vc[3] = {a0.x * (1.0f - (float)(clamp_bits & 1u)), a0.y * (1.0f - (float)((clamp_bits >> 1) & 1u)),
                            a0.z * (1.0f - (float)((clamp_bits >> 2) & 1u))};
@@ -788,7 +819,13 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
             float b[16];
             sh_basis<DEG>(dir, b);
             constexpr int NB = (DEG + 1) * (DEG + 1);
-            if (vcolors) {
+            if constexpr (FUSED) {
+                f_nb = NB;
+#pragma unroll
+                for (int c = 0; c < 3; c++) f_vc[c] = vc[c];
+#pragma unroll
+                for (int k = 0; k < NB; k++) f_b[k] = b[k];
+            } else if (vcolors) {
                 // factored form for the multi-view exchange: ∇shs of a view is the outer product
                 // basis(dir) x vc, so 3 floats per Gaussian travel instead of 3K (sh_grad_views_kernel
                 // rebuilds Σ_views on every rank)
@@ -801,7 +838,7 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
                 for (int k = 3 * NB; k < 3 * K; k++) vsh[k] = 0.0f;
             }
             float dcx[3] = {0, 0, 0}, dcy[3] = {0, 0, 0}, dcz[3] = {0, 0, 0};
-#define SHC(k_, c_) sh[3 * (k_) + (c_)]
+#define SHC(k_, c_) sh[3 * ((k_) - 1) + (c_)]
             if (DEG > 0) {
                 const float x = dx, y = dy, z = dz;
 #pragma unroll
@@ -849,8 +886,61 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
             vmsh[1] = (-d0[0] * d0[1] * vdir[0] + (s2 - d0[1] * d0[1]) * vdir[1] - d0[2] * d0[1] * vdir[2]) * inv_s;
             vmsh[2] = (-d0[0] * d0[2] * vdir[0] - d0[1] * d0[2] * vdir[1] + (s2 - d0[2] * d0[2]) * vdir[2]) * inv_s;
 #pragma unroll
-            for (int c = 0; c < 3; c++) vmeans[3 * i + c] = vmean[c] + vmsh[c];
+            for (int c = 0; c < 3; c++) {
+                if constexpr (FUSED) f_vmean[c] = vmean[c] + vmsh[c]; else vmeans[3 * i + c] = vmean[c] + vmsh[c];
+            }
         }
+    }
+    if constexpr (FUSED) {
+        __shared__ float tail_b[256][17];  // SH basis of each Gaussian of the workgroup (odd stride: no bank conflicts)
+        __shared__ float tail_vc[256][3];  // its colour cotangent (clamp mask applied)
+        __shared__ int tail_nb[256];
+#pragma unroll
+        for (int k = 0; k < 16; k++) tail_b[threadIdx.x][k] = f_b[k];
+#pragma unroll
+        for (int c = 0; c < 3; c++) tail_vc[threadIdx.x][c] = f_vc[c];
+        tail_nb[threadIdx.x] = f_nb;
+        if (i < n) gsr::tail_gauss_apply(TS, i, f_vmean, f_vopac, f_vs, f_vq);
+        __syncthreads();
+        const int i0 = blockIdx.x * 256;
+        const int cnt = min(256, n - i0);
+        const int K3 = 3 * K;
+        // one SH group of the workgroup's Gaussians, element-major: R floats per Gaussian starting at band k0
+        auto sh_group = [&](float* __restrict__ th, float* __restrict__ mu, float* __restrict__ nu, int R, int k0,
+                            const gsr::AdamHyper& hy) {
+            const size_t base = (size_t)i0 * R;
+            const int total = cnt * R;
+            const uint32_t inv = (1u << 20) / (uint32_t)R + 1u;  // e / R == (e * inv) >> 20 for e < 2^20 / R (R <= 45, e < 256 R)
+            th += base; mu += base; nu += base;
+            const bool aligned = ((((uintptr_t)th) | ((uintptr_t)mu) | ((uintptr_t)nu)) & 15) == 0;
+            const int total4 = aligned ? total >> 2 : 0;
+            auto element = [&](int e, float& t, float& m, float& v) {
+                const int il = (int)(((uint32_t)e * inv) >> 20);
+                const int j = e - il * R;
+                const int kb = j / 3, c = j - 3 * kb, k = k0 + kb;
+                const float g = k < tail_nb[il] ? tail_b[il][k] * tail_vc[il][c] : 0.0f;
+                t = gsr::adam_update(t, g, m, v, hy);
+                TS.shs[(size_t)(i0 + il) * K3 + 3 * k0 + j] = t;  // hcat(sh_color, sh_remainder) of the next forward
+            };
+            for (int f = threadIdx.x; f < total4; f += 256) {
+                float4 t4 = reinterpret_cast<float4*>(th)[f], m4 = reinterpret_cast<float4*>(mu)[f],
+                       v4 = reinterpret_cast<float4*>(nu)[f];
+                element(4 * f, t4.x, m4.x, v4.x);
+                element(4 * f + 1, t4.y, m4.y, v4.y);
+                element(4 * f + 2, t4.z, m4.z, v4.z);
+                element(4 * f + 3, t4.w, m4.w, v4.w);
+                reinterpret_cast<float4*>(th)[f] = t4;
+                reinterpret_cast<float4*>(mu)[f] = m4;
+                reinterpret_cast<float4*>(nu)[f] = v4;
+            }
+            for (int e = 4 * total4 + threadIdx.x; e < total; e += 256) {
+                float t = th[e], m = mu[e], v = nu[e];
+                element(e, t, m, v);
+                th[e] = t; mu[e] = m; nu[e] = v;
+            }
+        };
+        sh_group(TS.dc, TS.dc_mu, TS.dc_nu, 3, 0, TS.h_dc);
+        if (K > 1) sh_group(TS.rest, TS.rest_mu, TS.rest_nu, 3 * (K - 1), 1, TS.h_rest);
     }
     if (vR_out) {  // projection.jl:243-256: thresholded per Gaussian, then summed
         // wave sum -> workgroup sum in LDS -> ONE atomic per workgroup and component (the 12
@@ -968,9 +1058,29 @@ void gsr_launch_pergauss_bwd(hipStream_t s, int n, int K, int degree, int channe
     dim3 grid((n + 255) / 256), block(256);
     const float4* r4 = reinterpret_cast<const float4*>(rots);
     float4* vr4 = reinterpret_cast<float4*>(vrots);
-#define LAUNCH(D)                                                                                                 \
-    hipLaunchKernelGGL(pergauss_bwd_kernel<D>, grid, block, 0, s, n, K, channels, means, scales, r4, shs, cam,    \
-                       geom, inst, vmean2d, vmeans, vshs, vopac, vscales, vr4, vR, vt, vcolors)
+    const gsr::TailState none{};
+#define LAUNCH(D)                                                                                                     \
+    hipLaunchKernelGGL((pergauss_bwd_kernel<D, false>), grid, block, 0, s, n, K, channels, means, scales, r4, shs,  \
+                       cam, geom, inst, vmean2d, vmeans, vshs, vopac, vscales, vr4, vR, vt, vcolors, none)
+    switch (degree) {
+        case 0: LAUNCH(0); break;
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        default: LAUNCH(3); break;
+    }
+#undef LAUNCH
+}
+
+void gsr_launch_pergauss_bwd_tail(hipStream_t s, int n, int K, int degree, int channels, GsrCam cam, GsrGeom geom,
+                                  GsrInst inst, float2* vmean2d, const gsr::TailState& S) {
+    if (n <= 0) return;
+    dim3 grid((n + 255) / 256), block(256);
+    const float4* r4 = reinterpret_cast<const float4*>(S.rots);
+#define LAUNCH(D)                                                                                                     \
+    hipLaunchKernelGGL((pergauss_bwd_kernel<D, true>), grid, block, 0, s, n, K, channels, S.points, S.scales_act,   \
+                       r4, (const float*)nullptr, cam, geom, inst, vmean2d, (float*)nullptr, (float*)nullptr,       \
+                       (float*)nullptr, (float*)nullptr, (float4*)nullptr, (float*)nullptr, (float*)nullptr,        \
+                       (float*)nullptr, S)
     switch (degree) {
         case 0: LAUNCH(0); break;
         case 1: LAUNCH(1); break;

@@ -5,10 +5,13 @@
 // allows, no FMA contraction (compiled with -ffp-contract=off) so the update is the same fp32
 // expression tree as the oracle's.
 #include "gsr_kernels.h"
+#include "adam_math.h"
 
 namespace {
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }  // NerfUtils.sigmoid
+using gsr::AdamHyper;
+using gsr::adam_update;
+using gsr::sigmoidf_;
 
 // shs (3,K,N) <- [sh_color (3,1,N) | sh_remainder (3,K-1,N)]: one thread per output float, coalesced writes
 __global__ __launch_bounds__(256) void prologue_shs_kernel(size_t total, int K3, const float* __restrict__ dc,
@@ -165,13 +168,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamGroups G, float beta1, fl
 // writes), the chain rule of the prologue is applied in registers, the six NU.Adam states are
 // advanced, and the activated copies the next rasterize() consumes are written straight away.
 // Same fp32 expression trees as the three separate kernels (bit-identical θ, μ, ν).
-struct AdamHyper { float lr_t, beta1, beta2, omb1, omb2, eps; };
-__device__ __forceinline__ float adam_update(float th, float g, float& m, float& v, const AdamHyper& h) {
-    m = h.beta1 * m + h.omb1 * g;
-    v = h.beta2 * v + h.omb2 * (g * g);
-    return th - h.lr_t * m / (sqrtf(v) + h.eps);
-}
-
+// (AdamHyper, adam_update and the per-Gaussian block live in adam_math.h, shared with pergauss.hip)
 // SH block: one thread per coefficient float of shs (N x 3K); element j of a Gaussian's row
 // belongs to sh_color (j < 3) or sh_remainder — two optimizers, two learning rates.
 __global__ __launch_bounds__(256) void tail_sh_kernel(size_t total, int K3, const float* __restrict__ vshs,
@@ -195,61 +192,16 @@ __global__ __launch_bounds__(256) void tail_sh_kernel(size_t total, int K3, cons
 }
 
 // per-Gaussian block: points (3), opacity logit (1), log-scales (3 or 1), rotations (4)
-__global__ __launch_bounds__(256) void tail_gauss_kernel(int n, int scale_dims, const float* __restrict__ vmeans,
+__global__ __launch_bounds__(256) void tail_gauss_kernel(int n, gsr::TailState S, const float* __restrict__ vmeans,
                                                          const float* __restrict__ vopac_act,
                                                          const float* __restrict__ vscales_act,
-                                                         const float* __restrict__ vrot,
-                                                         float* __restrict__ points, float* __restrict__ p_mu, float* __restrict__ p_nu,
-                                                         float* __restrict__ opac, float* __restrict__ o_mu, float* __restrict__ o_nu,
-                                                         float* __restrict__ scales, float* __restrict__ s_mu, float* __restrict__ s_nu,
-                                                         float* __restrict__ rots, float* __restrict__ r_mu, float* __restrict__ r_nu,
-                                                         AdamHyper h_p, AdamHyper h_o, AdamHyper h_s, AdamHyper h_r,
-                                                         float* __restrict__ opac_act, float* __restrict__ scales_act) {
+                                                         const float* __restrict__ vrot) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const size_t k = 3 * (size_t)i + c;
-        float m = p_mu[k], v = p_nu[k];
-        points[k] = adam_update(points[k], vmeans[k], m, v, h_p);
-        p_mu[k] = m; p_nu[k] = v;
-    }
-    {   // σ' = σ(1-σ) with the σ the forward used (the caller's activated copy)
-        const float a = opac_act[i];
-        const float g = vopac_act[i] * (a * (1.0f - a));
-        float m = o_mu[i], v = o_nu[i];
-        const float t = adam_update(opac[i], g, m, v, h_o);
-        opac[i] = t; o_mu[i] = m; o_nu[i] = v;
-        opac_act[i] = sigmoidf_(t);
-    }
-    {
-        float g[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) g[c] = vscales_act[3 * (size_t)i + c] * scales_act[3 * (size_t)i + c];
-        if (scale_dims == 1) {
-            float m = s_mu[i], v = s_nu[i];
-            const float t = adam_update(scales[i], (g[0] + g[1]) + g[2], m, v, h_s);
-            scales[i] = t; s_mu[i] = m; s_nu[i] = v;
-            const float e = expf(t);
-            scales_act[3 * (size_t)i] = e; scales_act[3 * (size_t)i + 1] = e; scales_act[3 * (size_t)i + 2] = e;
-        } else {
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const size_t k = 3 * (size_t)i + c;
-                float m = s_mu[k], v = s_nu[k];
-                const float t = adam_update(scales[k], g[c], m, v, h_s);
-                scales[k] = t; s_mu[k] = m; s_nu[k] = v;
-                scales_act[k] = expf(t);
-            }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const size_t k = 4 * (size_t)i + c;
-        float m = r_mu[k], v = r_nu[k];
-        rots[k] = adam_update(rots[k], vrot[k], m, v, h_r);
-        r_mu[k] = m; r_nu[k] = v;
-    }
+    const float vm[3] = {vmeans[3 * (size_t)i], vmeans[3 * (size_t)i + 1], vmeans[3 * (size_t)i + 2]};
+    const float vs[3] = {vscales_act[3 * (size_t)i], vscales_act[3 * (size_t)i + 1], vscales_act[3 * (size_t)i + 2]};
+    const float vq[4] = {vrot[4 * (size_t)i], vrot[4 * (size_t)i + 1], vrot[4 * (size_t)i + 2], vrot[4 * (size_t)i + 3]};
+    gsr::tail_gauss_apply(S, i, vm, vopac_act[i], vs, vq);
 }
 
 // ---- boolean-mask compaction: findall(mask) and x[:, idxs] (densification.jl:138-191,279-288) ----
@@ -452,7 +404,7 @@ void gsr_launch_trainer_tail(hipStream_t s, int n, int k_rest, int scale_dims, c
     const size_t total = (size_t)n * K3;
     hipLaunchKernelGGL(tail_sh_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, K3, grads[1],
                        theta[1], mu[1], nu[1], theta[2], mu[2], nu[2], h[1], h[2], shs);
-    hipLaunchKernelGGL(tail_gauss_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, scale_dims, grads[0], grads[2],
-                       grads[3], grads[4], theta[0], mu[0], nu[0], theta[3], mu[3], nu[3], theta[4], mu[4], nu[4],
-                       theta[5], mu[5], nu[5], h[0], h[3], h[4], h[5], opac_act, scales_act);
+    const gsr::TailState S = gsr_make_tail_state(theta, mu, nu, lr_t, beta1, beta2, eps, scale_dims, shs, opac_act, scales_act);
+    hipLaunchKernelGGL(tail_gauss_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, S, grads[0], grads[2], grads[3],
+                       grads[4]);
 }

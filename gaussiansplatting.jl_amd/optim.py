@@ -114,6 +114,45 @@ def trainer_tail_step(opts, raw, grads, shs, opacities_act, scales_act):
         o.current_step += 1
 
 
+def tail_state(opts, raw, shs, opacities_act, scales_act):
+    """gsr_tail_state of a trainer (`opts`, `raw`: dicts keyed by GROUPS) + the optimizers whose counter the
+    step will advance.  The counters in the struct are the ones AFTER the increment."""
+    o0 = opts["points"]
+    st = L.TailState()
+    bump = []
+    for g, name in enumerate(GROUPS):
+        o, t = opts[name], raw[name]
+        if (o.beta1, o.beta2, o.eps) != (o0.beta1, o0.beta2, o0.eps):
+            raise ValueError("the six optimizers must share β1, β2, ϵ")
+        empty = t is None or t.numel() == 0
+        if not empty:
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()) or t.numel() != o.mu.numel():
+                raise ValueError(f"{name}: parameter / optimizer state mismatch")
+            bump.append(o)
+        st.theta[g] = None if empty else t.data_ptr()
+        st.mu[g] = None if empty else o.mu.data_ptr()
+        st.nu[g] = None if empty else o.nu.data_ptr()
+        st.lr[g], st.current_step[g] = o.lr, o.current_step + (0 if empty else 1)
+    st.beta1, st.beta2, st.eps = o0.beta1, o0.beta2, o0.eps
+    st.scale_dims = 1 if raw["scales"].shape[-1] == 1 else 3
+    st.shs, st.opacities_act, st.scales_act = shs.data_ptr(), opacities_act.data_ptr(), scales_act.data_ptr()
+    return st, bump
+
+
+def fused_backward_tail_step(rast, vpixels, opts, raw, shs, opacities_act, scales_act, camera, sh_degree, background,
+                             forward_generation: int = 0):
+    """The single-GPU `step!` after the loss: ∇rasterize + prologue pullback + the six `NU.step!` + the
+    prologue of the next forward, without the gradients ever reaching memory (gsr_backward_trainer_tail).
+    Same results, bit for bit, as `rast.backward_raw(...)` followed by `trainer_tail_step(...)`.
+    `opts`, `raw`: dicts keyed by GROUPS; raw["points"] / raw["rotations"] are the arrays the forward
+    was given as means / rotations, `shs` / `opacities_act` / `scales_act` its other inputs."""
+    st, bump = tail_state(opts, raw, shs, opacities_act, scales_act)
+    rast.backward_trainer_tail(vpixels, st, raw["points"], shs, opacities_act, scales_act, raw["rotations"], camera,
+                               sh_degree, background, forward_generation=forward_generation)
+    for o in bump:  # committed only after validation and a successful launch
+        o.current_step += 1
+
+
 def nonfinite_gradient_report(names, grads, n: int):
     """The GSP_DEBUG guard of `step!` + the per-parameter part of `nonfinite_gradient_report` (training.jl:534-552,772-777):
     for gradient arrays `grads` (each with the Gaussian index first, n rows; empty ones are skipped) returns

@@ -343,6 +343,22 @@ class GaussianRasterizer:
         return vmeans, vshs, vopac, vscales, vrot, vR, vt
 
 
+    def backward_trainer_tail(self, vpixels, tail_state: "L.TailState", means_3d, shs, opacities, scales, rotations,
+                              camera, sh_degree, background, forward_generation: int = 0):
+        """∇rasterize with the trainer tail applied in its epilogue (gsr_backward_trainer_tail): no gradient
+        arrays; the raw parameters, Adam moments and activated copies named by `tail_state` are updated in
+        place.  `means_3d` / `rotations` must be the raw points / rotations, `shs` / `opacities` / `scales` the
+        activated copies of `tail_state` (the library checks the pointers).  gstate.∇means_2d is written as usual."""
+        inp = self._inputs(means_3d, shs, opacities, scales, rotations, sh_degree, background)
+        cs = self._camera(camera, None, None)
+        _chk(vpixels, "vpixels", (self.height, self.width, self.channels))
+        tail_state.vmeans2d = self.gstate._grad_means_2d.data_ptr() if inp.n else None
+        tail_state.forward_generation = int(forward_generation)
+        with torch.cuda.device(self.device):
+            L.check(self._lib.gsr_backward_trainer_tail(self._h, C.byref(inp), C.byref(cs), _ptr(vpixels),
+                                                        C.byref(tail_state), _stream()))
+
+
 def sh_grad_from_views(means_3d, vcolors_all, camera_centers, n_coeffs: int, sh_degree: int, out=None):
     """∇shs (N,K,3) of a batch of views from their factored colour cotangents `vcolors_all` (V,N,3)
     and camera centres (V,3) (gsr_sh_grad_from_views); V = 1 reproduces backward_raw's vshs bit for bit."""

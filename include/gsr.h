@@ -296,6 +296,36 @@ GSR_API int gsr_trainer_tail_step(int32_t n, int32_t k_rest, int32_t scale_dims,
                                   const uint32_t current_step[6], float beta1, float beta2, float eps, float* shs,
                                   float* opacities_act, float* scales_act, void* stream);
 
+/* Single-GPU trainer step: gsr_backward with gsr_trainer_tail_step applied in its epilogue
+ * ("fuse the trainer tail into the per-Gaussian backward").  Equivalent to
+ *     gsr_backward(h, in, cam, vpixels, &grads, stream);
+ *     gsr_trainer_tail_step(n, K-1, scale_dims, &grads, theta, mu, nu, ..., stream);
+ * with bit-identical θ, μ, ν and activated copies, but the 59·N gradient floats are never written:
+ * they live in registers between ∇project / ∇spherical_harmonics and the Adam update.  Not for the
+ * multi-GPU step (the gradients must be exchanged before the update) and not with pose gradients.
+ *   in : the inputs of the matching gsr_forward.  They must BE the trainer's arrays —
+ *        in->means == theta[0], in->rotations == theta[5], in->shs == shs,
+ *        in->opacities == opacities_act, in->scales == scales_act (checked; GSR_E_INVALID_ARG) —
+ *        because they are updated in place.  K = in->n_coeffs; features_rest holds K-1 bands.
+ *   vmeans2d : (2,N) gstate.∇means_2d of this backward, or NULL (handle-owned GSR_BUF_GRAD_MEANS2D)
+ *   forward_generation : gsr_stats.generation of the forward being differentiated, or 0 */
+typedef struct gsr_tail_state {
+    float* theta[6];            /* points, features_dc, features_rest, opacities, scales, rotations */
+    float* mu[6];
+    float* nu[6];
+    float lr[6];
+    uint32_t current_step[6];   /* counters AFTER increment (NU.Adam counts from 1) */
+    float beta1, beta2, eps;
+    int32_t scale_dims;         /* 3, or 1 for isotropic scenes */
+    float* shs;                 /* (3,K,N) */
+    float* opacities_act;       /* (1,N) */
+    float* scales_act;          /* (3,N) */
+    float* vmeans2d;
+    uint64_t forward_generation;
+} gsr_tail_state;
+GSR_API int gsr_backward_trainer_tail(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam,
+                                      const float* vpixels, const gsr_tail_state* st, void* stream);
+
 /* Boolean-mask compaction of per-Gaussian arrays — the `x[:, mask]` / `x[:, :, mask]` /
  * `x[mask]` logical indexing that `prune_points!`, `densify_clone!`, `densify_split!` and
  * `_prune_optimizer!` apply to every parameter, both Adam moments and the densification

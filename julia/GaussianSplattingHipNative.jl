@@ -191,4 +191,29 @@ function trainer_tail_step!(θ::NTuple{6}, opts::NTuple{6}, ∇, shs, opacities_
     foreach(o -> o.current_step += 0x1, opts)
 end
 
+# The same tail applied in the epilogue of the backward (gsr_backward_trainer_tail): the single-GPU `step!` after
+# the loss with no gradient arrays at all.  `vpixels` is the loss cotangent of rast.image; θ[1] / θ[6] must be the
+# arrays the forward was given as means_3d / rotations, shs / opacities_act / scales_act its other inputs.
+struct GsrTailState
+    theta::NTuple{6, Ptr{Float32}}; mu::NTuple{6, Ptr{Float32}}; nu::NTuple{6, Ptr{Float32}}
+    lr::NTuple{6, Float32}; current_step::NTuple{6, UInt32}
+    beta1::Float32; beta2::Float32; eps::Float32; scale_dims::Int32
+    shs::Ptr{Float32}; opacities_act::Ptr{Float32}; scales_act::Ptr{Float32}
+    vmeans2d::Ptr{Float32}; forward_generation::UInt64
+end
+function backward_trainer_tail!(rast::GaussianRasterizer, vpixels, θ::NTuple{6}, opts::NTuple{6}, shs, opacities_act,
+        scales_act; camera::Camera, sh_degree::Int, background::SVector{3, Float32}, β1=0.9f0, β2=0.999f0, ϵ=1f-15)
+    st = native(rast)
+    st === nothing && error("backward_trainer_tail! needs enable_hip_native!(rast)")
+    inp, cam = _structs(θ[1], shs, opacities_act, scales_act, θ[6], nothing, nothing, camera, sh_degree, background)
+    p(xs) = ntuple(i -> dptr(xs[i]), 6)
+    ts = GsrTailState(p(θ), p(map(o -> o.μ[1], opts)), p(map(o -> o.ν[1], opts)), ntuple(i -> Float32(opts[i].lr), 6),
+        ntuple(i -> UInt32(opts[i].current_step + 0x1), 6), β1, β2, ϵ, size(θ[5], 1),
+        dptr(shs), dptr(opacities_act), dptr(scales_act), Ptr{Float32}(UInt(pointer(rast.gstate.∇means_2d))), st.generation)
+    check(ccall((:gsr_backward_trainer_tail, LIB), Cint,
+        (Ptr{Cvoid}, Ref{GsrInputs}, Ref{GsrCamera}, Ptr{Float32}, Ref{GsrTailState}, Ptr{Cvoid}),
+        st.handle, inp, cam, dptr(vpixels), ts, hipstream()))
+    foreach(o -> o.current_step += 0x1, opts)
+end
+
 end # module

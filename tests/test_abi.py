@@ -30,6 +30,24 @@ def test_struct_sizes_match_header(pkg):
     assert C.sizeof(L.Stats) == 40
     assert C.sizeof(L.Grads) == 80
     assert C.sizeof(L.Aux) == 24
+    assert C.sizeof(L.TailState) == 248
+
+
+def test_struct_sizes_match_the_c_compiler(pkg, tmp_path):
+    """sizeof of every struct of include/gsr.h as gcc lays it out == the ctypes mirror."""
+    import subprocess
+    L = pkg._lib
+    pairs = {"gsr_config": L.Config, "gsr_inputs": L.Inputs, "gsr_camera": L.CameraS, "gsr_aux": L.Aux,
+             "gsr_stats": L.Stats, "gsr_grads": L.Grads, "gsr_adam_group": L.AdamGroup, "gsr_tail_grads": L.TailGrads,
+             "gsr_tail_state": L.TailState, "gsr_compose_group": L.ComposeGroup, "gsr_gather_group": L.GatherGroup}
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "gsr.h"\nint main(void){' +
+                   "".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in pairs) + "return 0;}\n")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.dirname(L.HEADER_PATH), str(src), "-o", str(exe)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for n, t in pairs.items():
+        assert int(out[n]) == C.sizeof(t), n
 
 
 def test_invalid_arguments_fail_before_touching_the_gpu(pkg):

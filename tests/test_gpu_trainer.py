@@ -302,3 +302,84 @@ def test_nonfinite_gradient_report(pkg):
     for nm, t in zip(names, grads):
         bad = (~torch.isfinite(t.reshape(n, -1))).any(1)
         assert int(bad.sum()) == rep.get(nm, (0, 0))[0]
+
+
+@pytest.mark.parametrize("n,deg,max_deg,iso,mode", [(600, 1, 1, False, "rgb"), (1500, 3, 3, False, "rgb"),
+                                                     (777, 1, 3, False, "rgbd"), (300, 0, 0, False, "rgb"),
+                                                     (513, 2, 2, True, "rgb"), (1100, 3, 3, False, "rgbdn")])
+def test_backward_with_the_tail_in_its_epilogue_equals_backward_then_tail(pkg, n, deg, max_deg, iso, mode):
+    """gsr_backward_trainer_tail == gsr_backward + gsr_trainer_tail_step, bit for bit (θ, μ, ν, the
+    activated copies, gstate.∇means_2d), over 4 training steps: culled Gaussians (zero gradient, moments
+    still decay), an active SH degree below the stored one, isotropic scales, no features_rest, n % 256 != 0,
+    every render mode."""
+    W, H = 112, 80
+    s = pkg.synthetic.make_scene(n, W, H, max_deg, 77, sigma_px=5.0)
+    cam = pkg.Camera(W, H, tuple(s.focal))
+    R, O = pkg.rasterizer, pkg.optim
+    C = pkg._lib.MODES[mode]
+    rng = np.random.default_rng(3)
+    target = dev(rng.uniform(0, 1, (H, W, C)).astype(np.float32))
+    scales_raw = s.scales_raw[:, :1].copy() if iso else s.scales_raw
+    s.means[::7, 2] = -1.0   # behind the camera: culled, zero gradient
+    host = dict(points=s.means, features_dc=s.shs[:, :1].copy(), features_rest=s.shs[:, 1:].copy(),
+                opacities=s.opacities_raw.reshape(-1, 1), scales=scales_raw, rotations=s.rotations)
+    lrs = dict(points=1.6e-3, features_dc=2.5e-2, features_rest=2.5e-3, opacities=5e-2, scales=5e-3, rotations=1e-2)
+    bg = (0.1, 0.2, 0.3)
+
+    def make():
+        raw = {k: dev(np.ascontiguousarray(v)) for k, v in host.items()}
+        opts = {k: O.Adam(raw[k], lrs[k], eps=1e-15) for k in O.GROUPS}
+        rest = raw["features_rest"] if raw["features_rest"].numel() else None
+        act = list(R.prologue_forward(raw["features_dc"], rest, raw["opacities"], raw["scales"]))
+        return raw, opts, act, R.GaussianRasterizer(W, H, mode=mode)
+
+    raw_a, opt_a, act_a, rast_a = make()   # backward, then the tail
+    raw_b, opt_b, act_b, rast_b = make()   # the tail in the epilogue
+    for step in range(1, 5):
+        img_a = rast_a.forward_raw(raw_a["points"], *act_a, raw_a["rotations"], cam, deg, bg)
+        img_b = rast_b.forward_raw(raw_b["points"], *act_b, raw_b["rotations"], cam, deg, bg)
+        assert torch.equal(img_a, img_b), step
+        vp = (img_a - target) * (2.0 / img_a.numel())     # any cotangent will do; the same one on both sides
+        vm, vsh, vo, vsc, vr, _, _ = rast_a.backward_raw(vp, raw_a["points"], *act_a, raw_a["rotations"], cam, deg, bg)
+        O.trainer_tail_step(opt_a, raw_a, dict(vmeans=vm, vshs=vsh, vopacities=vo, vscales=vsc, vrot=vr), *act_a)
+        O.fused_backward_tail_step(rast_b, vp.clone(), opt_b, raw_b, *act_b, cam, deg, bg,
+                                   forward_generation=rast_b.stats.generation)
+        torch.cuda.synchronize()
+        assert (rast_a.gstate.radii <= 0).any() and (rast_a.gstate.radii > 0).any()
+        for k in O.GROUPS:
+            if not raw_a[k].numel():
+                continue
+            assert torch.equal(raw_a[k], raw_b[k]), (k, step)
+            assert torch.equal(opt_a[k].mu, opt_b[k].mu) and torch.equal(opt_a[k].nu, opt_b[k].nu), (k, step)
+            assert opt_b[k].current_step == step
+        for x, y in zip(act_a, act_b):
+            assert torch.equal(x, y), step
+        assert torch.equal(rast_a.gstate.grad_means_2d, rast_b.gstate.grad_means_2d), step
+    assert not torch.equal(raw_b["points"], dev(host["points"]))   # it did train
+
+
+def test_fused_step_checks_its_contract(pkg):
+    """The fused step updates the forward's inputs in place: foreign arrays are refused, and so is a second
+    backward on the same forward."""
+    W, H, n, deg = 64, 48, 200, 1
+    s = pkg.synthetic.make_scene(n, W, H, deg, 5, sigma_px=4.0)
+    cam = pkg.Camera(W, H, tuple(s.focal))
+    R, O, L = pkg.rasterizer, pkg.optim, pkg._lib
+    raw = dict(points=dev(s.means), features_dc=dev(s.shs[:, :1].copy()), features_rest=dev(s.shs[:, 1:].copy()),
+               opacities=dev(s.opacities_raw.reshape(-1, 1)), scales=dev(s.scales_raw), rotations=dev(s.rotations))
+    opts = {k: O.Adam(raw[k], 1e-3, eps=1e-15) for k in O.GROUPS}
+    shs, oa, sa = R.prologue_forward(raw["features_dc"], raw["features_rest"], raw["opacities"], raw["scales"])
+    rast = R.GaussianRasterizer(W, H, mode="rgb")
+    img = rast.forward_raw(raw["points"], shs, oa, sa, raw["rotations"], cam, deg, (0, 0, 0))
+    vp = torch.ones_like(img)
+    st, _ = O.tail_state(opts, raw, shs.clone(), oa, sa)                # NOT the array the forward was given
+    with pytest.raises(L.GsrError, match="trainer's own arrays"):
+        rast.backward_trainer_tail(vp, st, raw["points"], shs, oa, sa, raw["rotations"], cam, deg, (0, 0, 0))
+    assert all(o.current_step == 0 for o in opts.values())          # a refused call moves no counter
+    with pytest.raises(L.GsrError, match="forward #"):
+        O.fused_backward_tail_step(rast, vp, opts, raw, shs, oa, sa, cam, deg, (0, 0, 0),
+                                   forward_generation=rast.stats.generation + 1)
+    O.fused_backward_tail_step(rast, vp, opts, raw, shs, oa, sa, cam, deg, (0, 0, 0))
+    with pytest.raises(L.GsrError, match="updated in place"):
+        rast.backward_raw(vp, raw["points"], shs, oa, sa, raw["rotations"], cam, deg, (0, 0, 0))
+    assert rast.gstate.radii.numel() == n                             # the forward's outputs stay readable

@@ -54,7 +54,8 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint
                                                          const uint32_t* __restrict__ bsum,
                                                          uint32_t* __restrict__ bpre,
                                                          const uint32_t* __restrict__ bvis,
-                                                         uint32_t* __restrict__ big_list) {
+                                                         uint32_t* __restrict__ big_list,
+                                                         uint32_t* __restrict__ host_mirror, uint32_t seq) {
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t red[3][16];
     __shared__ uint32_t big_fill, mid8_fill, mid4_fill;
@@ -145,6 +146,14 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint
             for (int w = 0; w < 16; w++) v += red[2][w];
             totals[4] = v;      // visible Gaussians
             totals[5] = total;  // sum of tile-rect areas = number of Gaussian-major instance slots (gradient rows)
+            if (host_mirror) {
+                // The host's copy, written straight into its pinned (fine-grained) memory: the seven totals, then the
+                // sequence number of this forward with system-scope release — the host spins on that word.  A D2H copy
+                // packet + an event record here cost an 8 us bubble on the stream (rocprofv3 kernel trace).
+#pragma unroll
+                for (int k = 0; k < 7; k++) host_mirror[k] = totals[k];
+                __hip_atomic_store(&host_mirror[7], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }
@@ -262,8 +271,13 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint32_t* __restric
                                                        const uint64_t* __restrict__ bins, uint32_t bin_cap, int grid_x,
                                                        GsrGeom geom, GsrStream stream,
                                                        uint32_t* __restrict__ values_sorted,
-                                                       uint32_t* __restrict__ ranges) {
+                                                       uint32_t* __restrict__ ranges,
+                                                       const uint32_t* __restrict__ totals, uint32_t cap_instances) {
     __shared__ uint64_t skeys[CAP];
+    // Launched BEFORE the host has read the instance count (totals != NULL): the output buffers hold cap_instances
+    // instances and the bins bin_cap keys — if this view needs more, every workgroup leaves without touching
+    // anything and the host, which sees the same totals, launches the pass again after growing them.
+    if (!LISTED && totals && (totals[0] > cap_instances || totals[1] > bin_cap)) return;
     const int tile = LISTED ? (int)tier_list[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;
     const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
     const uint32_t n = end - start;
@@ -389,9 +403,9 @@ __global__ __launch_bounds__(BIG_THREADS) void tile_sort_big_kernel(const uint32
 
 void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count, uint32_t* tile_start,
                           uint32_t* totals, int n_blocks, const uint32_t* bsum, uint32_t* bpre,
-                          const uint32_t* bvis, uint32_t* big_list) {
+                          const uint32_t* bvis, uint32_t* big_list, uint32_t* host_mirror, uint32_t seq) {
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, tile_count, tile_start, totals,
-                       n_blocks, bsum, bpre, bvis, big_list);
+                       n_blocks, bsum, bpre, bvis, big_list, host_mirror, seq);
 }
 
 __global__ void tile_order_identity_kernel(int n_tiles, uint32_t* __restrict__ order) {
@@ -409,22 +423,25 @@ void gsr_launch_tile_order(hipStream_t s, int n_tiles, const uint32_t* tile_coun
         hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, n_tiles, tile_count, totals, order);
 }
 
-void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start,
+void gsr_launch_tile_sort(hipStream_t s, int passes, int n_tiles, int grid_x, int channels, const uint32_t* tile_start,
                           uint32_t* tile_count, const uint64_t* bins, uint32_t bin_cap, uint32_t n_mid4, uint32_t n_mid8,
                           uint32_t n_big, const uint32_t* tier_lists, uint64_t* big_scratch, size_t slab_stride, GsrGeom geom,
-                          GsrStream stream, uint32_t* values_sorted, uint32_t* ranges) {
-#define LAUNCH(CC, CAPV, LISTEDV, NTV, GRID, LIST)                                                                 \
+                          GsrStream stream, uint32_t* values_sorted, uint32_t* ranges, const uint32_t* totals,
+                          uint32_t cap_instances) {
+#define LAUNCH(CC, CAPV, LISTEDV, NTV, GRID, LIST, TOT)                                                            \
     hipLaunchKernelGGL((tile_sort_kernel<CC, CAPV, LISTEDV, NTV>), dim3(GRID), dim3(NTV), 0, s, tile_start, tile_count, \
-                       LIST, bins, bin_cap, grid_x, geom, stream, values_sorted, ranges)
+                       LIST, bins, bin_cap, grid_x, geom, stream, values_sorted, ranges, TOT, cap_instances)
 #define LAUNCH_BIG(CC)                                                                                            \
     hipLaunchKernelGGL((tile_sort_big_kernel<CC>), dim3(n_big), dim3(BIG_THREADS), 0, s, tile_start, tier_lists, bins, \
                        bin_cap, big_scratch, slab_stride, grid_x, geom, stream, values_sorted)
 #define ALL(CC)                                                                                                   \
-    LAUNCH(CC, 1024, false, 256, n_tiles, tier_lists);                                                            \
-    if (n_mid4 > 0) LAUNCH(CC, 4096, true, 512, n_mid4, tier_lists + 2 * (size_t)n_tiles);                        \
-    if (n_mid8 > 0) LAUNCH(CC, GSR_SORT_LDS_CAP, true, 1024, n_mid8, tier_lists + (size_t)n_tiles);                \
-    if (n_big > 0) LAUNCH_BIG(CC)
-    if (channels > 5) { ALL(8); } else { ALL(3); }
+    if (passes & GSR_SORT_PASS_MAIN) LAUNCH(CC, 1024, false, 256, n_tiles, tier_lists, totals);                   \
+    if (passes & GSR_SORT_PASS_TIERS) {                                                                           \
+        if (n_mid4 > 0) LAUNCH(CC, 4096, true, 512, n_mid4, tier_lists + 2 * (size_t)n_tiles, nullptr);           \
+        if (n_mid8 > 0) LAUNCH(CC, GSR_SORT_LDS_CAP, true, 1024, n_mid8, tier_lists + (size_t)n_tiles, nullptr);  \
+        if (n_big > 0) LAUNCH_BIG(CC);                                                                            \
+    }
+    if (channels > 5) { ALL(8) } else { ALL(3) }
 #undef ALL
 #undef LAUNCH
 #undef LAUNCH_BIG

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -171,8 +172,9 @@ struct gsr_handle {
     DevBuf rows, vmean2d;
     // loss-head scratch
     DevBuf d0, d1, d2, partial;
-    hipEvent_t totals_ready = nullptr;  // recorded after the D2H copy of the totals
-    uint32_t* host_totals = nullptr;  // pinned: D, max tile count, #oversized tiles, slab ctr, n_visible
+    uint32_t* host_totals = nullptr;  // pinned: D, max tile count, #oversized tiles, slab ctr, n_visible, ..., [7] = sequence
+    uint32_t* host_totals_dev = nullptr;  // the same words as the device addresses them
+    uint32_t totals_seq = 0;
     bool fwd_valid = false, bwd_valid = false;
     bool inputs_consumed = false;  // gsr_backward_trainer_tail updated the forward's inputs in place
     uint64_t generation = 0;             // ordinal of the last gsr_forward (gsr_stats.generation)
@@ -213,6 +215,31 @@ GsrStream stream_of(const gsr_handle* h) {
     return GsrStream{h->s0.as<float4>(), h->s1.as<float4>(), h->s2.as<float4>(), h->s3.as<float4>()};
 }
 GsrInst inst_of(const gsr_handle* h) { return GsrInst{h->rows.as<float4>()}; }
+
+// Spin until tile_scan of forward `seq` published its totals.  A wait that lasts longer than any sane queue depth
+// (50 ms) starts polling the stream, so that a failed launch or a faulted kernel ends with an error instead of
+// hanging the caller — not earlier: hipStreamQuery puts a marker packet on the stream, and a marker between two
+// kernels is a 5 us bubble (rocprofv3 kernel trace, tools/gap_report.py).
+int wait_totals(gsr_handle* h, uint32_t seq, hipStream_t s) {
+    volatile uint32_t* word = h->host_totals + 7;
+    auto next_poll = std::chrono::steady_clock::time_point::max();
+    for (uint64_t spins = 1;; spins++) {
+        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) return GSR_OK;
+        __builtin_ia32_pause();
+        if ((spins & 0xFFF) == 0) {
+            const auto now = std::chrono::steady_clock::now();
+            if (next_poll == std::chrono::steady_clock::time_point::max()) next_poll = now + std::chrono::milliseconds(50);
+            if (now < next_poll) continue;
+            next_poll = now + std::chrono::milliseconds(50);
+            const hipError_t q = hipStreamQuery(s);
+            if (q == hipSuccess) {  // everything enqueued has finished: the word is there, or it never will be
+                if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) return GSR_OK;
+                return fail(GSR_E_HIP, "tile scan finished without publishing its totals");
+            }
+            if (q != hipErrorNotReady) return fail(GSR_E_HIP, "HIP error while waiting for the tile scan: %s", hipGetErrorString(q));
+        }
+    }
+}
 
 int check_inputs(const gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam) {
     if (!h || !in || !cam) return fail(GSR_E_INVALID_ARG, "null handle / inputs / camera");
@@ -261,8 +288,11 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
         gsr_destroy(h);
         return rc;
     }
-    hipError_t e = hipHostMalloc((void**)&h->host_totals, 8 * sizeof(uint32_t), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->totals_ready, hipEventDisableTiming);
+    hipError_t e = hipHostMalloc((void**)&h->host_totals, 8 * sizeof(uint32_t), hipHostMallocDefault);  // fine-grained
+    if (e == hipSuccess) {
+        memset(h->host_totals, 0, 8 * sizeof(uint32_t));
+        e = hipHostGetDevicePointer((void**)&h->host_totals_dev, h->host_totals, 0);
+    }
     if (e != hipSuccess) {
         gsr_destroy(h);
         return fail(GSR_E_HIP, "hipHostMalloc failed: %s", hipGetErrorString(e));
@@ -277,7 +307,6 @@ int gsr_destroy(gsr_handle* h) {
     if (!h) return GSR_OK;
     for (int i = 0; i < h->n_all; i++) h->all[i]->release();
     if (h->host_totals) (void)hipHostFree(h->host_totals);
-    if (h->totals_ready) (void)hipEventDestroy(h->totals_ready);
     h->prof.destroy();
     delete h;
     return GSR_OK;
@@ -362,18 +391,32 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
                           in->shs, k, geom_of(h), h->tile_count.as<uint32_t>(), h->bvis.as<uint32_t>(),
                           h->bins.as<uint64_t>(), h->bin_cap_view /* 0: count only */);
     h->prof.end(s);
+    const uint32_t seq = ++h->totals_seq ? h->totals_seq : ++h->totals_seq;  // never 0
     h->prof.begin(ST_SCAN, s);
     gsr_launch_tile_scan(s, h->n_tiles, h->tile_count.as<uint32_t>(), h->tile_start.as<uint32_t>(), totals,
                          n_blocks, h->bsum.as<uint32_t>(), h->bpre.as<uint32_t>(), h->bvis.as<uint32_t>(),
-                         h->big_list.as<uint32_t>());
+                         h->big_list.as<uint32_t>(), h->host_totals_dev, seq);
     h->prof.end(s);
     HIPCHK(hipGetLastError());
-    // the one host sync of the path: instance count D (reference: rasterizer.jl:337)
-    HIPCHK(hipMemcpyAsync(h->host_totals, totals, 8 * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipEventRecord(h->totals_ready, s));
     // launch order of the compositing workgroups (longest tile lists first); runs while the host waits
     gsr_launch_tile_order(s, h->n_tiles, h->tile_count.as<uint32_t>(), totals, h->tile_order.as<uint32_t>());
-    HIPCHK(hipEventSynchronize(h->totals_ready));
+    // the one host sync of the path: instance count D (reference: rasterizer.jl:337).  tile_scan stores the totals
+    // and then this forward's sequence number into pinned host memory; no copy packet, no event on the stream.
+    // The sort's main pass (lists of up to 1024 keys: nearly every tile) goes out BEHIND the scan without waiting for
+    // the host: its buffers have a capacity from earlier views (grow-only, 25 % slack), and the kernel itself checks
+    // the scan's totals against it.  The host's wait below then overlaps the sort instead of idling the GPU.
+    uint64_t cap_instances = std::min(std::min(h->values_sorted.cap / 4, h->s0.cap / 16), std::min(h->s1.cap / 16, h->s2.cap / 16));
+    if (C > 5) cap_instances = std::min<uint64_t>(cap_instances, h->s3.cap / 16);
+    cap_instances = std::min<uint64_t>(cap_instances, 0xFFFFFFFFull);
+    const bool spec = use_bins && cap_instances > 0;
+    if (spec) {
+        h->prof.begin(ST_SORT, s);
+        gsr_launch_tile_sort(s, GSR_SORT_PASS_MAIN, h->n_tiles, h->grid_x, C, h->tile_start.as<uint32_t>(),
+                             h->tile_count.as<uint32_t>(), h->bins.as<uint64_t>(), h->bin_cap_view, 0, 0, 0,
+                             h->big_list.as<uint32_t>(), nullptr, 0, geom_of(h), stream_of(h),
+                             h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>(), totals, (uint32_t)cap_instances);
+    }
+    if ((rc = wait_totals(h, seq, s))) return rc;
     const bool overflow = use_bins && h->host_totals[1] > h->bin_cap_view;
     const bool compact = !use_bins || overflow;
     {   // capacity for the NEXT view: longest list + 25 %, if that fits the budget of a scene of this size
@@ -400,7 +443,10 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
         stats->compact_binning = compact ? 1 : 0;
         stats->bins_bytes = (int64_t)(compact ? D * 8 : (uint64_t)(T + 1) * h->bin_cap_used(use_bins) * 8ull);
     }
+    // did the early main pass run?  (same two comparisons as in the kernel, on the same numbers)
+    const bool main_done = spec && !overflow && D <= cap_instances;
     if (D == 0) {
+        if (spec) h->prof.end(s);
         h->tile_count_dirty = false;  // every counter is zero
         // rasterizer.jl:283,338: all-zero image, background not applied
         HIPCHK(hipMemsetAsync(image_out, 0, P * C * 4, s));
@@ -422,7 +468,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
         slab_stride = ((size_t)max_tile + 63) & ~(size_t)63;
         if ((rc = h->big_scratch.ensure((size_t)n_big * 2 * slab_stride * 8))) return rc;
     }
-    h->prof.begin(ST_SORT, s);
+    if (!spec) h->prof.begin(ST_SORT, s);
     const uint64_t* keys = h->bins.as<uint64_t>();
     uint32_t key_cap = h->bin_cap_used(use_bins);
     if (compact) {
@@ -434,9 +480,11 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
         keys = h->keys_compact.as<uint64_t>();
         key_cap = 0;
     }
-    gsr_launch_tile_sort(s, h->n_tiles, h->grid_x, C, h->tile_start.as<uint32_t>(), h->tile_count.as<uint32_t>(), keys, key_cap,
+    gsr_launch_tile_sort(s, (main_done ? 0 : GSR_SORT_PASS_MAIN) | GSR_SORT_PASS_TIERS, h->n_tiles, h->grid_x, C,
+                         h->tile_start.as<uint32_t>(), h->tile_count.as<uint32_t>(), keys, key_cap,
                          h->host_totals[3], h->host_totals[6], n_big, h->big_list.as<uint32_t>(), h->big_scratch.as<uint64_t>(),
-                         slab_stride, geom_of(h), stream_of(h), h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>());
+                         slab_stride, geom_of(h), stream_of(h), h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>(),
+                         nullptr, 0);
     h->prof.end(s);
     h->tile_count_dirty = false;  // tile_sort zeroed the counters
     h->prof.begin(ST_COMPOSITE_FWD, s);

@@ -90,17 +90,25 @@ void gsr_launch_update_stats(hipStream_t s, int n, const int32_t* radii, const f
 // totals[0] = D, totals[1] = max count, totals[2] = #tiles over GSR_SORT_LDS_CAP, totals[3] = slab counter (0)
 void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count, uint32_t* tile_start,
                           uint32_t* totals, int n_blocks, const uint32_t* bsum, uint32_t* bpre,
-                          const uint32_t* bvis, uint32_t* tier_lists /* [3 * n_tiles], see gsr_launch_tile_sort */);
+                          const uint32_t* bvis, uint32_t* tier_lists /* [3 * n_tiles], see gsr_launch_tile_sort */,
+                          uint32_t* host_mirror /* pinned host, 8 words: totals[0..6] + seq, or NULL */, uint32_t seq);
 // order[0..n_tiles) = tile ids by descending list length (launch order of the compositing workgroups)
 void gsr_launch_tile_order(hipStream_t s, int n_tiles, const uint32_t* tile_count, const uint32_t* totals,
                            uint32_t* order);
 // bin_cap > 0: keys of tile t at bins + t * bin_cap; bin_cap == 0: compact layout, keys of tile t at bins + tile_start[t].
 // tier_lists (written by tile_scan): [0, T) tiles with lists > 8192, [T, 2T) lists in (4096, 8192], [2T, 3T) in (1024, 4096]
-void gsr_launch_tile_sort(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start,
+// passes: GSR_SORT_PASS_MAIN = the T-workgroup pass over lists of up to 1024 keys (also writes `ranges` and re-zeroes the
+// counters), GSR_SORT_PASS_TIERS = the launches over the tier lists (their sizes are host-side numbers).  totals != NULL:
+// the main pass is launched before the host knows the counts and leaves everything untouched when the view needs more
+// than cap_instances instances or bin_cap keys in a bin (the host then launches it again with totals == NULL).
+#define GSR_SORT_PASS_MAIN 1
+#define GSR_SORT_PASS_TIERS 2
+void gsr_launch_tile_sort(hipStream_t s, int passes, int n_tiles, int grid_x, int channels, const uint32_t* tile_start,
                           uint32_t* tile_count /* re-zeroed for the next view */, const uint64_t* bins, uint32_t bin_cap,
                           uint32_t n_mid4, uint32_t n_mid8, uint32_t n_big, const uint32_t* tier_lists,
                           uint64_t* big_scratch /* 2 slabs of slab_stride keys per tile over 8192 */, size_t slab_stride, GsrGeom geom,
-                          GsrStream stream, uint32_t* values_sorted, uint32_t* ranges);
+                          GsrStream stream, uint32_t* values_sorted, uint32_t* ranges, const uint32_t* totals,
+                          uint32_t cap_instances);
 
 // ---- composite.hip ----
 void gsr_launch_composite_fwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,

@@ -21,7 +21,8 @@ Prints ONE JSON line (rank 0) with the contract fields plus
   cpu_baseline — the oracle (C restatement of the reference algorithm, OpenMP) timed on
                  this host's cores on the same workload (rank 0, N = 1 only).
 `value` / `ms_per_step` follow the driver contract (K steps between two barriers+synchronize, total / K);
-`ms_per_step_median` is the median of the K per-step HIP-event times.
+`ms_per_step_median` is the median of the K-1 launch-to-launch intervals of the dominant stage's HIP events
+inside the timed region.
 """
 import argparse
 import json
@@ -239,16 +240,16 @@ def main():
     survey = {k: (ms / max(c, 1), c) for k, (ms, c) in rast.profile_read().items() if c > 0}
     dom = max(survey, key=lambda k: survey[k][0] * survey[k][1])
     rast.profile(True, stages=[dom])
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        marks[k].record()
         step()
-    marks[args.steps].record()
     sync()
     dt = time.perf_counter() - t0
-    per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
-    ms_median = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
+    # per-step times = launch-to-launch intervals of the dominant stage's own event pairs (a separate per-step
+    # marker would be one more ~6 us bubble on the stream, tools/gap_report.py): K-1 samples
+    per_step = sorted(rast.profile_intervals(dom))
+    ms_median = (None if not per_step else per_step[len(per_step) // 2] if len(per_step) % 2 else
+                 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2]))
     tail_collect()
     prof = rast.profile_read()
     rast.profile(False)
@@ -316,7 +317,7 @@ def main():
     out = {
         "metric": "fwd+bwd Mpixels/s @1920x1080, 1M Gaussians SH=3",
         "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_step, 4), "ms_per_step_median": round(ms_median, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_step, 4), "ms_per_step_median": round(ms_median if ms_median is not None else ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic" if args.ply is None else "ply scene, synthetic camera and target",
         "config": {"workload": ("config3: 1M Gaussians, SH deg 3, 1920x1080, fwd + L1/0.2*DSSIM loss + bwd"
                                 if not args.no_loss and args.ply is None and args.mode == "rgb" and (N, W, H, deg) == (1_000_000, 1920, 1080, 3) else

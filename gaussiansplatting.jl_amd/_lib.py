@@ -94,7 +94,7 @@ class GatherGroup(C.Structure):
 EXPORTS = ["gsr_create", "gsr_destroy", "gsr_release_scene_buffers", "gsr_memory_usage", "gsr_forward",
            "gsr_backward", "gsr_buffer", "gsr_copy_buffer", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_loss_l1_ssim",
            "gsr_allreduce_grads", "gsr_last_error_string", "gsr_version", "gsr_profile_enable",
-           "gsr_profile_stage_count", "gsr_profile_stages", "gsr_profile_stage_name", "gsr_profile_read", "gsr_update_stats",
+           "gsr_profile_stage_count", "gsr_profile_stages", "gsr_profile_stage_name", "gsr_profile_read", "gsr_profile_read_intervals", "gsr_update_stats",
            "gsr_prologue_forward", "gsr_prologue_backward", "gsr_adam_step", "gsr_stream_triad",
            "gsr_mask_findall_scratch_bytes", "gsr_mask_findall", "gsr_gather_rows", "gsr_sh_grad_from_views", "gsr_trainer_tail_step",
            "gsr_backward_trainer_tail",
@@ -165,6 +165,7 @@ def load():
     lib.gsr_profile_stages.argtypes = [vp, C.c_uint32]
     lib.gsr_profile_stage_name.argtypes = [i32]
     lib.gsr_profile_stage_name.restype = C.c_char_p
+    lib.gsr_profile_read_intervals.argtypes = [vp, i32, C.POINTER(C.c_double), i32, C.POINTER(C.c_int)]
     lib.gsr_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int), i32]
     lib.gsr_last_error_string.restype = C.c_char_p
     lib.gsr_version.restype = C.c_char_p

@@ -678,6 +678,28 @@ int gsr_profile_read(gsr_handle* h, double* ms_sum, int* launches, int reset) {
     return GSR_OK;
 }
 
+int gsr_profile_read_intervals(gsr_handle* h, int stage, double* ms_out, int max_n, int* n_out) {
+    if (!h || !n_out || (max_n > 0 && !ms_out)) return fail(GSR_E_INVALID_ARG, "null argument");
+    if (stage < 0 || stage >= ST_COUNT) return fail(GSR_E_INVALID_ARG, "unknown stage %d", stage);
+    int n = 0;
+    hipEvent_t prev = nullptr;
+    for (auto& r : h->prof.recs) {
+        if (r.stage != stage) continue;
+        if (prev) {
+            if (n < max_n) {
+                float ms = 0.0f;
+                HIPCHK(hipEventSynchronize(r.a));
+                HIPCHK(hipEventElapsedTime(&ms, prev, r.a));
+                ms_out[n] = ms;
+            }
+            n++;
+        }
+        prev = r.a;
+    }
+    *n_out = n;
+    return GSR_OK;
+}
+
 int gsr_prologue_forward(int32_t n, int32_t k_rest, int32_t scale_dims, const float* sh_color,
                          const float* sh_remainder, const float* opacities, const float* scales, float* shs,
                          float* opacities_act, float* scales_act, void* stream) {

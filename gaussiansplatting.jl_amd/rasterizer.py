@@ -175,6 +175,17 @@ class GaussianRasterizer:
         L.check(self._lib.gsr_profile_read(self._h, ms, cnt, 1 if reset else 0))
         return {self._lib.gsr_profile_stage_name(i).decode(): (ms[i], cnt[i]) for i in range(ns)}
 
+    def profile_intervals(self, stage: str) -> list:
+        """Milliseconds from each recorded launch of `stage` to the next (gsr_profile_read_intervals): the per-step
+        times of a run with one launch of the stage per step.  Call before profile_read(reset=True)."""
+        ns = self._lib.gsr_profile_stage_count()
+        names = [self._lib.gsr_profile_stage_name(i).decode() for i in range(ns)]
+        n = C.c_int()
+        L.check(self._lib.gsr_profile_read_intervals(self._h, names.index(stage), None, 0, C.byref(n)))
+        out = (C.c_double * max(n.value, 1))()
+        L.check(self._lib.gsr_profile_read_intervals(self._h, names.index(stage), out, n.value, C.byref(n)))
+        return [out[i] for i in range(n.value)]
+
     # ---- views into gstate / bstate / istate ----
     def _buffer(self, which: int, dtype, shape):
         p, sz = C.c_void_p(), C.c_size_t()

@@ -445,6 +445,11 @@ GSR_API int gsr_profile_stages(gsr_handle* h, uint32_t stage_mask);
 GSR_API int gsr_profile_stage_count(void);
 GSR_API const char* gsr_profile_stage_name(int stage);
 GSR_API int gsr_profile_read(gsr_handle* h, double* ms_sum, int* launches, int reset);
+/* Time from each recorded launch of `stage` to the next one (begin event to begin event), in milliseconds, oldest
+ * first: with one launch of the stage per step these are the per-step times of a run, from the event pairs that are
+ * on the stream anyway (a separate per-step marker would be one more bubble).  Writes min(count-1, max_n) values,
+ * *n_out = count-1 (0 when fewer than two launches are recorded).  Does not reset. */
+GSR_API int gsr_profile_read_intervals(gsr_handle* h, int stage, double* ms_out, int max_n, int* n_out);
 
 GSR_API const char* gsr_last_error_string(void);
 GSR_API const char* gsr_version(void);

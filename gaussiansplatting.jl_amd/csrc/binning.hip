@@ -48,6 +48,60 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32
     return woff + x - v;
 }
 
+// ---- launch order of the compositing workgroups ----
+// Tiles in descending order of list length (longest-processing-time-first): the compositing
+// kernels hand the heavy tiles out first and the light ones fill the gaps, so the makespan over
+// the 1024 SIMDs is ~1 % above the mean load instead of 5-8 % (synthetic) or far more (real
+// scenes with a few very deep tiles).  Counting sort over 1024 length classes in one workgroup;
+// the order inside a class is arbitrary — tiles are independent, outputs do not depend on it.
+__device__ __forceinline__ void tile_order_body(int n_tiles, const uint32_t* __restrict__ tile_count,
+                                                uint32_t* __restrict__ order, uint32_t* hist /* [1024] LDS */,
+                                                uint32_t* wave_sums /* [16] LDS */) {
+    constexpr int NB = 1024;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    hist[tid] = 0;
+    uint32_t vmax = 0;  // the longest list (this workgroup does not wait for the scan's)
+    for (int i = tid; i < n_tiles; i += NB) vmax = max(vmax, tile_count[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor(vmax, off));
+    if (lane == 0) wave_sums[wave] = vmax;
+    __syncthreads();
+    vmax = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) vmax = max(vmax, wave_sums[w]);
+    const uint64_t maxc = vmax > 0u ? vmax : 1u;
+    __syncthreads();  // wave_sums is reused below
+    for (int i = tid; i < n_tiles; i += NB) {
+        const uint32_t b = (NB - 1) - (uint32_t)(((uint64_t)tile_count[i] * (NB - 1)) / maxc);
+        atomicAdd(&hist[b], 1u);
+    }
+    __syncthreads();
+    const uint32_t v = hist[tid];
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(x, off);
+        if (lane >= off) x += y;
+    }
+    if (lane == 63) wave_sums[wave] = x;
+    __syncthreads();
+    uint32_t wave_off = 0;
+    for (int w = 0; w < wave; w++) wave_off += wave_sums[w];
+    hist[tid] = wave_off + x - v;
+    __syncthreads();
+    for (int i = tid; i < n_tiles; i += NB) {
+        const uint32_t b = (NB - 1) - (uint32_t)(((uint64_t)tile_count[i] * (NB - 1)) / maxc);
+        order[atomicAdd(&hist[b], 1u)] = (uint32_t)i;
+    }
+}
+
+// Three single-workgroup jobs between the per-Gaussian pass and the sort, all of them chains of a few
+// memory round trips and barriers — run as THREE workgroups of one launch instead of one after the other
+// (the whole GPU waits for them: 26 us as two launches, scan then order):
+//   block 0: exclusive scan of the tile counts -> tile_start, D, longest list, tier lists
+//   block 1: exclusive scan of the per-block rect-area sums -> bpre, slot total, visible count
+//   block 2: tile launch order (order == NULL: skipped)
+// Whichever of blocks 0 / 1 finishes second (ticket in totals[7], left at zero) hands the totals to the host.
 __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint32_t* __restrict__ tile_count,
                                                          uint32_t* __restrict__ tile_start,
                                                          uint32_t* __restrict__ totals, int n_blocks,
@@ -55,15 +109,21 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint
                                                          uint32_t* __restrict__ bpre,
                                                          const uint32_t* __restrict__ bvis,
                                                          uint32_t* __restrict__ big_list,
-                                                         uint32_t* __restrict__ host_mirror, uint32_t seq) {
+                                                         uint32_t* __restrict__ host_mirror, uint32_t seq,
+                                                         uint32_t* __restrict__ order) {
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t red[3][16];
+    __shared__ uint32_t hist[1024];
     __shared__ uint32_t big_fill, mid8_fill, mid4_fill;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { big_fill = 0; mid8_fill = 0; mid4_fill = 0; }
-    __syncthreads();
-    // tiles: exclusive scan of the counts, longest list, lists beyond the LDS sort
-    {
+    if (blockIdx.x == 2) {
+        if (order) tile_order_body(n_tiles, tile_count, order, hist, wave_sums);
+        return;
+    }
+    if (blockIdx.x == 0) {
+        // tiles: exclusive scan of the counts, longest list, lists beyond the LDS sort
+        if (tid == 0) { big_fill = 0; mid8_fill = 0; mid4_fill = 0; }
+        __syncthreads();
         constexpr int PER = 8;  // a wave reads 2 KB contiguous per round; rounds of 8192 elements carry a running total
         uint32_t vmax = 0, big = 0, total = 0;
         for (int base = 0; base < n_tiles; base += 1024 * PER) {
@@ -113,10 +173,9 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint
             totals[3] = mid4_fill;  // #tiles with a list in (1024, 4096]
             totals[6] = mid8_fill;  // #tiles with a list in (4096, 8192]
         }
-    }
-    // Gaussian blocks: per-block sums of tile-rect areas -> bpre (Gaussian-major instance-slot
-    // offsets), and the visible count (per-block counts written by preprocess)
-    {
+    } else {
+        // Gaussian blocks: per-block sums of tile-rect areas -> bpre (Gaussian-major instance-slot
+        // offsets), and the visible count (per-block counts written by preprocess)
         constexpr int PER = 8;
         uint32_t vis = 0, total = 0;
         for (int base = 0; base < n_blocks; base += 1024 * PER) {
@@ -146,55 +205,21 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint
             for (int w = 0; w < 16; w++) v += red[2][w];
             totals[4] = v;      // visible Gaussians
             totals[5] = total;  // sum of tile-rect areas = number of Gaussian-major instance slots (gradient rows)
+        }
+    }
+    if (tid == 0) {
+        __threadfence();  // this block's totals before its ticket
+        if (atomicAdd(&totals[7], 1u) == 1u) {
+            totals[7] = 0u;  // ready for the next view
             if (host_mirror) {
                 // The host's copy, written straight into its pinned (fine-grained) memory: the seven totals, then the
                 // sequence number of this forward with system-scope release — the host spins on that word.  A D2H copy
                 // packet + an event record here cost an 8 us bubble on the stream (rocprofv3 kernel trace).
 #pragma unroll
-                for (int k = 0; k < 7; k++) host_mirror[k] = totals[k];
+                for (int k = 0; k < 7; k++) host_mirror[k] = __hip_atomic_load(&totals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&host_mirror[7], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
-    }
-}
-
-// ---- launch order of the compositing workgroups ----
-// Tiles in descending order of list length (longest-processing-time-first): the compositing
-// kernels hand the heavy tiles out first and the light ones fill the gaps, so the makespan over
-// the 1024 SIMDs is ~1 % above the mean load instead of 5-8 % (synthetic) or far more (real
-// scenes with a few very deep tiles).  Counting sort over 1024 length classes in one workgroup;
-// the order inside a class is arbitrary — tiles are independent, outputs do not depend on it.
-__global__ __launch_bounds__(1024) void tile_order_kernel(int n_tiles, const uint32_t* __restrict__ tile_count,
-                                                          const uint32_t* __restrict__ totals,
-                                                          uint32_t* __restrict__ order) {
-    constexpr int NB = 1024;
-    __shared__ uint32_t hist[NB];
-    __shared__ uint32_t wave_sums[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    hist[tid] = 0;
-    __syncthreads();
-    const uint64_t maxc = totals[1] > 0u ? totals[1] : 1u;
-    for (int i = tid; i < n_tiles; i += NB) {
-        const uint32_t b = (NB - 1) - (uint32_t)(((uint64_t)tile_count[i] * (NB - 1)) / maxc);
-        atomicAdd(&hist[b], 1u);
-    }
-    __syncthreads();
-    const uint32_t v = hist[tid];
-    uint32_t x = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t y = __shfl_up(x, off);
-        if (lane >= off) x += y;
-    }
-    if (lane == 63) wave_sums[wave] = x;
-    __syncthreads();
-    uint32_t wave_off = 0;
-    for (int w = 0; w < wave; w++) wave_off += wave_sums[w];
-    hist[tid] = wave_off + x - v;
-    __syncthreads();
-    for (int i = tid; i < n_tiles; i += NB) {
-        const uint32_t b = (NB - 1) - (uint32_t)(((uint64_t)tile_count[i] * (NB - 1)) / maxc);
-        order[atomicAdd(&hist[b], 1u)] = (uint32_t)i;
     }
 }
 
@@ -401,26 +426,21 @@ __global__ __launch_bounds__(BIG_THREADS) void tile_sort_big_kernel(const uint32
 
 }  // namespace
 
-void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count, uint32_t* tile_start,
-                          uint32_t* totals, int n_blocks, const uint32_t* bsum, uint32_t* bpre,
-                          const uint32_t* bvis, uint32_t* big_list, uint32_t* host_mirror, uint32_t seq) {
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, tile_count, tile_start, totals,
-                       n_blocks, bsum, bpre, bvis, big_list, host_mirror, seq);
-}
-
 __global__ void tile_order_identity_kernel(int n_tiles, uint32_t* __restrict__ order) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_tiles) order[i] = (uint32_t)i;
 }
 
-void gsr_launch_tile_order(hipStream_t s, int n_tiles, const uint32_t* tile_count, const uint32_t* totals,
-                           uint32_t* order) {
+void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count, uint32_t* tile_start,
+                          uint32_t* totals, int n_blocks, const uint32_t* bsum, uint32_t* bpre,
+                          const uint32_t* bvis, uint32_t* big_list, uint32_t* host_mirror, uint32_t seq,
+                          uint32_t* order) {
     // GSR_TILE_ORDER=raster: row-major launch order (A/B measurements only; outputs are the same)
     static const bool raster = [] { const char* e = getenv("GSR_TILE_ORDER"); return e && e[0] == 'r'; }();
     if (raster)
         hipLaunchKernelGGL(tile_order_identity_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, s, n_tiles, order);
-    else
-        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, n_tiles, tile_count, totals, order);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(3), dim3(1024), 0, s, n_tiles, tile_count, tile_start, totals,
+                       n_blocks, bsum, bpre, bvis, big_list, host_mirror, seq, raster ? nullptr : order);
 }
 
 void gsr_launch_tile_sort(hipStream_t s, int passes, int n_tiles, int grid_x, int channels, const uint32_t* tile_start,

@@ -297,6 +297,7 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
         gsr_destroy(h);
         return fail(GSR_E_HIP, "hipHostMalloc failed: %s", hipGetErrorString(e));
     }
+    (void)hipMemset(h->totals.p, 0, 8 * 4);  // [7]: the scan's ticket word
     (void)hipMemset(h->ranges.p, 0, 2 * T * 4);
     (void)hipMemset(h->tile_count.p, 0, (T + 2) * 4);
     *out = h;
@@ -395,11 +396,9 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     h->prof.begin(ST_SCAN, s);
     gsr_launch_tile_scan(s, h->n_tiles, h->tile_count.as<uint32_t>(), h->tile_start.as<uint32_t>(), totals,
                          n_blocks, h->bsum.as<uint32_t>(), h->bpre.as<uint32_t>(), h->bvis.as<uint32_t>(),
-                         h->big_list.as<uint32_t>(), h->host_totals_dev, seq);
+                         h->big_list.as<uint32_t>(), h->host_totals_dev, seq, h->tile_order.as<uint32_t>());
     h->prof.end(s);
     HIPCHK(hipGetLastError());
-    // launch order of the compositing workgroups (longest tile lists first); runs while the host waits
-    gsr_launch_tile_order(s, h->n_tiles, h->tile_count.as<uint32_t>(), totals, h->tile_order.as<uint32_t>());
     // the one host sync of the path: instance count D (reference: rasterizer.jl:337).  tile_scan stores the totals
     // and then this forward's sequence number into pinned host memory; no copy packet, no event on the stream.
     // The sort's main pass (lists of up to 1024 keys: nearly every tile) goes out BEHIND the scan without waiting for

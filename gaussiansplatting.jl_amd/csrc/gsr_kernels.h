@@ -89,12 +89,12 @@ void gsr_launch_update_stats(hipStream_t s, int n, const int32_t* radii, const f
 // rect-area sums bsum[nb] -> bpre[nb];
 // totals[0] = D, totals[1] = max count, totals[2] = #tiles over GSR_SORT_LDS_CAP, totals[3] = slab counter (0)
 void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count, uint32_t* tile_start,
-                          uint32_t* totals, int n_blocks, const uint32_t* bsum, uint32_t* bpre,
-                          const uint32_t* bvis, uint32_t* tier_lists /* [3 * n_tiles], see gsr_launch_tile_sort */,
-                          uint32_t* host_mirror /* pinned host, 8 words: totals[0..6] + seq, or NULL */, uint32_t seq);
-// order[0..n_tiles) = tile ids by descending list length (launch order of the compositing workgroups)
-void gsr_launch_tile_order(hipStream_t s, int n_tiles, const uint32_t* tile_count, const uint32_t* totals,
-                           uint32_t* order);
+                          uint32_t* totals /* 8 words, [7] = ticket (zero between launches) */, int n_blocks,
+                          const uint32_t* bsum, uint32_t* bpre, const uint32_t* bvis,
+                          uint32_t* tier_lists /* [3 * n_tiles], see gsr_launch_tile_sort */,
+                          uint32_t* host_mirror /* pinned host, 8 words: totals[0..6] + seq, or NULL */, uint32_t seq,
+                          uint32_t* order /* [n_tiles] tile ids by descending list length: launch order of the compositing
+                                             workgroups, computed by a third workgroup of the same launch */);
 // bin_cap > 0: keys of tile t at bins + t * bin_cap; bin_cap == 0: compact layout, keys of tile t at bins + tile_start[t].
 // tier_lists (written by tile_scan): [0, T) tiles with lists > 8192, [T, 2T) lists in (4096, 8192], [2T, 3T) in (1024, 4096]
 // passes: GSR_SORT_PASS_MAIN = the T-workgroup pass over lists of up to 1024 keys (also writes `ranges` and re-zeroes the

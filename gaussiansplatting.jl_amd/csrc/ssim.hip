@@ -170,6 +170,30 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(Src src, int W, int H, fl
     }
 }
 
+// The scalar loss (training.jl:656,684-694) from the per-workgroup partial sums the forward kernel left: the work of
+// ONE workgroup, done by an extra workgroup of the backward launch (a launch of its own was 4 us during which the
+// whole GPU waited).  Fixed summation order: bit-reproducible.
+__device__ __forceinline__ void loss_finish_body(const float* __restrict__ partial, int n_blocks, float lambda,
+                                                 float inv_count, float* __restrict__ loss_out) {
+    __shared__ float red[2][4];
+    float a = 0.0f, b = 0.0f;
+    for (int i = threadIdx.x; i < n_blocks; i += 256) {
+        const float2 p = reinterpret_cast<const float2*>(partial)[i];
+        a += p.x; b += p.y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = 0.0f; b = 0.0f;
+        for (int w = 0; w < 4; w++) { a += red[0][w]; b += red[1][w]; }
+        const float l1 = a * inv_count;
+        const float s = 1.0f - b * inv_count;
+        loss_out[0] = (1.0f - lambda) * l1 + lambda * s;
+    }
+}
+
 // fused_ssim.jl:241-371.  LOSS: dL_dmap is the constant -λ/(3P) (pullback of
 // λ·(1-mean(map))), the L1 pullback is added, output goes to the (C,W,H) rasterizer layout.
 template <class Src, bool LOSS, int NCH>
@@ -177,10 +201,15 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(Src src, int W, int H, co
                                                        float chain_const, float l1_scale,
                                                        const float* __restrict__ d0, const float* __restrict__ d1,
                                                        const float* __restrict__ d2, float* __restrict__ out,
-                                                       int outC) {
+                                                       int outC, const float* __restrict__ partial, int n_partial,
+                                                       float lambda, float inv_count, float* __restrict__ loss_out) {
     __shared__ float sd[3][SH_DIM][IN_STRIDE];
     __shared__ float hc[3][SH_DIM][HC_STRIDE];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    if (LOSS && blockIdx.x == gridDim.x - 1) {  // the extra workgroup of the loss head's launch
+        loss_finish_body(partial, n_partial, lambda, inv_count, loss_out);
+        return;
+    }
     int x0, y0;
     if (!ssim_tile_of_block(W, H, x0, y0)) return;
     const size_t P = (size_t)W * H;
@@ -245,28 +274,6 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(Src src, int W, int H, co
     }
 }
 
-__global__ __launch_bounds__(1024) void loss_finish_kernel(const float* __restrict__ partial, int n_blocks,
-                                                           float lambda, float inv_count,
-                                                           float* __restrict__ loss_out) {
-    __shared__ float red[2][16];
-    float a = 0.0f, b = 0.0f;
-    for (int i = threadIdx.x; i < n_blocks; i += 1024) {
-        const float2 p = reinterpret_cast<const float2*>(partial)[i];
-        a += p.x; b += p.y;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        a = 0.0f; b = 0.0f;
-        for (int w = 0; w < 16; w++) { a += red[0][w]; b += red[1][w]; }
-        const float l1 = a * inv_count;
-        const float s = 1.0f - b * inv_count;
-        loss_out[0] = (1.0f - lambda) * l1 + lambda * s;
-    }
-}
-
 // zero the non-RGB channels of vpixels (C > 3): the loss head only sees features[1:3]
 __global__ void zero_extra_channels_kernel(float* __restrict__ vpixels, int C, size_t P) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -292,7 +299,7 @@ void gsr_launch_ssim_bwd(hipStream_t s, int W, int H, int CH, int B, const float
                          const float* dL_dmap, const float* d0, const float* d1, const float* d2, float* dL_dimg) {
     PlanarSrc src{img, ref, W, H};
     hipLaunchKernelGGL((ssim_bwd_kernel<PlanarSrc, false, 1>), ssim_grid(W, H, CH * B), dim3(256), 0, s, src, W, H,
-                       dL_dmap, 0.0f, 0.0f, d0, d1, d2, dL_dimg, 0);
+                       dL_dmap, 0.0f, 0.0f, d0, d1, d2, dL_dimg, 0, (const float*)nullptr, 0, 0.0f, 0.0f, (float*)nullptr);
 }
 
 void gsr_launch_loss_fwd(hipStream_t s, int W, int H, int C, const float* image, const float* target, float C1,
@@ -312,10 +319,10 @@ void gsr_launch_loss_bwd(hipStream_t s, int W, int H, int C, const float* image,
         const size_t P = (size_t)W * H;
         hipLaunchKernelGGL(zero_extra_channels_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, vpixels, C, P);
     }
-    hipLaunchKernelGGL((ssim_bwd_kernel<RasterSrc, true, 3>), ssim_grid(W, H, 1), dim3(256), 0, s, src, W, H,
+    dim3 g = ssim_grid(W, H, 1);
+    const int n_partial = (int)(g.x * g.y * g.z);  // one pair per workgroup of the forward launch
+    g.x += 1;                                      // + the workgroup that finishes the scalar loss
+    hipLaunchKernelGGL((ssim_bwd_kernel<RasterSrc, true, 3>), g, dim3(256), 0, s, src, W, H,
                        (const float*)nullptr, -lambda * inv_count, (1.0f - lambda) * inv_count, d0, d1, d2, vpixels,
-                       C);
-    const dim3 g = ssim_grid(W, H, 1);
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, s, partial, (int)(g.x * g.y * g.z), lambda,
-                       inv_count, loss_out);
+                       C, partial, n_partial, lambda, inv_count, loss_out);
 }

@@ -292,7 +292,9 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
             for (int q = 0; q < PPL; q++) {
 #ifndef GSR_BWD_NO_ROW_SKIP
                 // pixel rows 4q..4q+3 of this wave: untouched by the splat's footprint -> wave-uniform skip
-                if (PPL > 1 && ((rowbits >> (4 * q)) & 0xFu) == 0u) continue;
+                // (readfirstlane of the already-uniform bits: tells the compiler that this branch, and everything that
+                // merges behind it — the ballot accumulator —, is scalar; without it the test and `any_active` were VALU)
+                if (PPL > 1 && __builtin_amdgcn_readfirstlane((int)((rowbits >> (4 * q)) & 0xFu)) == 0) continue;
 #endif
                 const float dy = a.y - fy[q], dy2 = __fmul_rn(dy, dy);
                 const float sigma = sigma_of(sx, b.x, dy, dy2);
@@ -322,6 +324,11 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
                 }
             }
             if (any_active == 0ull) continue;  // wave-uniform: none of this wave's pixels is touched
+            // row of this splat in the wave's accumulator slab: j is wave-uniform, the multiply belongs on the scalar
+            // unit (left to itself the compiler folds `j * ST + slot` into a quarter-rate v_mad_u64_u32 per store)
+            int jrow;
+            asm("s_mul_i32 %0, %1, %2" : "=s"(jrow) : "s"(j), "n"(ST));
+            float* const my_row = my + jrow;
 #pragma unroll
             for (int w = 0; w < BB / 64; w++)
                 if ((j >> 6) == w) touched[w] |= 1ull << (j & 63);
@@ -329,12 +336,12 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
                 // :rgb — reduce {P, U1, U2, rgb} over the 4 lanes of each pixel column first, apply the
                 // column's dx weights, then finish over the 16 columns (wave_reduce.h: 5 swaps, not 8)
                 const float total = gsr::wave_reduce_rowcol_rgb(P, U1, U2, col[0], col[1], col[2], dx, lane_bits, rowcol);
-                if (rowcol.slot >= 0) my[j * ST + rowcol.slot] = total;
+                if (rowcol.slot >= 0) my_row[rowcol.slot] = total;
             } else if (C == 5) {
                 // :rgbd (the reference's default training mode): the same row-then-column scheme with the depth sum
                 // riding along — six swaps instead of the generic network's eight; feature 4 (constant 1) is not a parameter
                 const float total = gsr::wave_reduce_rowcol_rgbd(P, U1, U2, col[0], col[1], col[2], col[C > 3 ? 3 : 0], dx, lane_bits, rowcol_d);
-                if (rowcol_d.slot >= 0) my[j * ST + rowcol_d.slot] = total;
+                if (rowcol_d.slot >= 0) my_row[rowcol_d.slot] = total;
             } else {
                 float part[16];
 #pragma unroll
@@ -353,7 +360,7 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
                 const float total = gsr::wave_reduce_transposed<NA>(part, lane_bits);
                 // (storing the sums straight into the global row when NW == 1 measured 3 % slower than
                 // the LDS slab + coalesced 64-byte row stores below)
-                if (red_writer) my[j * ST + red_slot] = total;
+                if (red_writer) my_row[red_slot] = total;
             }
           }
         }

@@ -317,7 +317,8 @@ def main():
     out = {
         "metric": "fwd+bwd Mpixels/s @1920x1080, 1M Gaussians SH=3",
         "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_step, 4), "ms_per_step_median": round(ms_median if ms_median is not None else ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_step, 4), "ms_per_step_median": round(ms_median if ms_median is not None else ms_step, 4),
+        "ms_per_step_max": round(per_step[-1], 4) if per_step else None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic" if args.ply is None else "ply scene, synthetic camera and target",
         "config": {"workload": ("config3: 1M Gaussians, SH deg 3, 1920x1080, fwd + L1/0.2*DSSIM loss + bwd"
                                 if not args.no_loss and args.ply is None and args.mode == "rgb" and (N, W, H, deg) == (1_000_000, 1920, 1080, 3) else

@@ -98,6 +98,9 @@ __global__ __launch_bounds__(64) void composite_fwd_strip_kernel(int W, int H, i
         const bool cand = jj < to_do && (__float_as_uint(r2.w) & strip_bits) != 0u;
         unsigned long long m = wave_ballot(cand);
         if (m == 0ull) continue;
+        // c2.y of a STAGED splat is its 1-based list position (written at staging, the forward has no use for the
+        // gradient-row slot the stream carries there): `last` is then a select between two VGPRs, not a v_mov of the
+        // scalar position + a select
         auto blend = [&](const float4& a, const float4& b, const float4& c2, const float4& c3, int j) {
             const float dx = a.x - fx, dy = a.y - fy;
             const float sigma = sigma_of(sigma_x(a.z, a.w, dx), b.x, dy, __fmul_rn(dy, dy));
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(64) void composite_fwd_strip_kernel(int W, int H, i
                 if (covis && ok && T > 0.5f) covis[values_sorted[start + base + j]] = 1;
             }
             T = ok ? Tn : T;
-            last = ok ? (uint32_t)(base + j + 1) : last;
+            last = ok ? __float_as_uint(c2.y) : last;
         };
         // (Fetching the wave-uniform splats with scalar loads straight from the stream — s_load_dwordx4,
         // one candidate ahead, no LDS — measured 2.6x slower: the scalar cache does not keep up.)
@@ -129,6 +132,7 @@ __global__ __launch_bounds__(64) void composite_fwd_strip_kernel(int W, int H, i
         if (cand) {
             l0[lane] = stream.s0[start + jj];
             l1[lane] = stream.s1[start + jj];
+            r2.y = __uint_as_float((uint32_t)(jj + 1));
             l2[lane] = r2;
             if (C > 5) l3[lane] = stream.s3[start + jj];
         }
@@ -137,7 +141,12 @@ __global__ __launch_bounds__(64) void composite_fwd_strip_kernel(int W, int H, i
         while (m) {
             const int j = __builtin_ctzll(m);
             m &= m - 1;
-            blend(l0[j], l1[j], l2[j], C > 5 ? l3[j] : l2[j], j);
+            // (x = third colour, y = list position: ONE 64-bit LDS read — left as two fields of l2[j] the compiler sinks
+            // the position's read under EXEC = ok, which costs a masked region per visit)
+            float4 c2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (C > 3) c2 = l2[j];
+            else { const float2 xy = *reinterpret_cast<const float2*>(&l2[j]); c2.x = xy.x; c2.y = xy.y; }
+            blend(l0[j], l1[j], c2, C > 5 ? l3[j] : c2, j);
         }
     }
     if (inside) {

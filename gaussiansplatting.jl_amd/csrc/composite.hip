@@ -262,7 +262,10 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
             const uint32_t idx = start + (uint32_t)(tile_last - 1 - base - tid);
             l0[tid] = stream.s0[idx];
             l1[tid] = stream.s1[idx];
-            l2[tid] = stream.s2[idx];
+            // staged as (third colour, footprint mask, depth, gradient-row slot): what the walk reads per splat is then
+            // one aligned 64-bit LDS read in :rgb mode
+            const float4 t2 = stream.s2[idx];
+            l2[tid] = make_float4(t2.x, t2.w, t2.z, t2.y);
             if (C > 5) l3[tid] = stream.s3[idx];
         }
         __syncthreads();
@@ -273,14 +276,17 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
         float* const my = lacc[wave];
         for (int c0 = 0; c0 < cnt; c0 += 64) {
           const int jj = c0 + lane;
-          const bool cand = jj < cnt && (__float_as_uint(l2[jj].w) & strip_bits) != 0u &&
+          const bool cand = jj < cnt && (__float_as_uint(l2[jj].y) & strip_bits) != 0u &&
                             (tile_last - 1 - base - jj) < wave_last;
           unsigned long long wl = wave_ballot(cand);  // splats whose footprint can touch this wave's rows
           while (wl) {
             const int j = c0 + __builtin_ctzll(wl);
             wl &= wl - 1;
             const int contributor = tile_last - 1 - base - j;  // 0-based position in the tile list
-            const float4 a = l0[j], b = l1[j], c2 = l2[j];
+            const float4 a = l0[j], b = l1[j];
+            float4 c2;  // (x: third colour, w: footprint mask, z: depth) as the stream has them
+            if (C == 3) { const float2 xm = *reinterpret_cast<const float2*>(&l2[j]); c2 = make_float4(xm.x, 0.0f, 0.0f, xm.y); }
+            else { const float4 t2 = l2[j]; c2 = make_float4(t2.x, 0.0f, t2.z, t2.y); }
             const float o = b.y;
             const float dx = a.x - fx;
             const SigmaX sx = sigma_x(a.z, a.w, dx);
@@ -399,7 +405,7 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
                 // order — no fp32 atomics (35 M per view before), bit-reproducible gradients
                 const float4 a = l0[tid], b = l1[tid];
                 const float mo = -b.y, mh = -0.5f * b.y;  // vσ = -o·G·vα (render.jl:260)
-                float4* row = inst.rows + (size_t)GSR_ROW_F4(C) * __float_as_uint(l2[tid].y);  // Gaussian-major slot
+                float4* row = inst.rows + (size_t)GSR_ROW_F4(C) * __float_as_uint(l2[tid].w);  // Gaussian-major slot
                 row[0] = make_float4(r[0], r[1], r[2], r[3]);
                 row[1] = make_float4(mh * r[4], mh * r[5], mh * r[6], C > 3 ? r[9 < NA ? 9 : 0] : 0.0f);
                 // conic a = 2·ha, c = 2·hc (the stream carries the halves)

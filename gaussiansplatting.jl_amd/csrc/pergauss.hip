@@ -643,7 +643,6 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
 #pragma unroll
     for (int k = 0; k < 16; k++) f_b[k] = 0.0f;
     if (i < n) {
-        float* vsh = FUSED ? nullptr : vshs + (size_t)3 * K * i;
         if (!visible) {
             vmean2d_out[i] = make_float2(0.0f, 0.0f);
             if constexpr (!FUSED) {
@@ -652,7 +651,7 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
                 vrots[i] = make_float4(0, 0, 0, 0);
                 vopac[i] = 0.0f;
                 if (vcolors) { vcolors[3 * i] = 0.0f; vcolors[3 * i + 1] = 0.0f; vcolors[3 * i + 2] = 0.0f; }
-                else for (int k = 0; k < 3 * K; k++) vsh[k] = 0.0f;
+                // (else: f_nb = 0 — the cooperative store below writes this Gaussian's zeros)
             }
         } else {
             const float4 a0 = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -831,11 +830,13 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
                 // rebuilds Σ_views on every rank)
                 vcolors[3 * i] = vc[0]; vcolors[3 * i + 1] = vc[1]; vcolors[3 * i + 2] = vc[2];
             } else {
+                // ∇shs = basis x vc is stored by the whole workgroup below (coalesced float4 rows instead of 48
+                // dword stores 192 bytes apart per lane)
+                f_nb = NB;
 #pragma unroll
-                for (int k = 0; k < NB; k++)
+                for (int c = 0; c < 3; c++) f_vc[c] = vc[c];
 #pragma unroll
-                    for (int c = 0; c < 3; c++) vsh[3 * k + c] = b[k] * vc[c];
-                for (int k = 3 * NB; k < 3 * K; k++) vsh[k] = 0.0f;
+                for (int k = 0; k < NB; k++) f_b[k] = b[k];
             }
             float dcx[3] = {0, 0, 0}, dcy[3] = {0, 0, 0}, dcz[3] = {0, 0, 0};
 #define SHC(k_, c_) sh[3 * ((k_) - 1) + (c_)]
@@ -891,20 +892,42 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
             }
         }
     }
-    if constexpr (FUSED) {
-        __shared__ float tail_b[256][17];  // SH basis of each Gaussian of the workgroup (odd stride: no bank conflicts)
-        __shared__ float tail_vc[256][3];  // its colour cotangent (clamp mask applied)
-        __shared__ int tail_nb[256];
+    // The SH part of the gradient is the outer product basis x colour cotangent: its factors wait in LDS and the whole
+    // workgroup writes (FUSED: updates) the workgroup's contiguous slice element-major, as full cache lines.
+    __shared__ float tail_b[256][17];  // SH basis of each Gaussian of the workgroup (odd stride: no bank conflicts)
+    __shared__ float tail_vc[256][3];  // its colour cotangent (clamp mask applied)
+    __shared__ int tail_nb[256];       // SH bands carrying a gradient (0: culled Gaussian)
+    const int i0 = blockIdx.x * 256;
+    const int cnt = min(256, n - i0);
+    const int K3 = 3 * K;
+    if (FUSED || !vcolors) {
 #pragma unroll
         for (int k = 0; k < 16; k++) tail_b[threadIdx.x][k] = f_b[k];
 #pragma unroll
         for (int c = 0; c < 3; c++) tail_vc[threadIdx.x][c] = f_vc[c];
         tail_nb[threadIdx.x] = f_nb;
+    }
+    if constexpr (!FUSED) {
+        if (!vcolors) {
+            __syncthreads();
+            const uint32_t inv = (1u << 20) / (uint32_t)K3 + 1u;  // e / K3 == (e * inv) >> 20 for e < 2^20 / K3 (K3 <= 48, e < 256 K3)
+            float* __restrict__ dst = vshs + (size_t)i0 * K3;
+            const int total = cnt * K3;
+            auto value = [&](int e) {
+                const int il = (int)(((uint32_t)e * inv) >> 20);
+                const int j = e - il * K3;
+                const int k = j / 3, c = j - 3 * k;
+                return k < tail_nb[il] ? tail_b[il][k] * tail_vc[il][c] : 0.0f;
+            };
+            const int total4 = (((uintptr_t)dst & 15) == 0) ? total >> 2 : 0;
+            for (int f = threadIdx.x; f < total4; f += 256)
+                reinterpret_cast<float4*>(dst)[f] = make_float4(value(4 * f), value(4 * f + 1), value(4 * f + 2), value(4 * f + 3));
+            for (int e = 4 * total4 + threadIdx.x; e < total; e += 256) dst[e] = value(e);
+        }
+    }
+    if constexpr (FUSED) {
         if (i < n) gsr::tail_gauss_apply(TS, i, f_vmean, f_vopac, f_vs, f_vq);
         __syncthreads();
-        const int i0 = blockIdx.x * 256;
-        const int cnt = min(256, n - i0);
-        const int K3 = 3 * K;
         // one SH group of the workgroup's Gaussians, element-major: R floats per Gaussian starting at band k0
         auto sh_group = [&](float* __restrict__ th, float* __restrict__ mu, float* __restrict__ nu, int R, int k0,
                             const gsr::AdamHyper& hy) {

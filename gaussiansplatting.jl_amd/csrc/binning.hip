@@ -265,11 +265,7 @@ __device__ __forceinline__ void emit_instance(uint64_t k, uint32_t pos, int X0, 
         const uint32_t x0 = lo & 0xFFFFu, y0 = lo >> 16, x1 = hi & 0xFFFFu;
         const uint32_t slot = geom.bpre[id >> 8] + __float_as_uint(rec.q2.w) +
                               ((uint32_t)(Y0 / GSR_TILE) - y0) * (x1 - x0) + ((uint32_t)(X0 / GSR_TILE) - x0);
-#ifdef GSR_EXP_NOMASK
-        const uint32_t mask_bits = 0xFFFFFu;
-#else
         const uint32_t mask_bits = instance_row_mask(rec.q0, rec.q1, X0, Y0);
-#endif
         stream.s2[start + i] = make_float4(rec.q2.x, __uint_as_float(slot), rec.q2.z, __uint_as_float(mask_bits));
         if (CH > 5) stream.s3[start + i] = geom.normal[id];
     }
@@ -363,9 +359,7 @@ __device__ __forceinline__ void wave_sort_and_emit(uint32_t* ids /* LDS [1024] *
         const uint32_t e = (uint32_t)(lane * KPT + r);
         v[r] = e < n ? keys[e] : ~0ull;  // padded with +inf to m = 64 KPT
     }
-#ifndef GSR_EXP_NOSORT
     wave_bitonic_sort<KPT>(v, 64u * KPT, lane);
-#endif
     // only the id of a sorted key is needed from here on; through LDS so that the stream is written lane-contiguous
 #pragma unroll
     for (int r = 0; r < KPT; r++) ids[lane * KPT + r] = (uint32_t)v[r];

@@ -183,16 +183,22 @@ constexpr int BWD_BATCH = GSR_BWD_BATCH;  // splats staged per round (LDS: one a
 // The LDS reads, the cross-lane reduction and the row store — ~60 % of the instructions of a
 // visited (strip, splat) pair — are paid once for 2x / 4x the pixels (measured at config 3:
 // 1.115 / 0.975 / 0.917 ms for PPL = 1 / 2 / 4).
-template <int C, int PPL>
+// LISTED: the tiles of one tier list of the scan (lists longer than GSR_BWD_SPLIT_LEN) — launched with PPL = 1, four
+// waves per tile on a second stream next to the main PPL = 4 launch, which leaves those tiles out: one wave walking a
+// list of 30 k instances is milliseconds long (real captures have such tiles; config 3 has none).
+template <int C, int PPL, bool LISTED>
 __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_kernel(int W, int H, int grid_x,
                                                                 const uint32_t* __restrict__ tile_start,
                                                                 const uint32_t* __restrict__ tile_order,
                                                                 GsrStream stream, Bg bg,
                                                                 const float* __restrict__ vpixels,
                                                                 const uint32_t* __restrict__ n_contrib,
-                                                                const float* __restrict__ final_T, GsrInst inst) {
+                                                                const float* __restrict__ final_T, GsrInst inst,
+                                                                GsrTierLists tiers) {
     constexpr int NA = AccRow<C>::N, ST = AccRow<C>::STRIDE;
     constexpr int BB = BWD_BATCH, NT = 256 / PPL, NW = NT / 64, ROWS = 4 * PPL;
+    // the long tiles are the critical path of the step and share their SIMDs with the main launch's waves: issue priority
+    if (LISTED) __builtin_amdgcn_s_setprio(3);
     static_assert(BB <= NT && BB % 64 == 0, "one staging thread per splat");
     __shared__ float4 l0[BB], l1[BB], l2[BB];
     __shared__ float4 l3[C > 5 ? BB : 1];
@@ -209,13 +215,23 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
     const bool red_writer = gsr::wave_reduce_writer(lane);
     const gsr::RowColConsts rowcol(lane);
     const gsr::RowColConstsD rowcol_d(lane);
-    const int tile = (int)tile_order[blockIdx.x];  // 1-D grid in launch order: longest lists first
+    // main launch: 1-D grid in launch order, longest lists first; LISTED: the scan's three tier lists back to back,
+    // longest tier first
+    int tile;
+    if (LISTED) {
+        uint32_t b = blockIdx.x;
+        const uint32_t* list = tiers.lists;                                              // lists > 8192
+        if (b >= tiers.n_big) { b -= tiers.n_big; list = tiers.lists + tiers.n_tiles;    // (4096, 8192]
+            if (b >= tiers.n_mid8) { b -= tiers.n_mid8; list = tiers.lists + 2 * (size_t)tiers.n_tiles; } }  // (1024, 4096]
+        tile = (int)list[b];
+    } else tile = (int)tile_order[blockIdx.x];
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
     const int px = tile_x * GSR_TILE + (lane & 15);
     const int py0 = tile_y * GSR_TILE + ROWS * wave + (lane >> 4);
     const float fx = (float)px;
     const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
     if (end == start) return;
+    if (!LISTED && end - start > tiers.split_len) return;  // the four-wave launch over the tier lists owns this tile
 
     // per-pixel state (PPL pixels per lane: rows py0 and py0 + 4)
     float fy[PPL], T[PPL], A[PPL], bgT[PPL], vp[PPL][C];
@@ -451,12 +467,31 @@ void gsr_launch_composite_fwd(hipStream_t s, int channels, GsrCam cam, const uin
 
 void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
                               const uint32_t* tile_order, GsrStream stream, const float* background,
-                              const float* vpixels, const uint32_t* n_contrib, const float* final_T, GsrInst inst) {
+                              const float* vpixels, const uint32_t* n_contrib, const float* final_T, GsrInst inst,
+                              uint32_t split_len) {
     dim3 grid(cam.grid_x * cam.grid_y), block(256 / GSR_BWD_PPL);
     Bg bg = make_bg(background, channels);
+    GsrTierLists none{};
+    none.split_len = split_len;
 #define LAUNCH(CC)                                                                                                 \
-    hipLaunchKernelGGL((composite_bwd_kernel<CC, GSR_BWD_PPL>), grid, block, 0, s, cam.width, cam.height,          \
-                       cam.grid_x, tile_start, tile_order, stream, bg, vpixels, n_contrib, final_T, inst)
+    hipLaunchKernelGGL((composite_bwd_kernel<CC, GSR_BWD_PPL, false>), grid, block, 0, s, cam.width, cam.height,   \
+                       cam.grid_x, tile_start, tile_order, stream, bg, vpixels, n_contrib, final_T, inst, none)
+    if (channels == 3) LAUNCH(3);
+    else if (channels == 5) LAUNCH(5);
+    else LAUNCH(8);
+#undef LAUNCH
+}
+
+void gsr_launch_composite_bwd_listed(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
+                                     GsrTierLists tiers, GsrStream stream, const float* background,
+                                     const float* vpixels, const uint32_t* n_contrib, const float* final_T, GsrInst inst) {
+    const uint32_t n_listed = tiers.n_big + tiers.n_mid8 + tiers.n_mid4;
+    if (n_listed == 0) return;
+    dim3 grid(n_listed), block(256);
+    Bg bg = make_bg(background, channels);
+#define LAUNCH(CC)                                                                                                 \
+    hipLaunchKernelGGL((composite_bwd_kernel<CC, 1, true>), grid, block, 0, s, cam.width, cam.height, cam.grid_x,  \
+                       tile_start, (const uint32_t*)nullptr, stream, bg, vpixels, n_contrib, final_T, inst, tiers)
     if (channels == 3) LAUNCH(3);
     else if (channels == 5) LAUNCH(5);
     else LAUNCH(8);

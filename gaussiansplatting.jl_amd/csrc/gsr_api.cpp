@@ -175,6 +175,9 @@ struct gsr_handle {
     uint32_t* host_totals = nullptr;  // pinned: D, max tile count, #oversized tiles, slab ctr, n_visible, ..., [7] = sequence
     uint32_t* host_totals_dev = nullptr;  // the same words as the device addresses them
     uint32_t totals_seq = 0;
+    uint32_t tier_n[3] = {0, 0, 0};    // tiles of the last forward with lists in (1024, 4096], (4096, 8192], > 8192
+    hipStream_t aux_stream = nullptr;  // the four-wave backward of those tiles runs here, next to the main launch
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool fwd_valid = false, bwd_valid = false;
     bool inputs_consumed = false;  // gsr_backward_trainer_tail updated the forward's inputs in place
     uint64_t generation = 0;             // ordinal of the last gsr_forward (gsr_stats.generation)
@@ -293,9 +296,12 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
         memset(h->host_totals, 0, 8 * sizeof(uint32_t));
         e = hipHostGetDevicePointer((void**)&h->host_totals_dev, h->host_totals, 0);
     }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) {
         gsr_destroy(h);
-        return fail(GSR_E_HIP, "hipHostMalloc failed: %s", hipGetErrorString(e));
+        return fail(GSR_E_HIP, "pinned memory / stream / event creation failed: %s", hipGetErrorString(e));
     }
     (void)hipMemset(h->totals.p, 0, 8 * 4);  // [7]: the scan's ticket word
     (void)hipMemset(h->ranges.p, 0, 2 * T * 4);
@@ -308,6 +314,9 @@ int gsr_destroy(gsr_handle* h) {
     if (!h) return GSR_OK;
     for (int i = 0; i < h->n_all; i++) h->all[i]->release();
     if (h->host_totals) (void)hipHostFree(h->host_totals);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
     h->prof.destroy();
     delete h;
     return GSR_OK;
@@ -431,6 +440,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     h->last_n = n;
     h->last_D = (int64_t)D;
     h->last_max_tile = max_tile;
+    h->tier_n[0] = h->host_totals[3]; h->tier_n[1] = h->host_totals[6]; h->tier_n[2] = n_big;
     h->last_slots = (int64_t)D_slots;
     if (stats) {
         stats->n_rendered = (int64_t)D;
@@ -496,6 +506,38 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     return GSR_OK;
 }
 
+// ∇render! of the last forward.  One wave walks a tile's list in the main launch; a list of tens of thousands of
+// instances is then milliseconds of ONE wave (§8 of DESIGN.md).  As long as such tiles are too few to fill the GPU by
+// themselves (at most one per CU), they are taken out of the main launch and walked by four waves each on the
+// handle's second stream, forked from and joined back into the caller's stream.  The cut is a tier boundary of the
+// scan (> 8192, > 4096 or > 1024 instances): the deepest tiers first, as many as fit the limit.  Four waves cost
+// ~20 % more work per instance, so when long tiles are plentiful they stay with the main launch.
+static int launch_composite_bwd(gsr_handle* h, hipStream_t s, int C, const GsrCam& k, const float* background,
+                                const float* vpixels) {
+    constexpr uint32_t kMaxSplitTiles = 256;
+    GsrTierLists tiers{h->big_list.as<uint32_t>(), (uint32_t)h->n_tiles, 0, 0, 0, 0xFFFFFFFFu};
+    const uint32_t cut[3] = {GSR_SORT_LDS_CAP, 4096u, 1024u};             // deepest tier first
+    const uint32_t have[3] = {h->tier_n[2], h->tier_n[1], h->tier_n[0]};
+    uint32_t* take[3] = {&tiers.n_big, &tiers.n_mid8, &tiers.n_mid4};
+    uint32_t n = 0;
+    for (int t = 0; t < 3 && n + have[t] <= kMaxSplitTiles; t++) {
+        n += *take[t] = have[t];
+        tiers.split_len = cut[t];
+    }
+    if (n == 0) tiers.split_len = 0xFFFFFFFFu;  // nothing to split (or the deepest tier alone is already plentiful)
+    if (n > 0) {
+        HIPCHK(hipEventRecord(h->ev_fork, s));
+        HIPCHK(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
+        gsr_launch_composite_bwd_listed(h->aux_stream, C, k, h->tile_start.as<uint32_t>(), tiers, stream_of(h), background,
+                                        vpixels, h->n_contrib.as<uint32_t>(), h->final_T.as<float>(), inst_of(h));
+        HIPCHK(hipEventRecord(h->ev_join, h->aux_stream));
+    }
+    gsr_launch_composite_bwd(s, C, k, h->tile_start.as<uint32_t>(), h->tile_order.as<uint32_t>(), stream_of(h), background,
+                             vpixels, h->n_contrib.as<uint32_t>(), h->final_T.as<float>(), inst_of(h), tiers.split_len);
+    if (n > 0) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
+    return GSR_OK;
+}
+
 int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, const float* vpixels,
                  const gsr_grads* g, void* stream_v) {
     int rc = check_inputs(h, in, cam);
@@ -529,9 +571,7 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
     }
     GsrCam k = make_cam(h, cam);
     h->prof.begin(ST_COMPOSITE_BWD, s);
-    if (h->last_D > 0)
-        gsr_launch_composite_bwd(s, C, k, h->tile_start.as<uint32_t>(), h->tile_order.as<uint32_t>(), stream_of(h), in->background, vpixels,
-                                 h->n_contrib.as<uint32_t>(), h->final_T.as<float>(), inst_of(h));
+    if (h->last_D > 0 && (rc = launch_composite_bwd(h, s, C, k, in->background, vpixels))) return rc;
     h->prof.end(s);
     h->prof.begin(ST_PERGAUSS_BWD, s);
     gsr_launch_pergauss_bwd(s, n, in->n_coeffs, in->sh_degree, C, in->means, in->scales, in->rotations, in->shs, k,
@@ -815,9 +855,7 @@ int gsr_backward_trainer_tail(gsr_handle* h, const gsr_inputs* in, const gsr_cam
     h->vmean2d_cur = st->vmeans2d ? reinterpret_cast<float2*>(st->vmeans2d) : h->vmean2d.as<float2>();
     GsrCam k = make_cam(h, cam);
     h->prof.begin(ST_COMPOSITE_BWD, s);
-    if (h->last_D > 0)
-        gsr_launch_composite_bwd(s, C, k, h->tile_start.as<uint32_t>(), h->tile_order.as<uint32_t>(), stream_of(h), in->background, vpixels,
-                                 h->n_contrib.as<uint32_t>(), h->final_T.as<float>(), inst_of(h));
+    if (h->last_D > 0 && (rc = launch_composite_bwd(h, s, C, k, in->background, vpixels))) return rc;
     h->prof.end(s);
     h->prof.begin(ST_PERGAUSS_BWD, s);
     const gsr::TailState S = gsr_make_tail_state(st->theta, st->mu, st->nu, lr_t, st->beta1, st->beta2, st->eps,

@@ -115,10 +115,22 @@ void gsr_launch_composite_fwd(hipStream_t s, int channels, GsrCam cam, const uin
                               const uint32_t* tile_order, GsrStream stream,
                               const float* background, float* image, uint32_t* n_contrib, float* final_T,
                               const uint32_t* values_sorted, uint8_t* covis, float* uncert);
+// Tiles whose list is longer than split_len (a tier boundary of the scan: 1024, 4096, 8192, or 0xFFFFFFFF for none)
+// are left out by gsr_launch_composite_bwd and walked by four waves each (one 16x4 pixel strip per wave) in the
+// listed launch, on a second stream.
+struct GsrTierLists {  // the scan's tier lists: [0, T) lists > 8192, [T, 2T) (4096, 8192], [2T, 3T) (1024, 4096]
+    const uint32_t* lists;
+    uint32_t n_tiles, n_big, n_mid8, n_mid4;  // a tier that is not split has count 0 here
+    uint32_t split_len;
+};
 void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
                               const uint32_t* tile_order, GsrStream stream,
                               const float* background, const float* vpixels, const uint32_t* n_contrib,
-                              const float* final_T, GsrInst inst);
+                              const float* final_T, GsrInst inst,
+                              uint32_t split_len /* tiles with a longer list are left to the listed launch */);
+void gsr_launch_composite_bwd_listed(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
+                                     GsrTierLists tiers, GsrStream stream, const float* background,
+                                     const float* vpixels, const uint32_t* n_contrib, const float* final_T, GsrInst inst);
 
 // ---- trainer.hip ----
 #define GSR_ADAM_MAX_GROUPS 8

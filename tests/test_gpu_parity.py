@@ -685,3 +685,42 @@ def test_early_sort_pass_hits_and_misses_give_the_same_result(pkg):
             assert torch.equal(x, y)
         seen.append(a[2])
     assert seen[1] < 1.25 * seen[0] < seen[2] and seen[3] < seen[0]   # the sequence did exercise hit / miss / hit
+
+
+@pytest.mark.parametrize("mode,n_hot", [("rgb", 1500), ("rgb", 5000), ("rgbd", 2200), ("rgbdn", 1300), ("rgb", 9000)])
+def test_backward_of_long_lists_runs_four_waves_per_tile_and_matches_the_oracle(pkg, orc, mode, n_hot):
+    """Tiles whose list exceeds 1024 instances are left out by the one-wave-per-tile backward and walked by four waves
+    each on the handle's second stream (all three tier lists here: (1024, 4096], (4096, 8192], > 8192), next to
+    ordinary tiles: gradients and gstate.∇means_2d equal the oracle's, and a second backward-capable step on the same
+    handle (no long tile any more) still does."""
+    W, H, deg, n = 96, 64, 1, 600
+    base = pkg.synthetic.make_scene(n, W, H, deg, 55, sigma_px=3.0)
+    rng = np.random.default_rng(56)
+    hot = pkg.synthetic.make_scene(n_hot, W, H, deg, 57, sigma_px=2.0)
+    # the extra Gaussians sit inside one tile (pixels 32..47 x 16..31), faint enough that deep ones still contribute
+    z = rng.uniform(2.0, 9.0, n_hot)
+    fx = base.focal[0]
+    u = rng.uniform(33.0, 46.0, n_hot) - W / 2.0
+    v = rng.uniform(17.0, 30.0, n_hot) - H / 2.0
+    hot.means[:] = np.stack([u * z / fx, v * z / base.focal[1], z], 1).astype(np.float32)
+    means = np.concatenate([base.means, hot.means]); shs = np.concatenate([base.shs, hot.shs])
+    opac = np.concatenate([base.opacities, np.full(n_hot, 0.004 + 40.0 / n_hot, np.float32)])
+    scales = np.concatenate([base.scales, hot.scales * 0.5]); rots = np.concatenate([base.rotations, hot.rotations])
+    cam = orc.Camera(W, H, base.focal)
+    bg = (0.2, 0.4, 0.1)
+    st = orc.forward(means, shs, opac, scales, rots, cam, deg, background=bg, mode=mode)
+    lens = st.ranges[:, 1].astype(np.int64) - st.ranges[:, 0]
+    assert lens.max() > 1024 and (lens > 0).sum() > 4 and np.median(lens[lens > 0]) < 1024
+    run = HipRun(pkg, means, shs, opac, scales, rots, cam, deg, bg, mode)
+    _compare_forward(st, run, run.forward())
+    vp = np.random.default_rng(58).standard_normal(st.image.shape).astype(np.float32)
+    g = orc.backward(st, vp, means, shs, opac, scales, rots, cam, deg, background=bg)
+    out = run.backward(vp)
+    _compare_backward(g, out, st.radii > 0)
+    assert rel_l2(run.rast.grad_means_2d.cpu().numpy(), g.vmeans2d) <= 1e-4
+    # same handle, an ordinary scene afterwards: nothing of the fork is left behind
+    st2 = orc.forward(base.means, base.shs, base.opacities, base.scales, base.rotations, cam, deg, background=bg, mode=mode)
+    run.t = [dev(base.means), dev(base.shs), dev(base.opacities.reshape(-1, 1)), dev(base.scales), dev(base.rotations)]
+    _compare_forward(st2, run, run.forward())
+    g2 = orc.backward(st2, vp, base.means, base.shs, base.opacities, base.scales, base.rotations, cam, deg, background=bg)
+    _compare_backward(g2, run.backward(vp), st2.radii > 0)

@@ -724,3 +724,27 @@ def test_backward_of_long_lists_runs_four_waves_per_tile_and_matches_the_oracle(
     _compare_forward(st2, run, run.forward())
     g2 = orc.backward(st2, vp, base.means, base.shs, base.opacities, base.scales, base.rotations, cam, deg, background=bg)
     _compare_backward(g2, run.backward(vp), st2.radii > 0)
+
+
+def test_profile_intervals_are_the_launch_to_launch_times_of_a_stage(pkg):
+    """gsr_profile_read_intervals: K launches of a stage give K-1 begin-to-begin intervals (bench.py's per-step times),
+    each at least as long as the stage itself; unknown stages are refused."""
+    W, H, deg, n = 128, 96, 1, 800
+    s = pkg.synthetic.make_scene(n, W, H, deg, 91, sigma_px=4.0)
+    cam = pkg.Camera(W, H, tuple(s.focal))
+    t = [dev(s.means), dev(s.shs), dev(s.opacities.reshape(-1, 1)), dev(s.scales), dev(s.rotations)]
+    rast = pkg.rasterizer.GaussianRasterizer(W, H, mode="rgb")
+    vp = torch.ones(H, W, 3, device="cuda")
+    rast.profile(True, stages=["composite_bwd"])
+    for _ in range(4):
+        rast.forward_raw(*t, cam, deg, (0, 0, 0))
+        rast.backward_raw(vp, *t, cam, deg, (0, 0, 0))
+    torch.cuda.synchronize()
+    iv = rast.profile_intervals("composite_bwd")
+    prof = rast.profile_read()
+    assert len(iv) == 3 and prof["composite_bwd"][1] == 4 and prof["composite_fwd"][1] == 0
+    assert all(x > 0 for x in iv) and min(iv) >= 0.5 * prof["composite_bwd"][0] / 4
+    assert rast.profile_intervals("composite_fwd") == []
+    with pytest.raises(ValueError):
+        rast.profile_intervals("no_such_stage")
+    rast.profile(False)

@@ -996,30 +996,48 @@ __global__ __launch_bounds__(256) void sh_grad_views_kernel(int n, int K, int n_
                                                             const float* __restrict__ vc_all,
                                                             float* __restrict__ vshs) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
     constexpr int NB = (DEG + 1) * (DEG + 1);
     float acc[3 * NB];
 #pragma unroll
     for (int k = 0; k < 3 * NB; k++) acc[k] = 0.0f;
-    const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
-    for (int v = 0; v < n_views; v++) {
-        const float* vcp = vc_all + ((size_t)v * n + i) * 3;
-        const float vc[3] = {vcp[0], vcp[1], vcp[2]};
-        if (vc[0] == 0.0f && vc[1] == 0.0f && vc[2] == 0.0f) continue;  // culled in this view (or zero cotangent)
-        float d0[3] = {p[0] - centers[3 * v], p[1] - centers[3 * v + 1], p[2] - centers[3 * v + 2]};
-        float inv = 1.0f / sqrtf(d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2]);
-        const float dir[3] = {d0[0] * inv, d0[1] * inv, d0[2] * inv};
-        float b[16];
-        sh_basis<DEG>(dir, b);
+    if (i < n) {
+        const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+        for (int v = 0; v < n_views; v++) {
+            const float* vcp = vc_all + ((size_t)v * n + i) * 3;
+            const float vc[3] = {vcp[0], vcp[1], vcp[2]};
+            if (vc[0] == 0.0f && vc[1] == 0.0f && vc[2] == 0.0f) continue;  // culled in this view (or zero cotangent)
+            float d0[3] = {p[0] - centers[3 * v], p[1] - centers[3 * v + 1], p[2] - centers[3 * v + 2]};
+            float inv = 1.0f / sqrtf(d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2]);
+            const float dir[3] = {d0[0] * inv, d0[1] * inv, d0[2] * inv};
+            float b[16];
+            sh_basis<DEG>(dir, b);
 #pragma unroll
-        for (int k = 0; k < NB; k++)
+            for (int k = 0; k < NB; k++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) acc[3 * k + c] = acc[3 * k + c] + b[k] * vc[c];
+                for (int c = 0; c < 3; c++) acc[3 * k + c] = acc[3 * k + c] + b[k] * vc[c];
+        }
     }
-    float* vsh = vshs + (size_t)3 * K * i;
+    // The rows leave through LDS: a lane's 3K floats are 12K bytes apart from its neighbour's, so storing them
+    // directly is 3K store instructions of 64 different cache lines each; the workgroup's slice is contiguous and
+    // goes out as coalesced float4 (same lesson as pergauss_bwd's ∇shs store).
+    __shared__ float stage[256 * (3 * NB + 1)];  // odd stride: conflict-free
+    constexpr int ST = 3 * NB + 1;
 #pragma unroll
-    for (int k = 0; k < 3 * NB; k++) vsh[k] = acc[k];
-    for (int k = 3 * NB; k < 3 * K; k++) vsh[k] = 0.0f;
+    for (int k = 0; k < 3 * NB; k++) stage[threadIdx.x * ST + k] = acc[k];
+    __syncthreads();
+    const int i0 = blockIdx.x * 256, cnt = min(256, n - i0), K3 = 3 * K;
+    float* __restrict__ dst = vshs + (size_t)i0 * K3;
+    const int total = cnt * K3;
+    const uint32_t inv = (1u << 20) / (uint32_t)K3 + 1u;  // e / K3 == (e * inv) >> 20 for e < 2^20 / K3 (K3 <= 48, e < 256 K3)
+    auto value = [&](int e) {
+        const int il = (int)(((uint32_t)e * inv) >> 20);
+        const int j = e - il * K3;
+        return j < 3 * NB ? stage[il * ST + j] : 0.0f;  // bands above the active degree: zeros
+    };
+    const int total4 = (((uintptr_t)dst & 15) == 0) ? total >> 2 : 0;
+    for (int f = threadIdx.x; f < total4; f += 256)
+        reinterpret_cast<float4*>(dst)[f] = make_float4(value(4 * f), value(4 * f + 1), value(4 * f + 2), value(4 * f + 3));
+    for (int e = 4 * total4 + threadIdx.x; e < total; e += 256) dst[e] = value(e);
 }
 
 // _update_stats! (src/strategy.jl:118-136): densification statistics from the side outputs of

@@ -270,15 +270,11 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(Src src, int W, int H, co
             float* o = out + (size_t)outC * ((size_t)px + (size_t)W * py) + (size_t)blockIdx.z * NCH;
 #pragma unroll
             for (int ch = 0; ch < NCH; ch++) o[ch] = gout[ch];  // adjacent floats of one pixel
+            // the loss head only sees features[1:3]: the other channels of vpixels (C > 3) get their zeros here, with
+            // the pixel's colour cotangent (a launch of its own for them was 17 us in :rgbd mode)
+            for (int c = NCH; c < outC; c++) o[c] = 0.0f;
         }
     }
-}
-
-// zero the non-RGB channels of vpixels (C > 3): the loss head only sees features[1:3]
-__global__ void zero_extra_channels_kernel(float* __restrict__ vpixels, int C, size_t P) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    for (int c = 3; c < C; c++) vpixels[(size_t)C * i + c] = 0.0f;
 }
 
 }  // namespace
@@ -315,10 +311,6 @@ void gsr_launch_loss_bwd(hipStream_t s, int W, int H, int C, const float* image,
     RasterSrc src{image, target, W, H, C};
     const float count = 3.0f * (float)W * (float)H;
     const float inv_count = 1.0f / count;
-    if (C > 3) {
-        const size_t P = (size_t)W * H;
-        hipLaunchKernelGGL(zero_extra_channels_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, vpixels, C, P);
-    }
     dim3 g = ssim_grid(W, H, 1);
     const int n_partial = (int)(g.x * g.y * g.z);  // one pair per workgroup of the forward launch
     g.x += 1;                                      // + the workgroup that finishes the scalar loss

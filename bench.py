@@ -57,6 +57,8 @@ def algorithmic_bytes(stage, N, V, D, P, T, C=3, K=16):
         "scatter": 0,  # (stage of earlier builds; now part of preprocess)
         "tile_sort": 12 * D + 12 * D + 8 * D + 8 * T,
         "composite_fwd": (28 + 4 * C) * D + 8 * T + (4 * C + 8) * P,
+        # the fused launch does the work of both stages (the stream is still written once and read once)
+        "sort_composite_fwd": 12 * D + 12 * D + 8 * D + 8 * T + (28 + 4 * C) * D + 8 * T + (4 * C + 8) * P,
         "composite_bwd": (4 * C + 8) * P + 8 * T + (28 + 4 * C) * D + 4 * (C + 6) * D,
         "pergauss_bwd": 4 * N + (87 + 12 * K) * V + (44 + 12 * K) * N,
         "zero_acc": 48,  # pose-gradient accumulators only (when requested)

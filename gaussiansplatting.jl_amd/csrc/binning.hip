@@ -19,8 +19,12 @@
 #include <cstdlib>
 #include "gsr_kernels.h"
 #include "tile_mask.h"
+#include "tile_sort_device.h"
 
 namespace {
+
+using gsr_sort::emit_instance;
+using gsr_sort::wave_sort_and_emit;
 
 // ---- single-workgroup scans (T = 8160 tiles at 1080p, 32400 at 4K; N/256 Gaussian blocks) ----
 // Each thread owns a CONTIGUOUS chunk of ceil(n/1024) elements: serial sum, one block-wide
@@ -243,34 +247,6 @@ __device__ __forceinline__ void bitonic_sort(uint64_t* buf, uint32_t m, int tid,
     }
 }
 
-// Load the tile's keys into `buf` (padded to a power of two with +inf), sort, and emit the
-// sorted ids + the packed splat stream.  Instantiated once on the LDS array and once on a
-// global slab so each copy uses ds_* / global_* instructions (no flat addressing).
-template <int CH>
-__device__ __forceinline__ void emit_instance(uint64_t k, uint32_t pos, int X0, int Y0, const GsrGeom& geom,
-                                              const GsrStream& stream, uint32_t* __restrict__ values_sorted) {
-    {
-        const uint32_t i = pos, start = 0;
-        const uint32_t id = (uint32_t)k;
-        values_sorted[start + i] = id;
-        const GsrGeoRec rec = geom.rec[id];  // one 64-byte line per gather
-        // the compositing kernels evaluate sigma = b·dx·dy + (a/2)·dx² + (c/2)·dy²: the stream carries the halves
-        stream.s0[start + i] = make_float4(rec.q0.x, rec.q0.y, 0.5f * rec.q0.z, rec.q0.w);
-        stream.s1[start + i] = make_float4(0.5f * rec.q1.x, rec.q1.y, rec.q1.z, rec.q1.w);
-        // Gaussian-major slot of this instance: offset of the Gaussian's rect (cumsum of
-        // tiles_touched, rasterizer.jl:333-335) + row-major rank of the tile inside the rect (the
-        // emit order of duplicate_with_keys!, utils.jl:112).  The backward writes the instance's
-        // gradient row there, so a Gaussian's rows are contiguous for the per-Gaussian sum.
-        const uint32_t lo = __float_as_uint(rec.q3.x), hi = __float_as_uint(rec.q3.y);
-        const uint32_t x0 = lo & 0xFFFFu, y0 = lo >> 16, x1 = hi & 0xFFFFu;
-        const uint32_t slot = geom.bpre[id >> 8] + __float_as_uint(rec.q2.w) +
-                              ((uint32_t)(Y0 / GSR_TILE) - y0) * (x1 - x0) + ((uint32_t)(X0 / GSR_TILE) - x0);
-        const uint32_t mask_bits = instance_row_mask(rec.q0, rec.q1, X0, Y0);
-        stream.s2[start + i] = make_float4(rec.q2.x, __uint_as_float(slot), rec.q2.z, __uint_as_float(mask_bits));
-        if (CH > 5) stream.s3[start + i] = geom.normal[id];
-    }
-}
-
 template <int CH, int NT>
 __device__ __forceinline__ void sort_and_emit(uint64_t* buf, uint32_t m, uint32_t n, uint32_t start, int tid,
                                               int X0, int Y0,
@@ -305,69 +281,7 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint32_t* __restric
     sort_and_emit<CH, NT>(skeys, m, n, start, tid, X0, Y0, keys, geom, stream, values_sorted);
 }
 
-// ---- the main pass: ONE wave64 per tile, keys in registers ----
-// A list of up to 1024 keys (nearly every tile) is sorted by a single wave with KPT = m / 64 keys per lane
-// (element e = lane * KPT + r).  Of the bitonic network's stages, those with stride j < KPT are compare-exchanges
-// between two registers of one lane; the others exchange with lane ^ (j / KPT) through ds_bpermute — no LDS traffic
-// for the keys and not a single workgroup barrier (the 256-thread LDS network paid one per stage: 45 for m = 512).
-// Per tile at m = 512: ~1.3 k wave instructions instead of ~3.6 k.  Same total order (unique keys).
-__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int s) {
-    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, s), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), s);
-    return ((uint64_t)hi << 32) | lo;
-}
-template <int KPT>
-__device__ __forceinline__ void wave_bitonic_sort(uint64_t (&v)[KPT], uint32_t m, int lane) {
-    for (uint32_t k = 2; k <= m; k <<= 1) {
-        // stages across lanes: j = s * KPT, partner lane ^ s; all KPT keys of a lane play the same role
-        const bool up = ((uint32_t)(lane * KPT) & k) == 0u;  // k >= 2 KPT here
-        for (uint32_t j = k >> 1; j >= (uint32_t)KPT; j >>= 1) {
-            const int s = (int)(j / KPT);
-            const bool keep_min = ((lane & s) == 0) == up;
-#pragma unroll
-            for (int r = 0; r < KPT; r++) {
-                const uint64_t p = shfl_xor_u64(v[r], s);
-                v[r] = ((v[r] < p) == keep_min) ? v[r] : p;
-            }
-        }
-        // stages inside a lane: j = KPT/2 ... 1 (those not larger than k/2)
-#pragma unroll
-        for (int jj = KPT >> 1; jj >= 1; jj >>= 1) {
-            if ((uint32_t)jj <= (k >> 1)) {
-#pragma unroll
-                for (int r = 0; r < KPT; r++) {
-                    if ((r & jj) == 0) {
-                        const bool upr = (((uint32_t)(lane * KPT + r)) & k) == 0u;
-                        const uint64_t a = v[r], b = v[r | jj];
-                        const bool sw = (a > b) == upr;
-                        v[r] = sw ? b : a;
-                        v[r | jj] = sw ? a : b;
-                    }
-                }
-            }
-        }
-    }
-}
-
-template <int CH, int KPT>
-__device__ __forceinline__ void wave_sort_and_emit(uint32_t* ids /* LDS [1024] */, uint32_t n, uint32_t start, int lane,
-                                                   int X0, int Y0, const uint64_t* __restrict__ keys,
-                                                   const GsrGeom& geom, const GsrStream& stream,
-                                                   uint32_t* __restrict__ values_sorted) {
-    uint64_t v[KPT];
-#pragma unroll
-    for (int r = 0; r < KPT; r++) {
-        const uint32_t e = (uint32_t)(lane * KPT + r);
-        v[r] = e < n ? keys[e] : ~0ull;  // padded with +inf to m = 64 KPT
-    }
-    wave_bitonic_sort<KPT>(v, 64u * KPT, lane);
-    // only the id of a sorted key is needed from here on; through LDS so that the stream is written lane-contiguous
-#pragma unroll
-    for (int r = 0; r < KPT; r++) ids[lane * KPT + r] = (uint32_t)v[r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t i = lane; i < n; i += 64) emit_instance<CH>((uint64_t)ids[i], start + i, X0, Y0, geom, stream, values_sorted);
-}
-
+// ---- the main pass: ONE wave64 per tile, keys in registers (tile_sort_device.h) ----
 template <int CH>
 __global__ __launch_bounds__(64) void tile_sort_wave_kernel(const uint32_t* __restrict__ tile_start,
                                                             uint32_t* __restrict__ tile_count,
@@ -400,13 +314,7 @@ __global__ __launch_bounds__(64) void tile_sort_wave_kernel(const uint32_t* __re
     if (n == 0 || n > 1024u) return;  // a longer list: a tier launch's tile
     const int X0 = (tile % grid_x) * GSR_TILE, Y0 = (tile / grid_x) * GSR_TILE;
     const uint64_t* __restrict__ keys = bin_cap ? bins + (size_t)tile * bin_cap : bins + start;
-#define GSR_WAVE_SORT(K) wave_sort_and_emit<CH, K>(ids, n, start, lane, X0, Y0, keys, geom, stream, values_sorted)
-    if (n <= 64u) GSR_WAVE_SORT(1);
-    else if (n <= 128u) GSR_WAVE_SORT(2);
-    else if (n <= 256u) GSR_WAVE_SORT(4);
-    else if (n <= 512u) GSR_WAVE_SORT(8);
-    else GSR_WAVE_SORT(16);
-#undef GSR_WAVE_SORT
+    wave_sort_and_emit<CH>(ids, n, start, lane, X0, Y0, keys, geom, stream, values_sorted);
 }
 
 // ---- lists beyond the LDS capacity: chunked LDS sort + merge passes (one 1024-thread workgroup per listed tile) ----

@@ -16,6 +16,7 @@
 // workgroup as plain stores; the per-Gaussian kernel sums a Gaussian's rows.
 #include "gsr_kernels.h"
 #include "wave_reduce.h"
+#include "tile_sort_device.h"
 
 namespace {
 
@@ -53,27 +54,16 @@ __device__ __forceinline__ void unpack_features(const float4& s1, const float4& 
 // square footprint is visited by 9.5 % fewer splats than a 16x4 strip).  No workgroup barriers, a strip stops as soon as ITS pixels have
 // saturated, and a wave stages only the splats its quadrant-mask ballot selected (the four quadrants
 // re-read the tile's stream through L2).  Same per-pixel arithmetic in the same order.
+// The body of one quadrant wave (l0..l3: its 64-entry LDS staging arrays), shared by the stand-alone forward kernel
+// and the fused sort + forward kernel.
 template <int C, bool AUX>
-__global__ __launch_bounds__(64) void composite_fwd_strip_kernel(int W, int H, int grid_x,
-                                                                 const uint32_t* __restrict__ tile_start,
-                                                                 const uint32_t* __restrict__ tile_order,
-                                                                 GsrStream stream, Bg bg, float* __restrict__ image,
-                                                                 uint32_t* __restrict__ n_contrib,
-                                                                 float* __restrict__ final_T,
-                                                                 const uint32_t* __restrict__ values_sorted,
-                                                                 uint8_t* __restrict__ covis,
-                                                                 float* __restrict__ uncert) {
-    __shared__ float4 l0[64], l1[64], l2[64];
-    __shared__ float4 l3[C > 5 ? 64 : 1];
-    const int lane = threadIdx.x;
-    // 1-D grid, workgroup id -> (launch slot, strip).  Workgroups are dealt round-robin to the 8
-    // XCDs (each with its own L2): the 4 strips of a tile get ids that are equal mod 8, so a tile's
-    // splat stream is fetched into ONE L2; slots follow tile_order (longest lists first).
-    const int id = blockIdx.x, k = id >> 3;
-    const int quad = k & 3;  // 8x8 quadrant (qx = quad & 1, qy = quad >> 1) of the tile
-    const int slot = ((k >> 2) << 3) | (id & 7);
-    if (slot >= grid_x * ((H + GSR_TILE - 1) / GSR_TILE)) return;
-    const int tile = (int)tile_order[slot];
+__device__ __forceinline__ void composite_fwd_quadrant(int W, int H, int grid_x, int tile, int quad, int lane,
+                                                       const uint32_t* __restrict__ tile_start, GsrStream stream,
+                                                       const Bg& bg, float* __restrict__ image,
+                                                       uint32_t* __restrict__ n_contrib, float* __restrict__ final_T,
+                                                       const uint32_t* __restrict__ values_sorted,
+                                                       uint8_t* __restrict__ covis, float* __restrict__ uncert,
+                                                       float4* l0, float4* l1, float4* l2, float4* l3) {
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
     const uint32_t strip_bits = 0x10000u << quad;  // the instance's quadrant bit (tile_mask.h)
     const int px = tile_x * GSR_TILE + 8 * (quad & 1) + (lane & 7), py = tile_y * GSR_TILE + 8 * (quad >> 1) + (lane >> 3);
@@ -157,6 +147,94 @@ __global__ __launch_bounds__(64) void composite_fwd_strip_kernel(int W, int H, i
         for (int c = 0; c < C; c++) image[(size_t)C * pi + c] = color[c] + T * bg.v[c];
         if (AUX && uncert) uncert[pi] = unc;
     }
+}
+
+template <int C, bool AUX>
+__global__ __launch_bounds__(64) void composite_fwd_strip_kernel(int W, int H, int grid_x,
+                                                                 const uint32_t* __restrict__ tile_start,
+                                                                 const uint32_t* __restrict__ tile_order,
+                                                                 GsrStream stream, Bg bg, float* __restrict__ image,
+                                                                 uint32_t* __restrict__ n_contrib,
+                                                                 float* __restrict__ final_T,
+                                                                 const uint32_t* __restrict__ values_sorted,
+                                                                 uint8_t* __restrict__ covis,
+                                                                 float* __restrict__ uncert, GsrTierLists tiers) {
+    __shared__ float4 l0[64], l1[64], l2[64];
+    __shared__ float4 l3[C > 5 ? 64 : 1];
+    // 1-D grid, workgroup id -> (launch slot, strip).  Workgroups are dealt round-robin to the 8
+    // XCDs (each with its own L2): the 4 strips of a tile get ids that are equal mod 8, so a tile's
+    // splat stream is fetched into ONE L2; slots follow tile_order (longest lists first).
+    const int id = blockIdx.x, k = id >> 3;
+    const int quad = k & 3;  // 8x8 quadrant (qx = quad & 1, qy = quad >> 1) of the tile
+    const int slot = ((k >> 2) << 3) | (id & 7);
+    int tile;
+    if (tile_order) {  // every tile, in launch order
+        if (slot >= grid_x * ((H + GSR_TILE - 1) / GSR_TILE)) return;
+        tile = (int)tile_order[slot];
+    } else {           // only the tiles of the scan's tier lists (the fused kernel did the others), longest tier first
+        uint32_t b = (uint32_t)slot;
+        if (b >= tiers.n_big + tiers.n_mid8 + tiers.n_mid4) return;
+        const uint32_t* list = tiers.lists;
+        if (b >= tiers.n_big) { b -= tiers.n_big; list = tiers.lists + tiers.n_tiles;
+            if (b >= tiers.n_mid8) { b -= tiers.n_mid8; list = tiers.lists + 2 * (size_t)tiers.n_tiles; } }
+        tile = (int)list[b];
+    }
+    composite_fwd_quadrant<C, AUX>(W, H, grid_x, tile, quad, (int)threadIdx.x, tile_start, stream, bg, image,
+                                   n_contrib, final_T, values_sorted, covis, uncert, l0, l1, l2, l3);
+}
+
+// Sort + forward of a tile in ONE workgroup (fixed-capacity bins; a tile with more than 1024 instances is left to the
+// tier sorts and a forward launch over the tier lists).
+// Wave 0 sorts the tile's keys in registers, all four waves emit the sorted instances (record gather -> stream), then
+// each wave composites its 8x8 quadrant from the stream the workgroup has just written (L2-hot).  tile_sort alone is
+// bound by HBM (gather + stream write at 4.8 TB/s) and the compositing alone by VALU issue; as two launches they run one
+// after the other — as phases of independent workgroups they share the CU at the same time.  Launched BEFORE the host
+// has read the scan's totals, like the sort's main pass was: every workgroup checks the totals against the capacity
+// of the buffers and leaves everything untouched when this view needs more (the host then runs the separate sort
+// and forward launches).
+template <int C, bool AUX>
+// (8 waves per SIMD: the sort needs 66 VGPRs left to itself; at 64 it does not spill and an eighth workgroup fits the CU)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void sort_composite_fwd_kernel(int W, int H, int grid_x,
+                                                                 const uint32_t* __restrict__ tile_start,
+                                                                 const uint32_t* __restrict__ tile_order,
+                                                                 uint32_t* __restrict__ tile_count,
+                                                                 const uint64_t* __restrict__ bins, uint32_t bin_cap,
+                                                                 GsrGeom geom, GsrStream stream, Bg bg,
+                                                                 float* __restrict__ image,
+                                                                 uint32_t* __restrict__ n_contrib,
+                                                                 float* __restrict__ final_T,
+                                                                 uint32_t* __restrict__ values_sorted,
+                                                                 uint32_t* __restrict__ ranges,
+                                                                 uint8_t* __restrict__ covis, float* __restrict__ uncert,
+                                                                 const uint32_t* __restrict__ totals,
+                                                                 uint32_t cap_instances) {
+    __shared__ uint32_t ids[1024];
+    __shared__ float4 l0[4][64], l1[4][64], l2[4][64];
+    __shared__ float4 l3[C > 5 ? 4 : 1][C > 5 ? 64 : 1];
+    if (totals[0] > cap_instances || totals[1] > bin_cap) return;  // [0] instances, [1] longest list
+    const int tile = (int)tile_order[blockIdx.x];  // launch order: longest lists first
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
+    const uint32_t n = end - start;
+    if (tid == 0) {
+        tile_count[tile] = 0u;  // counter ready for the next view
+        // identify_tile_range! (utils.jl:56-78): empty tiles keep the (0,0) of the prior fill!
+        ranges[2 * tile] = n ? start : 0u;
+        ranges[2 * tile + 1] = n ? end : 0u;
+    }
+    if (n > 1024u) return;  // a tier launch's tile (sort and forward)
+    if (n > 0) {
+        const int X0 = (tile % grid_x) * GSR_TILE, Y0 = (tile / grid_x) * GSR_TILE;
+        if (wave == 0) gsr_sort::wave_sort_ids_any(ids, n, lane, bins + (size_t)tile * bin_cap);
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += 256) gsr_sort::emit_instance<C == 5 ? 3 : C>((uint64_t)ids[i], start + i, X0, Y0, geom, stream, values_sorted);
+        // the stream entries are read back by the other waves of this workgroup: stores complete, then the barrier
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    composite_fwd_quadrant<C, AUX>(W, H, grid_x, tile, wave, lane, tile_start, stream, bg, image, n_contrib, final_T,
+                                   values_sorted, covis, uncert, l0[wave], l1[wave], l2[wave], l3[C > 5 ? wave : 0]);
 }
 
 // ---------------------------------------------------------------------------------
@@ -451,14 +529,35 @@ Bg make_bg(const float* background, int channels) {
 void gsr_launch_composite_fwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
                               const uint32_t* tile_order, GsrStream stream, const float* background, float* image,
                               uint32_t* n_contrib, float* final_T, const uint32_t* values_sorted, uint8_t* covis,
-                              float* uncert) {
-    const int n_tiles = cam.grid_x * cam.grid_y;
-    dim3 grid(32 * ((n_tiles + 7) / 8)), block(64);  // 8 XCD lanes x 4 strips per launch slot
+                              float* uncert, const GsrTierLists* listed) {
+    // tile_order == NULL: only the tiles of *listed
+    const int n_slots = tile_order ? cam.grid_x * cam.grid_y : (int)(listed->n_big + listed->n_mid8 + listed->n_mid4);
+    if (n_slots <= 0) return;
+    dim3 grid(32 * ((n_slots + 7) / 8)), block(64);  // 8 XCD lanes x 4 strips per launch slot
+    Bg bg = make_bg(background, channels);
+    const bool aux = covis || uncert;
+    const GsrTierLists tiers = listed ? *listed : GsrTierLists{};
+#define LAUNCH(CC, AA)                                                                                             \
+    hipLaunchKernelGGL((composite_fwd_strip_kernel<CC, AA>), grid, block, 0, s, cam.width, cam.height, cam.grid_x, \
+                       tile_start, tile_order, stream, bg, image, n_contrib, final_T, values_sorted, covis, uncert, tiers)
+    if (channels == 3) { if (aux) LAUNCH(3, true); else LAUNCH(3, false); }
+    else if (channels == 5) { if (aux) LAUNCH(5, true); else LAUNCH(5, false); }
+    else { if (aux) LAUNCH(8, true); else LAUNCH(8, false); }
+#undef LAUNCH
+}
+
+void gsr_launch_sort_composite_fwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
+                                   const uint32_t* tile_order, uint32_t* tile_count, const uint64_t* bins, uint32_t bin_cap,
+                                   GsrGeom geom, GsrStream stream, const float* background, float* image,
+                                   uint32_t* n_contrib, float* final_T, uint32_t* values_sorted, uint32_t* ranges,
+                                   uint8_t* covis, float* uncert, const uint32_t* totals, uint32_t cap_instances) {
+    dim3 grid(cam.grid_x * cam.grid_y), block(256);
     Bg bg = make_bg(background, channels);
     const bool aux = covis || uncert;
 #define LAUNCH(CC, AA)                                                                                             \
-    hipLaunchKernelGGL((composite_fwd_strip_kernel<CC, AA>), grid, block, 0, s, cam.width, cam.height, cam.grid_x, \
-                       tile_start, tile_order, stream, bg, image, n_contrib, final_T, values_sorted, covis, uncert)
+    hipLaunchKernelGGL((sort_composite_fwd_kernel<CC, AA>), grid, block, 0, s, cam.width, cam.height, cam.grid_x,  \
+                       tile_start, tile_order, tile_count, bins, bin_cap, geom, stream, bg, image, n_contrib,      \
+                       final_T, values_sorted, ranges, covis, uncert, totals, cap_instances)
     if (channels == 3) { if (aux) LAUNCH(3, true); else LAUNCH(3, false); }
     else if (channels == 5) { if (aux) LAUNCH(5, true); else LAUNCH(5, false); }
     else { if (aux) LAUNCH(8, true); else LAUNCH(8, false); }

@@ -69,9 +69,12 @@ struct DevBuf {
 
 // Optional per-stage timing with HIP events on the caller's stream (gsr_profile_*).
 enum Stage { ST_PREPROCESS, ST_SCAN, ST_SORT, ST_COMPOSITE_FWD, ST_LOSS_FWD, ST_LOSS_BWD, ST_ZERO_ACC,
-             ST_COMPOSITE_BWD, ST_PERGAUSS_BWD, ST_COUNT };
+             ST_COMPOSITE_BWD, ST_PERGAUSS_BWD, ST_SORT_COMPOSITE_FWD, ST_COUNT };
+// "sort_composite_fwd": the fused launch (sort + forward of every tile of up to 1024 instances); "tile_sort" and
+// "composite_fwd" then only hold the tier launches of longer lists, or the whole passes when the fused launch does not apply
 const char* const kStageNames[ST_COUNT] = {"preprocess", "tile_scan", "tile_sort", "composite_fwd",
-                                           "loss_fwd", "loss_bwd", "zero_acc", "composite_bwd", "pergauss_bwd"};
+                                           "loss_fwd", "loss_bwd", "zero_acc", "composite_bwd", "pergauss_bwd",
+                                           "sort_composite_fwd"};
 // roctx ranges per stage: resolved lazily from the ROCm tools library, only when asked for
 // (GSR_ROCTX=1 in the environment, or gsr_profile_enable(h, 2 | ...)); rocprofv3 --marker-trace then
 // slices the kernel trace by stage without kernel-name matching.
@@ -410,19 +413,24 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     HIPCHK(hipGetLastError());
     // the one host sync of the path: instance count D (reference: rasterizer.jl:337).  tile_scan stores the totals
     // and then this forward's sequence number into pinned host memory; no copy packet, no event on the stream.
-    // The sort's main pass (lists of up to 1024 keys: nearly every tile) goes out BEHIND the scan without waiting for
-    // the host: its buffers have a capacity from earlier views (grow-only, 25 % slack), and the kernel itself checks
-    // the scan's totals against it.  The host's wait below then overlaps the sort instead of idling the GPU.
+    // Sort + forward of every tile of up to 1024 instances (nearly all of them) go out BEHIND the scan, as ONE launch,
+    // without waiting for the host: the buffers have a capacity from earlier views (grow-only, 25 % slack), and the
+    // kernel itself checks the scan's totals against it.  The host's wait below then overlaps that launch instead of
+    // idling the GPU, and inside it the HBM-bound sort of one tile shares the CU with the VALU-bound compositing of others.
     uint64_t cap_instances = std::min(std::min(h->values_sorted.cap / 4, h->s0.cap / 16), std::min(h->s1.cap / 16, h->s2.cap / 16));
     if (C > 5) cap_instances = std::min<uint64_t>(cap_instances, h->s3.cap / 16);
     cap_instances = std::min<uint64_t>(cap_instances, 0xFFFFFFFFull);
-    const bool spec = use_bins && cap_instances > 0;
+    static const bool no_fused = [] { const char* e = getenv("GSR_NO_FUSED_FWD"); return e && e[0] == '1'; }();  // A/B only
+    const bool spec = use_bins && cap_instances > 0 && !no_fused;
     if (spec) {
-        h->prof.begin(ST_SORT, s);
-        gsr_launch_tile_sort(s, GSR_SORT_PASS_MAIN, h->n_tiles, h->grid_x, C, h->tile_start.as<uint32_t>(),
-                             h->tile_count.as<uint32_t>(), h->bins.as<uint64_t>(), h->bin_cap_view, 0, 0, 0,
-                             h->big_list.as<uint32_t>(), nullptr, 0, geom_of(h), stream_of(h),
-                             h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>(), totals, (uint32_t)cap_instances);
+        h->prof.begin(ST_SORT_COMPOSITE_FWD, s);
+        gsr_launch_sort_composite_fwd(s, C, k, h->tile_start.as<uint32_t>(), h->tile_order.as<uint32_t>(),
+                                      h->tile_count.as<uint32_t>(), h->bins.as<uint64_t>(), h->bin_cap_view, geom_of(h),
+                                      stream_of(h), in->background, image_out, h->n_contrib.as<uint32_t>(),
+                                      h->final_T.as<float>(), h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>(),
+                                      aux ? aux->covisibilities : nullptr, aux ? aux->uncertainties : nullptr, totals,
+                                      (uint32_t)cap_instances);
+        h->prof.end(s);
     }
     if ((rc = wait_totals(h, seq, s))) return rc;
     const bool overflow = use_bins && h->host_totals[1] > h->bin_cap_view;
@@ -452,10 +460,9 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
         stats->compact_binning = compact ? 1 : 0;
         stats->bins_bytes = (int64_t)(compact ? D * 8 : (uint64_t)(T + 1) * h->bin_cap_used(use_bins) * 8ull);
     }
-    // did the early main pass run?  (same two comparisons as in the kernel, on the same numbers)
-    const bool main_done = spec && !overflow && D <= cap_instances;
+    // did the early launch run?  (same two comparisons as in the kernel, on the same numbers)
+    const bool fused_done = spec && !overflow && D <= cap_instances;
     if (D == 0) {
-        if (spec) h->prof.end(s);
         h->tile_count_dirty = false;  // every counter is zero
         // rasterizer.jl:283,338: all-zero image, background not applied
         HIPCHK(hipMemsetAsync(image_out, 0, P * C * 4, s));
@@ -477,30 +484,37 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
         slab_stride = ((size_t)max_tile + 63) & ~(size_t)63;
         if ((rc = h->big_scratch.ensure((size_t)n_big * 2 * slab_stride * 8))) return rc;
     }
-    if (!spec) h->prof.begin(ST_SORT, s);
-    const uint64_t* keys = h->bins.as<uint64_t>();
-    uint32_t key_cap = h->bin_cap_used(use_bins);
-    if (compact) {
-        // count -> scan -> scatter: the counters become the fill cursors of the scatter pass
-        if ((rc = h->keys_compact.ensure(D * 8, slack))) return rc;
-        HIPCHK(hipMemsetAsync(h->tile_count.p, 0, (T + 2) * 4, s));
-        gsr_launch_emit_compact(s, n, k, geom_of(h), h->tile_start.as<uint32_t>(), h->tile_count.as<uint32_t>(),
-                                h->keys_compact.as<uint64_t>());
-        keys = h->keys_compact.as<uint64_t>();
-        key_cap = 0;
+    const uint32_t n_mid4 = h->host_totals[3], n_mid8 = h->host_totals[6];
+    const bool long_tiles = (n_mid4 | n_mid8 | n_big) != 0u;
+    if (!fused_done || long_tiles) {
+        h->prof.begin(ST_SORT, s);
+        const uint64_t* keys = h->bins.as<uint64_t>();
+        uint32_t key_cap = h->bin_cap_used(use_bins);
+        if (compact) {
+            // count -> scan -> scatter: the counters become the fill cursors of the scatter pass
+            if ((rc = h->keys_compact.ensure(D * 8, slack))) return rc;
+            HIPCHK(hipMemsetAsync(h->tile_count.p, 0, (T + 2) * 4, s));
+            gsr_launch_emit_compact(s, n, k, geom_of(h), h->tile_start.as<uint32_t>(), h->tile_count.as<uint32_t>(),
+                                    h->keys_compact.as<uint64_t>());
+            keys = h->keys_compact.as<uint64_t>();
+            key_cap = 0;
+        }
+        gsr_launch_tile_sort(s, (fused_done ? 0 : GSR_SORT_PASS_MAIN) | GSR_SORT_PASS_TIERS, h->n_tiles, h->grid_x, C,
+                             h->tile_start.as<uint32_t>(), h->tile_count.as<uint32_t>(), keys, key_cap,
+                             n_mid4, n_mid8, n_big, h->big_list.as<uint32_t>(), h->big_scratch.as<uint64_t>(),
+                             slab_stride, geom_of(h), stream_of(h), h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>(),
+                             nullptr, 0);
+        h->prof.end(s);
+        h->prof.begin(ST_COMPOSITE_FWD, s);
+        // after the fused launch only the tiles of the tier lists are left; otherwise every tile
+        const GsrTierLists tiers{h->big_list.as<uint32_t>(), (uint32_t)h->n_tiles, n_big, n_mid8, n_mid4, 0u};
+        gsr_launch_composite_fwd(s, C, k, h->tile_start.as<uint32_t>(), fused_done ? nullptr : h->tile_order.as<uint32_t>(),
+                                 stream_of(h), in->background, image_out, h->n_contrib.as<uint32_t>(), h->final_T.as<float>(),
+                                 h->values_sorted.as<uint32_t>(), aux ? aux->covisibilities : nullptr,
+                                 aux ? aux->uncertainties : nullptr, &tiers);
+        h->prof.end(s);
     }
-    gsr_launch_tile_sort(s, (main_done ? 0 : GSR_SORT_PASS_MAIN) | GSR_SORT_PASS_TIERS, h->n_tiles, h->grid_x, C,
-                         h->tile_start.as<uint32_t>(), h->tile_count.as<uint32_t>(), keys, key_cap,
-                         h->host_totals[3], h->host_totals[6], n_big, h->big_list.as<uint32_t>(), h->big_scratch.as<uint64_t>(),
-                         slab_stride, geom_of(h), stream_of(h), h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>(),
-                         nullptr, 0);
-    h->prof.end(s);
-    h->tile_count_dirty = false;  // tile_sort zeroed the counters
-    h->prof.begin(ST_COMPOSITE_FWD, s);
-    gsr_launch_composite_fwd(s, C, k, h->tile_start.as<uint32_t>(), h->tile_order.as<uint32_t>(), stream_of(h), in->background, image_out,
-                             h->n_contrib.as<uint32_t>(), h->final_T.as<float>(), h->values_sorted.as<uint32_t>(),
-                             aux ? aux->covisibilities : nullptr, aux ? aux->uncertainties : nullptr);
-    h->prof.end(s);
+    h->tile_count_dirty = false;  // the sort (fused or not) zeroed the counters
     HIPCHK(hipGetLastError());
     h->fwd_valid = true;
     return GSR_OK;

@@ -111,10 +111,6 @@ void gsr_launch_tile_sort(hipStream_t s, int passes, int n_tiles, int grid_x, in
                           uint32_t cap_instances);
 
 // ---- composite.hip ----
-void gsr_launch_composite_fwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
-                              const uint32_t* tile_order, GsrStream stream,
-                              const float* background, float* image, uint32_t* n_contrib, float* final_T,
-                              const uint32_t* values_sorted, uint8_t* covis, float* uncert);
 // Tiles whose list is longer than split_len (a tier boundary of the scan: 1024, 4096, 8192, or 0xFFFFFFFF for none)
 // are left out by gsr_launch_composite_bwd and walked by four waves each (one 16x4 pixel strip per wave) in the
 // listed launch, on a second stream.
@@ -123,6 +119,18 @@ struct GsrTierLists {  // the scan's tier lists: [0, T) lists > 8192, [T, 2T) (4
     uint32_t n_tiles, n_big, n_mid8, n_mid4;  // a tier that is not split has count 0 here
     uint32_t split_len;
 };
+void gsr_launch_composite_fwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
+                              const uint32_t* tile_order /* NULL: only the tiles of *listed */, GsrStream stream,
+                              const float* background, float* image, uint32_t* n_contrib, float* final_T,
+                              const uint32_t* values_sorted, uint8_t* covis, float* uncert,
+                              const GsrTierLists* listed /* or NULL */);
+// sort + forward of every tile in one launch (fixed-capacity bins, no list beyond 1024 instances; checked on the
+// device against the scan's totals — a view that does not qualify leaves everything untouched)
+void gsr_launch_sort_composite_fwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
+                                   const uint32_t* tile_order, uint32_t* tile_count, const uint64_t* bins, uint32_t bin_cap,
+                                   GsrGeom geom, GsrStream stream, const float* background, float* image,
+                                   uint32_t* n_contrib, float* final_T, uint32_t* values_sorted, uint32_t* ranges,
+                                   uint8_t* covis, float* uncert, const uint32_t* totals, uint32_t cap_instances);
 void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
                               const uint32_t* tile_order, GsrStream stream,
                               const float* background, const float* vpixels, const uint32_t* n_contrib,

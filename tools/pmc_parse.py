@@ -17,7 +17,7 @@ import json
 import os
 from collections import defaultdict
 
-STAGES = {"preprocess_kernel": "preprocess", "tile_scan_kernel": "tile_scan", "tile_sort_kernel": "tile_sort", "tile_sort_wave_kernel": "tile_sort",
+STAGES = {"preprocess_kernel": "preprocess", "tile_scan_kernel": "tile_scan", "sort_composite_fwd_kernel": "sort_composite_fwd", "tile_sort_kernel": "tile_sort", "tile_sort_wave_kernel": "tile_sort",
           "tile_count_kernel": "tile_sort", "tile_scatter_kernel": "tile_sort", "tile_radix": "tile_sort",
           "composite_fwd_": "composite_fwd", "composite_bwd_kernel": "composite_bwd",
           "pergauss_bwd_kernel": "pergauss_bwd", "ssim_fwd_kernel": "loss_fwd", "ssim_bwd_kernel": "loss_bwd"}

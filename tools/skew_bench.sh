@@ -17,5 +17,5 @@ for f in sorted(glob.glob(sys.argv[1] + "/skew_*.json")):
         print(f, "FAILED", e); continue
     st = d["roofline"]["stages_ms"]; b = d["config"]["binning"]
     print(f.split("/")[-1], "ms/step", d["ms_per_step"], "tile_sort", st.get("tile_sort"), "preprocess", st.get("preprocess"),
-          "composite_fwd", st.get("composite_fwd"), "composite_bwd", st.get("composite_bwd"), b)
+          "sort_composite_fwd", st.get("sort_composite_fwd"), "composite_fwd", st.get("composite_fwd"), "composite_bwd", st.get("composite_bwd"), b)
 PY

@@ -225,7 +225,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void s
     if (n > 1024u) return;  // a tier launch's tile (sort and forward)
     if (n > 0) {
         const int X0 = (tile % grid_x) * GSR_TILE, Y0 = (tile / grid_x) * GSR_TILE;
-        if (wave == 0) gsr_sort::wave_sort_ids_any(ids, n, lane, bins + (size_t)tile * bin_cap);
+        // (the sorting wave rotates with the workgroup id: wave w of every workgroup sits on SIMD w of its CU, and a fixed
+        // sorter would load one SIMD of four with all the sorting)
+        if (wave == (int)(blockIdx.x & 3u)) gsr_sort::wave_sort_ids_any(ids, n, lane, bins + (size_t)tile * bin_cap);
         __syncthreads();
         for (uint32_t i = tid; i < n; i += 256) gsr_sort::emit_instance<C == 5 ? 3 : C>((uint64_t)ids[i], start + i, X0, Y0, geom, stream, values_sorted);
         // the stream entries are read back by the other waves of this workgroup: stores complete, then the barrier

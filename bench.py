@@ -99,6 +99,10 @@ def main():
     ap.add_argument("--skew", default=None, metavar="KIND",
                     help="skewed variant of the synthetic scene (synthetic.add_skew): 'hot:K' = K extra Gaussians in ONE tile, "
                          "'dense:P:F' = a fraction P of the tiles at F x the mean density; reports tile_sort time and bins bytes")
+    ap.add_argument("--order", default="random", choices=["random", "morton"],
+                    help="order of the Gaussians in memory: 'random' = the synthetic scene as generated (the headline "
+                         "configuration); 'morton' = the same Gaussians sorted along a 3-D Z-order curve (what a caller "
+                         "could do at densification time) - reported, never the headline")
     ap.add_argument("--no-other-lists", action="store_true", help="skip the secondary timing of the other tile-list mode")
     args = ap.parse_args()
 
@@ -119,6 +123,8 @@ def main():
     s = pkg.synthetic.make_scene(N if args.ply is None else 16, W, H, deg, args.seed)
     if args.skew:
         s = pkg.synthetic.add_skew(s, args.skew, args.seed)
+    if args.order == "morton":
+        s = pkg.synthetic.reorder(s, pkg.synthetic.morton_order(s.means))
         N = s.n
     if args.ply is not None:
         gm = pkg.ply.import_ply(args.ply)
@@ -274,7 +280,8 @@ def main():
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
     # PMC-counted HBM bytes and VALU instructions per launch: only a measurement of EXACTLY this configuration
     # (tools/pmc_workload.py + tools/pmc_parse.py under rocprofv3 --pmc, committed per round) is reported
-    key = config_key(N, W, H, deg, args.mode, not args.reference_lists, not args.no_loss) if args.ply is None and not args.skew else None
+    key = (config_key(N, W, H, deg, args.mode, not args.reference_lists, not args.no_loss)
+           if args.ply is None and not args.skew and args.order == "random" else None)
     traffic, valu, pmc_src = None, None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if key is not None and os.path.exists(tpath) and not (tail is not None):
@@ -327,7 +334,8 @@ def main():
                                 f"ply scene {os.path.basename(args.ply)}: N={N} SH{deg} {W}x{H} fwd{'' if args.no_loss else '+loss'}+bwd"
                                 if args.ply is not None else
                                 f"N={N} SH{deg} {W}x{H} :{args.mode} fwd{'' if args.no_loss else '+loss'}+bwd"
-                                + (f" skew={args.skew}" if args.skew else "")),
+                                + (f" skew={args.skew}" if args.skew else "")
+                                + (" [Gaussians in Morton order: NOT the headline configuration]" if args.order == "morton" else "")),
                    "n_gaussians": N, "visible": V, "tile_instances": Dn, "views_per_gpu": 1,
                    "binning": {"mode": "compact (count -> scan -> scatter)" if rast.stats.compact_binning else "fixed-capacity bins",
                                "unsorted_key_bytes": int(rast.stats.bins_bytes), "longest_tile_list": int(rast.stats.max_tile_instances),

@@ -7,7 +7,7 @@ numpy only; no oracle, no torch.  Layouts are the reference's boundary layouts
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass
+from dataclasses import dataclass, replace
 
 import numpy as np
 
@@ -86,6 +86,26 @@ def make_vpixels(width: int, height: int, channels: int, seed: int) -> np.ndarra
     p = width * height
     g = np.random.default_rng(seed + 104729).standard_normal((height, width, channels))
     return (g / (channels * p)).astype(np.float32)
+
+
+def morton_order(means: np.ndarray, bits: int = 10) -> np.ndarray:
+    """Permutation that sorts points along a 3-D Morton (Z-order) curve: neighbours in the array are neighbours in space,
+    so the Gaussians of a wave project into the same few tiles whatever the camera.  What a caller would apply to the
+    parameters (and Adam moments) at densification time; the binning atomics of a wave then fall into a few cache lines
+    instead of 64 (tools/atomic_rates.hip: 129 vs 23 G atomics/s)."""
+    lo, hi = means.min(0), means.max(0)
+    q = np.clip(((means - lo) / np.maximum(hi - lo, 1e-30) * ((1 << bits) - 1)).astype(np.uint64), 0, (1 << bits) - 1)
+    code = np.zeros(means.shape[0], np.uint64)
+    for b in range(bits):
+        for d in range(3):
+            code |= ((q[:, d] >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + d)
+    return np.argsort(code, kind="stable")
+
+
+def reorder(scene: Scene, perm: np.ndarray) -> Scene:
+    """The same scene with its Gaussians permuted (every per-Gaussian array)."""
+    return replace(scene, means=scene.means[perm], scales_raw=scene.scales_raw[perm], rotations=scene.rotations[perm],
+                   opacities_raw=scene.opacities_raw[perm], shs=scene.shs[perm])
 
 
 def add_skew(scene: Scene, kind: str, seed: int = 7) -> Scene:

@@ -8,6 +8,18 @@
 
 __device__ __forceinline__ uint32_t mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 
+// lanes of a wave on CONSECUTIVE words (what a spatially ordered scene would give the binning atomics)
+__global__ __launch_bounds__(256) void atomics_coalesced_kernel(unsigned long long* words, uint32_t n_words, int rounds,
+                                                                unsigned long long* sink) {
+    const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long acc = 0;
+    for (int r = 0; r < rounds; r++) {
+        const uint32_t base = mix((tid >> 6) * 977u + (uint32_t)r * 0x9e3779b9u) % (n_words - 64u);
+        acc += atomicAdd(words + base + (tid & 63u), 1ull);
+    }
+    if (acc == 0xdeadbeefcafeull) sink[0] = acc;
+}
+
 template <int INFLIGHT>
 __global__ __launch_bounds__(256) void atomics_kernel(unsigned long long* words, uint32_t n_words, uint32_t stride_words,
                                                       int rounds, unsigned long long* sink) {
@@ -53,6 +65,13 @@ int main() {
             float ms; hipEventElapsedTime(&ms, a, b);
             if (rep == 2) printf("words %u stride %5u B: %.3f ms = %.1f G/s\n", nw, stride_bytes, ms, threads * (double)rounds * inflight / ms * 1e-6);
         }
+    }
+    for (int rep = 0; rep < 3; rep++) {
+        hipEventRecord(a);
+        atomics_coalesced_kernel<<<threads / 256, 256>>>(buf, 4080, 3, sink);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        if (rep == 2) printf("words 4080, lanes of a wave on 64 consecutive words: %.3f ms = %.1f G/s\n", ms, threads * 3.0 / ms * 1e-6);
     }
     return 0;
 }

@@ -7,6 +7,8 @@ import gsr_pkg
 pkg = gsr_pkg.load()
 W, H, N, deg = 1920, 1080, 1_000_000, 3
 s = pkg.synthetic.make_scene(N, W, H, deg, 1003)
+if os.environ.get("GSR_ORDER") == "morton":
+    s = pkg.synthetic.reorder(s, pkg.synthetic.morton_order(s.means))
 dev = torch.device("cuda:0")
 to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 t = [to(s.means), to(s.shs), to(s.opacities.reshape(-1, 1)), to(s.scales), to(s.rotations)]

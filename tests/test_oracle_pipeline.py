@@ -202,3 +202,20 @@ def test_partial_tiles_1080_rows(orc, pkg):
     st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, 1)
     assert st.ranges.shape[0] == 4 * 3 and st.image.shape == (H, W, 3)
     assert st.n_contrib[32:, :].max() > 0
+
+
+def test_morton_order_is_a_permutation_that_keeps_neighbours_together_and_the_image(pkg, orc):
+    """synthetic.morton_order / reorder (bench.py --order morton): a permutation of the Gaussians; consecutive
+    Gaussians end up close in space; the rendered image does not depend on the order (equal-depth ties aside)."""
+    W, H, deg, n = 96, 64, 1, 700
+    s = pkg.synthetic.make_scene(n, W, H, deg, 11, sigma_px=4.0)
+    perm = pkg.synthetic.morton_order(s.means)
+    assert sorted(perm.tolist()) == list(range(n))
+    s2 = pkg.synthetic.reorder(s, perm)
+    step = lambda m: np.linalg.norm(np.diff(m, axis=0), axis=1).mean()
+    assert step(s2.means) < 0.4 * step(s.means)
+    cam = orc.Camera(W, H, s.focal)
+    a = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg)
+    b = orc.forward(s2.means, s2.shs, s2.opacities, s2.scales, s2.rotations, cam, deg)
+    assert a.n_rendered == b.n_rendered
+    np.testing.assert_allclose(a.image, b.image, rtol=0, atol=1e-5)

@@ -274,3 +274,38 @@ def test_config4_eight_views_on_one_gpu(pkg, orc):
         assert torch.equal(small_sum[a:b], ref[k].reshape(-1)), k
     rebuilt = pkg.rasterizer.sh_grad_from_views(p[0], torch.stack(vcs), dev(np.stack(centers).astype(np.float32)), K, deg)
     assert float((rebuilt - ref["vshs"]).norm() / ref["vshs"].norm()) <= 1e-6
+
+
+def test_config3_trainer_step_with_the_tail_in_the_backward_is_bit_identical(pkg):
+    """At the benchmarked size (1 M Gaussians, SH 3, 1080p): two training steps with gsr_backward_trainer_tail leave
+    exactly the parameters, Adam moments and activated copies that gsr_backward + gsr_trainer_tail_step leave."""
+    W, H, n, deg = 1920, 1080, 1_000_000, 3
+    s = pkg.synthetic.make_scene(n, W, H, deg, 1003)
+    cam = pkg.Camera(W, H, tuple(s.focal))
+    R, O = pkg.rasterizer, pkg.optim
+    host = dict(points=s.means, features_dc=s.shs[:, :1].copy(), features_rest=s.shs[:, 1:].copy(),
+                opacities=s.opacities_raw.reshape(-1, 1), scales=s.scales_raw, rotations=s.rotations)
+    lrs = dict(points=1.6e-4, features_dc=2.5e-3, features_rest=2.5e-3 / 20, opacities=2.5e-2, scales=5e-3, rotations=1e-3)
+    vp = dev(pkg.synthetic.make_vpixels(W, H, 3, 1003))
+
+    def make():
+        raw = {k: dev(np.ascontiguousarray(v)) for k, v in host.items()}
+        opts = {k: O.Adam(raw[k], lrs[k], eps=1e-15) for k in O.GROUPS}
+        act = list(R.prologue_forward(raw["features_dc"], raw["features_rest"], raw["opacities"], raw["scales"]))
+        return raw, opts, act, R.GaussianRasterizer(W, H, mode="rgb")
+
+    raw_a, opt_a, act_a, rast_a = make()
+    raw_b, opt_b, act_b, rast_b = make()
+    for step in range(2):
+        rast_a.forward_raw(raw_a["points"], *act_a, raw_a["rotations"], cam, deg, (0, 0, 0))
+        rast_b.forward_raw(raw_b["points"], *act_b, raw_b["rotations"], cam, deg, (0, 0, 0))
+        vm, vsh, vo, vsc, vr, _, _ = rast_a.backward_raw(vp, raw_a["points"], *act_a, raw_a["rotations"], cam, deg, (0, 0, 0))
+        O.trainer_tail_step(opt_a, raw_a, dict(vmeans=vm, vshs=vsh, vopacities=vo, vscales=vsc, vrot=vr), *act_a)
+        O.fused_backward_tail_step(rast_b, vp, opt_b, raw_b, *act_b, cam, deg, (0, 0, 0))
+        torch.cuda.synchronize()
+        for k in O.GROUPS:
+            assert torch.equal(raw_a[k], raw_b[k]), (k, step)
+            assert torch.equal(opt_a[k].mu, opt_b[k].mu) and torch.equal(opt_a[k].nu, opt_b[k].nu), (k, step)
+        for x, y in zip(act_a, act_b):
+            assert torch.equal(x, y), step
+        assert torch.equal(rast_a.gstate.grad_means_2d, rast_b.gstate.grad_means_2d)

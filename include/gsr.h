@@ -168,13 +168,20 @@ GSR_API int64_t gsr_memory_usage(const gsr_handle* h);
 /* rasterize(...) — rasterizer.jl:255-408: project! + spherical_harmonics! +
  * count_tiles_per_gaussian! + cumsum! + duplicate_with_keys! + sortperm!/_permute! +
  * identify_tile_range! + render!.  Writes image_out (C,W,H); returns an all-zero image
- * when nothing is visible (rasterizer.jl:338).  aux and stats may be NULL. */
+ * when nothing is visible (rasterizer.jl:338).  aux and stats may be NULL.
+ * Synchronisation: all device work is ordered on `stream`.  The call returns after the host has read the instance
+ * count of this view (the reference's one read-back, rasterizer.jl:337) — it spins on a word of pinned host memory
+ * the tile scan writes; by then the sort + forward of the tiles is already queued behind the scan (it checks the
+ * scan's totals against the capacity of the handle's buffers on the device), so the GPU does not wait for the host. */
 GSR_API int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, float* image_out,
                         const gsr_aux* aux, void* stream, gsr_stats* stats);
 
 /* ∇rasterize(vpixels, ...) — rasterizer.jl:416-550 (the pullback of the rrule,
  * rasterizer.jl:552-573): ∇render! + ∇project! + ∇spherical_harmonics!.
- * vpixels: device (C,W,H).  `in`/`cam` must be the ones given to gsr_forward. */
+ * vpixels: device (C,W,H).  `in`/`cam` must be the ones given to gsr_forward.
+ * All work is ordered on `stream`; when the view has a few very long tile lists (> 1024 instances, at most 256 such
+ * tiles) their part of ∇render! runs on a stream the handle owns, forked from and joined back into `stream` with
+ * events — nothing the caller has to do. */
 GSR_API int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, const float* vpixels,
                          const gsr_grads* grads, void* stream);
 

@@ -3,13 +3,22 @@
 1920x1080 on 1 M synthetic Gaussians, SH degree 3 (config 3), one view per GPU.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+Launch contract.  One process per GPU.  Two equivalent ways to get them:
+  * `python bench.py --gpus N` with NO `RANK` in the environment: this process starts N fresh rank
+    processes itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set) BEFORE it
+    imports torch or touches HIP, forwards rank 0's JSON line, and exits non-zero if ANY rank fails;
+  * `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`: `RANK` is set, this
+    process IS a rank.
+Either way a rank refuses to run (exit 2) when the world size that came up differs from `--gpus`, and the
+JSON line carries `ranks_seen` = `dist.get_world_size()` next to `n_gpus`.
+`--dry-launch` exercises the launch step alone (each child prints its RANK / WORLD_SIZE and exits before
+importing torch): a CPU test of the launcher.
 
 A step = gsr_forward (project + SH + binning + per-tile sort + composite) + the L1/SSIM
 loss head and its pullback + gsr_backward (composite backward + per-Gaussian backward),
-with all inputs already resident in HBM, plus — for N > 1 — the single RCCL all-reduce
-of the 59·N-float gradient arena.  Rank r renders view r of the batch (weak scaling:
-per-GPU work is fixed, `value` counts the pixels of all views).
+with all inputs already resident in HBM, plus — for N > 1 — the gradient exchange over RCCL / xGMI.
+Rank r renders view r of the batch (weak scaling: per-GPU work is fixed, `value` counts the pixels of all views).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline     — dominant kernel: algorithmic HBM bytes per launch / mean launch time
@@ -17,9 +26,19 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                  PMC-counted HBM bytes per launch of that kernel, ONLY when profiles/pmc_traffic.json
                  holds a measurement of exactly this configuration (else null); `valu` = the VALU-issue
                  roofline of the same kernel (SQ_INSTS_VALU x 2 cycles / 1024 SIMDs, the bound that
-                 actually binds the compositing kernels), from the same file;
+                 actually binds the compositing kernels), from the same file.
+                 `stages_ms`: the dominant stage is timed inside the timed region; the OTHER stages come from a
+                 5-step survey pass just before it in which every stage carries an event pair (eight marker
+                 packets per step) — so they may sum to a few % MORE than `ms_per_step`;
   cpu_baseline — the oracle (C restatement of the reference algorithm, OpenMP) timed on
-                 this host's cores on the same workload (rank 0, N = 1 only).
+                 this host's cores on the same workload (rank 0, N = 1 only);
+  extra_configs — (N = 1, headline configuration only) the same measurement for BASELINE.json's other single-GPU
+                 configs and the §8f rows: config2 (100 k, fwd+bwd), config5 (5 M @ 4K, fwd+bwd), rgbd (the
+                 reference's default training mode, config-3 size), trainer_step (prologue + Adam: `tail_step` =
+                 gsr_trainer_tail_step after the backward, `tail_in_backward` = gsr_backward_trainer_tail);
+  exchange     — (N > 1) the gradient exchange: form that the headline ran, HIP-event time around the collectives,
+                 bytes each GPU sends over xGMI, the resulting GB/s against 7 x 153 GB/s, and every form
+                 (factored+overlap / factored / plain all-reduce) timed in the same run.
 `value` / `ms_per_step` follow the driver contract (K steps between two barriers+synchronize, total / K);
 `ms_per_step_median` is the median of the K-1 launch-to-launch intervals of the dominant stage's HIP events
 inside the timed region.
@@ -27,20 +46,18 @@ inside the timed region.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-import gsr_pkg  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+XGMI_PEAK_GBS = 7 * 153.0  # 7 point-to-point links per GPU
 N_SIMD, CLOCK_HZ, VALU_CYCLES = 1024, 2.4e9, 2.0  # 256 CUs x 4 SIMD-32; a wave64 VALU op issues over 2 cycles
+EXCHANGE_FORMS = ("factored+overlap", "factored", "plain")
 
 
 def config_key(N, W, H, deg, mode, exact_cull, loss):
@@ -64,10 +81,10 @@ def algorithmic_bytes(stage, N, V, D, P, T, C=3, K=16):
         "zero_acc": 48,  # pose-gradient accumulators only (when requested)
         "loss_fwd": 72 * P,
         "loss_bwd": 84 * P + 24 * P,
-    }[stage]
+    }.get(stage, 0)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -104,200 +121,395 @@ def main():
                          "configuration); 'morton' = the same Gaussians sorted along a 3-D Z-order curve (what a caller "
                          "could do at densification time) - reported, never the headline")
     ap.add_argument("--no-other-lists", action="store_true", help="skip the secondary timing of the other tile-list mode")
-    args = ap.parse_args()
+    ap.add_argument("--no-extra", action="store_true", help="skip `extra_configs` (configs 2 / 5, :rgbd, trainer step)")
+    ap.add_argument("--extra-steps", type=int, default=10, help="timed steps per `extra_configs` entry")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher test: start the rank processes, each prints its RANK / WORLD_SIZE / MASTER_* as JSON and "
+                         "exits BEFORE importing torch; the parent prints the collected list")
+    ap.add_argument("--launch-timeout", type=float, default=1800.0, help="seconds before the self-launcher gives up on its ranks")
+    return ap.parse_args(argv)
 
-    if os.environ.get("GSR_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after N seconds
-        import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["GSR_BENCH_WATCHDOG"]), exit=True)
-    pkg = gsr_pkg.load()
-    D = pkg.distributed
-    rank, world, local = D.init_from_env()
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-    assert torch.cuda.is_available(), "bench.py needs a HIP device (the product path has no CPU fallback)"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
 
-    W, H, N, deg = args.width, args.height, args.n, args.sh_degree
-    s = pkg.synthetic.make_scene(N if args.ply is None else 16, W, H, deg, args.seed)
-    if args.skew:
-        s = pkg.synthetic.add_skew(s, args.skew, args.seed)
-    if args.order == "morton":
-        s = pkg.synthetic.reorder(s, pkg.synthetic.morton_order(s.means))
+# ------------------------------------------------------------------------------------------------------------------
+# self-launch: `--gpus N` without RANK in the environment
+# ------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """Start `args.gpus` fresh rank processes of this script and wait for them.  This process has not imported torch
+    and never touches HIP (a process that has initialised the GPU must not spawn-and-exec on this pool), so the
+    children are ordinary fork+exec'd interpreters.  rank 0 inherits stdout (its JSON line is THE line); the other
+    ranks' stdout goes to stderr.  Returns the exit code: 0 only if every rank exited 0."""
+    n = args.gpus
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, GSR_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this pool
+        out = subprocess.PIPE if args.dry_launch else (None if r == 0 else sys.stderr)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
+    deadline = time.time() + args.launch_timeout
+    rcs = [None] * n
+    failed = False
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+                if rcs[i] not in (None, 0):
+                    failed = True
+        if failed or time.time() > deadline:
+            # one rank died (or the launch timed out): the others would wait in a collective for ever — stop exactly the
+            # processes this launcher started (by PID), after a short grace period for their own error messages
+            t_end = time.time() + 5.0
+            while time.time() < t_end and any(p.poll() is None for p in procs):
+                time.sleep(0.1)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            rcs = [p.wait() for p in procs]
+            break
+        time.sleep(0.05)
+    if args.dry_launch:
+        seen = []
+        for p in procs:
+            txt = p.stdout.read().decode() if p.stdout else ""
+            for line in txt.splitlines():
+                if line.startswith("{"):
+                    seen.append(json.loads(line))
+        print(json.dumps({"dry_launch": sorted(seen, key=lambda d: d["rank"]), "rc": rcs}))
+    bad = [(i, rc) for i, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: rank(s) failed: {bad} (of {n})", file=sys.stderr)
+        return 1
+    return 0
+
+
+def dry_rank():
+    """`--dry-launch` child: report the environment the launcher gave this rank; no torch, no HIP."""
+    print(json.dumps({k.lower(): (int(os.environ[k]) if k not in ("MASTER_ADDR",) else os.environ[k])
+                      for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}))
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# one workload = one (scene, camera, rasterizer, step function)
+# ------------------------------------------------------------------------------------------------------------------
+class Workload:
+    def __init__(self, pkg, dev, rank, world, *, n, width, height, sh_degree, seed, mode="rgb", no_loss=False,
+                 reference_lists=False, with_optimizer=False, unfused_tail=False, tail_in_backward=False, views=8,
+                 skew=None, order="random", ply=None, exchange_form=None):
+        import numpy as np
+        import torch
+        self.pkg, self.dev, self.rank, self.world = pkg, dev, rank, world
+        self.torch, self.np = torch, np
+        self.D = pkg.distributed
+        W, H, N, deg = width, height, n, sh_degree
+        s = pkg.synthetic.make_scene(N if ply is None else 16, W, H, deg, seed)
+        if skew:
+            s = pkg.synthetic.add_skew(s, skew, seed)
+        if order == "morton":
+            s = pkg.synthetic.reorder(s, pkg.synthetic.morton_order(s.means))
         N = s.n
-    if args.ply is not None:
-        gm = pkg.ply.import_ply(args.ply)
-        N, deg = gm.n, gm.max_sh_degree
-        s.means, s.rotations = gm.points, gm.rotations
-        s.shs = np.ascontiguousarray(np.concatenate([gm.features_dc, gm.features_rest], 1))
-        s.scales_raw, s.opacities_raw, s.sh_degree = gm.scales, gm.opacities.reshape(-1), deg
-    K = s.shs.shape[1]
-    view = rank % args.views
-    if world == 1:
-        R, t = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)  # §8(d): R = I, t = 0
-    else:
-        R, t = pkg.synthetic.view_pose(view, args.views)
-    cam = pkg.Camera(W, H, tuple(s.focal), (0.5, 0.5), R, t)
-    to = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(dev)  # noqa: E731
-    params = [to(s.means), to(s.shs), to(s.opacities.reshape(-1, 1)), to(s.scales), to(s.rotations)]
-    target = to(pkg.synthetic.make_target(W, H, args.seed + view))
-    vpix_fixed = to(pkg.synthetic.make_vpixels(W, H, pkg.rasterizer.n_color_features(args.mode), args.seed + view))
-    rast = pkg.rasterizer.GaussianRasterizer(W, H, mode=args.mode, device=dev, exact_tile_cull=not args.reference_lists)
-    # world > 1: factored exchange (distributed.py) unless GSR_DIST_FULL_ARENA=1 asks for the plain
-    # all-reduce of the whole (11+3K)·N arena
-    dist_on = world > 1 or D.forced()  # GSR_DIST_FORCE=1: the collectives run on a 1-rank RCCL communicator
-    if args.tail_in_backward and (dist_on or not args.with_optimizer):
-        raise SystemExit("--tail-in-backward is the single-GPU trainer step: it needs --with-optimizer and no gradient exchange")
-    factored = dist_on and os.environ.get("GSR_DIST_FULL_ARENA", "0") != "1"
-    overlap = factored and os.environ.get("GSR_DIST_NO_OVERLAP", "0") != "1"
-    if overlap:
-        D.overlap_groups()
-    arena = torch.empty(D.factored_arena_numel(N) if factored else D.arena_numel(N, K), device=dev, dtype=torch.float32)
-    if factored:
-        centers = []
-        for r in range(world):
-            Rr, tr = pkg.synthetic.view_pose(r % args.views, args.views) if world > 1 else (R, t)
-            centers.append(pkg.Camera(W, H, tuple(s.focal), (0.5, 0.5), Rr, tr).camera_center)
-        centers_d = to(np.stack(centers).astype(np.float32))
-        gathered = torch.empty(world * 3 * N, device=dev, dtype=torch.float32)
-        vshs_sum = torch.empty((N, K, 3), device=dev, dtype=torch.float32)
-    bg = (0.0, 0.0, 0.0)
+        if ply is not None:
+            gm = pkg.ply.import_ply(ply)
+            N, deg = gm.n, gm.max_sh_degree
+            s.means, s.rotations = gm.points, gm.rotations
+            s.shs = np.ascontiguousarray(np.concatenate([gm.features_dc, gm.features_rest], 1))
+            s.scales_raw, s.opacities_raw, s.sh_degree = gm.scales, gm.opacities.reshape(-1), deg
+        self.scene, self.N, self.W, self.H, self.deg = s, N, W, H, deg
+        self.K = K = s.shs.shape[1]
+        self.mode, self.no_loss, self.reference_lists = mode, no_loss, reference_lists
+        self.seed, self.ply, self.skew, self.order = seed, ply, skew, order
+        self.view = view = rank % views
+        self.views = views
+        if world == 1:
+            R, t = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)  # §8(d): R = I, t = 0
+        else:
+            R, t = pkg.synthetic.view_pose(view, views)
+        self.R, self.t = R, t
+        self.cam = pkg.Camera(W, H, tuple(s.focal), (0.5, 0.5), R, t)
+        to = self.to = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        self.params = [to(s.means), to(s.shs), to(s.opacities.reshape(-1, 1)), to(s.scales), to(s.rotations)]
+        self.target = to(pkg.synthetic.make_target(W, H, seed + view))
+        self.vpix_fixed = to(pkg.synthetic.make_vpixels(W, H, pkg.rasterizer.n_color_features(mode), seed + view))
+        self.rast = pkg.rasterizer.GaussianRasterizer(W, H, mode=mode, device=dev, exact_tile_cull=not reference_lists)
+        self.bg = (0.0, 0.0, 0.0)
+        self.dist_on = world > 1 or self.D.forced()  # GSR_DIST_FORCE=1: collectives on a 1-rank RCCL communicator
+        self.exchange_events = None  # [(e0, e1)] when the exchange is being timed
+        self.set_exchange_form(exchange_form)
+        self.with_optimizer, self.unfused_tail, self.tail_in_backward = with_optimizer, unfused_tail, tail_in_backward
+        self.tail = None
+        if with_optimizer:
+            # raw parameters the trainer optimises (training.jl:234-239): points, f_dc, f_rest, opacity logits,
+            # log-scales, rotations; one NU.Adam each
+            p = self.params
+            self.raw = [p[0].clone(), p[1][:, :1].contiguous(), p[1][:, 1:].contiguous(),
+                        to(s.opacities_raw.reshape(-1, 1)), to(s.scales_raw), p[4].clone()]
+            lrs = [1.6e-4, 2.5e-3, 2.5e-3 / 20, 2.5e-2, 5e-3, 1e-3]
+            self.opts = [pkg.optim.Adam(t_, lr, eps=1e-15) for t_, lr in zip(self.raw, lrs)]
+            self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            self.tail = {"prologue_fwd": 0.0, "prologue_bwd": 0.0, "adam": 0.0, "n": 0, "n_steps": 0}
+            self.opt_map = dict(zip(pkg.optim.GROUPS, self.opts))
+            self.raw_map = dict(zip(pkg.optim.GROUPS, self.raw))
 
-    tail = None
-    if args.with_optimizer:
-        # raw parameters the trainer optimises (training.jl:234-239): points, f_dc, f_rest, opacity logits,
-        # log-scales, rotations; one NU.Adam each
-        raw = [params[0].clone(), params[1][:, :1].contiguous(), params[1][:, 1:].contiguous(),
-               to(s.opacities_raw.reshape(-1, 1)), to(s.scales_raw), params[4].clone()]
-        lrs = [1.6e-4, 2.5e-3, 2.5e-3 / 20, 2.5e-2, 5e-3, 1e-3]
-        opts = [pkg.optim.Adam(t, lr, eps=1e-15) for t, lr in zip(raw, lrs)]
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        tail = {"prologue_fwd": 0.0, "prologue_bwd": 0.0, "adam": 0.0, "n": 0, "n_steps": 0}
-        opt_map = dict(zip(pkg.optim.GROUPS, opts))
-        raw_map = dict(zip(pkg.optim.GROUPS, raw))
+    # -- gradient exchange ------------------------------------------------------------------------------------
+    def default_exchange_form(self):
+        if not self.dist_on:
+            return None
+        if os.environ.get("GSR_DIST_FULL_ARENA", "0") == "1":
+            return "plain"
+        return "factored" if os.environ.get("GSR_DIST_NO_OVERLAP", "0") == "1" else "factored+overlap"
 
-    def step():
+    def set_exchange_form(self, form):
+        """(Re)allocate the arena for an exchange form: 'plain' = ONE all-reduce of the (11+3K)·N arena (what north_star
+        names); 'factored' = all-reduce of 11·N floats + all-gather of the (N,3) colour cotangents + ∇shs rebuild;
+        'factored+overlap' = the same with the two collectives in flight together on two communicators."""
+        torch, D, pkg = self.torch, self.D, self.pkg
+        form = form or self.default_exchange_form()
+        self.exchange_form = form
+        self.factored = self.dist_on and form in ("factored", "factored+overlap")
+        self.overlap = form == "factored+overlap"
+        self.overlap_ran = False
+        N, K, W, H, s = self.N, self.K, self.W, self.H, self.scene
+        if self.overlap:
+            D.overlap_groups()
+        self.arena = torch.empty(D.factored_arena_numel(N) if self.factored else D.arena_numel(N, K), device=self.dev,
+                                 dtype=torch.float32)
+        self.gathered = self.vshs_sum = self.centers_d = None
+        if self.factored:
+            centers = []
+            for r in range(self.world):
+                Rr, tr = pkg.synthetic.view_pose(r % self.views, self.views) if self.world > 1 else (self.R, self.t)
+                centers.append(pkg.Camera(W, H, tuple(s.focal), (0.5, 0.5), Rr, tr).camera_center)
+            self.centers_d = self.to(self.np.stack(centers).astype(self.np.float32))
+            self.gathered = torch.empty(self.world * 3 * N, device=self.dev, dtype=torch.float32)
+            self.vshs_sum = torch.empty((N, K, 3), device=self.dev, dtype=torch.float32)
+
+    def exchange_bytes_per_gpu(self):
+        """Bytes each GPU SENDS over xGMI per step under bandwidth-optimal algorithms: an all-reduce of S bytes over n
+        ranks = reduce-scatter + all-gather = 2·(n-1)/n·S; an all-gather of one s-byte piece per rank = (n-1)·s."""
+        n, N, K = self.world, self.N, self.K
+        if not self.dist_on or n < 2:
+            return 0
+        if self.factored:
+            return int(2 * (n - 1) / n * 11 * N * 4 + (n - 1) * 3 * N * 4)
+        return int(2 * (n - 1) / n * (11 + 3 * K) * N * 4)
+
+    def _exchange(self):
+        D, pkg, N, K = self.D, self.pkg, self.N, self.K
+        p = self.params
+        if self.factored and self.overlap:
+            # all-gather(vc) || all-reduce(11·N): the ∇shs rebuild runs while the all-reduce is in flight
+            ran = D.exchange_factored_overlapped(self.arena, N, self.gathered, lambda vc_all: pkg.rasterizer.sh_grad_from_views(
+                p[0], vc_all, self.centers_d, K, self.deg, out=self.vshs_sum))
+            self.overlap_ran = bool(D.last_exchange_overlapped())
+            return ran
+        if self.factored:
+            vc_all = D.exchange_factored(self.arena, N, self.gathered)
+            return pkg.rasterizer.sh_grad_from_views(p[0], vc_all, self.centers_d, K, self.deg, out=self.vshs_sum)
+        return D.allreduce_arena(self.arena)
+
+    # -- one step -----------------------------------------------------------------------------------------------
+    def step(self):
+        torch, pkg, D = self.torch, self.pkg, self.D
+        params, rast, tail = self.params, self.rast, self.tail
+        N, K = self.N, self.K
         if tail is not None:
+            ev, raw = self.ev, self.raw
             ev[0].record()
-            if args.unfused_tail or tail["n_steps"] == 0:
+            if self.unfused_tail or tail["n_steps"] == 0:
                 shs, oa, sa = pkg.rasterizer.prologue_forward(raw[1], raw[2], raw[3], raw[4])
                 params[1], params[2], params[3] = shs, oa, sa
             # (fused tail: the previous step's gsr_trainer_tail_step already wrote the activated copies)
             ev[1].record()
             params[0], params[4] = raw[0], raw[5]
             tail["n_steps"] += 1
-        img = rast.forward_raw(*params, cam, deg, bg)
-        if args.no_loss:
-            vp = vpix_fixed
+        img = rast.forward_raw(*params, self.cam, self.deg, self.bg)
+        if self.no_loss:
+            vp = self.vpix_fixed
         else:
-            _, vp = pkg.fused_ssim.l1_ssim_loss(rast, img, target)
-        if tail is not None and args.tail_in_backward:
+            _, vp = pkg.fused_ssim.l1_ssim_loss(rast, img, self.target)
+        if tail is not None and self.tail_in_backward:
             ev[2].record(); ev[3].record()
-            pkg.optim.fused_backward_tail_step(rast, vp, opt_map, raw_map, params[1], params[2], params[3], cam, deg, bg)
+            pkg.optim.fused_backward_tail_step(rast, vp, self.opt_map, self.raw_map, params[1], params[2], params[3], self.cam,
+                                               self.deg, self.bg)
             e4 = torch.cuda.Event(enable_timing=True); e4.record()
             tail["_last"] = (ev[0], ev[1], ev[2], ev[3], e4)
             return
-        rast.backward_raw(vp, *params, cam, deg, bg, arena=arena, factored_sh=factored)
-        if factored and overlap:
-            # all-gather(vc) || all-reduce(11·N): the ∇shs rebuild runs while the all-reduce is in flight
-            D.exchange_factored_overlapped(arena, N, gathered, lambda vc_all: pkg.rasterizer.sh_grad_from_views(
-                params[0], vc_all, centers_d, K, deg, out=vshs_sum))
-        elif factored:
-            vc_all = D.exchange_factored(arena, N, gathered)
-            pkg.rasterizer.sh_grad_from_views(params[0], vc_all, centers_d, K, deg, out=vshs_sum)
-        else:
-            D.allreduce_arena(arena)
+        rast.backward_raw(vp, *params, self.cam, self.deg, self.bg, arena=self.arena, factored_sh=self.factored)
+        if self.dist_on:
+            if self.exchange_events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self._exchange()
+                e1.record()
+                self.exchange_events.append((e0, e1))
+            else:
+                self._exchange()
         if tail is not None:
-            g = D.split_arena(arena, N, K) if not factored else dict(D.split_factored_arena(arena, N), vshs=vshs_sum)
+            g = (D.split_arena(self.arena, N, K) if not self.factored else
+                 dict(D.split_factored_arena(self.arena, N), vshs=self.vshs_sum))
             ev[2].record()
-            if args.unfused_tail:
-                vdc, vrest, vo, vs = pkg.rasterizer.prologue_backward(params[2], params[3], g["vshs"], g["vopacities"].view(-1, 1),
-                                                                      g["vscales"], 3)
+            if self.unfused_tail:
+                vdc, vrest, vo, vs = pkg.rasterizer.prologue_backward(params[2], params[3], g["vshs"],
+                                                                      g["vopacities"].view(-1, 1), g["vscales"], 3)
                 ev[3].record()
-                pkg.optim.step_all(opts, raw, [g["vmeans"], vdc, vrest, vo, vs, g["vrot"]])
+                pkg.optim.step_all(self.opts, raw, [g["vmeans"], vdc, vrest, vo, vs, g["vrot"]])
             else:
                 ev[3].record()
-                pkg.optim.trainer_tail_step(opt_map, raw_map, dict(g, vopacities=g["vopacities"].view(-1, 1)),
+                pkg.optim.trainer_tail_step(self.opt_map, self.raw_map, dict(g, vopacities=g["vopacities"].view(-1, 1)),
                                             params[1], params[2], params[3])
             e4 = torch.cuda.Event(enable_timing=True); e4.record()
             tail["_last"] = (ev[0], ev[1], ev[2], ev[3], e4)
 
-    def tail_collect():
+    def tail_collect(self):
+        tail = self.tail
         if tail is not None and "_last" in tail:
             a, b, c, d, e = tail["_last"]
             e.synchronize()
             tail["prologue_fwd"] += a.elapsed_time(b); tail["prologue_bwd"] += c.elapsed_time(d)
             tail["adam"] += d.elapsed_time(e); tail["n"] += 1
 
-    def sync():
-        if dist_on:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def sync(self):
+        if self.dist_on:
+            self.torch.distributed.barrier()
+        self.torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    # Stage survey (untimed): every stage timed with HIP events for a few steps -> stages_ms and the dominant stage.
-    # In the TIMED region only the dominant stage keeps its event pair: an event record is a marker packet between two
-    # kernels, and eight pairs per step cost 0.06 ms of a 1.8 ms step (measured: 1.81 vs 1.745 ms).
-    rast.profile(True)
-    for _ in range(5):
-        step()
-    sync()
-    survey = {k: (ms / max(c, 1), c) for k, (ms, c) in rast.profile_read().items() if c > 0}
-    dom = max(survey, key=lambda k: survey[k][0] * survey[k][1])
-    rast.profile(True, stages=[dom])
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
-    # per-step times = launch-to-launch intervals of the dominant stage's own event pairs (a separate per-step
-    # marker would be one more ~6 us bubble on the stream, tools/gap_report.py): K-1 samples
-    per_step = sorted(rast.profile_intervals(dom))
-    ms_median = (None if not per_step else per_step[len(per_step) // 2] if len(per_step) % 2 else
-                 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2]))
-    tail_collect()
-    prof = rast.profile_read()
-    rast.profile(False)
-    if dist_on:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def max_over_ranks(self, dt):
+        if self.dist_on:
+            tt = self.torch.tensor([dt], device=self.dev, dtype=self.torch.float64)
+            self.torch.distributed.all_reduce(tt, op=self.torch.distributed.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
 
-    P, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
-    Dn, V = int(rast.stats.n_rendered), int(rast.stats.n_visible)
-    ms_step = 1e3 * dt / args.steps
-    value = world * P / (dt / args.steps) / 1e6
+    def close(self):
+        self.rast.close()
 
-    live = {k: (ms / max(c, 1), c) for k, (ms, c) in prof.items() if c > 0}
-    dom_ms = live[dom][0]            # the dominant kernel's mean launch time, HIP events INSIDE the timed region
-    stages = dict(survey)            # the other stages: from the survey pass just before it
-    stages[dom] = live[dom]
-    Cn = pkg.rasterizer.n_color_features(args.mode)
-    dom_bytes = algorithmic_bytes(dom, N, V, Dn, P, T, Cn, K)
-    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-    # PMC-counted HBM bytes and VALU instructions per launch: only a measurement of EXACTLY this configuration
-    # (tools/pmc_workload.py + tools/pmc_parse.py under rocprofv3 --pmc, committed per round) is reported
-    key = (config_key(N, W, H, deg, args.mode, not args.reference_lists, not args.no_loss)
-           if args.ply is None and not args.skew and args.order == "random" else None)
-    traffic, valu, pmc_src = None, None, None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if key is not None and os.path.exists(tpath) and not (tail is not None):
-        try:
-            rec = json.load(open(tpath)).get("configs", {}).get(key)
-            if rec is not None and int(rec.get("tile_instances", -1)) == Dn:
-                traffic = rec.get("hbm_bytes", {}).get(dom)
-                insts = rec.get("sq", {}).get(dom, {}).get("SQ_INSTS_VALU")
-                pmc_src = rec.get("source")
-                if insts:
-                    issue_ms = insts * VALU_CYCLES / N_SIMD / CLOCK_HZ * 1e3
-                    valu = {"kernel": dom, "insts": int(insts), "issue_cycles_peak": int(insts * VALU_CYCLES / N_SIMD),
-                            "peak_ms_at_2.4GHz": round(issue_ms, 4), "frac": round(issue_ms / dom_ms, 4)}
-        except Exception:
-            traffic, valu = None, None
-    # measured HBM ceiling of this device in this run: STREAM triad over 3 x 512 MiB
+    # -- measurement --------------------------------------------------------------------------------------------
+    def time_plain(self, steps, warmup):
+        """K steps between two barrier+synchronize pairs, max over ranks; no per-stage events."""
+        for _ in range(warmup):
+            self.step()
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.sync()
+        return self.max_over_ranks(time.perf_counter() - t0) / steps
+
+    def measure(self, steps, warmup, survey_steps=5):
+        """The bench contract: W warm-up steps, an (untimed) stage survey, then EXACTLY K timed steps in which only the
+        dominant stage keeps its HIP-event pair.  Returns a dict of raw measurements."""
+        rast = self.rast
+        for _ in range(warmup):
+            self.step()
+        self.sync()
+        # Stage survey (untimed): every stage timed with HIP events for a few steps -> stages_ms and the dominant stage.
+        # In the TIMED region only the dominant stage keeps its event pair: an event record is a marker packet between two
+        # kernels, and eight pairs per step cost 0.06 ms of a 1.8 ms step (measured: 1.81 vs 1.745 ms).
+        rast.profile(True)
+        for _ in range(survey_steps):
+            self.step()
+        self.sync()
+        survey = {k: (ms / max(c, 1), c) for k, (ms, c) in rast.profile_read().items() if c > 0}
+        dom = max(survey, key=lambda k: survey[k][0] * survey[k][1])
+        rast.profile(True, stages=[dom])
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.sync()
+        dt = time.perf_counter() - t0
+        # per-step times = launch-to-launch intervals of the dominant stage's own event pairs (a separate per-step
+        # marker would be one more ~6 us bubble on the stream, tools/gap_report.py): K-1 samples
+        per_step = sorted(rast.profile_intervals(dom))
+        self.tail_collect()
+        prof = rast.profile_read()
+        rast.profile(False)
+        dt = self.max_over_ranks(dt)
+        live = {k: (ms / max(c, 1), c) for k, (ms, c) in prof.items() if c > 0}
+        return {"dt": dt, "steps": steps, "per_step": per_step, "dom": dom, "survey": survey, "live": live}
+
+    def roofline(self, m, triad_gbs=None):
+        """The `roofline` object of the JSON line for measurement `m` of this workload."""
+        pkg, rast = self.pkg, self.rast
+        N, W, H, deg, K = self.N, self.W, self.H, self.deg, self.K
+        P, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+        Dn, V = int(rast.stats.n_rendered), int(rast.stats.n_visible)
+        dom, live, survey = m["dom"], m["live"], m["survey"]
+        ms_step = 1e3 * m["dt"] / m["steps"]
+        dom_ms = live[dom][0]            # the dominant kernel's mean launch time, HIP events INSIDE the timed region
+        stages = dict(survey)            # the other stages: from the survey pass just before it
+        stages[dom] = live[dom]
+        Cn = pkg.rasterizer.n_color_features(self.mode)
+        dom_bytes = algorithmic_bytes(dom, N, V, Dn, P, T, Cn, K)
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        # PMC-counted HBM bytes and VALU instructions per launch: only a measurement of EXACTLY this configuration
+        # (tools/pmc_workload.py + tools/pmc_parse.py under rocprofv3 --pmc, committed per round) is reported
+        key = (config_key(N, W, H, deg, self.mode, not self.reference_lists, not self.no_loss)
+               if self.ply is None and not self.skew and self.order == "random" else None)
+        traffic, valu, pmc_src = None, None, None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if key is not None and os.path.exists(tpath) and self.tail is None:
+            try:
+                rec = json.load(open(tpath)).get("configs", {}).get(key)
+                if rec is not None and int(rec.get("tile_instances", -1)) == Dn:
+                    traffic = rec.get("hbm_bytes", {}).get(dom)
+                    insts = rec.get("sq", {}).get(dom, {}).get("SQ_INSTS_VALU")
+                    pmc_src = rec.get("source")
+                    if insts:
+                        issue_ms = insts * VALU_CYCLES / N_SIMD / CLOCK_HZ * 1e3
+                        valu = {"kernel": dom, "insts": int(insts), "issue_cycles_peak": int(insts * VALU_CYCLES / N_SIMD),
+                                "peak_ms_at_2.4GHz": round(issue_ms, 4), "frac": round(issue_ms / dom_ms, 4)}
+            except Exception:
+                traffic, valu = None, None
+        r = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "valu": valu, "pmc_source": pmc_src,
+             "pmc_config_key": key}
+        if triad_gbs:
+            r["measured_triad_GBps"] = round(triad_gbs, 1)
+            r["frac_of_measured_triad"] = round(achieved / triad_gbs, 5)
+        r.update({
+            "algorithmic_bytes": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
+            "avg_launch_ms_source": f"HIP events around {dom} on the launch stream, {live[dom][1]} launches inside the timed region",
+            "stages_ms": {k: round(v[0], 4) for k, v in stages.items()},
+            "stages_ms_source": "5-step survey with every stage timed, just before the timed region (all stages timed "
+                                "inside it would slow the step by 3 %, so these may sum to more than ms_per_step); the "
+                                "dominant stage: the timed region",
+            "whole_step_algorithmic_GBps": round(
+                sum(algorithmic_bytes(k, N, V, Dn, P, T, Cn, K) for k in stages) / (ms_step * 1e-3) / 1e9, 2)})
+        return r
+
+    def summary(self, m):
+        """Compact record for `extra_configs`: ms_per_step, value, dominant kernel, roofline fractions."""
+        r = self.roofline(m)
+        ms_step = 1e3 * m["dt"] / m["steps"]
+        per = m["per_step"]
+        out = {"ms_per_step": round(ms_step, 4),
+               "ms_per_step_median": round(per[len(per) // 2], 4) if per else None,
+               "value": round(self.world * self.W * self.H / (m["dt"] / m["steps"]) / 1e6, 3), "unit": "Mpixels/s",
+               "steps": m["steps"], "n_gaussians": self.N, "resolution": [self.W, self.H], "mode": self.mode,
+               "loss": not self.no_loss, "visible": int(self.rast.stats.n_visible),
+               "tile_instances": int(self.rast.stats.n_rendered),
+               "dominant_kernel": r["kernel"], "dominant_ms": r["avg_launch_ms"],
+               "roofline": {"bound": "hbm", "frac": r["frac"], "achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "algorithmic_bytes": r["algorithmic_bytes"], "traffic": r["traffic"],
+                            "valu_frac": (r["valu"] or {}).get("frac"), "pmc_config_key": r["pmc_config_key"],
+                            "whole_step_algorithmic_GBps": r["whole_step_algorithmic_GBps"]},
+               "stages_ms": r["stages_ms"]}
+        if self.tail is not None and self.tail["n"]:
+            out["trainer_tail"] = {k: round(self.tail[k] / self.tail["n"], 4) for k in ("prologue_fwd", "prologue_bwd", "adam")}
+        return out
+
+
+def measure_triad(pkg, dev):
+    """Measured HBM ceiling of this device in this run: STREAM triad over 3 x 512 MiB."""
+    import torch
     lib = pkg._lib.load()
     n_tri = 128 * 1024 * 1024
     ta, tb, tc = (torch.ones(n_tri, device=dev) for _ in range(3))
@@ -309,28 +521,151 @@ def main():
     for _ in range(5):
         pkg._lib.check(lib.gsr_stream_triad(ta.data_ptr(), tb.data_ptr(), tc.data_ptr(), n_tri, 0.5, cs))
     e1.record(); e1.synchronize()
-    triad_gbs = 5 * 12.0 * n_tri / (e0.elapsed_time(e1) * 1e-3) / 1e9
-    del ta, tb, tc
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "valu": valu, "pmc_source": pmc_src,
-                "pmc_config_key": key,
-                "measured_triad_GBps": round(triad_gbs, 1), "frac_of_measured_triad": round(achieved / triad_gbs, 5),
-                "algorithmic_bytes": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
-                "avg_launch_ms_source": f"HIP events around {dom} on the launch stream, {live[dom][1]} launches inside the timed region",
-                "stages_ms": {k: round(v[0], 4) for k, v in stages.items()},
-                "stages_ms_source": "5-step survey with every stage timed, just before the timed region (all stages timed "
-                                    "inside it would slow the step by 3 %); the dominant stage: the timed region",
-                "whole_step_algorithmic_GBps": round(
-                    sum(algorithmic_bytes(k, N, V, Dn, P, T, Cn, K) for k in stages) / (ms_step * 1e-3) / 1e9, 2)}
+    return 5 * 12.0 * n_tri / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
+
+def exchange_report(wl, steps, warmup, headline_form):
+    """Every exchange form timed in the same run: whole step (barrier to barrier, max over ranks) and the exchange
+    alone (HIP events on the compute stream around the collectives — with RCCL the compute stream waits on the
+    communicator's stream inside that bracket, so the pair spans the collectives and the ∇shs rebuild)."""
+    torch = wl.torch
+    forms = {}
+    for form in EXCHANGE_FORMS:
+        wl.set_exchange_form(form)
+        wl.exchange_events = []
+        for _ in range(max(1, warmup)):
+            wl.step()
+        wl.sync()
+        wl.exchange_events = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            wl.step()
+        wl.sync()
+        dt = wl.max_over_ranks(time.perf_counter() - t0) / steps
+        ms = [a.elapsed_time(b) for a, b in wl.exchange_events]
+        ex_ms = wl.max_over_ranks(sum(ms) / max(len(ms), 1))
+        wl.exchange_events = None
+        b = wl.exchange_bytes_per_gpu()
+        forms[form] = {"ms_per_step": round(1e3 * dt, 4), "exchange_ms": round(ex_ms, 4), "bytes_per_gpu": b,
+                       "xgmi_GBps": round(b / (ex_ms * 1e-3) / 1e9, 2) if ex_ms > 0 else None,
+                       "overlap": bool(wl.overlap and wl.overlap_ran),
+                       "form_that_ran": ("factored (sequential: this backend cannot keep two communicators in flight)"
+                                         if wl.overlap and not wl.overlap_ran else form)}
+    wl.set_exchange_form(headline_form)
+    h = forms[headline_form]
+    return {"form": h["form_that_ran"], "ms": h["exchange_ms"], "bytes_per_gpu": h["bytes_per_gpu"],
+            "xgmi_GBps": h["xgmi_GBps"], "overlap": h["overlap"], "xgmi_peak_GBps": XGMI_PEAK_GBS,
+            "frac_of_xgmi_peak": round((h["xgmi_GBps"] or 0.0) / XGMI_PEAK_GBS, 4),
+            "backend": torch.distributed.get_backend(),
+            "timing": "HIP events on the compute stream around the collectives (+ the ∇shs rebuild of the factored forms), "
+                      "mean over the steps of a separate pass, max over ranks; ms_per_step of that pass includes the event pair",
+            "bytes_model": "sent per GPU: all-reduce 2(n-1)/n x S, all-gather (n-1) x s",
+            "forms": forms}
+
+
+def extra_configs(pkg, dev, args):
+    """BASELINE.json's other single-GPU configs and the §8f rows, measured like the headline (same contract, fewer
+    steps): every entry = its own scene, handle and warm-up; handles are closed before the next entry."""
+    import gc
+    import torch
+    out = {}
+    specs = [
+        ("config2", dict(n=100_000, width=1920, height=1080, sh_degree=3, seed=1002, no_loss=True)),
+        ("config5", dict(n=5_000_000, width=3840, height=2160, sh_degree=3, seed=1005, no_loss=True)),
+        ("rgbd", dict(n=1_000_000, width=1920, height=1080, sh_degree=3, seed=1003, mode="rgbd")),
+        ("trainer_step.tail_step", dict(n=1_000_000, width=1920, height=1080, sh_degree=3, seed=1003, with_optimizer=True)),
+        ("trainer_step.tail_in_backward", dict(n=1_000_000, width=1920, height=1080, sh_degree=3, seed=1003,
+                                               with_optimizer=True, tail_in_backward=True)),
+    ]
+    for name, kw in specs:
+        t0 = time.perf_counter()
+        wl = Workload(pkg, dev, 0, 1, **kw)
+        try:
+            rec = wl.summary(wl.measure(args.extra_steps, max(2, args.warmup)))
+        finally:
+            wl.close()
+        rec["wall_s"] = round(time.perf_counter() - t0, 2)
+        rec["workload"] = {
+            "config2": "config2: 100k Gaussians, SH deg 3, 1920x1080, fwd+bwd (random cotangent)",
+            "config5": "config5: 5M Gaussians, SH deg 3, 3840x2160, fwd+bwd (random cotangent)",
+            "rgbd": "N=1M SH3 1920x1080 :rgbd (the reference's default training mode), fwd + L1/0.2*DSSIM loss + bwd",
+            "trainer_step.tail_step": "config3 + prologue + Adam: gsr_backward then gsr_trainer_tail_step",
+            "trainer_step.tail_in_backward": "config3 + prologue + Adam: gsr_backward_trainer_tail (no gradient arrays)",
+        }[name]
+        if "." in name:
+            a, b = name.split(".")
+            out.setdefault(a, {})[b] = rec
+        else:
+            out[name] = rec
+        del wl
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
+def run_rank(args):
+    import torch
+    import torch.distributed as dist
+
+    import gsr_pkg
+
+    if os.environ.get("GSR_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["GSR_BENCH_WATCHDOG"]), exit=True)
+    pkg = gsr_pkg.load()
+    D = pkg.distributed
+    rank, world, local = D.init_from_env()
+    if world != args.gpus:
+        # never a silent 1-GPU number under an N-GPU label (round-2 verdict #1, ADVICE bench.py:115)
+        print(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s) "
+              f"(WORLD_SIZE={os.environ.get('WORLD_SIZE')}): refusing to run", file=sys.stderr)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return 2
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (the product path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    ranks_seen = dist.get_world_size() if dist.is_initialized() else 1
+
+    wl = Workload(pkg, dev, rank, world, n=args.n, width=args.width, height=args.height, sh_degree=args.sh_degree,
+                  seed=args.seed, mode=args.mode, no_loss=args.no_loss, reference_lists=args.reference_lists,
+                  with_optimizer=args.with_optimizer, unfused_tail=args.unfused_tail, tail_in_backward=args.tail_in_backward,
+                  views=args.views, skew=args.skew, order=args.order, ply=args.ply)
+    if args.tail_in_backward and (wl.dist_on or not args.with_optimizer):
+        raise SystemExit("--tail-in-backward is the single-GPU trainer step: it needs --with-optimizer and no gradient exchange")
+    N, W, H, deg, K, s = wl.N, wl.W, wl.H, wl.deg, wl.K, wl.scene
+    headline_form = wl.exchange_form
+
+    m = wl.measure(args.steps, args.warmup)
+    dt, per_step = m["dt"], m["per_step"]
+    ms_median = (None if not per_step else per_step[len(per_step) // 2] if len(per_step) % 2 else
+                 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2]))
+    P = W * H
+    Dn, V = int(wl.rast.stats.n_rendered), int(wl.rast.stats.n_visible)
+    ms_step = 1e3 * dt / args.steps
+    value = world * P / (dt / args.steps) / 1e6
+    roofline = wl.roofline(m, triad_gbs=measure_triad(pkg, dev))
+    rast, tail = wl.rast, wl.tail
+    is_headline = (not args.no_loss and args.ply is None and args.mode == "rgb" and not args.skew and args.order == "random"
+                   and (N, W, H, deg) == (1_000_000, 1920, 1080, 3))
+
+    if wl.factored:
+        par = (f"view-parallel x{world}, all-reduce of {11 * N * 4 / 1e6:.0f} MB + all-gather of "
+               f"{world} x {3 * N * 4 / 1e6:.0f} MB colour cotangents (factored SH gradient"
+               f"{'; the two collectives overlapped on two communicators' if wl.overlap and wl.overlap_ran else ''}); "
+               f"GSR_DIST_FULL_ARENA=1 selects the plain all-reduce of the whole arena")
+    else:
+        par = (f"view-parallel x{world}, 1 all-reduce of {wl.arena.numel() * 4 / 1e6:.0f} MB" if wl.dist_on else
+               "single GPU, one view (no collective)")
     out = {
         "metric": "fwd+bwd Mpixels/s @1920x1080, 1M Gaussians SH=3",
-        "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps,
+        "warmup": args.warmup,
         "ms_per_step": round(ms_step, 4), "ms_per_step_median": round(ms_median if ms_median is not None else ms_step, 4),
         "ms_per_step_max": round(per_step[-1], 4) if per_step else None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic" if args.ply is None else "ply scene, synthetic camera and target",
         "config": {"workload": ("config3: 1M Gaussians, SH deg 3, 1920x1080, fwd + L1/0.2*DSSIM loss + bwd"
-                                if not args.no_loss and args.ply is None and args.mode == "rgb" and (N, W, H, deg) == (1_000_000, 1920, 1080, 3) else
+                                if is_headline else
                                 f"ply scene {os.path.basename(args.ply)}: N={N} SH{deg} {W}x{H} fwd{'' if args.no_loss else '+loss'}+bwd"
                                 if args.ply is not None else
                                 f"N={N} SH{deg} {W}x{H} :{args.mode} fwd{'' if args.no_loss else '+loss'}+bwd"
@@ -342,11 +677,9 @@ def main():
                                "handle_bytes": int(rast.memory_usage())},
                    "tile_lists": ("reference lists (GSR_FLAG_REFERENCE_TILE_LISTS)" if args.reference_lists else
                                   "library default: exact footprint cull (same image / gradients)"),
-                   "parallelism": (f"view-parallel x{world}, all-reduce of {11 * N * 4 / 1e6:.0f} MB + all-gather of "
-                                   f"{world} x {3 * N * 4 / 1e6:.0f} MB colour cotangents (factored SH gradient"
-                                   f"{'; the two collectives overlapped on two communicators' if overlap else ''}); "
-                                   f"GSR_DIST_FULL_ARENA=1 selects the plain all-reduce of the whole arena" if factored else
-                                   f"view-parallel x{world}, 1 all-reduce of {arena.numel() * 4 / 1e6:.0f} MB")},
+                   "parallelism": par,
+                   "launch": ("self-launched ranks (bench.py --gpus N)" if os.environ.get("GSR_BENCH_SELF_LAUNCHED") else
+                              "external launcher (RANK in the environment)" if "RANK" in os.environ else "single process")},
         "roofline": roofline,
     }
 
@@ -359,29 +692,30 @@ def main():
                                        "inside the backward (gsr_backward_trainer_tail: 'adam' = composite_bwd + per-Gaussian backward + tail)"
                                        if args.tail_in_backward else "fused (gsr_trainer_tail_step: 'adam' is the whole tail)")
         out["config"]["workload"] += " + prologue + Adam (trainer tail, not the headline metric)"
-    if world == 1 and not dist_on and tail is None and not args.no_other_lists:
+    if wl.dist_on and tail is None:
+        out["exchange"] = exchange_report(wl, max(5, args.steps // 2), 2, headline_form)
+    if world == 1 and not wl.dist_on and tail is None and not args.no_other_lists:
         # the same step with the OTHER tile-list mode, timed in the same run (headline = the library default)
         rast2 = pkg.rasterizer.GaussianRasterizer(W, H, mode=args.mode, device=dev, exact_tile_cull=args.reference_lists)
-        rast_main, rast = rast, rast2
-        for _ in range(max(args.warmup, 2)):
-            step()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync()
-        dt2 = (time.perf_counter() - t0) / args.steps
+        rast_main, wl.rast = wl.rast, rast2
+        dt2 = wl.time_plain(args.steps, max(args.warmup, 2))
         out["other_tile_lists"] = {"tile_lists": "exact footprint cull" if args.reference_lists else "reference lists",
                                    "ms_per_step": round(1e3 * dt2, 4), "value": round(P / dt2 / 1e6, 3),
                                    "tile_instances": int(rast2.stats.n_rendered)}
-        rast = rast_main
+        wl.rast = rast_main
         rast2.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, s, W, H, deg, args)
+    if world == 1 and not wl.dist_on and is_headline and tail is None and not args.reference_lists and not args.no_extra:
+        wl.close()
+        del wl
+        torch.cuda.empty_cache()
+        out["extra_configs"] = extra_configs(pkg, dev, args)
     if rank == 0:
-        print(json.dumps(out))
-    if dist_on:
+        print(json.dumps(out), flush=True)
+    if dist.is_initialized():
         dist.destroy_process_group()
+    return 0
 
 
 def cpu_baseline(pkg, s, W, H, deg, args):
@@ -404,5 +738,16 @@ def cpu_baseline(pkg, s, W, H, deg, args):
                       f"form over OpenMP threads (non-deterministic summation order, as render.jl:242,275-282)"}
 
 
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if "RANK" not in os.environ and (args.gpus > 1 or args.dry_launch):
+        # N ranks asked for and nobody has started them: do it here, BEFORE torch / HIP are touched by this process
+        return launch_ranks(args, argv)
+    if args.dry_launch:
+        return dry_rank()
+    return run_rank(args)
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

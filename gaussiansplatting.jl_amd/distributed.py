@@ -104,15 +104,33 @@ def split_factored_arena(arena, n: int):
 
 
 _overlap_groups = None
+_last_overlapped = False
+
+
+def _can_overlap(arena_is_cuda: bool) -> bool:
+    """Two communicators in flight at once: RCCL ("nccl") with device tensors, or gloo with HOST tensors.  gloo moving
+    DEVICE tensors through the host (several ranks sharing one GPU in logic tests) deadlocks after a few steps with two
+    communicators in flight, so that combination runs the sequential form.  Decided from the backend and the tensor,
+    not from torch.cuda.is_available() (a GPU host running the gloo/CPU-tensor tests must still overlap)."""
+    if not active():
+        return False
+    return dist.get_backend() == "nccl" or not arena_is_cuda
 
 
 def overlap_groups():
     """Two extra process groups (= two RCCL communicators with their own streams) so that the two collectives
-    of the factored exchange can be in flight at the same time.  Created once, collectively, by every rank."""
+    of the factored exchange can be in flight at the same time.  Created once, collectively, by every rank,
+    whenever collectives are active (cheap; whether they are USED is decided per exchange by `_can_overlap`)."""
     global _overlap_groups
-    if _overlap_groups is None and active() and (dist.get_backend() == "nccl" or not torch.cuda.is_available()):
+    if _overlap_groups is None and active():
         _overlap_groups = (dist.new_group(), dist.new_group())
     return _overlap_groups
+
+
+def last_exchange_overlapped() -> bool:
+    """Whether the most recent exchange_factored_overlapped really had its two collectives in flight together
+    (False: it fell back to the sequential form) — so that callers report the form that actually ran."""
+    return _last_overlapped
 
 
 def exchange_factored_overlapped(arena: torch.Tensor, n: int, gathered: torch.Tensor, rebuild):
@@ -121,21 +139,24 @@ def exchange_factored_overlapped(arena: torch.Tensor, n: int, gathered: torch.Te
     `rebuild(vcolors_all)` — the ∇shs reconstruction kernel, which needs only the gathered cotangents — runs on the
     compute stream as soon as the all-gather lands, WHILE the all-reduce is still crossing the links; the compute
     stream joins the all-reduce last.  Same results as exchange_factored + rebuild (the collectives are
-    independent); world == 1: no collective."""
+    independent); world == 1: no collective.  Falls back to the sequential form when the backend cannot keep two
+    communicators in flight for this tensor (`_can_overlap`) or the groups were never created."""
+    global _last_overlapped
     world = dist.get_world_size() if dist.is_initialized() else 1
     vc = arena[11 * n:]
+    _last_overlapped = False
     if not active():
         return rebuild(vc.view(1, n, 3))
-    if arena.is_cuda and dist.get_backend() != "nccl":
-        # gloo moving device tensors through the host (several ranks sharing one GPU in logic tests): two
-        # communicators in flight at once deadlock there after a few steps — same results from the sequential form
+    groups = overlap_groups() if _can_overlap(arena.is_cuda) else None
+    if groups is None:
         return rebuild(exchange_factored(arena, n, gathered))
-    ga, gb = overlap_groups()
+    ga, gb = groups
     h_gather = dist.all_gather_into_tensor(gathered.view(-1), vc, group=ga, async_op=True)
     h_reduce = dist.all_reduce(arena[:11 * n], op=dist.ReduceOp.SUM, group=gb, async_op=True)
     h_gather.wait()  # nccl: the compute stream waits for the gather (no host block); gloo: host wait
     out = rebuild(gathered.view(world, n, 3))
     h_reduce.wait()
+    _last_overlapped = True
     return out
 
 

@@ -1,7 +1,7 @@
 """Child-process launcher for the GPU box: started by tests/conftest.py BEFORE anything in the pytest process touches
 the GPU, it never touches the GPU itself, so its fork+exec of worker processes is always allowed (a process that
 has initialised HIP must not exec; the pytest process has, by the time the multi-rank test runs).
-Protocol: one JSON request per line on stdin {"argv": [...], "env": {...}, "n": ranks, "timeout": s} ->
+Protocol: one JSON request per line on stdin {"argv": [...], "env": {...}, "n": ranks, "timeout": s, "raw": bool} ->
 one JSON reply per line {"rc": [..], "out": [tail per rank]}."""
 import json
 import os
@@ -16,7 +16,8 @@ def main():
         for r in range(req["n"]):
             env = dict(os.environ)
             env.update(req["env"])
-            env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(req["n"]))
+            if not req.get("raw"):  # "raw": a plain child (e.g. bench.py --gpus N, which starts its own ranks)
+                env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(req["n"]))
             procs.append(subprocess.Popen(req["argv"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
         rc, out = [], []
         for p in procs:

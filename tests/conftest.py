@@ -36,10 +36,10 @@ def pytest_unconfigure(config):
 @pytest.fixture(scope="session")
 def launch_ranks():
     """launch_ranks(argv, n, env, timeout) -> (return codes, output tails) of n fresh rank processes."""
-    def run(argv, n, env=None, timeout=600):
+    def run(argv, n, env=None, timeout=600, raw=False):
         if _launcher is None:
             pytest.skip("rank launcher not started (run with -m gpu)")
-        _launcher.stdin.write(json.dumps({"argv": argv, "n": n, "env": env or {}, "timeout": timeout}) + "\n")
+        _launcher.stdin.write(json.dumps({"argv": argv, "n": n, "env": env or {}, "timeout": timeout, "raw": raw}) + "\n")
         _launcher.stdin.flush()
         rep = json.loads(_launcher.stdout.readline())
         return rep["rc"], rep["out"]

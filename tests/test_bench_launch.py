@@ -1,0 +1,89 @@
+"""bench.py's launch contract (round-2 verdict #1): `bench.py --gpus N` with no RANK in the environment starts N
+fresh rank processes itself before touching torch / HIP; a world size that differs from --gpus is an error, never a silent
+1-GPU number; a failing rank makes the launcher exit non-zero.  CPU tests of the launch step; the -m gpu test runs the
+real thing (two ranks sharing the box's GPU, gloo carrying the collectives)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+def test_dry_launch_starts_n_children_with_the_rank_environment():
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "3", "--dry-launch"], env=_env(), capture_output=True, text=True,
+                       timeout=120)
+    assert p.returncode == 0, p.stderr
+    rep = json.loads(p.stdout.strip().splitlines()[-1])
+    kids = rep["dry_launch"]
+    assert rep["rc"] == [0, 0, 0]
+    assert [k["rank"] for k in kids] == [0, 1, 2] and [k["local_rank"] for k in kids] == [0, 1, 2]
+    assert all(k["world_size"] == 3 and k["master_addr"] == "127.0.0.1" for k in kids)
+    assert len({k["master_port"] for k in kids}) == 1 and kids[0]["master_port"] > 0
+
+
+def test_dry_launch_child_never_imports_torch():
+    """The launcher parent and the dry children must finish without importing torch (= without any chance of touching HIP):
+    poison the import."""
+    poison = os.path.join(ROOT, "tests", "_poison")
+    os.makedirs(os.path.join(poison, "torch"), exist_ok=True)
+    with open(os.path.join(poison, "torch", "__init__.py"), "w") as f:
+        f.write("raise ImportError('torch must not be imported by the launcher or by --dry-launch children')\n")
+    try:
+        p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-launch"], env=_env(PYTHONPATH=poison),
+                           capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr
+        assert len(json.loads(p.stdout.strip().splitlines()[-1])["dry_launch"]) == 2
+    finally:
+        import shutil
+        shutil.rmtree(poison, ignore_errors=True)
+
+
+def test_world_size_mismatch_is_an_error():
+    """RANK set (we ARE a rank) but the world has 1 rank while --gpus says 2: exit 2, no JSON line."""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=_env(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1"), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2, (p.returncode, p.stderr[-2000:])
+    assert "refusing to run" in p.stderr and not p.stdout.strip()
+
+
+@pytest.mark.skipif(__import__("torch").cuda.is_available(), reason="on a GPU box the ranks would run the real bench")
+def test_a_failing_rank_fails_the_launch():
+    """Here (no GPU) every rank comes up under gloo, passes the world-size check and then fails on 'no HIP device': the
+    launcher must report that as a non-zero exit code and must not print a JSON line."""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--gaussians", "100",
+                        "--width", "64", "--height", "48"], env=_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert "rank(s) failed" in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]  # (gloo itself prints a connection note to stdout)
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_self_launches_two_ranks(launch_ranks):
+    """`python bench.py --gpus 2 ...` WITHOUT torchrun, started from the GPU-free launcher (the pytest process has touched
+    HIP): two ranks share the one GPU of the box, gloo carries the collectives.  The JSON line must say n_gpus = 2 =
+    ranks_seen and carry the exchange report with every form timed."""
+    rc, out = launch_ranks([sys.executable, BENCH, "--gpus", "2", "--gaussians", "20000", "--width", "640", "--height", "480",
+                            "--steps", "4", "--warmup", "1", "--no-cpu-baseline"], 1,
+                           env={"GSR_DIST_BACKEND": "gloo"}, timeout=900, raw=True)
+    assert rc == [0], out[0]
+    line = [ln for ln in out[0].splitlines() if ln.startswith("{")][-1]
+    rep = json.loads(line)
+    assert rep["n_gpus"] == 2 and rep["ranks_seen"] == 2
+    assert rep["config"]["launch"].startswith("self-launched")
+    ex = rep["exchange"]
+    assert set(ex["forms"]) == {"factored+overlap", "factored", "plain"}
+    assert ex["bytes_per_gpu"] == int(2 * 0.5 * 11 * 20000 * 4 + 1 * 3 * 20000 * 4)
+    assert ex["forms"]["plain"]["bytes_per_gpu"] == int(2 * 0.5 * 59 * 20000 * 4)
+    assert ex["ms"] > 0 and ex["backend"] == "gloo"
+    # gloo with device tensors cannot keep two communicators in flight: the line must say which form really ran
+    assert ex["overlap"] is False and "sequential" in ex["form"]

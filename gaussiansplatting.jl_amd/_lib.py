@@ -15,7 +15,8 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gsr.h")
 
 GSR_OK, GSR_E_INVALID_ARG, GSR_E_OOM, GSR_E_HIP, GSR_E_STATE = 0, -1, -2, -3, -4
 MODES = {"rgb": 3, "rgbd": 5, "rgbdn": 8}
-FLAG_REFERENCE_TILE_LISTS = 1  # flags = 0: exact footprint culling (the default)
+FLAG_REFERENCE_TILE_LISTS = 2  # flags = 0: exact footprint culling (the default); bit 1 is retired (rejected)
+ABI_VERSION = 3  # GSR_ABI_VERSION of the include/gsr.h this mirror was written against
 
 (BUF_RADII, BUF_GRAD_MEANS2D, BUF_N_CONTRIB, BUF_FINAL_T, BUF_TILE_RANGES, BUF_VALUES_SORTED, BUF_GEOM, BUF_NORMALS,
  BUF_GRAD_ROWS, BUF_INSTANCE_AUX) = range(10)
@@ -92,8 +93,8 @@ class GatherGroup(C.Structure):
 
 
 EXPORTS = ["gsr_create", "gsr_destroy", "gsr_release_scene_buffers", "gsr_memory_usage", "gsr_forward",
-           "gsr_backward", "gsr_buffer", "gsr_copy_buffer", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_loss_l1_ssim",
-           "gsr_allreduce_grads", "gsr_last_error_string", "gsr_version", "gsr_profile_enable",
+           "gsr_backward", "gsr_host_wait_policy", "gsr_buffer", "gsr_copy_buffer", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_loss_l1_ssim",
+           "gsr_allreduce_grads", "gsr_last_error_string", "gsr_version", "gsr_abi_version", "gsr_check_abi", "gsr_profile_enable",
            "gsr_profile_stage_count", "gsr_profile_stages", "gsr_profile_stage_name", "gsr_profile_read", "gsr_profile_read_intervals", "gsr_update_stats",
            "gsr_prologue_forward", "gsr_prologue_backward", "gsr_adam_step", "gsr_stream_triad",
            "gsr_mask_findall_scratch_bytes", "gsr_mask_findall", "gsr_gather_rows", "gsr_sh_grad_from_views", "gsr_trainer_tail_step",
@@ -133,6 +134,7 @@ def load():
     lib.gsr_memory_usage.restype = C.c_int64
     lib.gsr_forward.argtypes = [vp, C.POINTER(Inputs), C.POINTER(CameraS), vp, C.POINTER(Aux), vp, C.POINTER(Stats)]
     lib.gsr_backward.argtypes = [vp, C.POINTER(Inputs), C.POINTER(CameraS), vp, C.POINTER(Grads), vp]
+    lib.gsr_host_wait_policy.argtypes = [i32, i32, i32]
     lib.gsr_buffer.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.gsr_copy_buffer.argtypes = [vp, i32, vp, C.c_size_t, vp]
     lib.gsr_ssim_forward.argtypes = [i32, i32, i32, i32, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp]
@@ -169,6 +171,11 @@ def load():
     lib.gsr_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int), i32]
     lib.gsr_last_error_string.restype = C.c_char_p
     lib.gsr_version.restype = C.c_char_p
+    lib.gsr_check_abi.argtypes = [i32] + [C.c_size_t] * 6
+    # a stale library next to a newer mirror (or the reverse) must fail here, loudly, not mis-read structs later
+    rc = lib.gsr_check_abi(ABI_VERSION, *[C.sizeof(t) for t in (Config, Inputs, CameraS, Aux, Stats, Grads)])
+    if rc != 0:
+        raise GsrError(rc, lib.gsr_last_error_string().decode())
     _lib = lib
     return lib
 

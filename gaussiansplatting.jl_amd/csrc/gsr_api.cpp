@@ -7,6 +7,8 @@
 
 #include <dlfcn.h>
 #include <math.h>
+#include <sched.h>
+#include <time.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -127,6 +129,16 @@ struct Profiler {
         rec_open = false;
         (void)hipEventRecord(recs.back().b, s);
     }
+    // error path: a stage that was begun but whose launch failed — close the roctx range and DROP the half-recorded
+    // pair (its end event was never recorded: gsr_profile_read would fail or mis-time on it)
+    void abort() {
+        if (in_range) { g_roctx.pop(); in_range = false; }
+        if (!rec_open) return;
+        rec_open = false;
+        pool.push_back(recs.back().a);
+        pool.push_back(recs.back().b);
+        recs.pop_back();
+    }
     void clear() {
         for (auto& r : recs) { pool.push_back(r.a); pool.push_back(r.b); }
         recs.clear();
@@ -151,6 +163,19 @@ void Profiler::begin(int stage, hipStream_t s) {
     recs.push_back(r);
     rec_open = true;
 }
+
+// One profiled stage: begun by the constructor, ended by close(); a scope left WITHOUT close() — an early `return rc`
+// or a HIPCHK between the two — aborts the stage instead of leaving a pushed roctx range and an open record behind.
+struct StageScope {
+    Profiler& p;
+    hipStream_t s;
+    bool open = true;
+    StageScope(Profiler& prof, int stage, hipStream_t stream) : p(prof), s(stream) { p.begin(stage, s); }
+    void close() { if (open) { p.end(s); open = false; } }
+    ~StageScope() { if (open) p.abort(); }
+    StageScope(const StageScope&) = delete;
+    StageScope& operator=(const StageScope&) = delete;
+};
 
 bool valid_mode(int m) { return m == GSR_MODE_RGB || m == GSR_MODE_RGBD || m == GSR_MODE_RGBDN; }
 
@@ -222,28 +247,58 @@ GsrStream stream_of(const gsr_handle* h) {
 }
 GsrInst inst_of(const gsr_handle* h) { return GsrInst{h->rows.as<float4>()}; }
 
-// Spin until tile_scan of forward `seq` published its totals.  A wait that lasts longer than any sane queue depth
-// (50 ms) starts polling the stream, so that a failed launch or a faulted kernel ends with an error instead of
-// hanging the caller — not earlier: hipStreamQuery puts a marker packet on the stream, and a marker between two
-// kernels is a 5 us bubble (rocprofv3 kernel trace, tools/gap_report.py).
+// CPU relax hint inside the spin phase: x86 `pause`, AArch64 `yield`, nothing elsewhere (the host side builds on any arch).
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#endif
+}
+
+// Host wait policy of the forward's single read-back (gsr_host_wait_policy): microseconds of pure spinning, then of
+// sched_yield() polling, then sleeps of `sleep_us`.  Process-wide.
+struct WaitPolicy { int spin_us = 20, yield_us = 80, sleep_us = 20; };
+WaitPolicy g_wait;
+
+// Wait until tile_scan of forward `seq` has published its totals (a word of pinned host memory).  POLITE: the wait is
+// typically 0.05-0.2 ms (preprocess + scan of this view); an 8-rank node has eight of these waiters next to RCCL's proxy
+// threads, so only the first `spin_us` are a busy spin; then the core is offered to other runnable threads
+// (sched_yield) and finally released for `sleep_us` at a time.  The GPU never waits for this thread (the next launch is
+// already queued behind the scan), so the wake-up latency of the sleep phase is hidden behind sort + forward.
+// A wait that lasts longer than any sane queue depth (50 ms) starts polling the stream, so that a failed launch or a
+// faulted kernel ends with an error instead of hanging the caller — not earlier: hipStreamQuery puts a marker packet on
+// the stream, and a marker between two kernels is a 5 us bubble (rocprofv3 kernel trace, tools/gap_report.py).
 int wait_totals(gsr_handle* h, uint32_t seq, hipStream_t s) {
+    using clk = std::chrono::steady_clock;
     volatile uint32_t* word = h->host_totals + 7;
-    auto next_poll = std::chrono::steady_clock::time_point::max();
-    for (uint64_t spins = 1;; spins++) {
-        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) return GSR_OK;
-        __builtin_ia32_pause();
-        if ((spins & 0xFFF) == 0) {
-            const auto now = std::chrono::steady_clock::now();
-            if (next_poll == std::chrono::steady_clock::time_point::max()) next_poll = now + std::chrono::milliseconds(50);
-            if (now < next_poll) continue;
-            next_poll = now + std::chrono::milliseconds(50);
-            const hipError_t q = hipStreamQuery(s);
-            if (q == hipSuccess) {  // everything enqueued has finished: the word is there, or it never will be
-                if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) return GSR_OK;
-                return fail(GSR_E_HIP, "tile scan finished without publishing its totals");
-            }
-            if (q != hipErrorNotReady) return fail(GSR_E_HIP, "HIP error while waiting for the tile scan: %s", hipGetErrorString(q));
+    if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) return GSR_OK;
+    const auto t0 = clk::now();
+    const auto t_spin = t0 + std::chrono::microseconds(g_wait.spin_us);
+    const auto t_yield = t_spin + std::chrono::microseconds(g_wait.yield_us);
+    auto next_poll = t0 + std::chrono::milliseconds(50);
+    for (;;) {
+        for (int i = 0; i < 64; i++) {
+            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) return GSR_OK;
+            cpu_relax();
         }
+        const auto now = clk::now();
+        if (now >= t_spin) {
+            if (now < t_yield || g_wait.sleep_us <= 0) {
+                sched_yield();
+            } else {
+                struct timespec ts = {0, (long)g_wait.sleep_us * 1000L};
+                nanosleep(&ts, nullptr);
+            }
+        }
+        if (now < next_poll) continue;
+        next_poll = now + std::chrono::milliseconds(50);
+        const hipError_t q = hipStreamQuery(s);
+        if (q == hipSuccess) {  // everything enqueued has finished: the word is there, or it never will be
+            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) return GSR_OK;
+            return fail(GSR_E_HIP, "tile scan finished without publishing its totals");
+        }
+        if (q != hipErrorNotReady) return fail(GSR_E_HIP, "HIP error while waiting for the tile scan: %s", hipGetErrorString(q));
     }
 }
 
@@ -266,13 +321,39 @@ int check_inputs(const gsr_handle* h, const gsr_inputs* in, const gsr_camera* ca
 extern "C" {
 
 const char* gsr_last_error_string(void) { return g_err; }
-const char* gsr_version(void) { return "gsr-hip 0.1 (gfx950)"; }
+#define GSR_STR2(x) #x
+#define GSR_STR(x) GSR_STR2(x)
+const char* gsr_version(void) { return "gsr-hip 0.3 abi " GSR_STR(GSR_ABI_VERSION) " (gfx950)"; }
+int gsr_abi_version(void) { return GSR_ABI_VERSION; }
+
+int gsr_host_wait_policy(int spin_us, int yield_us, int sleep_us) {
+    if (spin_us < 0 || yield_us < 0 || sleep_us < 0) return fail(GSR_E_INVALID_ARG, "negative wait time");
+    g_wait.spin_us = spin_us; g_wait.yield_us = yield_us; g_wait.sleep_us = sleep_us;
+    return GSR_OK;
+}
+
+int gsr_check_abi(int abi_version, size_t sizeof_config, size_t sizeof_inputs, size_t sizeof_camera, size_t sizeof_aux,
+                  size_t sizeof_stats, size_t sizeof_grads) {
+    if (abi_version != GSR_ABI_VERSION)
+        return fail(GSR_E_INVALID_ARG, "binding was written for gsr ABI %d, this library is ABI %d", abi_version, GSR_ABI_VERSION);
+    const struct { const char* name; size_t theirs, ours; } t[] = {
+        {"gsr_config", sizeof_config, sizeof(gsr_config)}, {"gsr_inputs", sizeof_inputs, sizeof(gsr_inputs)},
+        {"gsr_camera", sizeof_camera, sizeof(gsr_camera)}, {"gsr_aux", sizeof_aux, sizeof(gsr_aux)},
+        {"gsr_stats", sizeof_stats, sizeof(gsr_stats)},    {"gsr_grads", sizeof_grads, sizeof(gsr_grads)}};
+    for (const auto& e : t)
+        if (e.theirs != e.ours)
+            return fail(GSR_E_INVALID_ARG, "sizeof(%s) is %zu in the binding, %zu in the library", e.name, e.theirs, e.ours);
+    return GSR_OK;
+}
 
 int gsr_create(const gsr_config* cfg, gsr_handle** out) {
     if (!cfg || !out) return fail(GSR_E_INVALID_ARG, "null config / out");
     if (cfg->width <= 0 || cfg->height <= 0) return fail(GSR_E_INVALID_ARG, "bad resolution %dx%d", cfg->width, cfg->height);
     if (!valid_mode(cfg->mode)) return fail(GSR_E_INVALID_ARG, "Invalid render mode: %d (3=rgb, 5=rgbd, 8=rgbdn)", cfg->mode);
     if (!(cfg->near_plane < cfg->far_plane)) return fail(GSR_E_INVALID_ARG, "near_plane >= far_plane");
+    if (cfg->flags & GSR_FLAG_RETIRED_BIT0)
+        return fail(GSR_E_INVALID_ARG, "flag bit 0x1 is retired (ABI 1's GSR_FLAG_EXACT_TILE_CULL): rebuild the caller against "
+                                       "include/gsr.h ABI %d", GSR_ABI_VERSION);
     if (cfg->flags & ~(uint32_t)GSR_FLAG_REFERENCE_TILE_LISTS) return fail(GSR_E_INVALID_ARG, "unknown flags 0x%x", cfg->flags);
     gsr_handle* h = new (std::nothrow) gsr_handle();
     if (!h) return fail(GSR_E_OOM, "host allocation failed");
@@ -399,17 +480,17 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     // Only a pass that did not reach the sort (an error) leaves them dirty.
     if (h->tile_count_dirty) HIPCHK(hipMemsetAsync(h->tile_count.p, 0, (T + 2) * 4, s));
     h->tile_count_dirty = true;
-    h->prof.begin(ST_PREPROCESS, s);
+    StageScope sc1(h->prof, ST_PREPROCESS, s);
     gsr_launch_preprocess(s, n, in->n_coeffs, in->sh_degree, C, in->means, in->scales, in->rotations, in->opacities,
                           in->shs, k, geom_of(h), h->tile_count.as<uint32_t>(), h->bvis.as<uint32_t>(),
                           h->bins.as<uint64_t>(), h->bin_cap_view /* 0: count only */);
-    h->prof.end(s);
+    sc1.close();
     const uint32_t seq = ++h->totals_seq ? h->totals_seq : ++h->totals_seq;  // never 0
-    h->prof.begin(ST_SCAN, s);
+    StageScope sc2(h->prof, ST_SCAN, s);
     gsr_launch_tile_scan(s, h->n_tiles, h->tile_count.as<uint32_t>(), h->tile_start.as<uint32_t>(), totals,
                          n_blocks, h->bsum.as<uint32_t>(), h->bpre.as<uint32_t>(), h->bvis.as<uint32_t>(),
                          h->big_list.as<uint32_t>(), h->host_totals_dev, seq, h->tile_order.as<uint32_t>());
-    h->prof.end(s);
+    sc2.close();
     HIPCHK(hipGetLastError());
     // the one host sync of the path: instance count D (reference: rasterizer.jl:337).  tile_scan stores the totals
     // and then this forward's sequence number into pinned host memory; no copy packet, no event on the stream.
@@ -423,14 +504,14 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     static const bool no_fused = [] { const char* e = getenv("GSR_NO_FUSED_FWD"); return e && e[0] == '1'; }();  // A/B only
     const bool spec = use_bins && cap_instances > 0 && !no_fused;
     if (spec) {
-        h->prof.begin(ST_SORT_COMPOSITE_FWD, s);
+        StageScope sc3(h->prof, ST_SORT_COMPOSITE_FWD, s);
         gsr_launch_sort_composite_fwd(s, C, k, h->tile_start.as<uint32_t>(), h->tile_order.as<uint32_t>(),
                                       h->tile_count.as<uint32_t>(), h->bins.as<uint64_t>(), h->bin_cap_view, geom_of(h),
                                       stream_of(h), in->background, image_out, h->n_contrib.as<uint32_t>(),
                                       h->final_T.as<float>(), h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>(),
                                       aux ? aux->covisibilities : nullptr, aux ? aux->uncertainties : nullptr, totals,
                                       (uint32_t)cap_instances);
-        h->prof.end(s);
+        sc3.close();
     }
     if ((rc = wait_totals(h, seq, s))) return rc;
     const bool overflow = use_bins && h->host_totals[1] > h->bin_cap_view;
@@ -487,7 +568,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     const uint32_t n_mid4 = h->host_totals[3], n_mid8 = h->host_totals[6];
     const bool long_tiles = (n_mid4 | n_mid8 | n_big) != 0u;
     if (!fused_done || long_tiles) {
-        h->prof.begin(ST_SORT, s);
+        StageScope sc4(h->prof, ST_SORT, s);
         const uint64_t* keys = h->bins.as<uint64_t>();
         uint32_t key_cap = h->bin_cap_used(use_bins);
         if (compact) {
@@ -504,15 +585,15 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
                              n_mid4, n_mid8, n_big, h->big_list.as<uint32_t>(), h->big_scratch.as<uint64_t>(),
                              slab_stride, geom_of(h), stream_of(h), h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>(),
                              nullptr, 0);
-        h->prof.end(s);
-        h->prof.begin(ST_COMPOSITE_FWD, s);
+        sc4.close();
+        StageScope sc5(h->prof, ST_COMPOSITE_FWD, s);
         // after the fused launch only the tiles of the tier lists are left; otherwise every tile
         const GsrTierLists tiers{h->big_list.as<uint32_t>(), (uint32_t)h->n_tiles, n_big, n_mid8, n_mid4, 0u};
         gsr_launch_composite_fwd(s, C, k, h->tile_start.as<uint32_t>(), fused_done ? nullptr : h->tile_order.as<uint32_t>(),
                                  stream_of(h), in->background, image_out, h->n_contrib.as<uint32_t>(), h->final_T.as<float>(),
                                  h->values_sorted.as<uint32_t>(), aux ? aux->covisibilities : nullptr,
                                  aux ? aux->uncertainties : nullptr, &tiers);
-        h->prof.end(s);
+        sc5.close();
     }
     h->tile_count_dirty = false;  // the sort (fused or not) zeroed the counters
     HIPCHK(hipGetLastError());
@@ -578,20 +659,20 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
     // (the gradient rows need no memset: composite_bwd writes the row of every emitted instance,
     // pergauss_bwd skips the slots of culled tiles; only the 12 pose-gradient floats are accumulated into)
     if (g->vR) {
-        h->prof.begin(ST_ZERO_ACC, s);
+        StageScope sc6(h->prof, ST_ZERO_ACC, s);
         HIPCHK(hipMemsetAsync(g->vR, 0, 9 * 4, s));
         HIPCHK(hipMemsetAsync(g->vt, 0, 3 * 4, s));
-        h->prof.end(s);
+        sc6.close();
     }
     GsrCam k = make_cam(h, cam);
-    h->prof.begin(ST_COMPOSITE_BWD, s);
+    StageScope sc7(h->prof, ST_COMPOSITE_BWD, s);
     if (h->last_D > 0 && (rc = launch_composite_bwd(h, s, C, k, in->background, vpixels))) return rc;
-    h->prof.end(s);
-    h->prof.begin(ST_PERGAUSS_BWD, s);
+    sc7.close();
+    StageScope sc8(h->prof, ST_PERGAUSS_BWD, s);
     gsr_launch_pergauss_bwd(s, n, in->n_coeffs, in->sh_degree, C, in->means, in->scales, in->rotations, in->shs, k,
                             geom_of(h), inst_of(h), h->vmean2d_cur, g->vmeans, g->vshs, g->vopacities,
                             g->vscales, g->vrotations, g->vR, g->vt, g->vcolors);
-    h->prof.end(s);
+    sc8.close();
     HIPCHK(hipGetLastError());
     h->bwd_valid = true;
     return GSR_OK;
@@ -679,14 +760,14 @@ int gsr_loss_l1_ssim(gsr_handle* h, const float* image, const float* target, flo
         (rc = h->partial.ensure((size_t)h->n_tiles * 3 * 2 * 4)))
         return rc;
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;  // fused_ssim.jl:374
-    h->prof.begin(ST_LOSS_FWD, s);
+    StageScope sc9(h->prof, ST_LOSS_FWD, s);
     gsr_launch_loss_fwd(s, W, H, C, image, target, C1, C2, h->d0.as<float>(), h->d1.as<float>(), h->d2.as<float>(),
                         h->partial.as<float>());
-    h->prof.end(s);
-    h->prof.begin(ST_LOSS_BWD, s);
+    sc9.close();
+    StageScope sc10(h->prof, ST_LOSS_BWD, s);
     gsr_launch_loss_bwd(s, W, H, C, image, target, lambda_dssim, h->d0.as<float>(), h->d1.as<float>(),
                         h->d2.as<float>(), h->partial.as<float>(), loss_out, vpixels);
-    h->prof.end(s);
+    sc10.close();
     HIPCHK(hipGetLastError());
     return GSR_OK;
 }
@@ -868,14 +949,14 @@ int gsr_backward_trainer_tail(gsr_handle* h, const gsr_inputs* in, const gsr_cam
     if (!st->vmeans2d && (rc = h->vmean2d.ensure((size_t)n * 8))) return rc;
     h->vmean2d_cur = st->vmeans2d ? reinterpret_cast<float2*>(st->vmeans2d) : h->vmean2d.as<float2>();
     GsrCam k = make_cam(h, cam);
-    h->prof.begin(ST_COMPOSITE_BWD, s);
+    StageScope sc11(h->prof, ST_COMPOSITE_BWD, s);
     if (h->last_D > 0 && (rc = launch_composite_bwd(h, s, C, k, in->background, vpixels))) return rc;
-    h->prof.end(s);
-    h->prof.begin(ST_PERGAUSS_BWD, s);
+    sc11.close();
+    StageScope sc12(h->prof, ST_PERGAUSS_BWD, s);
     const gsr::TailState S = gsr_make_tail_state(st->theta, st->mu, st->nu, lr_t, st->beta1, st->beta2, st->eps,
                                                  st->scale_dims, st->shs, st->opacities_act, st->scales_act);
     gsr_launch_pergauss_bwd_tail(s, n, K, in->sh_degree, C, k, geom_of(h), inst_of(h), h->vmean2d_cur, S);
-    h->prof.end(s);
+    sc12.close();
     HIPCHK(hipGetLastError());
     h->bwd_valid = true;
     // the forward's inputs no longer exist (updated in place): a second backward on this forward would differentiate

@@ -105,6 +105,16 @@ class DefaultStrategy:
         self.dense_percent, self.densify_from_iter, self.densify_until_iter = float(dense_percent), int(densify_from_iter), int(densify_until_iter)
         self.densification_interval, self.densify_grad_threshold = int(densification_interval), float(densify_grad_threshold)
         self.opacity_reset_interval, self.min_opacity = int(opacity_reset_interval), float(min_opacity)
+        # Split noise is a pure function of (seed, appended row, draw): the seed MUST differ between densification rounds
+        # or appended row i would get the same normal triple every round (the reference draws fresh randn each time,
+        # densification.jl:121-135).  `split_seed_base` identifies the run; `split_rounds` advances on every split.
+        self.split_seed_base = 0
+        self.split_rounds = 0
+
+    def next_split_seed(self) -> int:
+        """Seed for the next split when the caller gives none: distinct for every round of this strategy object."""
+        self.split_rounds += 1
+        return (self.split_seed_base * 0x9E3779B1 + self.split_rounds * 0x85EBCA6B) & 0xFFFFFFFF
 
 
 def _ptr(t):
@@ -161,9 +171,12 @@ def densify_clone(strategy, gs, optimizers, grad, grad_threshold, extent, dense_
     return mask
 
 
-def densify_split(strategy, gs, optimizers, grad, grad_threshold, extent, dense_percent, seed=0):
+def densify_split(strategy, gs, optimizers, grad, grad_threshold, extent, dense_percent, seed=None):
     """densify_split! (densification.jl:64-119): replace big Gaussians with a high gradient by two smaller ones
-    sampled inside them; the originals are pruned in the same composition."""
+    sampled inside them; the originals are pruned in the same composition.  `seed` selects the noise stream of THIS
+    round and must differ from round to round; None = the strategy's own advancing counter (never a constant)."""
+    if seed is None:
+        seed = strategy.next_split_seed()
     n = len(gs)
     mask = _mask(L.DENSIFY_SPLIT, gs, grad.numel(), grad, thr=grad_threshold, gamma=np.float32(extent) * np.float32(dense_percent))
     sel = findall(mask)
@@ -187,7 +200,7 @@ def prune_points(strategy, gs, optimizers, valid_mask):
         [strategy.max_radii, strategy.accum_grad_means_2d, strategy.denom], keep)
 
 
-def densify_and_prune(strategy: DefaultStrategy, gs: GaussianModel, optimizers, extent, pruning_extent, max_screen_size, seed=0):
+def densify_and_prune(strategy: DefaultStrategy, gs: GaussianModel, optimizers, extent, pruning_extent, max_screen_size, seed=None):
     """densify_and_prune! (densification.jl:1-27).  Returns the three masks (clone, split, valid) for inspection."""
     n = len(gs)
     grad = torch.empty(n, dtype=torch.float32, device=gs.points.device)
@@ -205,9 +218,10 @@ def reset_opacity(gs: GaussianModel):
     L.check(L.load().gsr_reset_opacity(gs.opacities.numel(), _ptr(gs.opacities), _stream()))
 
 
-def post_train_step(strategy: DefaultStrategy, gs: GaussianModel, optimizers, rast, step: int, extent: float, seed=0):
+def post_train_step(strategy: DefaultStrategy, gs: GaussianModel, optimizers, rast, step: int, extent: float, seed=None):
     """post_train_step! (strategy.jl:78-105), called once per train step after the optimizer update: statistics from
     `rast.gstate.radii` / `rast.gstate.∇means_2d`, densification on its schedule, periodic opacity reset.
+    `seed` = noise stream of this step's split (None: derived from the strategy's round counter — distinct per round).
     Returns (densified, reset)."""
     if step > strategy.densify_until_iter:
         return False, False

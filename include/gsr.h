@@ -74,7 +74,17 @@ typedef struct gsr_config {
  * those (bstate / istate are private to rasterize / ∇rasterize).
  * GSR_FLAG_REFERENCE_TILE_LISTS: keep exactly the reference's lists (duplicate_with_keys!,
  * utils.jl:85-120) — for list-level parity checks; ~7 % slower at 1 M Gaussians @1080p. */
-#define GSR_FLAG_REFERENCE_TILE_LISTS 1u
+#define GSR_FLAG_REFERENCE_TILE_LISTS 2u
+/* Bit 1u is RETIRED: ABI 1 used it for GSR_FLAG_EXACT_TILE_CULL (the opposite meaning, when exact culling was opt-in).
+ * gsr_create rejects it with GSR_E_INVALID_ARG so that a caller built against the old header fails loudly instead of
+ * silently getting the other list mode. */
+#define GSR_FLAG_RETIRED_BIT0 1u
+
+/* ABI version of this header: bumped whenever a struct of this file changes size or a flag / enum value changes meaning.
+ *   1: round-1 layout (flag bit 1u = exact tile cull, smaller gsr_config / gsr_aux / gsr_stats / gsr_grads)
+ *   2: round-2 layout (flag bit 1u = reference tile lists) — never given a number at the time
+ *   3: this layout (GSR_FLAG_REFERENCE_TILE_LISTS = 2u, bit 1u rejected, gsr_check_abi). */
+#define GSR_ABI_VERSION 3
 
 /* Positional arguments of `rasterize(means_3d, shs, opacities, scales, rotations, ...)`
  * (rasterizer.jl:255-267).  opacities / scales are the ACTIVATED values, as the
@@ -184,6 +194,14 @@ GSR_API int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* c
  * events — nothing the caller has to do. */
 GSR_API int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, const float* vpixels,
                          const gsr_grads* grads, void* stream);
+
+/* How the host thread waits inside gsr_forward for the instance count (the reference blocks in a synchronous
+ * device->host copy there, rasterizer.jl:337).  The wait lasts about as long as preprocess + scan of the view
+ * (0.05-0.2 ms at 1 M Gaussians).  Policy, process-wide: busy-spin for `spin_us` microseconds (default 20), then poll
+ * with sched_yield() for `yield_us` (default 80), then sleep `sleep_us` (default 20) between polls — so eight ranks on one
+ * host do not pin eight cores next to RCCL's proxy threads.  The GPU never waits for the host here (the next launch
+ * is already queued), so the sleep's wake-up latency is hidden.  (1000000, 0, 0) restores a pure spin. */
+GSR_API int gsr_host_wait_policy(int spin_us, int yield_us, int sleep_us);
 
 /* Views into the state the reference keeps in rast.gstate / bstate / istate
  * (states.jl:2-111); valid until the next gsr_forward / release on this handle.
@@ -459,7 +477,14 @@ GSR_API int gsr_profile_read(gsr_handle* h, double* ms_sum, int* launches, int r
 GSR_API int gsr_profile_read_intervals(gsr_handle* h, int stage, double* ms_out, int max_n, int* n_out);
 
 GSR_API const char* gsr_last_error_string(void);
-GSR_API const char* gsr_version(void);
+GSR_API const char* gsr_version(void);   /* "gsr-hip <release> abi <GSR_ABI_VERSION> (gfx950)" */
+GSR_API int gsr_abi_version(void);        /* GSR_ABI_VERSION the library was built from */
+/* Binding self-check, to be called once by every binding right after it loads the library (the Python mirror and the
+ * Julia binding do): the caller's GSR_ABI_VERSION and its sizeof of the six structs that cross gsr_create / gsr_forward
+ * / gsr_backward.  Any mismatch — a caller built against another header — is GSR_E_INVALID_ARG with a message naming the
+ * struct, instead of mis-sized structs being read silently. */
+GSR_API int gsr_check_abi(int abi_version, size_t sizeof_config, size_t sizeof_inputs, size_t sizeof_camera,
+                          size_t sizeof_aux, size_t sizeof_stats, size_t sizeof_grads);
 
 #ifdef __cplusplus
 }

@@ -60,6 +60,17 @@ struct GsrGrads
 end
 
 check(rc) = rc == 0 || error(unsafe_string(ccall((:gsr_last_error_string, LIB), Cstring, ())))
+
+# GSR_ABI_VERSION of the include/gsr.h these struct definitions mirror; checked (with the six struct sizes) against
+# the loaded library by the first enable_hip_native!: a stale libgsr_hip.so or a stale binding fails here, loudly.
+const GSR_ABI_VERSION = 3
+const ABI_CHECKED = Ref(false)
+function check_abi()
+    ABI_CHECKED[] && return
+    check(ccall((:gsr_check_abi, LIB), Cint, (Cint, Csize_t, Csize_t, Csize_t, Csize_t, Csize_t, Csize_t), GSR_ABI_VERSION,
+        sizeof(GsrConfig), sizeof(GsrInputs), sizeof(GsrCamera), sizeof(GsrAux), sizeof(GsrStats), sizeof(GsrGrads)))
+    ABI_CHECKED[] = true
+end
 dptr(::Type{T}, x) where T = x === nothing ? Ptr{T}(C_NULL) : Ptr{T}(UInt(pointer(x)))
 dptr(x) = dptr(Float32, x)
 hipstream() = Ptr{Cvoid}(UInt(AMDGPU.stream().stream))  # the task-local stream (gui/worker.jl:47-51)
@@ -81,10 +92,11 @@ are the rasterizer's own (rasterizer.jl:60-90).  Returns `rast`.
 """
 function enable_hip_native!(rast::GaussianRasterizer; reference_tile_lists::Bool = false)
     native(rast) === nothing || return rast
+    check_abi()
     c, w, h = size(rast.image)
     href = Ref{Ptr{Cvoid}}()
     check(ccall((:gsr_create, LIB), Cint, (Ref{GsrConfig}, Ref{Ptr{Cvoid}}),
-        GsrConfig(w, h, c, rast.near_plane, rast.far_plane, 3, 0.3f0, reference_tile_lists ? 0x1 : 0x0, 0), href))
+        GsrConfig(w, h, c, rast.near_plane, rast.far_plane, 3, 0.3f0, reference_tile_lists ? 0x2 : 0x0, 0), href))
     st = NativeState(href[], 0)
     finalizer(s -> ccall((:gsr_destroy, LIB), Cint, (Ptr{Cvoid},), s.handle), st)
     lock(() -> (NATIVE[rast] = st), NATIVE_LOCK)

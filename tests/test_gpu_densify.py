@@ -130,3 +130,37 @@ def test_train_densify_train_chain_matches_oracle_chain(pkg, orc):
             assert opt_d[k].mu.numel() == opt_o[k]["mu"].size
         assert opt_d["opacities"].current_step == opt_o["opacities"]["step"]
     assert sizes[1] != n0 and sizes[3] != sizes[2], f"densification must have changed the model: {sizes}"
+
+
+def test_default_split_seed_differs_between_rounds(pkg):
+    """ADVICE r2 (densification.py:208): the split noise is a pure function of (seed, row, draw), so a constant default
+    seed would hand appended row i the same normal triple at every densification round.  With seed=None the strategy's
+    own round counter picks the stream: two rounds on the SAME inputs must give different children (the reference draws
+    fresh randn each time, densification.jl:121-135), and an explicit seed must stay reproducible."""
+    Dz = pkg.densification
+    n, extent = 4000, 5.0
+    gs_o = make_model(n, 3, 51, 3)
+    st_o = dz.Strategy.for_model(n)
+    fill_stats(st_o, 52)
+
+    def one_round(strategy, seed):
+        gs_d = to_device(pkg, gs_o)
+        opt_d = device_optimizers(pkg, gs_d, dz.new_optimizers(gs_o))
+        strategy.max_radii, strategy.accum_grad_means_2d, strategy.denom = (dev(st_o.max_radii, torch.int32),
+                                                                              dev(st_o.accum_grad_means_2d), dev(st_o.denom))
+        grad = torch.empty(n, dtype=torch.float32, device="cuda")
+        L = pkg._lib
+        L.check(L.load().gsr_densify_grad_mean(n, strategy.accum_grad_means_2d.data_ptr(), strategy.denom.data_ptr(),
+                                               grad.data_ptr(), None))
+        m = Dz.densify_split(strategy, gs_d, opt_d, grad, strategy.densify_grad_threshold, extent, strategy.dense_percent, seed)
+        torch.cuda.synchronize()
+        assert int(m.sum()) > 50
+        return gs_d.points.cpu().numpy()
+
+    st_d = Dz.DefaultStrategy(to_device(pkg, gs_o))
+    a, b = one_round(st_d, None), one_round(st_d, None)
+    assert st_d.split_rounds == 2
+    assert a.shape == b.shape and not np.array_equal(a, b), "two default-seeded rounds must not repeat the noise"
+    c, d = one_round(st_d, 7), one_round(st_d, 7)
+    assert np.array_equal(c, d), "an explicit seed is reproducible"
+    assert st_d.split_rounds == 2, "explicit seeds do not advance the counter"

@@ -728,10 +728,15 @@ ORC_API void orc_render(int W, int H, int C, const uint32_t *values, const float
         }
 }
 
-/* A.9 ∇render! (render.jl:132-286).  Deterministic: tiles are processed in
- * parallel into per-thread-safe accumulators only when `deterministic`==0;
- * with deterministic!=0 the tile loop is serial and accumulates in double
- * ("truth" gradients).  Outputs must be zero-filled by caller. */
+/* A.9 ∇render! (render.jl:132-286).  `deterministic`:
+ *   0  the reference's own form: parallel tiles, float atomics on the outputs (render.jl:242,275-282; summation
+ *      order varies run to run) — the "like-for-like" run and the timed CPU baseline;
+ *   1  serial tile loop, DOUBLE accumulators ("truth" gradients; bit-reproducible);
+ *   2  parallel tile loop, atomic adds on the same DOUBLE accumulators: the truth gradients at a cost that allows the
+ *      large configs (5 M Gaussians @ 4K).  Every per-(pixel, splat) term is the same float value as in mode 1; only
+ *      the order of the double additions varies, i.e. results agree with mode 1 to ~1e-16 relative before the final
+ *      rounding to float (tested: identical floats but for rare last-bit ties).
+ * Outputs must be zero-filled by caller. */
 ORC_API void orc_render_bwd(int W, int H, int C, int n, const float *vpixels, const uint32_t *n_contrib,
                             const float *accum_alpha, const uint32_t *values, const float *means2d, const float *opac,
                             const float *conics, const float *features, const uint32_t *ranges,
@@ -741,7 +746,7 @@ ORC_API void orc_render_bwd(int W, int H, int C, int n, const float *vpixels, co
     double *acc = NULL;
     int S = C + 6;
     if (deterministic) acc = (double *)calloc((size_t)n * S, sizeof(double));
-#pragma omp parallel for schedule(dynamic, 1) collapse(2) if (!deterministic)
+#pragma omp parallel for schedule(dynamic, 1) collapse(2) if (deterministic != 1)
     for (int gy = 0; gy < gy_n; gy++)
         for (int gx = 0; gx < gx_n; gx++) {
             int tile = gy * gx_n + gx;
@@ -789,10 +794,21 @@ ORC_API void orc_render_bwd(int W, int H, int C, int n, const float *vpixels, co
                               vc2 = 0.5f * vsigma * (dy * dy);
                         float vx = vsigma * (a * dx + b * dy), vy = vsigma * (b * dx + c * dy);
                         float vo = G * valpha;
-                        if (deterministic) {
+                        if (deterministic == 1) {
                             double *A = acc + (size_t)S * id;
                             for (int ch = 0; ch < C; ch++) A[ch] += vf[ch];
                             A[C] += vo; A[C + 1] += vc0; A[C + 2] += vc1; A[C + 3] += vc2; A[C + 4] += vx; A[C + 5] += vy;
+                        } else if (deterministic == 2) {
+                            double *A = acc + (size_t)S * id;
+                            const double term[6] = {vo, vc0, vc1, vc2, vx, vy};
+                            for (int ch = 0; ch < C; ch++) {
+#pragma omp atomic
+                                A[ch] += (double)vf[ch];
+                            }
+                            for (int q = 0; q < 6; q++) {
+#pragma omp atomic
+                                A[C + q] += term[q];
+                            }
                         } else {
                             for (int ch = 0; ch < C; ch++) {
 #pragma omp atomic

@@ -224,7 +224,8 @@ def render_bwd(W, H, Cn, n, vpixels, n_contrib, accum, values, means2d, opac, co
     lib().orc_render_bwd(C.c_int(W), C.c_int(H), C.c_int(Cn), C.c_int(n), _p(_f(vpixels)),
                          _p(n_contrib, C.c_uint32), _p(accum), _p(values, C.c_uint32), _p(means2d), _p(_f(opac)),
                          _p(conics), _p(_f(features)), _p(ranges, C.c_uint32), _p(_f(background)),
-                         _p(vfeat), _p(vopac), _p(vconics), _p(vmeans2d), C.c_int(1 if deterministic else 0))
+                         _p(vfeat), _p(vopac), _p(vconics), _p(vmeans2d),
+                         C.c_int(2 if deterministic == "parallel" else 1 if deterministic else 0))
     return vfeat, vopac, vconics, vmeans2d
 
 
@@ -338,7 +339,10 @@ class Grads:
 
 def backward(st: FwdState, vpixels, means, shs, opacities, scales, rots, cam: Camera, sh_degree: int,
              background=(0, 0, 0), pose_grad=False, deterministic=True) -> Grads:
-    """rasterizer.jl:416-550.  `vpixels` is (H,W,C)."""
+    """rasterizer.jl:416-550.  `vpixels` is (H,W,C).  `deterministic`: True = serial tile loop with double accumulators
+    (truth gradients, bit-reproducible); "parallel" = the same double accumulators updated atomically from an OpenMP tile
+    loop (truth gradients at large sizes; equal to True up to the order of double additions); False = the reference's
+    float-atomic form (render.jl:242,275-282)."""
     Cn = n_color_features(st.mode)
     means, shs, scales, rots = _f(means), _f(shs), _f(scales), _f(rots)
     opacities = _f(opacities).reshape(-1)

@@ -219,3 +219,24 @@ def test_morton_order_is_a_permutation_that_keeps_neighbours_together_and_the_im
     b = orc.forward(s2.means, s2.shs, s2.opacities, s2.scales, s2.rotations, cam, deg)
     assert a.n_rendered == b.n_rendered
     np.testing.assert_allclose(a.image, b.image, rtol=0, atol=1e-5)
+
+
+def test_parallel_truth_backward_equals_the_serial_one(orc, pkg):
+    """oracle/gsr_oracle.c orc_render_bwd, deterministic = 2 (OpenMP tile loop, atomic adds on the DOUBLE accumulators —
+    what makes the truth backward affordable at 5 M Gaussians / 4K) against deterministic = 1 (serial tile loop): every
+    term is the same float, only the order of the double additions differs."""
+    W, H, n, deg = 320, 240, 20_000, 2
+    s = pkg.synthetic.make_scene(n, W, H, deg, 77, sigma_px=4.0)
+    cam = orc.Camera(W, H, s.focal)
+    for mode in ("rgb", "rgbd"):
+        st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, mode=mode)
+        C = st.image.shape[2]
+        vp = pkg.synthetic.make_vpixels(W, H, C, 78) * 1e3
+        a = orc.backward(st, vp, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, deterministic=True)
+        b = orc.backward(st, vp, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, deterministic="parallel")
+        for name in ("vmeans", "vshs", "vopacities", "vscales", "vrots", "vmeans2d", "vconics", "vfeatures"):
+            x, y = getattr(a, name), getattr(b, name)
+            assert np.abs(x).max() > 0
+            # identical up to last-bit ties in the double -> float rounding (and what ∇project makes of them)
+            assert np.allclose(x, y, rtol=2e-6, atol=1e-12 * np.abs(x).max()), (mode, name)
+            assert (x != y).mean() < 1e-3, (mode, name)

@@ -18,6 +18,10 @@
 #include "wave_reduce.h"
 #include "tile_sort_device.h"
 
+#ifndef GSR_FWD_IPT
+#define GSR_FWD_IPT 1
+#endif
+
 namespace {
 
 struct Bg { float v[8]; };
@@ -39,6 +43,16 @@ __device__ __forceinline__ float sigma_of(const SigmaX sx, float hc, float dy, f
 }
 __device__ __forceinline__ float alpha_of(float opacity, float G) { return fminf(0.99f, __fmul_rn(opacity, G)); }
 
+// N splats staged in LDS: the three (four with a normal) float4 planes of their stream entries in ONE array, so that the
+// per-visit reads of a wave-uniform entry are one address (16·j: a scalar shift + one v_mov) and compile-time immediate
+// offsets (plane · 16·N) instead of one address computation per plane — 2 VALU instructions per visit less in loops that
+// are VALU-issue-bound; planes (not 48-byte records) keep the lane-contiguous staging stores conflict-free.
+template <int C, int N> struct LdsSplats {
+    float4 q[C > 5 ? 4 : 3][N];
+    __device__ __forceinline__ const float4& operator()(int plane, int j) const { return q[plane][j]; }
+    __device__ __forceinline__ float4& operator()(int plane, int j) { return q[plane][j]; }
+};
+
 // feature c of a staged splat: rgb | depth | 1 | normal  (rasterizer.jl:380-385)
 template <int C>
 __device__ __forceinline__ void unpack_features(const float4& s1, const float4& s2, const float4& s3, float f[C]) {
@@ -50,12 +64,86 @@ __device__ __forceinline__ void unpack_features(const float4& s1, const float4& 
 // ---------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------
-// Forward: one wave64 per 8x8 quadrant, four independent single-wave workgroups per tile (a
-// square footprint is visited by 9.5 % fewer splats than a 16x4 strip).  No workgroup barriers, a strip stops as soon as ITS pixels have
-// saturated, and a wave stages only the splats its quadrant-mask ballot selected (the four quadrants
-// re-read the tile's stream through L2).  Same per-pixel arithmetic in the same order.
-// The body of one quadrant wave (l0..l3: its 64-entry LDS staging arrays), shared by the stand-alone forward kernel
-// and the fused sort + forward kernel.
+// Forward: one wave64 per 8x8 quadrant (a square footprint is visited by 9.5 % fewer splats than a 16x4 strip).
+// No workgroup barriers inside a batch, a quadrant stops as soon as ITS pixels have saturated, and a wave visits only
+// the splats its quadrant-mask ballot selected.  Same per-pixel arithmetic in the same order as render.jl:82-117.
+//
+// The per-pixel state of a lane and the blend of the LDS-resident splats a ballot selected are shared by
+//   * composite_fwd_strip_kernel: four independent single-wave workgroups per tile, each staging the splats its ballot
+//     selected from the global stream into its own 64-entry LDS arrays (tiers of long lists; views in compact mode);
+//   * sort_composite_fwd_kernel: the fused sort + forward, which composites straight from the 256-entry LDS chunk the
+//     workgroup has just emitted — the stream in HBM is written for the backward and never read back here.
+template <int C> struct FwdPixel {
+    bool done;
+    float T, unc;
+    uint32_t last;
+    float color[C];
+};
+
+template <int C>
+__device__ __forceinline__ void fwd_pixel_init(FwdPixel<C>& p, bool inside) {
+    p.done = !inside; p.T = 1.0f; p.unc = 0.0f; p.last = 0;
+#pragma unroll
+    for (int c = 0; c < C; c++) p.color[c] = 0.0f;
+}
+
+// Blend the LDS entries whose bits are set in `m` (bit k <-> entry e0 + k), front to back.  Plane 2 of an entry holds
+// (third colour, 1-BASED LIST POSITION, depth, -): `last` is then a select between two VGPRs, not a v_mov of the scalar
+// position + a select.  `ids`: Gaussian id of entry 0, 1, ... (only read for the covisibility output).
+template <int C, bool AUX, int N>
+__device__ __forceinline__ void fwd_blend_selected(FwdPixel<C>& p, unsigned long long m, const LdsSplats<C, N>& e, int e0, float fx, float fy,
+                                                   const uint32_t* __restrict__ ids, uint8_t* __restrict__ covis) {
+    while (m) {
+        const int jb = __builtin_ctzll(m), j = e0 + jb;
+        m &= m - 1;
+        // (x = third colour, y = list position: ONE 64-bit LDS read — left as two fields of q[2] the compiler sinks
+        // the position's read under EXEC = ok, which costs a masked region per visit)
+        float4 c2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (C > 3) c2 = e(2, j);
+        else { const float2 xy = *reinterpret_cast<const float2*>(&e(2, j)); c2.x = xy.x; c2.y = xy.y; }
+        const float4 a = e(0, j), b = e(1, j);
+        const float4 c3 = C > 5 ? e(C > 5 ? 3 : 0, j) : c2;
+        const float dx = a.x - fx, dy = a.y - fy;
+        const float sigma = sigma_of(sigma_x(a.z, a.w, dx), b.x, dy, __fmul_rn(dy, dy));
+        const float alpha = alpha_of(b.y, __expf(-sigma));
+        // Branch-free body: a lane that is done, or whose pixel this splat does not touch, blends
+        // with weight 0 (what `continue`/`break` leave behind, render.jl:92-101).  (Handling the
+        // saturating lanes in a wave-uniform rare path instead measured 10 % slower.)
+        const float Tn = p.T * (1.0f - alpha);
+        const bool small = Tn < 1e-4f;
+        bool ok = !p.done && sigma >= 0.0f && alpha >= (1.0f / 255.0f);
+        const bool stop = ok && small;
+        p.done = p.done || stop;
+        ok = ok != stop;  // stop implies ok: the xor stays on the scalar unit (`ok && !small` costs a second v_cmp)
+        float f[C];
+        unpack_features<C>(b, c2, c3, f);
+        const float w = ok ? alpha * p.T : 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; c++) p.color[c] += f[c] * w;
+        if (AUX) {
+            p.unc += w;
+            if (covis && ok && p.T > 0.5f) covis[ids[jb]] = 1;
+        }
+        p.T = ok ? Tn : p.T;
+        p.last = ok ? __float_as_uint(c2.y) : p.last;
+    }
+}
+
+template <int C, bool AUX>
+__device__ __forceinline__ void fwd_pixel_store(const FwdPixel<C>& p, bool inside, int px, int py, int W, const Bg& bg,
+                                                float* __restrict__ image, uint32_t* __restrict__ n_contrib,
+                                                float* __restrict__ final_T, float* __restrict__ uncert) {
+    if (inside) {
+        const size_t pi = (size_t)px + (size_t)W * py;
+        final_T[pi] = p.T;
+        n_contrib[pi] = p.last;
+#pragma unroll
+        for (int c = 0; c < C; c++) image[(size_t)C * pi + c] = p.color[c] + p.T * bg.v[c];
+        if (AUX && uncert) uncert[pi] = p.unc;
+    }
+}
+
+// One quadrant wave walking its tile's slice of the GLOBAL stream (e: its 64-entry LDS staging array).
 template <int C, bool AUX>
 __device__ __forceinline__ void composite_fwd_quadrant(int W, int H, int grid_x, int tile, int quad, int lane,
                                                        const uint32_t* __restrict__ tile_start, GsrStream stream,
@@ -63,7 +151,7 @@ __device__ __forceinline__ void composite_fwd_quadrant(int W, int H, int grid_x,
                                                        uint32_t* __restrict__ n_contrib, float* __restrict__ final_T,
                                                        const uint32_t* __restrict__ values_sorted,
                                                        uint8_t* __restrict__ covis, float* __restrict__ uncert,
-                                                       float4* l0, float4* l1, float4* l2, float4* l3) {
+                                                       LdsSplats<C, 64>& e) {
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
     const uint32_t strip_bits = 0x10000u << quad;  // the instance's quadrant bit (tile_mask.h)
     const int px = tile_x * GSR_TILE + 8 * (quad & 1) + (lane & 7), py = tile_y * GSR_TILE + 8 * (quad >> 1) + (lane >> 3);
@@ -71,82 +159,31 @@ __device__ __forceinline__ void composite_fwd_quadrant(int W, int H, int grid_x,
     const float fx = (float)px, fy = (float)py;
     const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
     const int to_do = (int)(end - start);
-
-    bool done = !inside;
-    float T = 1.0f;
-    uint32_t last = 0;
-    float color[C];
-#pragma unroll
-    for (int c = 0; c < C; c++) color[c] = 0.0f;
-    float unc = 0.0f;
-
+    FwdPixel<C> p;
+    fwd_pixel_init<C>(p, inside);
     for (int base = 0; base < to_do; base += 64) {
-        if (wave_ballot(!done) == 0ull) break;  // the whole strip has saturated
+        if (wave_ballot(!p.done) == 0ull) break;  // the whole quadrant has saturated
         const int jj = base + lane;
         float4 r2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (jj < to_do) r2 = stream.s2[start + jj];
         const bool cand = jj < to_do && (__float_as_uint(r2.w) & strip_bits) != 0u;
-        unsigned long long m = wave_ballot(cand);
+        const unsigned long long m = wave_ballot(cand);
         if (m == 0ull) continue;
-        // c2.y of a STAGED splat is its 1-based list position (written at staging, the forward has no use for the
-        // gradient-row slot the stream carries there): `last` is then a select between two VGPRs, not a v_mov of the
-        // scalar position + a select
-        auto blend = [&](const float4& a, const float4& b, const float4& c2, const float4& c3, int j) {
-            const float dx = a.x - fx, dy = a.y - fy;
-            const float sigma = sigma_of(sigma_x(a.z, a.w, dx), b.x, dy, __fmul_rn(dy, dy));
-            const float alpha = alpha_of(b.y, __expf(-sigma));
-            // Branch-free body: a lane that is done, or whose pixel this splat does not touch, blends
-            // with weight 0 (what `continue`/`break` leave behind, render.jl:92-101).  (Handling the
-            // saturating lanes in a wave-uniform rare path instead measured 10 % slower.)
-            const float Tn = T * (1.0f - alpha);
-            const bool small = Tn < 1e-4f;
-            bool ok = !done && sigma >= 0.0f && alpha >= (1.0f / 255.0f);
-            const bool stop = ok && small;
-            done = done || stop;
-            ok = ok != stop;  // stop implies ok: the xor stays on the scalar unit (`ok && !small` costs a second v_cmp)
-            float f[C];
-            unpack_features<C>(b, c2, c3, f);
-            const float w = ok ? alpha * T : 0.0f;
-#pragma unroll
-            for (int c = 0; c < C; c++) color[c] += f[c] * w;
-            if (AUX) {
-                unc += w;
-                if (covis && ok && T > 0.5f) covis[values_sorted[start + base + j]] = 1;
-            }
-            T = ok ? Tn : T;
-            last = ok ? __float_as_uint(c2.y) : last;
-        };
         // (Fetching the wave-uniform splats with scalar loads straight from the stream — s_load_dwordx4,
         // one candidate ahead, no LDS — measured 2.6x slower: the scalar cache does not keep up.)
         __builtin_amdgcn_wave_barrier();  // previous batch's LDS reads are done (single wave, in order)
         if (cand) {
-            l0[lane] = stream.s0[start + jj];
-            l1[lane] = stream.s1[start + jj];
-            r2.y = __uint_as_float((uint32_t)(jj + 1));
-            l2[lane] = r2;
-            if (C > 5) l3[lane] = stream.s3[start + jj];
+            e(0, lane) = stream.s0[start + jj];
+            e(1, lane) = stream.s1[start + jj];
+            r2.y = __uint_as_float((uint32_t)(jj + 1));  // the forward has no use for the gradient-row slot: list position
+            e(2, lane) = r2;
+            if (C > 5) e(C > 5 ? 3 : 0, lane) = stream.s3[start + jj];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        while (m) {
-            const int j = __builtin_ctzll(m);
-            m &= m - 1;
-            // (x = third colour, y = list position: ONE 64-bit LDS read — left as two fields of l2[j] the compiler sinks
-            // the position's read under EXEC = ok, which costs a masked region per visit)
-            float4 c2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (C > 3) c2 = l2[j];
-            else { const float2 xy = *reinterpret_cast<const float2*>(&l2[j]); c2.x = xy.x; c2.y = xy.y; }
-            blend(l0[j], l1[j], c2, C > 5 ? l3[j] : c2, j);
-        }
+        fwd_blend_selected<C, AUX, 64>(p, m, e, 0, fx, fy, values_sorted + start + base, covis);
     }
-    if (inside) {
-        const size_t pi = (size_t)px + (size_t)W * py;
-        final_T[pi] = T;
-        n_contrib[pi] = last;
-#pragma unroll
-        for (int c = 0; c < C; c++) image[(size_t)C * pi + c] = color[c] + T * bg.v[c];
-        if (AUX && uncert) uncert[pi] = unc;
-    }
+    fwd_pixel_store<C, AUX>(p, inside, px, py, W, bg, image, n_contrib, final_T, uncert);
 }
 
 template <int C, bool AUX>
@@ -159,8 +196,7 @@ __global__ __launch_bounds__(64) void composite_fwd_strip_kernel(int W, int H, i
                                                                  const uint32_t* __restrict__ values_sorted,
                                                                  uint8_t* __restrict__ covis,
                                                                  float* __restrict__ uncert, GsrTierLists tiers) {
-    __shared__ float4 l0[64], l1[64], l2[64];
-    __shared__ float4 l3[C > 5 ? 64 : 1];
+    __shared__ LdsSplats<C, 64> e;
     // 1-D grid, workgroup id -> (launch slot, strip).  Workgroups are dealt round-robin to the 8
     // XCDs (each with its own L2): the 4 strips of a tile get ids that are equal mod 8, so a tile's
     // splat stream is fetched into ONE L2; slots follow tile_order (longest lists first).
@@ -180,18 +216,21 @@ __global__ __launch_bounds__(64) void composite_fwd_strip_kernel(int W, int H, i
         tile = (int)list[b];
     }
     composite_fwd_quadrant<C, AUX>(W, H, grid_x, tile, quad, (int)threadIdx.x, tile_start, stream, bg, image,
-                                   n_contrib, final_T, values_sorted, covis, uncert, l0, l1, l2, l3);
+                                   n_contrib, final_T, values_sorted, covis, uncert, e);
 }
 
 // Sort + forward of a tile in ONE workgroup (fixed-capacity bins; a tile with more than 1024 instances is left to the
 // tier sorts and a forward launch over the tier lists).
-// Wave 0 sorts the tile's keys in registers, all four waves emit the sorted instances (record gather -> stream), then
-// each wave composites its 8x8 quadrant from the stream the workgroup has just written (L2-hot).  tile_sort alone is
-// bound by HBM (gather + stream write at 4.8 TB/s) and the compositing alone by VALU issue; as two launches they run one
-// after the other — as phases of independent workgroups they share the CU at the same time.  Launched BEFORE the host
-// has read the scan's totals, like the sort's main pass was: every workgroup checks the totals against the capacity
-// of the buffers and leaves everything untouched when this view needs more (the host then runs the separate sort
-// and forward launches).
+// Wave 0 sorts the tile's keys in registers; then, 256 instances at a time, all four waves EMIT a chunk of the sorted
+// list — record gather -> packed stream entry, stored to HBM for the backward AND kept in LDS — and each wave composites
+// its 8x8 quadrant straight from that LDS chunk.  Round 2 read the entries back from HBM (the workgroup's own stores,
+// four times: 950 MB counted against 322 MB algorithmic, because a line lives ~18 us in an L2 the sort's gathers stream
+// through); now the forward never reads the stream, needs no workgroup-scope release/acquire on global memory between
+// the two phases, and no per-batch staging copy.  tile_sort alone is bound by HBM (gather + stream write) and the
+// compositing alone by VALU issue; as phases of independent workgroups they share the CU at the same time.  Launched
+// BEFORE the host has read the scan's totals, like the sort's main pass was: every workgroup checks the totals against
+// the capacity of the buffers and leaves everything untouched when this view needs more (the host then runs the
+// separate sort and forward launches).
 template <int C, bool AUX>
 // (8 waves per SIMD: the sort needs 66 VGPRs left to itself; at 64 it does not spill and an eighth workgroup fits the CU)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void sort_composite_fwd_kernel(int W, int H, int grid_x,
@@ -208,9 +247,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void s
                                                                  uint8_t* __restrict__ covis, float* __restrict__ uncert,
                                                                  const uint32_t* __restrict__ totals,
                                                                  uint32_t cap_instances) {
+    constexpr int IPT = GSR_FWD_IPT;     // instances per thread and round
+    constexpr int CHUNK = 256 * IPT;     // instances resident in LDS at a time
     __shared__ uint32_t ids[1024];
-    __shared__ float4 l0[4][64], l1[4][64], l2[4][64];
-    __shared__ float4 l3[C > 5 ? 4 : 1][C > 5 ? 64 : 1];
+    __shared__ LdsSplats<C, CHUNK> e;
     if (totals[0] > cap_instances || totals[1] > bin_cap) return;  // [0] instances, [1] longest list
     const int tile = (int)tile_order[blockIdx.x];  // launch order: longest lists first
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -223,20 +263,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void s
         ranges[2 * tile + 1] = n ? end : 0u;
     }
     if (n > 1024u) return;  // a tier launch's tile (sort and forward)
+    const int tile_x = tile % grid_x, tile_y = tile / grid_x;
+    const int X0 = tile_x * GSR_TILE, Y0 = tile_y * GSR_TILE;
+    const int quad = wave;  // 8x8 quadrant (qx = quad & 1, qy = quad >> 1) of the tile
+    const uint32_t strip_bits = 0x10000u << quad;
+    const int px = X0 + 8 * (quad & 1) + (lane & 7), py = Y0 + 8 * (quad >> 1) + (lane >> 3);
+    const bool inside = px < W && py < H;
+    float fx = (float)px, fy = (float)py;
+    // (opaque to the optimiser: left alone it re-converts px / py inside the per-visit loop to save two registers —
+    // two more VALU instructions per visit in a VALU-bound loop)
+    asm volatile("" : "+v"(fx), "+v"(fy));
+    FwdPixel<C> p;
+    fwd_pixel_init<C>(p, inside);
     if (n > 0) {
-        const int X0 = (tile % grid_x) * GSR_TILE, Y0 = (tile / grid_x) * GSR_TILE;
         // (the sorting wave rotates with the workgroup id: wave w of every workgroup sits on SIMD w of its CU, and a fixed
         // sorter would load one SIMD of four with all the sorting)
         if (wave == (int)(blockIdx.x & 3u)) gsr_sort::wave_sort_ids_any(ids, n, lane, bins + (size_t)tile * bin_cap);
         __syncthreads();
-        for (uint32_t i = tid; i < n; i += 256) gsr_sort::emit_instance<C == 5 ? 3 : C>((uint64_t)ids[i], start + i, X0, Y0, geom, stream, values_sorted);
-        // the stream entries are read back by the other waves of this workgroup: stores complete, then the barrier
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (uint32_t cbase = 0; cbase < n; cbase += CHUNK) {
+#pragma unroll
+            for (int r = 0; r < IPT; r++) {
+                const int slot = tid + 256 * r;
+                const uint32_t i = cbase + (uint32_t)slot;
+                if (i < n) {
+                    const uint32_t id = ids[i];
+                    const gsr_sort::InstanceVals v = gsr_sort::instance_vals<C == 5 ? 3 : C>(id, X0, Y0, geom);
+                    const uint32_t pos = start + i;
+                    values_sorted[pos] = id;
+                    stream.s0[pos] = v.v0; stream.s1[pos] = v.v1; stream.s2[pos] = v.v2;
+                    if (C > 5) stream.s3[pos] = v.v3;
+                    e(0, slot) = v.v0; e(1, slot) = v.v1;
+                    // LDS copy: (third colour, 1-based list position, depth, footprint masks)
+                    e(2, slot) = make_float4(v.v2.x, __uint_as_float(i + 1u), v.v2.z, v.v2.w);
+                    if (C > 5) e(C > 5 ? 3 : 0, slot) = v.v3;
+                }
+            }
+            __syncthreads();
+            const int cnt = (int)min((uint32_t)CHUNK, n - cbase);
+            for (int b = 0; b < cnt; b += 64) {
+                if (wave_ballot(!p.done) == 0ull) break;  // the whole quadrant has saturated
+                const int k = b + lane;
+                const bool cand = k < cnt && (__float_as_uint(e(2, k).w) & strip_bits) != 0u;
+                const unsigned long long m = wave_ballot(cand);
+                if (m == 0ull) continue;
+                fwd_blend_selected<C, AUX, CHUNK>(p, m, e, b, fx, fy, ids + cbase + b, covis);
+            }
+            if (cbase + CHUNK < n) __syncthreads();  // the chunk is consumed before the next one overwrites it
+        }
     }
-    composite_fwd_quadrant<C, AUX>(W, H, grid_x, tile, wave, lane, tile_start, stream, bg, image, n_contrib, final_T,
-                                   values_sorted, covis, uncert, l0[wave], l1[wave], l2[wave], l3[C > 5 ? wave : 0]);
+    fwd_pixel_store<C, AUX>(p, inside, px, py, W, bg, image, n_contrib, final_T, uncert);
 }
 
 // ---------------------------------------------------------------------------------
@@ -246,6 +321,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void s
 // [7..8] v mean2d, [9] v depth (C>=5), [10..12] v normal (C==8)
 template <int C> struct AccRow { static constexpr int N = C == 3 ? 9 : (C == 5 ? 10 : 13); static constexpr int STRIDE = N | 1; };
 
+#ifndef GSR_BWD_MINWAVES_GUARD_
+#define GSR_BWD_MINWAVES_GUARD_
+#endif
 #ifndef GSR_BWD_MINWAVES
 #define GSR_BWD_MINWAVES 1
 #endif

@@ -7,30 +7,55 @@
 
 namespace gsr_sort {
 
+// The packed stream entry of one sorted instance (record gather -> three / four float4).
+struct InstanceVals { float4 v0, v1, v2, v3; };
+// What instance_vals reads from HBM for one instance (split from the arithmetic so that a kernel can have the gathers of
+// its next instances in flight while it does something else).
+struct InstanceRaw { GsrGeoRec rec; uint32_t bpre; float4 normal; };
+template <int CH>
+__device__ __forceinline__ InstanceRaw instance_load(uint32_t id, const GsrGeom& geom) {
+    InstanceRaw r;
+    r.rec = geom.rec[id];  // one 64-byte line per gather
+    r.bpre = geom.bpre[id >> 8];
+    r.normal = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (CH > 5) r.normal = geom.normal[id];
+    return r;
+}
+__device__ __forceinline__ InstanceVals instance_vals_of(const InstanceRaw& r, int X0, int Y0) {
+    InstanceVals o;
+    const GsrGeoRec& rec = r.rec;
+    // the compositing kernels evaluate sigma = b·dx·dy + (a/2)·dx² + (c/2)·dy²: the stream carries the halves
+    o.v0 = make_float4(rec.q0.x, rec.q0.y, 0.5f * rec.q0.z, rec.q0.w);
+    o.v1 = make_float4(0.5f * rec.q1.x, rec.q1.y, rec.q1.z, rec.q1.w);
+    // Gaussian-major slot of this instance: offset of the Gaussian's rect (cumsum of
+    // tiles_touched, rasterizer.jl:333-335) + row-major rank of the tile inside the rect (the
+    // emit order of duplicate_with_keys!, utils.jl:112).  The backward writes the instance's
+    // gradient row there, so a Gaussian's rows are contiguous for the per-Gaussian sum.
+    const uint32_t lo = __float_as_uint(rec.q3.x), hi = __float_as_uint(rec.q3.y);
+    const uint32_t x0 = lo & 0xFFFFu, y0 = lo >> 16, x1 = hi & 0xFFFFu;
+    const uint32_t slot = r.bpre + __float_as_uint(rec.q2.w) +
+                          ((uint32_t)(Y0 / GSR_TILE) - y0) * (x1 - x0) + ((uint32_t)(X0 / GSR_TILE) - x0);
+    const uint32_t mask_bits = instance_row_mask(rec.q0, rec.q1, X0, Y0);
+    o.v2 = make_float4(rec.q2.x, __uint_as_float(slot), rec.q2.z, __uint_as_float(mask_bits));
+    o.v3 = r.normal;
+    return o;
+}
+template <int CH>
+__device__ __forceinline__ InstanceVals instance_vals(uint32_t id, int X0, int Y0, const GsrGeom& geom) {
+    return instance_vals_of(instance_load<CH>(id, geom), X0, Y0);
+}
+
 // Emit one sorted instance: its id, and its entry of the packed splat stream.
 template <int CH>
 __device__ __forceinline__ void emit_instance(uint64_t k, uint32_t pos, int X0, int Y0, const GsrGeom& geom,
                                               const GsrStream& stream, uint32_t* __restrict__ values_sorted) {
-    {
-        const uint32_t i = pos, start = 0;
-        const uint32_t id = (uint32_t)k;
-        values_sorted[start + i] = id;
-        const GsrGeoRec rec = geom.rec[id];  // one 64-byte line per gather
-        // the compositing kernels evaluate sigma = b·dx·dy + (a/2)·dx² + (c/2)·dy²: the stream carries the halves
-        stream.s0[start + i] = make_float4(rec.q0.x, rec.q0.y, 0.5f * rec.q0.z, rec.q0.w);
-        stream.s1[start + i] = make_float4(0.5f * rec.q1.x, rec.q1.y, rec.q1.z, rec.q1.w);
-        // Gaussian-major slot of this instance: offset of the Gaussian's rect (cumsum of
-        // tiles_touched, rasterizer.jl:333-335) + row-major rank of the tile inside the rect (the
-        // emit order of duplicate_with_keys!, utils.jl:112).  The backward writes the instance's
-        // gradient row there, so a Gaussian's rows are contiguous for the per-Gaussian sum.
-        const uint32_t lo = __float_as_uint(rec.q3.x), hi = __float_as_uint(rec.q3.y);
-        const uint32_t x0 = lo & 0xFFFFu, y0 = lo >> 16, x1 = hi & 0xFFFFu;
-        const uint32_t slot = geom.bpre[id >> 8] + __float_as_uint(rec.q2.w) +
-                              ((uint32_t)(Y0 / GSR_TILE) - y0) * (x1 - x0) + ((uint32_t)(X0 / GSR_TILE) - x0);
-        const uint32_t mask_bits = instance_row_mask(rec.q0, rec.q1, X0, Y0);
-        stream.s2[start + i] = make_float4(rec.q2.x, __uint_as_float(slot), rec.q2.z, __uint_as_float(mask_bits));
-        if (CH > 5) stream.s3[start + i] = geom.normal[id];
-    }
+    const uint32_t id = (uint32_t)k;
+    values_sorted[pos] = id;
+    const InstanceVals v = instance_vals<CH>(id, X0, Y0, geom);
+    stream.s0[pos] = v.v0;
+    stream.s1[pos] = v.v1;
+    stream.s2[pos] = v.v2;
+    if (CH > 5) stream.s3[pos] = v.v3;
 }
 
 // ---- the main pass: ONE wave64 per tile, keys in registers ----

@@ -18,6 +18,9 @@
 #include "wave_reduce.h"
 #include "tile_sort_device.h"
 
+#ifndef GSR_LDS_PLANE_PAD
+#define GSR_LDS_PLANE_PAD 0
+#endif
 #ifndef GSR_FWD_IPT
 #define GSR_FWD_IPT 1
 #endif
@@ -48,7 +51,7 @@ __device__ __forceinline__ float alpha_of(float opacity, float G) { return fminf
 // offsets (plane · 16·N) instead of one address computation per plane — 2 VALU instructions per visit less in loops that
 // are VALU-issue-bound; planes (not 48-byte records) keep the lane-contiguous staging stores conflict-free.
 template <int C, int N> struct LdsSplats {
-    float4 q[C > 5 ? 4 : 3][N];
+    float4 q[C > 5 ? 4 : 3][N + GSR_LDS_PLANE_PAD];
     __device__ __forceinline__ const float4& operator()(int plane, int j) const { return q[plane][j]; }
     __device__ __forceinline__ float4& operator()(int plane, int j) { return q[plane][j]; }
 };

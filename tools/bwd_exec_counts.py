@@ -81,6 +81,8 @@ lx = torch.arange(16, device=dev).view(1, 1, 16).float()
 ly = torch.arange(16, device=dev).view(1, 16, 1).float()
 cidx = torch.nonzero(cand).squeeze(1)
 grp_visits = int(rowgrp[cidx].sum())
+grp_visits_q = [int(rowgrp[cidx][:, q].sum()) for q in range(4)]
+act_groups_q = [0, 0, 0, 0]
 act_groups = 0
 reduced = 0
 active_px = 0
@@ -101,6 +103,8 @@ for b0 in range(0, cidx.numel(), B):
     g4 = act.view(-1, 4, 4, 16).any(3).any(2)                            # rows 4q..4q+3
     g4 = g4 & rowgrp[ii]                                                 # only visited groups are evaluated
     act_groups += int(g4.sum())
+    for q in range(4):
+        act_groups_q[q] += int(g4[:, q].sum())
     reduced += int(g4.any(1).sum())
     active_px += int((act & rowgrp[ii].view(-1, 4, 1, 1).expand(-1, 4, 4, 16).reshape(-1, 16, 16)).sum())
 
@@ -110,6 +114,7 @@ out = {
     "instances_walked": int(walked.sum()), "batches_of_64": batches, "zero_rows_beyond_tile_last": zero_rows,
     "candidates_after_row_mask_ballot": int(cand.sum()),
     "group_visits_16x4": grp_visits, "group_visits_with_an_active_lane": act_groups,
+    "group_visits_by_q": grp_visits_q, "active_group_visits_by_q": act_groups_q,
     "instances_reduced": reduced, "evaluated_lane_slots": evaluated_px, "active_lane_slots": active_px,
     "per_instance": {"group_visits": round(grp_visits / max(int(cand.sum()), 1), 4),
                      "active_group_visits": round(act_groups / max(int(cand.sum()), 1), 4),

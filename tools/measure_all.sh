@@ -1,21 +1,24 @@
 #!/bin/bash
-# On the GPU box: everything the round's profiles/ directory is built from.   tools/measure_all.sh <tag>
+# On the GPU box: everything the round's profiles/<round>/final directory is built from.   tools/measure_all.sh <tag>
 set -x
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/$R
 mkdir -p $O
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
-python bench.py > $O/bench_cfg3.json 2> $O/bench_cfg3.err
-python bench.py --gaussians 100000 --no-loss --seed 1002 > $O/bench_cfg2.json 2>/dev/null
-python bench.py --gaussians 5000000 --width 3840 --height 2160 --no-loss --seed 1005 --steps 10 > $O/bench_cfg5.json 2>/dev/null
-python bench.py --no-cpu-baseline --no-other-lists --with-optimizer > $O/bench_optimizer.json 2>/dev/null
-python bench.py --no-cpu-baseline --no-other-lists --mode rgbd > $O/bench_rgbd.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 bench.py --no-cpu-baseline --no-other-lists --steps 20 --warmup 3 > $O/prof.log 2>&1
+# PMC passes first: bench.py reads roofline.traffic / roofline.valu of exactly the measured configuration from them
 tools/measure_pmc.sh ${R}_cfg3
 tools/measure_pmc.sh ${R}_cfg2 --gaussians 100000 --no-loss --seed 1002
 tools/measure_pmc.sh ${R}_cfg5 --gaussians 5000000 --width 3840 --height 2160 --no-loss --seed 1005 --steps 3
 cp profiles/pmc_traffic.json $O/pmc_traffic.json
-# the driver's line again, now that the PMC file of this build exists
-python bench.py --no-cpu-baseline > $O/bench_cfg3_with_pmc.json 2>/dev/null
-tail -2 $O/smoke.log; cut -c1-300 $O/bench_cfg3.json
+# the driver's line (config 3 + extra_configs: config 2, config 5, :rgbd, trainer step both ways + cpu_baseline)
+python bench.py > $O/bench_driver_line.json 2> $O/bench_driver_line.err
+# the same command under the profiler: per-kernel average durations to set against the line's HIP-event times
+# (--no-extra: only config 3's kernels, so that the averages are config 3's)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 bench.py --no-cpu-baseline --no-extra > $O/prof.log 2>&1
+python3 tools/short_kernel_stats.py $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
+find $O/prof -name "*kernel_trace.csv" -delete; find $O/prof -name "*agent_info.csv" -delete
+# two ranks on this one GPU, gloo carrying the collectives: the N > 1 code path of bench.py and its `exchange` object
+# (NOT a scaling number: both ranks share the device)
+GSR_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 10 > $O/bench_2ranks_one_gpu_gloo.json 2> $O/bench_2ranks.err
+tail -2 $O/smoke.log; cut -c1-300 $O/bench_driver_line.json

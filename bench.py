@@ -123,6 +123,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-other-lists", action="store_true", help="skip the secondary timing of the other tile-list mode")
     ap.add_argument("--no-extra", action="store_true", help="skip `extra_configs` (configs 2 / 5, :rgbd, trainer step)")
     ap.add_argument("--extra-steps", type=int, default=10, help="timed steps per `extra_configs` entry")
+    ap.add_argument("--host-wait", default=None, metavar="SPIN,YIELD,SLEEP",
+                    help="gsr_host_wait_policy in microseconds (default: the library's 100,0,50; '1000000,0,0' = pure spin)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher test: start the rank processes, each prints its RANK / WORLD_SIZE / MASTER_* as JSON and "
                          "exits BEFORE importing torch; the parent prints the collected list")
@@ -613,6 +615,8 @@ def run_rank(args):
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["GSR_BENCH_WATCHDOG"]), exit=True)
     pkg = gsr_pkg.load()
+    if args.host_wait:
+        pkg._lib.check(pkg._lib.load().gsr_host_wait_policy(*[int(x) for x in args.host_wait.split(",")]))
     D = pkg.distributed
     rank, world, local = D.init_from_env()
     if world != args.gpus:

@@ -258,14 +258,17 @@ static inline void cpu_relax() {
 
 // Host wait policy of the forward's single read-back (gsr_host_wait_policy): microseconds of pure spinning, then of
 // sched_yield() polling, then sleeps of `sleep_us`.  Process-wide.
-struct WaitPolicy { int spin_us = 20, yield_us = 80, sleep_us = 20; };
+struct WaitPolicy { int spin_us = 100, yield_us = 0, sleep_us = 50; };
 WaitPolicy g_wait;
 
 // Wait until tile_scan of forward `seq` has published its totals (a word of pinned host memory).  POLITE: the wait is
 // typically 0.05-0.2 ms (preprocess + scan of this view); an 8-rank node has eight of these waiters next to RCCL's proxy
-// threads, so only the first `spin_us` are a busy spin; then the core is offered to other runnable threads
-// (sched_yield) and finally released for `sleep_us` at a time.  The GPU never waits for this thread (the next launch is
-// already queued behind the scan), so the wake-up latency of the sleep phase is hidden behind sort + forward.
+// threads, so only the first `spin_us` are a busy spin; then (optionally) the core is offered to other runnable threads
+// with sched_yield for `yield_us`, and finally released for `sleep_us` at a time.  The GPU never waits for this thread
+// while sort + forward run (the launch is already queued behind the scan), so the wake-up latency of the sleep phase is
+// hidden on views whose sort + forward outlast it.  Default 100 / 0 / 50 us, measured (bench.py --host-wait, MI355X):
+// config 3 (wait ~190 us) 1.55 ms whatever the policy; config 2 (0.23 ms steps, wait ~48 us: inside the spin) 0.228 ms
+// = a pure spin's, against 0.238 ms with a 20 us spin + sched_yield polling (the yield syscalls delay the wake-up).
 // A wait that lasts longer than any sane queue depth (50 ms) starts polling the stream, so that a failed launch or a
 // faulted kernel ends with an error instead of hanging the caller — not earlier: hipStreamQuery puts a marker packet on
 // the stream, and a marker between two kernels is a 5 us bubble (rocprofv3 kernel trace, tools/gap_report.py).

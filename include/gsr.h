@@ -197,10 +197,11 @@ GSR_API int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* 
 
 /* How the host thread waits inside gsr_forward for the instance count (the reference blocks in a synchronous
  * device->host copy there, rasterizer.jl:337).  The wait lasts about as long as preprocess + scan of the view
- * (0.05-0.2 ms at 1 M Gaussians).  Policy, process-wide: busy-spin for `spin_us` microseconds (default 20), then poll
- * with sched_yield() for `yield_us` (default 80), then sleep `sleep_us` (default 20) between polls — so eight ranks on one
- * host do not pin eight cores next to RCCL's proxy threads.  The GPU never waits for the host here (the next launch
- * is already queued), so the sleep's wake-up latency is hidden.  (1000000, 0, 0) restores a pure spin. */
+ * (0.05-0.2 ms at 1 M Gaussians).  Policy, process-wide: busy-spin for `spin_us` microseconds (default 100), then poll
+ * with sched_yield() for `yield_us` (default 0), then sleep `sleep_us` (default 50) between polls — so eight ranks on one
+ * host do not pin eight cores next to RCCL's proxy threads.  The GPU does not wait for the host here (the next launch
+ * is already queued), so the sleep's wake-up latency is hidden behind sort + forward; short views finish inside the
+ * spin.  (1000000, 0, 0) restores a pure spin. */
 GSR_API int gsr_host_wait_policy(int spin_us, int yield_us, int sleep_us);
 
 /* Views into the state the reference keeps in rast.gstate / bstate / istate

@@ -1,6 +1,6 @@
 """The host side of gsr_forward's single read-back (gsr.h: gsr_host_wait_policy; round-2 verdict "make the host sync
 polite"): eight handles driven by eight host threads — the shape of an 8-rank node's host load — must step as fast
-with the default back-off (20 us spin, 80 us sched_yield, then 20 us sleeps) as with a pure busy spin, while
+with the default back-off (100 us spin, then 50 us sleeps) as with a pure busy spin, while
 burning far less CPU."""
 import os
 import threading
@@ -60,9 +60,9 @@ def _run(pkg, policy, n_threads=8, steps=40):
 def test_eight_threads_step_time_unchanged_with_the_back_off(pkg):
     try:
         spin_wall, spin_cpu, img_a = _run(pkg, (1_000_000, 0, 0))   # pure spin: the round-2 behaviour
-        pol_wall, pol_cpu, img_b = _run(pkg, (20, 80, 20))           # the default
+        pol_wall, pol_cpu, img_b = _run(pkg, (100, 0, 50))          # the default
     finally:
-        pkg._lib.check(pkg._lib.load().gsr_host_wait_policy(20, 80, 20))
+        pkg._lib.check(pkg._lib.load().gsr_host_wait_policy(100, 0, 50))
     print(f"8 threads x 8 handles: pure spin {spin_wall * 1e3:.3f} ms/step ({spin_cpu * 1e3:.2f} CPU-ms/step), "
           f"back-off {pol_wall * 1e3:.3f} ms/step ({pol_cpu * 1e3:.2f} CPU-ms/step)")
     for a, b in zip(img_a, img_b):

@@ -144,8 +144,8 @@ def _free_port():
 def launch_ranks(args, argv):
     """Start `args.gpus` fresh rank processes of this script and wait for them.  This process has not imported torch
     and never touches HIP (a process that has initialised the GPU must not spawn-and-exec on this pool), so the
-    children are ordinary fork+exec'd interpreters.  rank 0 inherits stdout (its JSON line is THE line); the other
-    ranks' stdout goes to stderr.  Returns the exit code: 0 only if every rank exited 0."""
+    children are ordinary fork+exec'd interpreters.  Rank 0's JSON line is forwarded to stdout (it is THE line);
+    everything else any rank prints goes to stderr.  Returns the exit code: 0 only if every rank exited 0."""
     n = args.gpus
     port = os.environ.get("MASTER_PORT") or str(_free_port())
     procs = []
@@ -154,7 +154,9 @@ def launch_ranks(args, argv):
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port, GSR_BENCH_SELF_LAUNCHED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this pool
-        out = subprocess.PIPE if args.dry_launch else (None if r == 0 else sys.stderr)
+        # rank 0's stdout is piped and only its JSON line(s) are forwarded (gloo, for one, prints connection notes to
+        # stdout): the launcher's stdout is THE line and nothing else.  The pipe holds 64 KB; a rank prints ~10 KB.
+        out = subprocess.PIPE if (args.dry_launch or r == 0) else sys.stderr
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
     deadline = time.time() + args.launch_timeout
     rcs = [None] * n
@@ -185,6 +187,10 @@ def launch_ranks(args, argv):
                 if line.startswith("{"):
                     seen.append(json.loads(line))
         print(json.dumps({"dry_launch": sorted(seen, key=lambda d: d["rank"]), "rc": rcs}))
+    if not args.dry_launch and procs[0].stdout is not None:
+        for line in procs[0].stdout.read().decode(errors="replace").splitlines():
+            (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
+        sys.stdout.flush()
     bad = [(i, rc) for i, rc in enumerate(rcs) if rc != 0]
     if bad:
         print(f"bench.py: rank(s) failed: {bad} (of {n})", file=sys.stderr)

@@ -20,5 +20,5 @@ python3 tools/short_kernel_stats.py $(find $O/prof -name "*kernel_stats.csv" | h
 find $O/prof -name "*kernel_trace.csv" -delete; find $O/prof -name "*agent_info.csv" -delete
 # two ranks on this one GPU, gloo carrying the collectives: the N > 1 code path of bench.py and its `exchange` object
 # (NOT a scaling number: both ranks share the device)
-GSR_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 10 > $O/bench_2ranks_one_gpu_gloo.json 2> $O/bench_2ranks.err
+GSR_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 10 2> $O/bench_2ranks.err | grep "^{" > $O/bench_2ranks_one_gpu_gloo.json  # (gloo prints a connection note to stdout)
 tail -2 $O/smoke.log; cut -c1-300 $O/bench_driver_line.json

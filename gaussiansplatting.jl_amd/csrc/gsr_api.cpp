@@ -194,6 +194,7 @@ struct gsr_handle {
     bool compact_sticky = false;    // the last view showed that fixed-capacity bins do not fit the budget
     bool last_compact = false;
     bool tile_count_dirty = false;  // counters not yet re-zeroed by the tile sort
+    double wait_ema_us = 0.0;       // running average of the host's wait for the instance count (wait_totals)
     DevBuf bins, keys_compact, big_list, values_sorted, s0, s1, s2, s3, big_scratch;
     uint32_t bin_cap_used(bool use_bins) const { return use_bins ? bin_cap_view : 0u; }
     // backward: per-instance gradient rows + instance position map; gstate.∇means_2d
@@ -256,19 +257,23 @@ static inline void cpu_relax() {
 #endif
 }
 
-// Host wait policy of the forward's single read-back (gsr_host_wait_policy): microseconds of pure spinning, then of
-// sched_yield() polling, then sleeps of `sleep_us`.  Process-wide.
+// Host wait policy of the forward's single read-back (gsr_host_wait_policy), process-wide:
+//   spin_us   the margin: the thread SLEEPS through the expected wait (an average of this handle's previous waits) except
+//             for its last spin_us microseconds, which it spins through — so a wake-up that comes late by the kernel's
+//             timer slack (50 us by default) still lands before the word is written;
+//   yield_us  once the expected time has passed and spin_us more have been spun: poll with sched_yield() this long;
+//   sleep_us  after that: sleep this long between polls (0: keep yielding).
 struct WaitPolicy { int spin_us = 100, yield_us = 0, sleep_us = 50; };
 WaitPolicy g_wait;
 
-// Wait until tile_scan of forward `seq` has published its totals (a word of pinned host memory).  POLITE: the wait is
-// typically 0.05-0.2 ms (preprocess + scan of this view); an 8-rank node has eight of these waiters next to RCCL's proxy
-// threads, so only the first `spin_us` are a busy spin; then (optionally) the core is offered to other runnable threads
-// with sched_yield for `yield_us`, and finally released for `sleep_us` at a time.  The GPU never waits for this thread
-// while sort + forward run (the launch is already queued behind the scan), so the wake-up latency of the sleep phase is
-// hidden on views whose sort + forward outlast it.  Default 100 / 0 / 50 us, measured (bench.py --host-wait, MI355X):
-// config 3 (wait ~190 us) 1.55 ms whatever the policy; config 2 (0.23 ms steps, wait ~48 us: inside the spin) 0.228 ms
-// = a pure spin's, against 0.238 ms with a 20 us spin + sched_yield polling (the yield syscalls delay the wake-up).
+// Wait until tile_scan of forward `seq` has published its totals (a word of pinned host memory).  The host runs ahead
+// of the GPU, so this wait lasts as long as whatever the GPU still has queued in front of the scan: ~0.2 ms on a
+// 0.23 ms step (config 2), ~1 ms on config 3's 1.5 ms step — every step about the same, which is what the policy uses:
+// sleep through the expected wait minus a margin, spin the rest.  An 8-rank node has eight of these waiters next to
+// RCCL's proxy threads; a pure spin pins eight cores.  Measured (bench.py --host-wait, MI355X): fixed thresholds either
+// burn the core (long spin) or oversleep short views (20 us spin + sched_yield: config 2 0.238 ms against 0.226 ms; 100 us
+// spin + 50 us sleeps: 0.265 ms — the sleep outlasts the sort + forward the GPU had queued); the adaptive form keeps a pure
+// spin's step time on both.
 // A wait that lasts longer than any sane queue depth (50 ms) starts polling the stream, so that a failed launch or a
 // faulted kernel ends with an error instead of hanging the caller — not earlier: hipStreamQuery puts a marker packet on
 // the stream, and a marker between two kernels is a 5 us bubble (rocprofv3 kernel trace, tools/gap_report.py).
@@ -277,15 +282,35 @@ int wait_totals(gsr_handle* h, uint32_t seq, hipStream_t s) {
     volatile uint32_t* word = h->host_totals + 7;
     if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) return GSR_OK;
     const auto t0 = clk::now();
-    const auto t_spin = t0 + std::chrono::microseconds(g_wait.spin_us);
+    const double expect_us = h->wait_ema_us;
+    if (expect_us > (double)g_wait.spin_us + 50.0) {  // worth a sleep: more than the margin + a timer slack
+        const long ns = (long)((expect_us - (double)g_wait.spin_us) * 1000.0);
+        struct timespec ts = {ns / 1000000000L, ns % 1000000000L};
+        nanosleep(&ts, nullptr);
+        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) {
+            // Overslept (or woke exactly on time): how long the wait really was is unknown — only that it was shorter.
+            // NOT a sample (an average fed with its own oversleeps ratchets upwards and starves the GPU): shrink the
+            // estimate instead, so that the next wake-up comes early enough to see the word arrive.
+            h->wait_ema_us = 0.85 * expect_us;
+            return GSR_OK;
+        }
+    }
+    const auto t_spin = t0 + std::chrono::microseconds((long)expect_us + g_wait.spin_us);
     const auto t_yield = t_spin + std::chrono::microseconds(g_wait.yield_us);
     auto next_poll = t0 + std::chrono::milliseconds(50);
+    int rc = GSR_OK;
     for (;;) {
-        for (int i = 0; i < 64; i++) {
-            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) return GSR_OK;
-            cpu_relax();
+        bool done = false;
+        for (int i = 0; i < 64 && !done; i++) {
+            done = __atomic_load_n(word, __ATOMIC_ACQUIRE) == seq;
+            if (!done) cpu_relax();
         }
         const auto now = clk::now();
+        if (done) {
+            const double us = std::chrono::duration<double, std::micro>(now - t0).count();
+            h->wait_ema_us = h->wait_ema_us == 0.0 ? us : 0.75 * h->wait_ema_us + 0.25 * us;
+            return GSR_OK;
+        }
         if (now >= t_spin) {
             if (now < t_yield || g_wait.sleep_us <= 0) {
                 sched_yield();
@@ -299,10 +324,13 @@ int wait_totals(gsr_handle* h, uint32_t seq, hipStream_t s) {
         const hipError_t q = hipStreamQuery(s);
         if (q == hipSuccess) {  // everything enqueued has finished: the word is there, or it never will be
             if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) return GSR_OK;
-            return fail(GSR_E_HIP, "tile scan finished without publishing its totals");
+            rc = fail(GSR_E_HIP, "tile scan finished without publishing its totals");
+            break;
         }
-        if (q != hipErrorNotReady) return fail(GSR_E_HIP, "HIP error while waiting for the tile scan: %s", hipGetErrorString(q));
+        if (q != hipErrorNotReady) { rc = fail(GSR_E_HIP, "HIP error while waiting for the tile scan: %s", hipGetErrorString(q)); break; }
     }
+    h->wait_ema_us = 0.0;
+    return rc;
 }
 
 int check_inputs(const gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam) {

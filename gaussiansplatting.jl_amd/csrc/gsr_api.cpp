@@ -284,15 +284,25 @@ int wait_totals(gsr_handle* h, uint32_t seq, hipStream_t s) {
     const auto t0 = clk::now();
     const double expect_us = h->wait_ema_us;
     if (expect_us > (double)g_wait.spin_us + 50.0) {  // worth a sleep: more than the margin + a timer slack
-        const long ns = (long)((expect_us - (double)g_wait.spin_us) * 1000.0);
-        struct timespec ts = {ns / 1000000000L, ns % 1000000000L};
-        nanosleep(&ts, nullptr);
-        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) {
-            // Overslept (or woke exactly on time): how long the wait really was is unknown — only that it was shorter.
-            // NOT a sample (an average fed with its own oversleeps ratchets upwards and starves the GPU): shrink the
-            // estimate instead, so that the next wake-up comes early enough to see the word arrive.
-            h->wait_ema_us = 0.85 * expect_us;
-            return GSR_OK;
+        // ... in doubling pieces (50, 100, 200, ... us) with a look at the word after each: the expectation comes from
+        // steps in which the host ran ahead of the GPU; the first forward after the caller synchronised finds the GPU
+        // idle and its wait is only preprocess + scan long — the small first pieces bound what that costs.
+        double remaining = expect_us - (double)g_wait.spin_us, piece = 50.0;
+        while (remaining > 0.0) {
+            const long ns = (long)((remaining < piece ? remaining : piece) * 1000.0);
+            struct timespec ts = {ns / 1000000000L, ns % 1000000000L};
+            nanosleep(&ts, nullptr);
+            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) {
+                // Overslept (or woke exactly on time): how long the wait really was is unknown — only that it was no
+                // longer than this.  NOT a sample of the average (an average fed with its own oversleeps ratchets upwards
+                // and starves the GPU): the estimate shrinks instead, so that the next wake-up comes early enough to see
+                // the word arrive.
+                const double slept = std::chrono::duration<double, std::micro>(clk::now() - t0).count();
+                h->wait_ema_us = 0.85 * (slept < expect_us ? slept : expect_us);
+                return GSR_OK;
+            }
+            remaining = expect_us - (double)g_wait.spin_us - std::chrono::duration<double, std::micro>(clk::now() - t0).count();
+            piece *= 2.0;
         }
     }
     const auto t_spin = t0 + std::chrono::microseconds((long)expect_us + g_wait.spin_us);

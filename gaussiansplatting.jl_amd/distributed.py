@@ -66,7 +66,12 @@ def init_from_env(backend: str | None = None):
                                        f"(set GSR_DIST_BACKEND=gloo to share a device in logic tests)")
                 local = local % max(ndev, 1)
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl" and torch.cuda.is_available():
+            # bind the communicator to this rank's device explicitly (RCCL otherwise guesses it from the global rank at the
+            # first collective — "can cause a hang if rank to GPU mapping is heterogeneous")
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 

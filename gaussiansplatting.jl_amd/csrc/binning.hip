@@ -461,7 +461,7 @@ void gsr_launch_tile_sort(hipStream_t s, int passes, int n_tiles, int grid_x, in
         if (n_mid8 > 0) LAUNCH(CC, GSR_SORT_LDS_CAP, 1024, n_mid8, tier_lists + (size_t)n_tiles);                 \
         if (n_big > 0) LAUNCH_BIG(CC);                                                                            \
     }
-    if (channels > 5) { ALL(8) } else { ALL(3) }
+    if (channels > 5) { ALL(8) } else if (channels > 3) { ALL(5) } else { ALL(3) }
 #undef ALL
 #undef LAUNCH
 #undef LAUNCH_BIG

@@ -102,8 +102,7 @@ __device__ __forceinline__ void fwd_blend_selected(FwdPixel<C>& p, unsigned long
         // (x = third colour, y = list position: ONE 64-bit LDS read — left as two fields of q[2] the compiler sinks
         // the position's read under EXEC = ok, which costs a masked region per visit)
         float4 c2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (C > 3) c2 = e(2, j);
-        else { const float2 xy = *reinterpret_cast<const float2*>(&e(2, j)); c2.x = xy.x; c2.y = xy.y; }
+        c2 = e(2, j);  // (x = third colour, y = list position, z = blend threshold (:rgb) or depth)
         const float4 a = e(0, j), b = e(1, j);
         const float4 c3 = C > 5 ? e(C > 5 ? 3 : 0, j) : c2;
         const float dx = a.x - fx, dy = a.y - fy;
@@ -114,7 +113,10 @@ __device__ __forceinline__ void fwd_blend_selected(FwdPixel<C>& p, unsigned long
         // saturating lanes in a wave-uniform rare path instead measured 10 % slower.)
         const float Tn = p.T * (1.0f - alpha);
         const bool small = Tn < 1e-4f;
-        bool ok = !p.done && sigma >= 0.0f && alpha >= (1.0f / 255.0f);
+        // :rgb: sigma >= 0 && alpha >= 1/255 as one unsigned compare against the instance's threshold (tile_sort_device.h)
+        const bool touch = C == 3 ? __float_as_uint(sigma) < __float_as_uint(c2.z)
+                                  : (sigma >= 0.0f && alpha >= (1.0f / 255.0f));
+        bool ok = !p.done && touch;
         const bool stop = ok && small;
         p.done = p.done || stop;
         ok = ok != stop;  // stop implies ok: the xor stays on the scalar unit (`ok && !small` costs a second v_cmp)
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void s
                 const uint32_t i = cbase + (uint32_t)slot;
                 if (i < n) {
                     const uint32_t id = ids[i];
-                    const gsr_sort::InstanceVals v = gsr_sort::instance_vals<C == 5 ? 3 : C>(id, X0, Y0, geom);
+                    const gsr_sort::InstanceVals v = gsr_sort::instance_vals<C>(id, X0, Y0, geom);
                     const uint32_t pos = start + i;
                     values_sorted[pos] = id;
                     stream.s0[pos] = v.v0; stream.s1[pos] = v.v1; stream.s2[pos] = v.v2;
@@ -462,8 +464,10 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
             const int contributor = tile_last - 1 - base - j;  // 0-based position in the tile list
             const float4 a = l0[j], b = l1[j];
             float4 c2;  // (x: third colour, w: footprint mask, z: depth) as the stream has them
-            if (C == 3) { const float2 xm = *reinterpret_cast<const float2*>(&l2[j]); c2 = make_float4(xm.x, 0.0f, 0.0f, xm.y); }
-            else { const float4 t2 = l2[j]; c2 = make_float4(t2.x, 0.0f, t2.z, t2.y); }
+            const float4 t2 = l2[j];  // staged as (third colour, footprint mask, depth | :rgb blend threshold, slot)
+            c2 = make_float4(t2.x, 0.0f, t2.z, t2.y);
+            const uint32_t thr_bits = __float_as_uint(t2.z);
+            (void)thr_bits;
             const float o = b.y;
             const float dx = a.x - fx;
             const SigmaX sx = sigma_x(a.z, a.w, dx);
@@ -490,13 +494,25 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
 #endif
                 const float dy = a.y - fy[q], dy2 = __fmul_rn(dy, dy);
                 const float sigma = sigma_of(sx, b.x, dy, dy2);
-                const float G = __expf(-sigma);
-                const float alpha = alpha_of(o, G);
-                const bool c_live = contributor < last_contributor[q], c_sig = sigma >= 0.0f, c_al = alpha >= (1.0f / 255.0f);
-                const bool active = c_live && c_sig && c_al;
-                // ballots of the bare compares are their SGPR masks; the AND/OR runs on the scalar unit
-                any_active |= wave_ballot(c_live) & wave_ballot(c_sig) & wave_ballot(c_al);
+                float G, alpha;
+                bool active;
+                const bool c_live = contributor < last_contributor[q];
+                if (C == 3) {
+                    // :rgb: the blend test is one unsigned compare of sigma against the instance's threshold; exp and
+                    // alpha are only computed for the lanes that pass (they run under EXEC = active)
+                    const bool c_touch = __float_as_uint(sigma) < thr_bits;
+                    active = c_live && c_touch;
+                    any_active |= wave_ballot(c_live) & wave_ballot(c_touch);
+                } else {
+                    G = __expf(-sigma);
+                    alpha = alpha_of(o, G);
+                    const bool c_sig = sigma >= 0.0f, c_al = alpha >= (1.0f / 255.0f);
+                    active = c_live && c_sig && c_al;
+                    // ballots of the bare compares are their SGPR masks; the AND/OR runs on the scalar unit
+                    any_active |= wave_ballot(c_live) & wave_ballot(c_sig) & wave_ballot(c_al);
+                }
                 if (active) {
+                    if (C == 3) { G = __expf(-sigma); alpha = alpha_of(o, G); }
                     // T /= (1-α) and -T_final/(1-α) (render.jl:237,259) share one hardware reciprocal
                     const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
                     T[q] = T[q] * rinv;

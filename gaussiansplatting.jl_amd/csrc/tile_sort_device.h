@@ -21,6 +21,19 @@ __device__ __forceinline__ InstanceRaw instance_load(uint32_t id, const GsrGeom&
     if (CH > 5) r.normal = geom.normal[id];
     return r;
 }
+// The blend test of a (pixel, splat) pair — sigma >= 0 && alpha >= 1/255 (render.jl:92-95) — as ONE unsigned compare in
+// :rgb mode: alpha = min(0.99, o·exp(-sigma)) >= 1/255  <=>  sigma <= ln(255·o) =: tau, and for non-negative floats the bit
+// patterns order like the values while any negative sigma has the sign bit set, so  bits(sigma) < X  with
+// X = bits(tau) + 1 (0 when tau < 0: opacity below 1/255 never blends) is the whole test.  X travels in the stream's depth
+// slot, which :rgb does not use.  Forward and backward compare the same sigma against the same X: identical contributor
+// sets by construction; against an alpha computed with another exp the decision differs only for pairs within an ulp
+// of the boundary, as it already does between two exp implementations.
+__device__ __forceinline__ uint32_t blend_threshold_bits(float opacity) {
+    const float tau = __logf(255.0f * opacity);
+    return tau >= 0.0f ? __float_as_uint(tau) + 1u : 0u;
+}
+
+template <int CH>
 __device__ __forceinline__ InstanceVals instance_vals_of(const InstanceRaw& r, int X0, int Y0) {
     InstanceVals o;
     const GsrGeoRec& rec = r.rec;
@@ -36,13 +49,15 @@ __device__ __forceinline__ InstanceVals instance_vals_of(const InstanceRaw& r, i
     const uint32_t slot = r.bpre + __float_as_uint(rec.q2.w) +
                           ((uint32_t)(Y0 / GSR_TILE) - y0) * (x1 - x0) + ((uint32_t)(X0 / GSR_TILE) - x0);
     const uint32_t mask_bits = instance_row_mask(rec.q0, rec.q1, X0, Y0);
-    o.v2 = make_float4(rec.q2.x, __uint_as_float(slot), rec.q2.z, __uint_as_float(mask_bits));
+    // (:rgb, CH == 3: the blend-test threshold in place of the depth, which only the :rgbd / :rgbdn features use)
+    const float z = CH == 3 ? __uint_as_float(blend_threshold_bits(rec.q1.y)) : rec.q2.z;
+    o.v2 = make_float4(rec.q2.x, __uint_as_float(slot), z, __uint_as_float(mask_bits));
     o.v3 = r.normal;
     return o;
 }
 template <int CH>
 __device__ __forceinline__ InstanceVals instance_vals(uint32_t id, int X0, int Y0, const GsrGeom& geom) {
-    return instance_vals_of(instance_load<CH>(id, geom), X0, Y0);
+    return instance_vals_of<CH>(instance_load<CH>(id, geom), X0, Y0);
 }
 
 // Emit one sorted instance: its id, and its entry of the packed splat stream.

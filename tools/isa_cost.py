@@ -16,8 +16,8 @@ Roles (execution count on one view):
   stage           per batch of 64 staged instances             stream -> LDS
   ballot          per 64-entry ballot (= per batch here)       row-mask work list
   head            per candidate instance                       3 LDS reads, dx, sigma's dx part, row-mask bits
-  test[q]         per visited 16x4 pixel group q               dy, sigma, exp, alpha, the three compares
-  active[q]       per visited group with >= 1 active lane      rcp, T, A, P/U1/U2, colour sums
+  test[q]         per visited 16x4 pixel group q               dy, sigma, the two compares (:rgb: live, sigma-bits < threshold)
+  active[q]       per visited group with >= 1 active lane      exp, alpha, rcp, T, A, P/U1/U2, colour sums
   skip[q]         per candidate whose mask misses group q      (scalar branch; the q = 0 path zero-fills 7 accumulators)
   reduce          per instance with >= 1 active lane           row-then-column wave64 reduction + LDS row store
   glue            per candidate                                loop control, ballot accumulation
@@ -53,8 +53,8 @@ def classify(blist):
     loop: the flush of batch k sits in front of the staging of batch k+1):
       * everything in front of the first block with a global_store_dwordx4 (the flush) is the per-tile prologue;
       * the instance loop runs from the block with s_ff1 + ds_read_b128 (head) to the last block that branches back to it;
-        inside it, blocks with v_exp are the four group tests, the all-VALU block with v_rcp behind each is its active
-        part, a block of zero-fills is the q = 0 "not visited" path, v_permlane32_swap marks the reduction (and the
+        inside it, the blocks that compute sigma, compare and narrow EXEC are the four group tests, the all-VALU block
+        with v_rcp behind each is its active part, a block of zero-fills is the q = 0 "not visited" path, v_permlane32_swap marks the reduction (and the
         ds_write block behind it), the rest is glue;
       * the batch loop is everything else between the flush and the loop's exit label (the largest label a block in front
         of the head branches to): flush (global stores), stage (global_load_dwordx4 + ds_write_b128), ballot (the rest);
@@ -85,11 +85,11 @@ def classify(blist):
         elif head <= i <= loop_end:
             if i == head:
                 role = "head"
-            elif has(i, r"v_exp_f32"):
-                q += 1
-                role = f"test{q}"
             elif has(i, r"v_rcp_f32") and all(l.startswith("v_") for l in b):
                 role = f"active{q}"
+            elif has(i, r"v_cmp") and has(i, r"s_and_saveexec_b64") and has(i, r"v_fma"):
+                q += 1
+                role = f"test{q}"
             elif has(i, r"v_permlane32_swap") or (roles and roles[-1][2] == "reduce" and has(i, r"ds_write")):
                 role = "reduce"
             elif sum(l.startswith("v_mov_b32") for l in b) >= 5:

@@ -45,7 +45,7 @@ struct GsrGeom {
 struct GsrStream {
     float4* s0;  // mean2d.x, mean2d.y, conic.a / 2, conic.b
     float4* s1;  // conic.c / 2, opacity, r, g
-    float4* s2;  // b, slot (uint bits: Gaussian-major instance slot), depth, row mask (uint bits: tile rows touched)
+    float4* s2;  // b, slot (uint bits: Gaussian-major instance slot), depth | :rgb: blend-test threshold bits (tile_sort_device.h), row mask (uint bits: tile rows touched)
     float4* s3;  // normal (C == 8) or nullptr
 };
 

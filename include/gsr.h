@@ -224,7 +224,8 @@ enum {
     GSR_BUF_GRAD_ROWS = 8,     /* 16 x float per (Gaussian, tile-of-its-rect) slot, Gaussian-major: the
                                 *   per-instance gradient rows of the last gsr_backward */
     GSR_BUF_INSTANCE_AUX = 9   /* 4 x 32-bit (D), sorted instance order (plane s2 of the splat stream):
-                                *   [0] blue, [1] u32 Gaussian-major slot, [2] depth, [3] u32 footprint masks
+                                *   [0] blue, [1] u32 Gaussian-major slot, [2] depth (:rgbd / :rgbdn) or, in :rgb mode, the u32 blend-test
+                                *   threshold bits(ln(255 opacity)) + 1 (0: never blends), [3] u32 footprint masks
                                 *   (bits 0..15 tile rows, 16..19 8x8 quadrants the instance can touch) */
 };
 GSR_API int gsr_buffer(const gsr_handle* h, int which, const void** dev_ptr, size_t* bytes);

@@ -124,7 +124,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-extra", action="store_true", help="skip `extra_configs` (configs 2 / 5, :rgbd, trainer step)")
     ap.add_argument("--extra-steps", type=int, default=10, help="timed steps per `extra_configs` entry")
     ap.add_argument("--host-wait", default=None, metavar="SPIN,YIELD,SLEEP",
-                    help="gsr_host_wait_policy in microseconds (default: the library's 100,0,50; '1000000,0,0' = pure spin)")
+                    help="gsr_host_wait_policy in microseconds (default: the library's 30,0,0 = spin then sched_yield polling; '100,0,50' = adaptive sleep; '1000000,0,0' = pure spin)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher test: start the rank processes, each prints its RANK / WORLD_SIZE / MASTER_* as JSON and "
                          "exits BEFORE importing torch; the parent prints the collected list")

@@ -257,23 +257,23 @@ static inline void cpu_relax() {
 #endif
 }
 
-// Host wait policy of the forward's single read-back (gsr_host_wait_policy), process-wide:
-//   spin_us   the margin: the thread SLEEPS through the expected wait (an average of this handle's previous waits) except
-//             for its last spin_us microseconds, which it spins through — so a wake-up that comes late by the kernel's
-//             timer slack (50 us by default) still lands before the word is written;
-//   yield_us  once the expected time has passed and spin_us more have been spun: poll with sched_yield() this long;
-//   sleep_us  after that: sleep this long between polls (0: keep yielding).
-struct WaitPolicy { int spin_us = 100, yield_us = 0, sleep_us = 50; };
+// Host wait policy of the forward's single read-back (gsr_host_wait_policy), process-wide.
+//   DEFAULT (sleep_us == 0): spin for spin_us microseconds, then poll with sched_yield() between looks at the word.  Any
+//   other runnable thread — RCCL's proxy threads on an 8-rank host — gets the core at once, no timer is involved, and
+//   the step time is a pure spin's (config 2: 0.2123-0.2137 ms, config 3: 1.494 ms per step over 200 steps, all three
+//   policies within noise of each other: tools/host_wait_ab.sh).
+//   OPT-IN (sleep_us > 0): the thread SLEEPS through the expected wait (a running average of this handle's previous
+//   waits: the host runs ahead of the GPU, so the wait is as long as the work still queued in front of the scan, about
+//   the same every step) except for its last spin_us microseconds — in doubling pieces of 50, 100, 200 ... us with a look
+//   at the word after each, so that the first forward after the caller synchronised (GPU idle: a short wait) costs one
+//   small piece; a wake-up that finds the word already written is not a sample (an average fed with its own oversleeps
+//   ratchets upwards and starves the GPU) but shrinks the estimate; after the expected time + spin_us: sched_yield() for
+//   yield_us, then sleeps of sleep_us.  Same step time on a quiet host, a fraction of the CPU time; NOT the default
+//   because a late timer wake-up (observed on one box of the pool: one step of twenty 3 ms late) lands in the step time.
+struct WaitPolicy { int spin_us = 30, yield_us = 0, sleep_us = 0; };
 WaitPolicy g_wait;
 
-// Wait until tile_scan of forward `seq` has published its totals (a word of pinned host memory).  The host runs ahead
-// of the GPU, so this wait lasts as long as whatever the GPU still has queued in front of the scan: ~0.2 ms on a
-// 0.23 ms step (config 2), ~1 ms on config 3's 1.5 ms step — every step about the same, which is what the policy uses:
-// sleep through the expected wait minus a margin, spin the rest.  An 8-rank node has eight of these waiters next to
-// RCCL's proxy threads; a pure spin pins eight cores.  Measured (bench.py --host-wait, MI355X): fixed thresholds either
-// burn the core (long spin) or oversleep short views (20 us spin + sched_yield: config 2 0.238 ms against 0.226 ms; 100 us
-// spin + 50 us sleeps: 0.265 ms — the sleep outlasts the sort + forward the GPU had queued); the adaptive form keeps a pure
-// spin's step time on both.
+// Wait until tile_scan of forward `seq` has published its totals (a word of pinned host memory).
 // A wait that lasts longer than any sane queue depth (50 ms) starts polling the stream, so that a failed launch or a
 // faulted kernel ends with an error instead of hanging the caller — not earlier: hipStreamQuery puts a marker packet on
 // the stream, and a marker between two kernels is a 5 us bubble (rocprofv3 kernel trace, tools/gap_report.py).
@@ -283,7 +283,7 @@ int wait_totals(gsr_handle* h, uint32_t seq, hipStream_t s) {
     if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) return GSR_OK;
     const auto t0 = clk::now();
     const double expect_us = h->wait_ema_us;
-    if (expect_us > (double)g_wait.spin_us + 50.0) {  // worth a sleep: more than the margin + a timer slack
+    if (g_wait.sleep_us > 0 && expect_us > (double)g_wait.spin_us + 50.0) {  // sleeping enabled and worth it
         // ... in doubling pieces (50, 100, 200, ... us) with a look at the word after each: the expectation comes from
         // steps in which the host ran ahead of the GPU; the first forward after the caller synchronised finds the GPU
         // idle and its wait is only preprocess + scan long — the small first pieces bound what that costs.
@@ -305,7 +305,7 @@ int wait_totals(gsr_handle* h, uint32_t seq, hipStream_t s) {
             piece *= 2.0;
         }
     }
-    const auto t_spin = t0 + std::chrono::microseconds((long)expect_us + g_wait.spin_us);
+    const auto t_spin = t0 + std::chrono::microseconds((g_wait.sleep_us > 0 ? (long)expect_us : 0L) + g_wait.spin_us);
     const auto t_yield = t_spin + std::chrono::microseconds(g_wait.yield_us);
     auto next_poll = t0 + std::chrono::milliseconds(50);
     int rc = GSR_OK;

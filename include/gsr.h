@@ -196,12 +196,14 @@ GSR_API int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* 
                          const gsr_grads* grads, void* stream);
 
 /* How the host thread waits inside gsr_forward for the instance count (the reference blocks in a synchronous
- * device->host copy there, rasterizer.jl:337).  The host runs ahead of the GPU, so the wait lasts about as long as the
- * work still queued in front of the scan — roughly the same every step.  Policy, process-wide: the thread SLEEPS through
- * the expected wait (a running average per handle) except for its last `spin_us` microseconds (default 100), which it
- * spins through; if the word is still not there it polls with sched_yield() for `yield_us` (default 0) and then sleeps
- * `sleep_us` (default 50) between polls — so eight ranks on one host do not pin eight cores next to RCCL's proxy threads,
- * and short views do not oversleep.  (1000000, 0, 0) is a pure spin. */
+ * device->host copy there, rasterizer.jl:337).  Process-wide.
+ *   sleep_us == 0 (default: 30, 0, 0): spin for `spin_us` microseconds, then poll with sched_yield() — other runnable threads
+ *   (RCCL's proxy threads on an 8-rank host) get the core at once; no timers; a pure spin's step time.
+ *   sleep_us > 0 (opt-in, e.g. 100, 0, 50): sleep through the expected wait (a running average per handle; the host runs
+ *   ahead of the GPU, so the wait is about the same every step) except for its last `spin_us` microseconds, then
+ *   sched_yield() for `yield_us`, then sleeps of `sleep_us` — a fraction of the CPU time, at the mercy of the host's timer
+ *   wake-up latency.
+ *   (1000000, 0, 0) is a pure spin. */
 GSR_API int gsr_host_wait_policy(int spin_us, int yield_us, int sleep_us);
 
 /* Views into the state the reference keeps in rast.gstate / bstate / istate

@@ -1,7 +1,6 @@
 """The host side of gsr_forward's single read-back (gsr.h: gsr_host_wait_policy; round-2 verdict "make the host sync
 polite"): eight handles driven by eight host threads — the shape of an 8-rank node's host load — must step as fast
-with the default back-off (100 us spin, then 50 us sleeps) as with a pure busy spin, while
-burning far less CPU."""
+with the default policy (30 us spin, then sched_yield polling) and with the opt-in adaptive sleep (100, 0, 50) as with a pure busy spin."""
 import os
 import threading
 import time
@@ -60,12 +59,15 @@ def _run(pkg, policy, n_threads=8, steps=40):
 def test_eight_threads_step_time_unchanged_with_the_back_off(pkg):
     try:
         spin_wall, spin_cpu, img_a = _run(pkg, (1_000_000, 0, 0))   # pure spin: the round-2 behaviour
-        pol_wall, pol_cpu, img_b = _run(pkg, (100, 0, 50))          # the default
+        pol_wall, pol_cpu, img_b = _run(pkg, (30, 0, 0))            # the default: spin, then sched_yield polling
+        slp_wall, slp_cpu, img_c = _run(pkg, (100, 0, 50))          # opt-in: adaptive sleep
     finally:
-        pkg._lib.check(pkg._lib.load().gsr_host_wait_policy(100, 0, 50))
+        pkg._lib.check(pkg._lib.load().gsr_host_wait_policy(30, 0, 0))
     print(f"8 threads x 8 handles: pure spin {spin_wall * 1e3:.3f} ms/step ({spin_cpu * 1e3:.2f} CPU-ms/step), "
-          f"back-off {pol_wall * 1e3:.3f} ms/step ({pol_cpu * 1e3:.2f} CPU-ms/step)")
-    for a, b in zip(img_a, img_b):
-        assert torch.equal(a, b)
+          f"yield polling {pol_wall * 1e3:.3f} ms/step ({pol_cpu * 1e3:.2f} CPU-ms/step), "
+          f"adaptive sleep {slp_wall * 1e3:.3f} ms/step ({slp_cpu * 1e3:.2f} CPU-ms/step)")
+    for a, b, c in zip(img_a, img_b, img_c):
+        assert torch.equal(a, b) and torch.equal(a, c)
     assert pol_wall <= 1.10 * spin_wall + 2e-5, (pol_wall, spin_wall)
+    assert slp_wall <= 1.25 * spin_wall + 5e-5, (slp_wall, spin_wall)
     assert pkg._lib.load().gsr_host_wait_policy(-1, 0, 0) == pkg._lib.GSR_E_INVALID_ARG

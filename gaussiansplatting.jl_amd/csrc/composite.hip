@@ -18,12 +18,6 @@
 #include "wave_reduce.h"
 #include "tile_sort_device.h"
 
-#ifndef GSR_LDS_PLANE_PAD
-#define GSR_LDS_PLANE_PAD 0
-#endif
-#ifndef GSR_FWD_IPT
-#define GSR_FWD_IPT 1
-#endif
 
 namespace {
 
@@ -51,7 +45,7 @@ __device__ __forceinline__ float alpha_of(float opacity, float G) { return fminf
 // offsets (plane · 16·N) instead of one address computation per plane — 2 VALU instructions per visit less in loops that
 // are VALU-issue-bound; planes (not 48-byte records) keep the lane-contiguous staging stores conflict-free.
 template <int C, int N> struct LdsSplats {
-    float4 q[C > 5 ? 4 : 3][N + GSR_LDS_PLANE_PAD];
+    float4 q[C > 5 ? 4 : 3][N];
     __device__ __forceinline__ const float4& operator()(int plane, int j) const { return q[plane][j]; }
     __device__ __forceinline__ float4& operator()(int plane, int j) { return q[plane][j]; }
 };
@@ -252,8 +246,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void s
                                                                  uint8_t* __restrict__ covis, float* __restrict__ uncert,
                                                                  const uint32_t* __restrict__ totals,
                                                                  uint32_t cap_instances) {
-    constexpr int IPT = GSR_FWD_IPT;     // instances per thread and round
-    constexpr int CHUNK = 256 * IPT;     // instances resident in LDS at a time
+    // instances resident in LDS at a time: one per thread and round (512 / 1024 — whole lists — cost 5 / 3 workgroups per CU
+    // instead of 8: +13 % / +48 %, profiles/r03/experiments/small_ab_notes.txt)
+    constexpr int CHUNK = 256;
     __shared__ uint32_t ids[1024];
     __shared__ LdsSplats<C, CHUNK> e;
     if (totals[0] > cap_instances || totals[1] > bin_cap) return;  // [0] instances, [1] longest list
@@ -286,22 +281,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void s
         if (wave == (int)(blockIdx.x & 3u)) gsr_sort::wave_sort_ids_any(ids, n, lane, bins + (size_t)tile * bin_cap);
         __syncthreads();
         for (uint32_t cbase = 0; cbase < n; cbase += CHUNK) {
-#pragma unroll
-            for (int r = 0; r < IPT; r++) {
-                const int slot = tid + 256 * r;
-                const uint32_t i = cbase + (uint32_t)slot;
-                if (i < n) {
-                    const uint32_t id = ids[i];
-                    const gsr_sort::InstanceVals v = gsr_sort::instance_vals<C>(id, X0, Y0, geom);
-                    const uint32_t pos = start + i;
-                    values_sorted[pos] = id;
-                    stream.s0[pos] = v.v0; stream.s1[pos] = v.v1; stream.s2[pos] = v.v2;
-                    if (C > 5) stream.s3[pos] = v.v3;
-                    e(0, slot) = v.v0; e(1, slot) = v.v1;
-                    // LDS copy: (third colour, 1-based list position, depth, footprint masks)
-                    e(2, slot) = make_float4(v.v2.x, __uint_as_float(i + 1u), v.v2.z, v.v2.w);
-                    if (C > 5) e(C > 5 ? 3 : 0, slot) = v.v3;
-                }
+            const uint32_t i = cbase + (uint32_t)tid;
+            if (i < n) {
+                const uint32_t id = ids[i];
+                const gsr_sort::InstanceVals v = gsr_sort::instance_vals<C>(id, X0, Y0, geom);
+                const uint32_t pos = start + i;
+                values_sorted[pos] = id;
+                stream.s0[pos] = v.v0; stream.s1[pos] = v.v1; stream.s2[pos] = v.v2;
+                if (C > 5) stream.s3[pos] = v.v3;
+                e(0, tid) = v.v0; e(1, tid) = v.v1;
+                // LDS copy: (third colour, 1-based list position, depth | :rgb blend threshold, footprint masks)
+                e(2, tid) = make_float4(v.v2.x, __uint_as_float(i + 1u), v.v2.z, v.v2.w);
+                if (C > 5) e(C > 5 ? 3 : 0, tid) = v.v3;
             }
             __syncthreads();
             const int cnt = (int)min((uint32_t)CHUNK, n - cbase);
@@ -326,9 +317,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void s
 // [7..8] v mean2d, [9] v depth (C>=5), [10..12] v normal (C==8)
 template <int C> struct AccRow { static constexpr int N = C == 3 ? 9 : (C == 5 ? 10 : 13); static constexpr int STRIDE = N | 1; };
 
-#ifndef GSR_BWD_MINWAVES_GUARD_
-#define GSR_BWD_MINWAVES_GUARD_
-#endif
 #ifndef GSR_BWD_MINWAVES
 #define GSR_BWD_MINWAVES 1
 #endif

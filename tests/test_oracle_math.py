@@ -264,3 +264,41 @@ def test_grad_gaussian_normal(orc):
         close(vq, qt.grad.numpy())
         done += 1
     assert done > 50
+
+
+def test_single_compare_blend_test_is_the_references_test():
+    """The :rgb compositing kernels decide `sigma >= 0 && min(0.99, o·exp(-sigma)) >= 1/255` (render.jl:92-95) with ONE
+    unsigned compare, bits(sigma) < X, X = bits(ln(255·o)) + 1 (0 when ln(255·o) < 0) — tile_sort_device.h
+    `blend_threshold_bits`.  Restated in numpy: the two tests agree for every (sigma, opacity) pair except those whose
+    sigma lies within a few ulps of the boundary ln(255·o) — where two exp implementations already disagree —, for
+    negative sigma (always rejected), sigma = +0, opacity below 1/255 (never blends) and NaN (rejected).  (sigma = -0.0, which
+    the reference accepts and the bit compare rejects, cannot come out of the kernels' sigma: its last operation is an fma whose
+    addend ha·dx² is >= +0, and x + (+0) is never -0 in round-to-nearest.)"""
+    rng = np.random.default_rng(11)
+    n = 2_000_000
+    o = rng.uniform(0.0, 1.0, n).astype(np.float32)
+    o[: n // 10] = rng.uniform(0.0, 1.0 / 200.0, n // 10).astype(np.float32)      # around and below 1/255
+    tau = np.log(np.float32(255.0) * o, dtype=np.float32)
+    sigma = (rng.uniform(-0.2, 1.3, n) * np.maximum(tau, np.float32(0.5))).astype(np.float32)
+    sigma[n // 2: n // 2 + 1000] = tau[n // 2: n // 2 + 1000]                      # exactly on the boundary
+    sigma[:200] = 0.0
+    sigma[200:300] = np.nan
+    with np.errstate(invalid="ignore", over="ignore"):
+        alpha = np.minimum(np.float32(0.99), o * np.exp(-sigma, dtype=np.float32))
+        ref = (sigma >= 0) & (alpha >= np.float32(1.0 / 255.0))
+    X = np.where(tau >= 0, tau.view(np.uint32).astype(np.uint64) + 1, 0).astype(np.uint32)
+    got = sigma.view(np.uint32) < X
+    differ = ref != got
+    # every disagreement sits within 4 ulps of the boundary
+    with np.errstate(invalid="ignore"):
+        near = np.abs(sigma - tau) <= 4 * np.spacing(np.abs(tau).astype(np.float32))
+    assert not (differ & ~near).any(), int((differ & ~near).sum())
+    assert differ.mean() < 2e-3                       # (most of them are the 1000 planted boundary cases)
+    assert not got[200:300].any() and not ref[200:300].any()          # NaN
+    neg = sigma < 0
+    assert not got[neg].any()
+    low = o < np.float32(1.0 / 255.0) * np.float32(0.999)
+    assert not got[low].any() and not ref[low].any()
+    zero = np.arange(n) < 200
+    ok0 = o[zero] >= np.float32(1.0 / 255.0) * np.float32(1.001)
+    assert np.array_equal(got[zero][ok0], ref[zero][ok0]) and ref[zero][ok0].all()

@@ -45,7 +45,7 @@ __device__ __forceinline__ float alpha_of(float opacity, float G) { return fminf
 // offsets (plane · 16·N) instead of one address computation per plane — 2 VALU instructions per visit less in loops that
 // are VALU-issue-bound; planes (not 48-byte records) keep the lane-contiguous staging stores conflict-free.
 template <int C, int N> struct LdsSplats {
-    float4 q[C > 5 ? 4 : 3][N];
+    float4 q[C > 3 ? 4 : 3][N];  // (fourth plane: normal xyz (:rgbdn) + the blend threshold in w, :rgbd / :rgbdn)
     __device__ __forceinline__ const float4& operator()(int plane, int j) const { return q[plane][j]; }
     __device__ __forceinline__ float4& operator()(int plane, int j) { return q[plane][j]; }
 };
@@ -98,7 +98,7 @@ __device__ __forceinline__ void fwd_blend_selected(FwdPixel<C>& p, unsigned long
         float4 c2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         c2 = e(2, j);  // (x = third colour, y = list position, z = blend threshold (:rgb) or depth)
         const float4 a = e(0, j), b = e(1, j);
-        const float4 c3 = C > 5 ? e(C > 5 ? 3 : 0, j) : c2;
+        const float4 c3 = C > 3 ? e(C > 3 ? 3 : 0, j) : c2;
         const float dx = a.x - fx, dy = a.y - fy;
         const float sigma = sigma_of(sigma_x(a.z, a.w, dx), b.x, dy, __fmul_rn(dy, dy));
         const float alpha = alpha_of(b.y, __expf(-sigma));
@@ -107,9 +107,8 @@ __device__ __forceinline__ void fwd_blend_selected(FwdPixel<C>& p, unsigned long
         // saturating lanes in a wave-uniform rare path instead measured 10 % slower.)
         const float Tn = p.T * (1.0f - alpha);
         const bool small = Tn < 1e-4f;
-        // :rgb: sigma >= 0 && alpha >= 1/255 as one unsigned compare against the instance's threshold (tile_sort_device.h)
-        const bool touch = C == 3 ? __float_as_uint(sigma) < __float_as_uint(c2.z)
-                                  : (sigma >= 0.0f && alpha >= (1.0f / 255.0f));
+        // sigma >= 0 && alpha >= 1/255 as one unsigned compare against the instance's threshold (tile_sort_device.h)
+        const bool touch = __float_as_uint(sigma) < __float_as_uint(C == 3 ? c2.z : c3.w);
         bool ok = !p.done && touch;
         const bool stop = ok && small;
         p.done = p.done || stop;
@@ -176,7 +175,7 @@ __device__ __forceinline__ void composite_fwd_quadrant(int W, int H, int grid_x,
             e(1, lane) = stream.s1[start + jj];
             r2.y = __uint_as_float((uint32_t)(jj + 1));  // the forward has no use for the gradient-row slot: list position
             e(2, lane) = r2;
-            if (C > 5) e(C > 5 ? 3 : 0, lane) = stream.s3[start + jj];
+            if (C > 3) e(C > 3 ? 3 : 0, lane) = stream.s3[start + jj];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -288,11 +287,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void s
                 const uint32_t pos = start + i;
                 values_sorted[pos] = id;
                 stream.s0[pos] = v.v0; stream.s1[pos] = v.v1; stream.s2[pos] = v.v2;
-                if (C > 5) stream.s3[pos] = v.v3;
+                if (C > 3) stream.s3[pos] = v.v3;
                 e(0, tid) = v.v0; e(1, tid) = v.v1;
                 // LDS copy: (third colour, 1-based list position, depth | :rgb blend threshold, footprint masks)
                 e(2, tid) = make_float4(v.v2.x, __uint_as_float(i + 1u), v.v2.z, v.v2.w);
-                if (C > 5) e(C > 5 ? 3 : 0, tid) = v.v3;
+                if (C > 3) e(C > 3 ? 3 : 0, tid) = v.v3;
             }
             __syncthreads();
             const int cnt = (int)min((uint32_t)CHUNK, n - cbase);
@@ -352,7 +351,7 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
     if (LISTED) __builtin_amdgcn_s_setprio(3);
     static_assert(BB <= NT && BB % 64 == 0, "one staging thread per splat");
     __shared__ float4 l0[BB], l1[BB], l2[BB];
-    __shared__ float4 l3[C > 5 ? BB : 1];
+    __shared__ float4 l3[C > 3 ? BB : 1];
     // One accumulator slab per wave: a wave stores its reduced partials with plain ds_write
     // (no LDS atomics: hipcc wraps those in a per-lane "atomic optimizer" loop), and a
     // per-wave bit mask records which rows it touched so nothing has to be zero-filled.
@@ -433,7 +432,7 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
             // one aligned 64-bit LDS read in :rgb mode
             const float4 t2 = stream.s2[idx];
             l2[tid] = make_float4(t2.x, t2.w, t2.z, t2.y);
-            if (C > 5) l3[tid] = stream.s3[idx];
+            if (C > 3) l3[tid] = stream.s3[idx];
         }
         __syncthreads();
 
@@ -454,13 +453,14 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
             float4 c2;  // (x: third colour, w: footprint mask, z: depth) as the stream has them
             const float4 t2 = l2[j];  // staged as (third colour, footprint mask, depth | :rgb blend threshold, slot)
             c2 = make_float4(t2.x, 0.0f, t2.z, t2.y);
-            const uint32_t thr_bits = __float_as_uint(t2.z);
-            (void)thr_bits;
+            float4 t3 = t2;
+            if (C > 3) t3 = l3[j];  // (normal xyz, blend threshold)
+            const uint32_t thr_bits = __float_as_uint(C == 3 ? t2.z : t3.w);
             const float o = b.y;
             const float dx = a.x - fx;
             const SigmaX sx = sigma_x(a.z, a.w, dx);
             float f[C];
-            unpack_features<C>(b, c2, C > 5 ? l3[j] : c2, f);
+            unpack_features<C>(b, c2, t3, f);
             // A lane accumulates only  P = Σ G·vα,  U1 = Σ G·vα·dy,  U2 = Σ G·vα·dy²  and the
             // feature sums.  The conic / mean2d gradients (render.jl:262-272) are linear in
             // {dx²·P, dx·U1, U2, dx·P, U1}: those five are what the wave reduces, and the
@@ -482,25 +482,16 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
 #endif
                 const float dy = a.y - fy[q], dy2 = __fmul_rn(dy, dy);
                 const float sigma = sigma_of(sx, b.x, dy, dy2);
-                float G, alpha;
-                bool active;
+                // the blend test is one unsigned compare of sigma against the instance's threshold; exp and alpha are only
+                // computed for the lanes that pass (they run under EXEC = active)
                 const bool c_live = contributor < last_contributor[q];
-                if (C == 3) {
-                    // :rgb: the blend test is one unsigned compare of sigma against the instance's threshold; exp and
-                    // alpha are only computed for the lanes that pass (they run under EXEC = active)
-                    const bool c_touch = __float_as_uint(sigma) < thr_bits;
-                    active = c_live && c_touch;
-                    any_active |= wave_ballot(c_live) & wave_ballot(c_touch);
-                } else {
-                    G = __expf(-sigma);
-                    alpha = alpha_of(o, G);
-                    const bool c_sig = sigma >= 0.0f, c_al = alpha >= (1.0f / 255.0f);
-                    active = c_live && c_sig && c_al;
-                    // ballots of the bare compares are their SGPR masks; the AND/OR runs on the scalar unit
-                    any_active |= wave_ballot(c_live) & wave_ballot(c_sig) & wave_ballot(c_al);
-                }
+                const bool c_touch = __float_as_uint(sigma) < thr_bits;
+                const bool active = c_live && c_touch;
+                // ballots of the bare compares are their SGPR masks; the AND/OR runs on the scalar unit
+                any_active |= wave_ballot(c_live) & wave_ballot(c_touch);
                 if (active) {
-                    if (C == 3) { G = __expf(-sigma); alpha = alpha_of(o, G); }
+                    const float G = __expf(-sigma);
+                    const float alpha = alpha_of(o, G);
                     // T /= (1-α) and -T_final/(1-α) (render.jl:237,259) share one hardware reciprocal
                     const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
                     T[q] = T[q] * rinv;

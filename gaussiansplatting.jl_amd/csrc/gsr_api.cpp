@@ -540,7 +540,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     // kernel itself checks the scan's totals against it.  The host's wait below then overlaps that launch instead of
     // idling the GPU, and inside it the HBM-bound sort of one tile shares the CU with the VALU-bound compositing of others.
     uint64_t cap_instances = std::min(std::min(h->values_sorted.cap / 4, h->s0.cap / 16), std::min(h->s1.cap / 16, h->s2.cap / 16));
-    if (C > 5) cap_instances = std::min<uint64_t>(cap_instances, h->s3.cap / 16);
+    if (C > 3) cap_instances = std::min<uint64_t>(cap_instances, h->s3.cap / 16);
     cap_instances = std::min<uint64_t>(cap_instances, 0xFFFFFFFFull);
     static const bool no_fused = [] { const char* e = getenv("GSR_NO_FUSED_FWD"); return e && e[0] == '1'; }();  // A/B only
     const bool spec = use_bins && cap_instances > 0 && !no_fused;
@@ -599,7 +599,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     if ((rc = h->values_sorted.ensure(D * 4, slack)) ||
         (rc = h->rows.ensure(D_slots * 64, slack)) ||
         (rc = h->s0.ensure(D * 16, slack)) || (rc = h->s1.ensure(D * 16, slack)) ||
-        (rc = h->s2.ensure(D * 16, slack)) || (C > 5 && (rc = h->s3.ensure(D * 16, slack))))
+        (rc = h->s2.ensure(D * 16, slack)) || (C > 3 && (rc = h->s3.ensure(D * 16, slack))))
         return rc;
     size_t slab_stride = 0;
     if (n_big > 0) {  // lists beyond the LDS sort: two merge slabs per listed tile

@@ -46,7 +46,7 @@ struct GsrStream {
     float4* s0;  // mean2d.x, mean2d.y, conic.a / 2, conic.b
     float4* s1;  // conic.c / 2, opacity, r, g
     float4* s2;  // b, slot (uint bits: Gaussian-major instance slot), depth | :rgb: blend-test threshold bits (tile_sort_device.h), row mask (uint bits: tile rows touched)
-    float4* s3;  // normal (C == 8) or nullptr
+    float4* s3;  // :rgbd / :rgbdn: normal xyz (C == 8, else 0) + the blend-test threshold bits in w (tile_sort_device.h); :rgb: nullptr
 };
 
 // Backward: per-INSTANCE gradient rows (plain stores, no atomics), indexed by the

@@ -419,7 +419,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
             rec.q1 = make_float4(conic[2], opac_v, rgb[0], rgb[1]);
             rec.q2 = make_float4(rgb[2], __uint_as_float(clamp_bits), mc_z, __uint_as_float(lpre));
             rec.q3 = make_float4(__uint_as_float((uint32_t)rmin[0] | ((uint32_t)rmin[1] << 16)),
-                                 __uint_as_float((uint32_t)rmax[0] | ((uint32_t)rmax[1] << 16)), 0.0f, 0.0f);
+                                 __uint_as_float((uint32_t)rmax[0] | ((uint32_t)rmax[1] << 16)),
+                                 __uint_as_float(blend_threshold_bits(opac_v)), 0.0f);
             geom.rec[i] = rec;
         }
     }

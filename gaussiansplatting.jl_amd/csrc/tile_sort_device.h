@@ -21,22 +21,12 @@ __device__ __forceinline__ InstanceRaw instance_load(uint32_t id, const GsrGeom&
     if (CH > 5) r.normal = geom.normal[id];
     return r;
 }
-// The blend test of a (pixel, splat) pair — sigma >= 0 && alpha >= 1/255 (render.jl:92-95) — as ONE unsigned compare in
-// :rgb mode: alpha = min(0.99, o·exp(-sigma)) >= 1/255  <=>  sigma <= ln(255·o) =: tau, and for non-negative floats the bit
-// patterns order like the values while any negative sigma has the sign bit set, so  bits(sigma) < X  with
-// X = bits(tau) + 1 (0 when tau < 0: opacity below 1/255 never blends) is the whole test.  X travels in the stream's depth
-// slot in :rgb mode (which does not use the depth) and in the w component of the fourth plane in :rgbd / :rgbdn mode (the
-// plane that carries the normal in :rgbdn; :rgbd gets it for X alone: 16 bytes per instance for one compare and, in the
-// backward, exp / alpha only on the lanes that pass).  Forward and backward compare the same sigma against the same X: identical contributor
-// sets by construction; against an alpha computed with another exp the decision differs only for pairs within an ulp
-// of the boundary, as it already does between two exp implementations.
-__device__ __forceinline__ uint32_t blend_threshold_bits(float opacity) {
-    // (the correctly rounded logf, not the 2-3 ulp __logf: once per instance, and every ulp of tau is a band of sigma in
-    // which this test and a test on a computed alpha may disagree)
-    const float tau = logf(255.0f * opacity);
-    return tau >= 0.0f ? __float_as_uint(tau) + 1u : 0u;
-}
-
+// The blend-test threshold X of an instance (tile_mask.h blend_threshold_bits: one unsigned compare, bits(sigma) < X, is
+// the reference's whole test) was computed by preprocess and sits in the Gaussian's record.  It travels in the stream's
+// depth slot in :rgb mode (which does not use the depth) and in the w component of the fourth plane in :rgbd / :rgbdn
+// mode (the plane that carries the normal in :rgbdn; :rgbd gets it for X alone: 16 bytes per instance for one compare
+// and, in the backward, exp / alpha only on the lanes that pass).  Forward and backward compare the same sigma against
+// the same X: identical contributor sets by construction.
 template <int CH>
 __device__ __forceinline__ InstanceVals instance_vals_of(const InstanceRaw& r, int X0, int Y0) {
     InstanceVals o;
@@ -55,7 +45,7 @@ __device__ __forceinline__ InstanceVals instance_vals_of(const InstanceRaw& r, i
     const uint32_t mask_bits = instance_row_mask(rec.q0, rec.q1, X0, Y0);
     // (:rgb, CH == 3: the blend-test threshold in place of the depth, which only the :rgbd / :rgbdn features use;
     //  otherwise in v3.w)
-    const float X = __uint_as_float(blend_threshold_bits(rec.q1.y));
+    const float X = rec.q3.z;  // (bit pattern)
     const float z = CH == 3 ? X : rec.q2.z;
     o.v2 = make_float4(rec.q2.x, __uint_as_float(slot), z, __uint_as_float(mask_bits));
     o.v3 = make_float4(r.normal.x, r.normal.y, r.normal.z, X);

@@ -14,6 +14,8 @@ Tolerances:
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -121,7 +123,7 @@ def test_randomised_sweep_vs_oracle(pkg, orc, case):
     st = orc.forward(s.means, s.shs, opac, s.scales, s.rotations, cam, deg, background=bg, mode=mode)
     run = HipRun(pkg, s.means, s.shs, opac, s.scales, s.rotations, cam, deg, bg, mode)
     img = run.forward().clone()
-    _compare_forward(st, run, img)
+    _compare_forward(st, run, img, opac)
     C = st.image.shape[2]
     vp = rng.standard_normal((H, W, C)).astype(np.float32)
     g = orc.backward(st, vp, s.means, s.shs, opac, s.scales, s.rotations, cam, deg, background=bg)

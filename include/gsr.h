@@ -221,13 +221,14 @@ enum {
     GSR_BUF_GEOM = 6,          /* 16 x 32-bit (N): one 64-byte record per Gaussian (stale where radii == 0):
                                 *   [0..1] mean2d, [2..4] conic a,b,c, [5] opacity, [6..8] rgb, [9] clamped bits (u32,
                                 *   bit c = channel c), [10] depth, [11] u32 instance-slot prefix inside the 256-block,
-                                *   [12] u32 rect xmin|ymin<<16, [13] u32 rect xmax|ymax<<16 (utils.jl:18-29), [14..15] - */
+                                *   [12] u32 rect xmin|ymin<<16, [13] u32 rect xmax|ymax<<16 (utils.jl:18-29), [14] u32 blend-test
+                                *   threshold X of the Gaussian (see GSR_BUF_INSTANCE_AUX), [15] - */
     GSR_BUF_NORMALS = 7,       /* float4 (N): camera-space normal (mode RGBDN only) */
     GSR_BUF_GRAD_ROWS = 8,     /* 16 x float per (Gaussian, tile-of-its-rect) slot, Gaussian-major: the
                                 *   per-instance gradient rows of the last gsr_backward */
     GSR_BUF_INSTANCE_AUX = 9   /* 4 x 32-bit (D), sorted instance order (plane s2 of the splat stream):
                                 *   [0] blue, [1] u32 Gaussian-major slot, [2] depth (:rgbd / :rgbdn) or, in :rgb mode, the u32 blend-test
-                                *   threshold bits(ln(255 opacity)) + 1 (0: never blends), [3] u32 footprint masks
+                                *   threshold X (bits(sigma) < X is the reference's blend test; 0: never blends), [3] u32 footprint masks
                                 *   (bits 0..15 tile rows, 16..19 8x8 quadrants the instance can touch) */
 };
 GSR_API int gsr_buffer(const gsr_handle* h, int which, const void** dev_ptr, size_t* bytes);

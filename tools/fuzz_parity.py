@@ -4,6 +4,9 @@ runs (cases 12 .. 12+N: modes, SH degrees, ragged resolutions, views, footprint 
 forward, every gradient).  Prints the failing cases with their assertion; exit code = number of failures.
 
   python tools/fuzz_parity.py [N = 300] [first case = 12]
+  python tools/fuzz_parity.py deep [N = 60] [first case = 0]     dense scenes on 1..9 tiles: lists of 300 .. 40 000 instances
+      per tile (the 1024 / 4096 / 8192 sort tiers, the tier launches of both compositing kernels, bins that overflow and
+      finish in compact mode), all three modes, forward + every gradient
 """
 import os
 import sys
@@ -18,15 +21,62 @@ pkg = gsr_pkg.load()
 from oracle import oracle as orc  # noqa: E402
 import test_gpu_parity as T  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-first = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from hip_helpers import HipRun  # noqa: E402
+
+
+def deep_case(case):
+    rng = np.random.default_rng(77000 + case)
+    mode = ["rgb", "rgbd", "rgbdn"][case % 3]
+    deg = int(rng.integers(0, 3))
+    W, H = int(rng.integers(16, 49)), int(rng.integers(16, 49))
+    target = int(np.exp(rng.uniform(np.log(300), np.log(40000))))          # instances in the deepest tile, roughly
+    n = int(target * rng.uniform(1.0, 1.6))
+    s = pkg.synthetic.make_scene(n, W, H, deg, 77100 + case)
+    spread = float(rng.uniform(0.02, 0.3))
+    means = np.stack([rng.uniform(-spread, spread, n), rng.uniform(-spread, spread, n), rng.uniform(2, 8, n)], 1).astype(np.float32)
+    cam = orc.Camera(W, H, s.focal)
+    opac = np.full(n, float(rng.uniform(0.004, 0.05)), np.float32) * rng.uniform(0.5, 1.5, n).astype(np.float32)
+    scales = s.scales * float(rng.uniform(1.0, 3.0))
+    bg = tuple(float(x) for x in rng.uniform(0, 1, 3))
+    st = orc.forward(means, s.shs, opac, scales, s.rotations, cam, deg, background=bg, mode=mode)
+    run = HipRun(pkg, means, s.shs, opac, scales, s.rotations, cam, deg, bg, mode)
+    img = run.forward().clone()
+    T._compare_forward(st, run, img, opac)
+    C = st.image.shape[2]
+    vp = rng.standard_normal((H, W, C)).astype(np.float32)
+    g = orc.backward(st, vp, means, s.shs, opac, scales, s.rotations, cam, deg, background=bg)
+    ok = st.n_rendered > 0 and np.linalg.norm(g.vmeans) > 0
+    if ok:
+        T._compare_backward(g, run.backward(vp), st.radii > 0)
+    cul = HipRun(pkg, means, s.shs, opac, scales, s.rotations, cam, deg, bg, mode, exact_tile_cull=True)
+    assert torch.equal(cul.forward(), img)
+    if ok:
+        T._compare_backward(g, cul.backward(vp), st.radii > 0)
+    return int((st.ranges[:, 1] - st.ranges[:, 0]).max())
+
+
+deep = len(sys.argv) > 1 and sys.argv[1] == "deep"
+if deep:
+    sys.argv.pop(1)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else (60 if deep else 300)
+first = int(sys.argv[2]) if len(sys.argv) > 2 else (0 if deep else 12)
 bad = []
+longest = []
 for case in range(first, first + n):
     try:
-        T.test_randomised_sweep_vs_oracle(pkg, orc, case)
+        if deep:
+            longest.append(deep_case(case))
+        else:
+            T.test_randomised_sweep_vs_oracle(pkg, orc, case)
     except Exception as e:  # noqa: BLE001
         tb = traceback.extract_tb(e.__traceback__)
         bad.append((case, f"{type(e).__name__}: {str(e)[:200]}", f"{tb[-1].filename.split('/')[-1]}:{tb[-1].lineno}"))
         print("FAIL case", case, bad[-1][1], "at", bad[-1][2], flush=True)
-print(f"{n - len(bad)} / {n} cases passed (cases {first}..{first + n - 1})")
+if deep and longest:
+    q = np.percentile(longest, [0, 25, 50, 75, 100]).astype(int)
+    print("deepest tile list per case: min / quartiles / max =", list(q), " cases over 1024 / 4096 / 8192:",
+          int((np.array(longest) > 1024).sum()), int((np.array(longest) > 4096).sum()), int((np.array(longest) > 8192).sum()))
+print(f"{n - len(bad)} / {n} {'deep ' if deep else ''}cases passed (cases {first}..{first + n - 1})")
 sys.exit(min(len(bad), 100))

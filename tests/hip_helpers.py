@@ -44,6 +44,8 @@ def rel_l2(a, b):
 
 def frac_bad(a, b, rtol, atol):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    if a.size == 0:
+        return 0.0
     return float((np.abs(a - b) > rtol * np.abs(b) + atol).mean())
 
 

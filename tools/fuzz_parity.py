@@ -11,6 +11,8 @@ forward, every gradient).  Prints the failing cases with their assertion; exit c
       translations, near / far planes that cut the scene, opacities of exactly 0 / 1 / above the 0.99 clamp, scales from
       sub-pixel (culled by radius) to screen-filling, negative, 27:1 anisotropic, means behind the camera / on the planes / far
       off-screen, SH values that clamp; pose gradients from device-resident poses
+  python tools/fuzz_parity.py ssim [N = 300] [first case = 0]    fused SSIM forward / backward (bit-exact) on random
+      (B, C, H, W) from 1 x 1 x 1 x 1 up, and the L1 + DSSIM loss head on ragged resolutions
 """
 import os
 import sys
@@ -112,13 +114,46 @@ def edge_case(case):
     return int((st.radii > 0).sum())
 
 
+def ssim_case(case):
+    rng = np.random.default_rng(33000 + case)
+    from hip_helpers import dev
+    shape = (int(rng.integers(1, 3)), int(rng.integers(1, 4)), int(rng.integers(1, 160)), int(rng.integers(1, 160)))
+    scale = float(rng.choice([1.0, 1e-3, 50.0]))
+    x = (rng.uniform(size=shape) * scale).astype(np.float32)
+    y = (rng.uniform(size=shape) * scale).astype(np.float32)
+    if case % 7 == 0:
+        y = x.copy()
+    m, d0, d1, d2 = orc.ssim_forward(x, y, train=True)
+    Fs = pkg.fused_ssim
+    hm, h0, h1, h2 = Fs._fused_ssim(dev(x), dev(y), train=True)
+    for a, b in ((hm, m), (h0, d0), (h1, d1), (h2, d2)):
+        assert np.array_equal(a.cpu().numpy(), b, equal_nan=True), ("ssim fwd", shape)
+    dl = rng.standard_normal(shape).astype(np.float32)
+    g = orc.ssim_backward(x, y, dl, d0, d1, d2)
+    hg = Fs.fused_ssim_bwd(dev(x), dev(y), dev(dl), h0, h1, h2)
+    assert np.array_equal(hg.cpu().numpy(), g, equal_nan=True), ("ssim bwd", shape)
+    # loss head on a ragged image
+    W, H = int(rng.integers(16, 200)), int(rng.integers(16, 150))
+    mode = ["rgb", "rgbd"][case % 2]
+    C = 3 if mode == "rgb" else 5
+    img = rng.uniform(size=(H, W, C)).astype(np.float32)
+    tgt = pkg.synthetic.make_target(W, H, case)
+    loss, vp = orc.loss_head(img, tgt)
+    rast = pkg.rasterizer.GaussianRasterizer(W, H, mode=mode)
+    hl, hv = Fs.l1_ssim_loss(rast, dev(img), dev(tgt))
+    torch.cuda.synchronize()
+    assert abs(float(hl) - float(loss)) <= 1e-5 * max(1.0, abs(float(loss))), ("loss", W, H)
+    assert T.rel_l2(hv.cpu().numpy(), vp) <= 1e-5, ("loss pullback", W, H)
+
+
 def main():
     deep = len(sys.argv) > 1 and sys.argv[1] == "deep"
     edge = len(sys.argv) > 1 and sys.argv[1] == "edge"
-    if deep or edge:
+    ssim = len(sys.argv) > 1 and sys.argv[1] == "ssim"
+    if deep or edge or ssim:
         sys.argv.pop(1)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else (60 if deep else 200 if edge else 300)
-    first = int(sys.argv[2]) if len(sys.argv) > 2 else (0 if deep or edge else 12)
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else (0 if deep or edge or ssim else 12)
     bad = []
     longest = []
     for case in range(first, first + n):
@@ -127,6 +162,8 @@ def main():
                 longest.append(deep_case(case))
             elif edge:
                 edge_case(case)
+            elif ssim:
+                ssim_case(case)
             else:
                 T.test_randomised_sweep_vs_oracle(pkg, orc, case)
         except Exception as e:  # noqa: BLE001
@@ -137,7 +174,7 @@ def main():
         q = np.percentile(longest, [0, 25, 50, 75, 100]).astype(int)
         print("deepest tile list per case: min / quartiles / max =", list(q), " cases over 1024 / 4096 / 8192:",
               int((np.array(longest) > 1024).sum()), int((np.array(longest) > 4096).sum()), int((np.array(longest) > 8192).sum()))
-    print(f"{n - len(bad)} / {n} {'deep ' if deep else 'edge ' if edge else ''}cases passed (cases {first}..{first + n - 1})")
+    print(f"{n - len(bad)} / {n} {'deep ' if deep else 'edge ' if edge else 'ssim ' if ssim else ''}cases passed (cases {first}..{first + n - 1})")
     sys.exit(min(len(bad), 100))
 
 

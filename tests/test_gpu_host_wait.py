@@ -1,73 +1,47 @@
 """The host side of gsr_forward's single read-back (gsr.h: gsr_host_wait_policy; round-2 verdict "make the host sync
 polite"): eight handles driven by eight host threads — the shape of an 8-rank node's host load — must step as fast
-with the default policy (30 us spin, then sched_yield polling) and with the opt-in adaptive sleep (100, 0, 50) as with a pure busy spin."""
+with the default policy (30 us spin, then sched_yield polling) and with the opt-in adaptive sleep (100, 0, 50) as with a
+pure busy spin.
+
+The eight threads are NATIVE (tools/host_wait_threads.cpp, built next to the library by its Makefile, straight through
+the C ABI): the first version of this test drove the handles from eight Python threads and measured the GIL — 0.8 to
+2.2 ms per step for one and the same policy, a failure in one run of three on an idle box.  The native program repeats to
+0.2 % (1.106 .. 1.111 ms per step in every policy over six runs; 7.35 CPU-ms per step spinning, 0.77 with the sleep)."""
 import os
-import threading
-import time
+import re
+import subprocess
 
-import numpy as np
 import pytest
-import torch
-
-from hip_helpers import dev
 
 pytestmark = pytest.mark.gpu
 
-
-def _run(pkg, policy, n_threads=8, steps=40):
-    lib = pkg._lib.load()
-    pkg._lib.check(lib.gsr_host_wait_policy(*policy))
-    W, H, N, deg = 640, 480, 60_000, 1
-    s = pkg.synthetic.make_scene(N, W, H, deg, 77)
-    cam = pkg.Camera(W, H, tuple(s.focal))
-    t = [dev(s.means), dev(s.shs), dev(s.opacities.reshape(-1, 1)), dev(s.scales), dev(s.rotations)]
-    vp = dev(pkg.synthetic.make_vpixels(W, H, 3, 5))
-    rasts = [pkg.rasterizer.GaussianRasterizer(W, H, mode="rgb") for _ in range(n_threads)]
-    streams = [torch.cuda.Stream() for _ in range(n_threads)]
-    images = [None] * n_threads
-    barrier = threading.Barrier(n_threads + 1)
-
-    def worker(i):
-        with torch.cuda.stream(streams[i]):
-            for _ in range(3):
-                rasts[i].forward_raw(*t, cam, deg, (0, 0, 0)); rasts[i].backward_raw(vp, *t, cam, deg, (0, 0, 0))
-            streams[i].synchronize()
-            barrier.wait()
-            for _ in range(steps):
-                rasts[i].forward_raw(*t, cam, deg, (0, 0, 0)); rasts[i].backward_raw(vp, *t, cam, deg, (0, 0, 0))
-            streams[i].synchronize()
-            images[i] = rasts[i].image.clone()
-        barrier.wait()
-
-    th = [threading.Thread(target=worker, args=(i,)) for i in range(n_threads)]
-    for x in th:
-        x.start()
-    barrier.wait()
-    c0, t0 = os.times(), time.perf_counter()
-    barrier.wait()
-    wall = time.perf_counter() - t0
-    c1 = os.times()
-    for x in th:
-        x.join()
-    torch.cuda.synchronize()
-    cpu = (c1.user - c0.user) + (c1.system - c0.system)
-    for r in rasts:
-        r.close()
-    return wall / steps, cpu / steps, images
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROG = os.path.join(ROOT, "gaussiansplatting.jl_amd", "host_wait_threads")
 
 
 def test_eight_threads_step_time_unchanged_with_the_back_off(pkg):
+    if not os.path.exists(PROG):
+        pkg._lib.build()  # (the Makefile's default target builds the program with the library)
+    assert os.path.exists(PROG), "gaussiansplatting.jl_amd/csrc/Makefile did not build host_wait_threads"
+    out = subprocess.run([PROG, "8", "300", "3"], capture_output=True, text=True, timeout=600)
+    print(out.stdout)
+    assert out.returncode == 0, out.stderr[-2000:]
+    m = re.search(r"RESULT spin ([\d.]+) default ([\d.]+) sleep ([\d.]+) images_equal (\d)", out.stdout)
+    assert m, out.stdout[-2000:]
+    spin, default, sleep, same = float(m.group(1)), float(m.group(2)), float(m.group(3)), int(m.group(4))
+    assert same == 1, "the policies must not change a single pixel"
+    assert default <= 1.05 * spin + 0.01, (default, spin)
+    assert sleep <= 1.10 * spin + 0.02, (sleep, spin)
+    # the adaptive sleep must actually free the cores: CPU time per step well below the spinning policies'
+    cpu = [float(x) for x in re.findall(r"([\d.]+) CPU-ms per step", out.stdout)]
+    assert len(cpu) == 3 and cpu[2] <= 0.5 * cpu[0], cpu
+
+
+def test_policy_arguments_are_checked(pkg):
+    lib = pkg._lib.load()
     try:
-        spin_wall, spin_cpu, img_a = _run(pkg, (1_000_000, 0, 0))   # pure spin: the round-2 behaviour
-        pol_wall, pol_cpu, img_b = _run(pkg, (30, 0, 0))            # the default: spin, then sched_yield polling
-        slp_wall, slp_cpu, img_c = _run(pkg, (100, 0, 50))          # opt-in: adaptive sleep
+        assert lib.gsr_host_wait_policy(-1, 0, 0) == pkg._lib.GSR_E_INVALID_ARG
+        assert lib.gsr_host_wait_policy(0, -5, 0) == pkg._lib.GSR_E_INVALID_ARG
+        assert lib.gsr_host_wait_policy(100, 0, 50) == 0
     finally:
-        pkg._lib.check(pkg._lib.load().gsr_host_wait_policy(30, 0, 0))
-    print(f"8 threads x 8 handles: pure spin {spin_wall * 1e3:.3f} ms/step ({spin_cpu * 1e3:.2f} CPU-ms/step), "
-          f"yield polling {pol_wall * 1e3:.3f} ms/step ({pol_cpu * 1e3:.2f} CPU-ms/step), "
-          f"adaptive sleep {slp_wall * 1e3:.3f} ms/step ({slp_cpu * 1e3:.2f} CPU-ms/step)")
-    for a, b, c in zip(img_a, img_b, img_c):
-        assert torch.equal(a, b) and torch.equal(a, c)
-    assert pol_wall <= 1.10 * spin_wall + 2e-5, (pol_wall, spin_wall)
-    assert slp_wall <= 1.25 * spin_wall + 5e-5, (slp_wall, spin_wall)
-    assert pkg._lib.load().gsr_host_wait_policy(-1, 0, 0) == pkg._lib.GSR_E_INVALID_ARG
+        pkg._lib.check(lib.gsr_host_wait_policy(30, 0, 0))

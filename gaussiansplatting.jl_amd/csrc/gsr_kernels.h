@@ -31,7 +31,8 @@ struct GsrCam {
 //   q1 = conic.c, opacity, r, g
 //   q2 = b, clamped bits (u32), depth, lpre (u32: exclusive prefix of tile-rect areas inside the
 //        Gaussian's 256-wide block; + bpre[i >> 8] = Gaussian-major slot of its first instance)
-//   q3 = rect xmin | ymin << 16, rect xmax | ymax << 16 (u32), blend-test threshold bits X (u32, tile_mask.h), unused
+//   q3 = rect xmin | ymin << 16, rect xmax | ymax << 16 (u32), blend-test threshold bits X (u32, tile_mask.h),
+//        emitted-tile mask of the rect (u32, row-major bit per tile; meaningful for rects of <= 32 tiles: pergauss.hip DENSE_RECT)
 struct GsrGeoRec { float4 q0, q1, q2, q3; };
 struct GsrGeom {
     GsrGeoRec* rec;

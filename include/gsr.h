@@ -224,8 +224,9 @@ enum {
                                 *   [12] u32 rect xmin|ymin<<16, [13] u32 rect xmax|ymax<<16 (utils.jl:18-29), [14] u32 blend-test
                                 *   threshold X of the Gaussian (see GSR_BUF_INSTANCE_AUX), [15] - */
     GSR_BUF_NORMALS = 7,       /* float4 (N): camera-space normal (mode RGBDN only) */
-    GSR_BUF_GRAD_ROWS = 8,     /* 16 x float per (Gaussian, tile-of-its-rect) slot, Gaussian-major: the
-                                *   per-instance gradient rows of the last gsr_backward */
+    GSR_BUF_GRAD_ROWS = 8,     /* 12 (:rgb) or 16 x float per slot, Gaussian-major: the per-instance gradient rows of the last
+                                *   gsr_backward.  A Gaussian whose tile rect has at most 32 tiles owns one slot per tile it
+                                *   was binned into (in row-major tile order); larger rects one per tile of the rect */
     GSR_BUF_INSTANCE_AUX = 9   /* 4 x 32-bit (D), sorted instance order (plane s2 of the splat stream):
                                 *   [0] blue, [1] u32 Gaussian-major slot, [2] depth (:rgbd / :rgbdn) or, in :rgb mode, the u32 blend-test
                                 *   threshold X (bits(sigma) < X is the reference's blend test; 0: never blends), [3] u32 footprint masks

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
             // instance (the reference keeps it and skips it pixel by pixel, render.jl:95).
             const uint64_t key = ((uint64_t)__float_as_uint(mc_z) << 32) | (uint32_t)i;
             constexpr int PEND = 8;
-            const int rect_w = rmax[0] - rmin[0];
+            uint32_t kk = 0u;
             uint32_t pend_t[PEND], pend_c[PEND];
             int np = 0;
             auto flush = [&]() {
@@ -355,10 +355,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
                     if (pair)
                         c1 = (!cam.exact_cull || tile_may_touch(m2[0], m2[1], conic[0], conic[1], conic[2], tau,
                                                                (x + 1) * GSR_TILE, y * GSR_TILE)) ? 1u : 0u;
-                    {   // (bits of the rect's row-major tile index; only read back when area <= DENSE_RECT)
-                        const uint32_t k0 = (uint32_t)((y - rmin[1]) * rect_w + (x - rmin[0])) & 31u;
-                        emitted |= (c0 << k0) | (c1 << ((k0 + 1u) & 31u));
-                    }
+                    // (bit kk = the rect's row-major tile index: the walk visits the tiles in exactly that order; only read
+                    //  back when area <= DENSE_RECT)
+                    emitted |= (c0 | (c1 << 1)) << (kk & 31u);
+                    kk += pair ? 2u : 1u;
                     if (c0 | c1) {
                         pend_t[np] = (uint32_t)(t & ~1);                 // aligned pair
                         pend_c[np] = odd ? (c0 << 1) : (c0 | (c1 << 1));  // bit 0: even tile, bit 1: odd tile

@@ -34,6 +34,9 @@ struct GsrCam {
 //   q3 = rect xmin | ymin << 16, rect xmax | ymax << 16 (u32), blend-test threshold bits X (u32, tile_mask.h),
 //        emitted-tile mask of the rect (u32, row-major bit per tile; meaningful for rects of <= 32 tiles: pergauss.hip DENSE_RECT)
 struct GsrGeoRec { float4 q0, q1, q2, q3; };
+// Tile rects of at most this many tiles get one gradient-row slot per EMITTED tile (ranked through the record's mask);
+// larger ones one per tile of the rect (pergauss.hip: preprocess, pergauss_bwd; tile_sort_device.h: the emit's slot).
+constexpr uint32_t GSR_DENSE_RECT = 32;
 struct GsrGeom {
     GsrGeoRec* rec;
     float4* normal;   // camera-space normal (C == 8) or nullptr

@@ -25,7 +25,7 @@ constexpr uint32_t EMIT_COOP = 48;  // tiles per rect above which the wave emits
 // sort's emit ranks a tile by a popcount below its bit, the per-Gaussian backward sums popcount(mask) contiguous rows
 // without repeating the tests.  Larger rects keep one slot per tile of the rect (the culled ones are never written or
 // read).  Exact culling drops 31 % of config 3's instances: the row buffer and its read in pergauss_bwd shrink with it.
-constexpr uint32_t DENSE_RECT = 32;
+constexpr uint32_t DENSE_RECT = GSR_DENSE_RECT;
 constexpr float SH0 = 0.28209479177387814f;
 constexpr float SH1 = 0.4886025119029199f;
 constexpr float SH2C1 = 1.0925484305920792f;

@@ -40,10 +40,10 @@ __device__ __forceinline__ InstanceVals instance_vals_of(const InstanceRaw& r, i
     // gradient row there, so a Gaussian's rows are contiguous for the per-Gaussian sum.
     const uint32_t lo = __float_as_uint(rec.q3.x), hi = __float_as_uint(rec.q3.y);
     const uint32_t x0 = lo & 0xFFFFu, y0 = lo >> 16, x1 = hi & 0xFFFFu, y1 = hi >> 16;
-    // rank of this tile among the Gaussian's slots: small rects (<= 32 tiles, pergauss.hip DENSE_RECT) have one slot per
+    // rank of this tile among the Gaussian's slots: small rects (<= GSR_DENSE_RECT tiles) have one slot per
     // EMITTED tile — the popcount of the record's emitted-tile mask below this tile's bit —, larger ones one per tile
     const uint32_t k = ((uint32_t)(Y0 / GSR_TILE) - y0) * (x1 - x0) + ((uint32_t)(X0 / GSR_TILE) - x0);
-    const uint32_t dense = (x1 - x0) * (y1 - y0) <= 32u;
+    const uint32_t dense = (x1 - x0) * (y1 - y0) <= GSR_DENSE_RECT;
     const uint32_t rank = dense ? (uint32_t)__popc(__float_as_uint(rec.q3.w) & ((1u << (k & 31u)) - 1u)) : k;
     const uint32_t slot = r.bpre + __float_as_uint(rec.q2.w) + rank;
     const uint32_t mask_bits = instance_row_mask(rec.q0, rec.q1, X0, Y0);

@@ -222,7 +222,8 @@ enum {
                                 *   [0..1] mean2d, [2..4] conic a,b,c, [5] opacity, [6..8] rgb, [9] clamped bits (u32,
                                 *   bit c = channel c), [10] depth, [11] u32 instance-slot prefix inside the 256-block,
                                 *   [12] u32 rect xmin|ymin<<16, [13] u32 rect xmax|ymax<<16 (utils.jl:18-29), [14] u32 blend-test
-                                *   threshold X of the Gaussian (see GSR_BUF_INSTANCE_AUX), [15] - */
+                                *   threshold X of the Gaussian (see GSR_BUF_INSTANCE_AUX), [15] u32 bit mask of the rect's tiles (row-major) the Gaussian
+                                *   was binned into (rects of at most 32 tiles) */
     GSR_BUF_NORMALS = 7,       /* float4 (N): camera-space normal (mode RGBDN only) */
     GSR_BUF_GRAD_ROWS = 8,     /* 12 (:rgb) or 16 x float per slot, Gaussian-major: the per-instance gradient rows of the last
                                 *   gsr_backward.  A Gaussian whose tile rect has at most 32 tiles owns one slot per tile it

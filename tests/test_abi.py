@@ -98,3 +98,75 @@ def test_host_mirror_rejects_cpu_tensors(pkg):
         pkg.rasterizer.n_color_features("rgba")
     with pytest.raises(ValueError):
         pkg.fused_ssim._fused_ssim(torch.zeros(1, 3, 16, 16), torch.zeros(1, 3, 16, 16))
+
+
+def test_julia_struct_layouts_match_the_header(pkg, tmp_path):
+    """No Julia in the image has ever parsed julia/GaussianSplattingHipNative.jl (round-2 verdict: "type-level risks by
+    inspection").  What CAN be checked here: every `struct Gsr*` of the binding, laid out by the C rules Julia applies to an
+    isbits struct (natural alignment of Int32 / UInt32 / Float32 / Int64 / UInt64 / Ptr / NTuple fields), must have the
+    field names, order, offsets and total size gcc gives the struct of the same role in include/gsr.h."""
+    import subprocess
+    L = pkg._lib
+    jl = open(os.path.join(os.path.dirname(L.HEADER_PATH), "..", "julia", "GaussianSplattingHipNative.jl")).read()
+    prim = {"Int32": (4, 4), "UInt32": (4, 4), "Float32": (4, 4), "Int64": (8, 8), "UInt64": (8, 8), "UInt8": (1, 1)}
+
+    def size_align(t):
+        t = t.strip()
+        if t.startswith("Ptr{"):
+            return 8, 8
+        m = re.fullmatch(r"NTuple\{(\d+),\s*(.+)\}", t)
+        if m:
+            s, a = size_align(m.group(2))
+            return int(m.group(1)) * s, a
+        return prim[t]
+
+    roles = {"GsrConfig": "gsr_config", "GsrInputs": "gsr_inputs", "GsrCamera": "gsr_camera", "GsrAux": "gsr_aux",
+             "GsrStats": "gsr_stats", "GsrGrads": "gsr_grads", "GsrTailGrads": "gsr_tail_grads", "GsrTailState": "gsr_tail_state"}
+    julia = {}
+    for name in roles:
+        m = re.search(r"^struct " + name + r";([^\n]*?); end$", jl, re.M) or \
+            re.search(r"^struct " + name + r"\n(.*?)^end", jl, re.S | re.M)
+        assert m, name
+        body = re.sub(r"#[^\n]*", "", m.group(1))
+        fields, off, amax = [], 0, 1
+        for decl in re.split(r"[;\n]", body):
+            decl = decl.strip()
+            if not decl:
+                continue
+            fname, ftype = decl.split("::")
+            s, a = size_align(ftype)
+            off = (off + a - 1) // a * a
+            fields.append((fname.strip(), off, s))
+            off += s
+            amax = max(amax, a)
+        julia[name] = (fields, (off + amax - 1) // amax * amax)
+    # the same from the C compiler
+    rename = {"opacities_act": "opacities_act"}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "gsr.h"', "int main(void){"]
+    for jn, cn in roles.items():
+        lines.append(f'printf("{jn} sizeof %zu\\n", sizeof({cn}));')
+        for fname, _, _ in julia[jn][0]:
+            lines.append(f'printf("{jn} {fname} %zu %zu\\n", offsetof({cn}, {rename.get(fname, fname)}), sizeof((({cn}*)0)->{fname}));')
+    lines.append("return 0;}")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.dirname(L.HEADER_PATH), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    c_fields, c_size = {}, {}
+    for line in out:
+        p = line.split()
+        if len(p) == 3:
+            c_size[p[0]] = int(p[2])
+        elif len(p) == 4:
+            c_fields.setdefault(p[0], []).append((p[1], int(p[2]), int(p[3])))
+    for jn in roles:
+        assert julia[jn][0] == c_fields[jn], (jn, julia[jn][0], c_fields[jn])
+        assert julia[jn][1] == c_size[jn], (jn, julia[jn][1], c_size[jn])
+    # and the number of fields: nothing of the C struct is missing at the end of the Julia one
+    hdr = open(L.HEADER_PATH).read()
+    for jn, cn in roles.items():
+        body = re.search(r"typedef struct " + cn + r" \{(.*?)\} " + cn + ";", hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        n_c = sum(len(d.split(",")) for d in body.split(";") if d.strip())
+        assert n_c == len(julia[jn][0]), (jn, n_c, len(julia[jn][0]))

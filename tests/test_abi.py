@@ -170,3 +170,63 @@ def test_julia_struct_layouts_match_the_header(pkg, tmp_path):
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         n_c = sum(len(d.split(",")) for d in body.split(";") if d.strip())
         assert n_c == len(julia[jn][0]), (jn, n_c, len(julia[jn][0]))
+
+
+def test_julia_ccall_signatures_match_the_header(pkg):
+    """Every `ccall((:gsr_*, LIB), ret, (argument types...), ...)` of the Julia binding against the prototype of the same
+    name in include/gsr.h: same number of arguments, each of the same machine class (pointer / 32-bit int / 64-bit int /
+    size_t / float), same return class."""
+    L = pkg._lib
+    jl = open(os.path.join(os.path.dirname(L.HEADER_PATH), "..", "julia", "GaussianSplattingHipNative.jl")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", open(L.HEADER_PATH).read(), flags=re.S)
+
+    def split_top(s):
+        out, depth, cur = [], 0, ""
+        for ch in s:
+            if ch in "({[":
+                depth += 1
+            elif ch in ")}]":
+                depth -= 1
+            if ch == "," and depth == 0:
+                out.append(cur.strip()); cur = ""
+            else:
+                cur += ch
+        if cur.strip():
+            out.append(cur.strip())
+        return out
+
+    def jl_class(t):
+        t = t.strip()
+        if t.startswith(("Ptr{", "Ref{")) or t == "Cstring":
+            return "ptr"
+        return {"Cint": "i32", "Int32": "i32", "UInt32": "i32", "Cuint": "i32", "Cfloat": "f32", "Float32": "f32",
+                "Int64": "i64", "UInt64": "i64", "Clonglong": "i64", "Csize_t": "size"}[t]
+
+    def c_class(t):
+        t = t.strip()
+        if "*" in t or "[" in t:
+            return "ptr"
+        t = re.sub(r"\b(const|GSR_API)\b", "", t).split()
+        base = " ".join(t[:-1]) if len(t) > 1 else t[0]  # drop the parameter name
+        return {"int": "i32", "int32_t": "i32", "uint32_t": "i32", "float": "f32", "int64_t": "i64", "uint64_t": "i64",
+                "size_t": "size", "void": "void"}[base]
+
+    calls = 0
+    for m in re.finditer(r"ccall\(\(:(gsr_\w+), LIB\),\s*(\w+),\s*\(", jl):
+        name, ret = m.group(1), m.group(2)
+        # the argument-type tuple: balanced parentheses from m.end() - 1
+        i, depth = m.end() - 1, 0
+        for j in range(i, len(jl)):
+            depth += jl[j] == "("
+            depth -= jl[j] == ")"
+            if depth == 0:
+                break
+        jargs = [jl_class(a) for a in split_top(jl[i + 1:j]) if a]
+        pm = re.search(r"GSR_API\s+([\w\s\*]+?)\b" + name + r"\s*\((.*?)\)\s*;", hdr, re.S)
+        assert pm, f"{name} is not declared in gsr.h"
+        cargs = [] if pm.group(2).strip() == "void" else [c_class(a) for a in split_top(pm.group(2))]
+        assert jargs == cargs, (name, jargs, cargs)
+        cret = "ptr" if "*" in pm.group(1) else c_class(pm.group(1) + " x")
+        assert jl_class(ret) == cret, (name, ret, pm.group(1))
+        calls += 1
+    assert calls >= 10

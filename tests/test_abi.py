@@ -230,3 +230,31 @@ def test_julia_ccall_signatures_match_the_header(pkg):
         assert jl_class(ret) == cret, (name, ret, pm.group(1))
         calls += 1
     assert calls >= 10
+
+
+def test_julia_files_are_block_and_bracket_balanced(pkg):
+    """The little that can be said about Julia syntax without a Julia: in julia/*.jl, with strings and comments removed,
+    every bracket closes in order, and at bracket depth 0 (comprehension `for`s and `a[end]` live inside brackets) the
+    block openers (module, function, struct, if, for, while, let, begin, do, try, quote, macro) equal the `end`s."""
+    root = os.path.join(os.path.dirname(pkg._lib.HEADER_PATH), "..", "julia")
+    files = [f for f in os.listdir(root) if f.endswith(".jl")]
+    assert files
+    for f in files:
+        s = open(os.path.join(root, f)).read()
+        s = re.sub(r'"""(.*?)"""', '""', s, flags=re.S)
+        s = re.sub(r'"(\\.|[^"\\])*"', '""', s)
+        s = re.sub(r"#=.*?=#", "", s, flags=re.S)
+        s = re.sub(r"#[^\n]*", "", s)
+        stack, flat = [], []
+        pairs = {")": "(", "]": "[", "}": "{"}
+        for ch in s:
+            if ch in "([{":
+                stack.append(ch)
+            elif ch in ")]}":
+                assert stack and stack.pop() == pairs[ch], (f, "bracket mismatch")
+            elif not stack:
+                flat.append(ch)
+        assert not stack, (f, "unclosed bracket")
+        toks = re.findall(r"(?<![\w:.!])(module|function|struct|if|for|while|let|begin|do|try|quote|macro|end)(?![\w!])", "".join(flat))
+        opens, ends = sum(t != "end" for t in toks), sum(t == "end" for t in toks)
+        assert opens == ends, (f, opens, ends)

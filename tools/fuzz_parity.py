@@ -13,6 +13,9 @@ forward, every gradient).  Prints the failing cases with their assertion; exit c
       off-screen, SH values that clamp; pose gradients from device-resident poses
   python tools/fuzz_parity.py ssim [N = 300] [first case = 0]    fused SSIM forward / backward (bit-exact) on random
       (B, C, H, W) from 1 x 1 x 1 x 1 up, and the L1 + DSSIM loss head on ragged resolutions
+  python tools/fuzz_parity.py trainer [N = 40] [first case = 0]  the bit-exact trainer-tail / compaction tests of
+      tests/test_gpu_trainer.py and the densification test of tests/test_gpu_densify.py at random sizes, SH degrees,
+      isotropic / anisotropic scales and render modes (their data seeds are fixed inside the tests)
 """
 import os
 import sys
@@ -146,14 +149,34 @@ def ssim_case(case):
     assert T.rel_l2(hv.cpu().numpy(), vp) <= 1e-5, ("loss pullback", W, H)
 
 
+def trainer_case(case):
+    import test_gpu_trainer as TT
+    import test_gpu_densify as TD
+    rng = np.random.default_rng(21000 + case)
+    n = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, int(rng.integers(300, 6000))]))
+    kr = int(rng.choice([0, 3, 8, 15]))
+    iso = bool(rng.integers(0, 2))
+    TT.test_prologue_forward_vs_oracle(pkg, orc, n, kr, iso)
+    TT.test_prologue_backward_vs_oracle_bit_exact(pkg, orc, n, kr, iso)
+    TT.test_mask_findall_vs_oracle(pkg, orc, int(rng.integers(1, 300000)), float(rng.choice([0.0, 1.0, rng.uniform()])))
+    TT.test_fused_trainer_tail_equals_the_three_kernels_and_the_oracle(pkg, orc, kr, iso)
+    max_deg = int(rng.integers(0, 4))
+    deg = int(rng.integers(0, max_deg + 1))
+    TT.test_backward_with_the_tail_in_its_epilogue_equals_backward_then_tail(
+        pkg, int(rng.integers(1, 2500)), deg, max_deg, iso, ["rgb", "rgbd", "rgbdn"][case % 3])
+    if case % 4 == 0:
+        TD.test_densify_and_prune_matches_oracle(pkg, 1 if iso else 3, kr, int(rng.choice([0, 20])))
+
+
 def main():
     deep = len(sys.argv) > 1 and sys.argv[1] == "deep"
     edge = len(sys.argv) > 1 and sys.argv[1] == "edge"
     ssim = len(sys.argv) > 1 and sys.argv[1] == "ssim"
-    if deep or edge or ssim:
+    trainer = len(sys.argv) > 1 and sys.argv[1] == "trainer"
+    if deep or edge or ssim or trainer:
         sys.argv.pop(1)
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else (60 if deep else 200 if edge else 300)
-    first = int(sys.argv[2]) if len(sys.argv) > 2 else (0 if deep or edge or ssim else 12)
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else (60 if deep else 200 if edge else 40 if trainer else 300)
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else (0 if deep or edge or ssim or trainer else 12)
     bad = []
     longest = []
     for case in range(first, first + n):
@@ -164,6 +187,8 @@ def main():
                 edge_case(case)
             elif ssim:
                 ssim_case(case)
+            elif trainer:
+                trainer_case(case)
             else:
                 T.test_randomised_sweep_vs_oracle(pkg, orc, case)
         except Exception as e:  # noqa: BLE001
@@ -174,7 +199,7 @@ def main():
         q = np.percentile(longest, [0, 25, 50, 75, 100]).astype(int)
         print("deepest tile list per case: min / quartiles / max =", list(q), " cases over 1024 / 4096 / 8192:",
               int((np.array(longest) > 1024).sum()), int((np.array(longest) > 4096).sum()), int((np.array(longest) > 8192).sum()))
-    print(f"{n - len(bad)} / {n} {'deep ' if deep else 'edge ' if edge else 'ssim ' if ssim else ''}cases passed (cases {first}..{first + n - 1})")
+    print(f"{n - len(bad)} / {n} {'deep ' if deep else 'edge ' if edge else 'ssim ' if ssim else 'trainer ' if trainer else ''}cases passed (cases {first}..{first + n - 1})")
     sys.exit(min(len(bad), 100))
 
 

@@ -29,7 +29,10 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                  actually binds the compositing kernels), from the same file.
                  `stages_ms`: the dominant stage is timed inside the timed region; the OTHER stages come from a
                  5-step survey pass just before it in which every stage carries an event pair (eight marker
-                 packets per step) — so they may sum to a few % MORE than `ms_per_step`;
+                 packets per step) — so they may sum to a few % MORE than `ms_per_step`.  In front of the survey run the
+                 W warm-up steps and 15 more untimed "settle" steps (`untimed_steps`): the first ~18 steps after the
+                 device has been idle are up to 5 % slower (tools/step_times.py), and the timed region should see the
+                 steady state of a training loop;
   cpu_baseline — the oracle (C restatement of the reference algorithm, OpenMP) timed on
                  this host's cores on the same workload (rank 0, N = 1 only);
   extra_configs — (N = 1, headline configuration only) the same measurement for BASELINE.json's other single-GPU
@@ -208,6 +211,9 @@ def dry_rank():
 # ------------------------------------------------------------------------------------------------------------------
 # one workload = one (scene, camera, rasterizer, step function)
 # ------------------------------------------------------------------------------------------------------------------
+SETTLE_STEPS = 15  # untimed steps in front of the stage survey (Workload.measure)
+
+
 class Workload:
     def __init__(self, pkg, dev, rank, world, *, n, width, height, sh_degree, seed, mode="rgb", no_loss=False,
                  reference_lists=False, with_optimizer=False, unfused_tail=False, tail_in_backward=False, views=8,
@@ -411,11 +417,15 @@ class Workload:
         self.sync()
         return self.max_over_ranks(time.perf_counter() - t0) / steps
 
-    def measure(self, steps, warmup, survey_steps=5):
-        """The bench contract: W warm-up steps, an (untimed) stage survey, then EXACTLY K timed steps in which only the
-        dominant stage keeps its HIP-event pair.  Returns a dict of raw measurements."""
+    def measure(self, steps, warmup, survey_steps=5, settle_steps=SETTLE_STEPS):
+        """The bench contract: W warm-up steps, (untimed) settle steps and a stage survey, then EXACTLY K timed steps in
+        which only the dominant stage keeps its HIP-event pair.  Returns a dict of raw measurements.
+        Settle steps: the first ~18 steps after the device has been idle (scene set-up, the triad) run up to 5 % slower —
+        1.56 -> 1.48 ms over the first dozen steps of a timed region that follows 3 + 5 untimed ones, flat from the start
+        after 25 + 5 (tools/step_times.py) — and a training loop runs thousands: the timed region, like the stage survey,
+        should see the steady state."""
         rast = self.rast
-        for _ in range(warmup):
+        for _ in range(warmup + settle_steps):
             self.step()
         self.sync()
         # Stage survey (untimed): every stage timed with HIP events for a few steps -> stages_ms and the dominant stage.
@@ -486,6 +496,7 @@ class Workload:
             "algorithmic_bytes": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
             "avg_launch_ms_source": f"HIP events around {dom} on the launch stream, {live[dom][1]} launches inside the timed region",
             "stages_ms": {k: round(v[0], 4) for k, v in stages.items()},
+            "untimed_steps": {"warmup": "W (--warmup)", "settle": SETTLE_STEPS, "stage_survey": 5},
             "stages_ms_source": "5-step survey with every stage timed, just before the timed region (all stages timed "
                                 "inside it would slow the step by 3 %, so these may sum to more than ms_per_step); the "
                                 "dominant stage: the timed region",

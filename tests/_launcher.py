@@ -28,7 +28,7 @@ def main():
                 o, _ = p.communicate()
                 o += "\n[launcher] timeout"
             rc.append(p.returncode)
-            out.append(o[-3000:])
+            out.append(o[-60000:])
         sys.stdout.write(json.dumps({"rc": rc, "out": out}) + "\n")
         sys.stdout.flush()
 

@@ -19,6 +19,7 @@ bytes are what an 8-GPU step pays for).
 from __future__ import annotations
 
 import os
+from datetime import timedelta
 
 import numpy as np
 import torch
@@ -71,8 +72,14 @@ def init_from_env(backend: str | None = None):
             # bind the communicator to this rank's device explicitly (RCCL otherwise guesses it from the global rank at the
             # first collective — "can cause a hang if rank to GPU mapping is heterogeneous")
             kw["device_id"] = torch.device("cuda", local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        # a collective that never completes (a rank died, a link hung) must end as an error after a bounded wait, not hang
+        # the job: rendezvous, gloo operations and the RCCL watchdog all take this limit (GSR_DIST_TIMEOUT_S, default 120 s)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=collective_timeout(), **kw)
     return rank, world, local
+
+
+def collective_timeout() -> timedelta:
+    return timedelta(seconds=float(os.environ.get("GSR_DIST_TIMEOUT_S", "120")))
 
 
 def forced() -> bool:
@@ -128,7 +135,7 @@ def overlap_groups():
     whenever collectives are active (cheap; whether they are USED is decided per exchange by `_can_overlap`)."""
     global _overlap_groups
     if _overlap_groups is None and active():
-        _overlap_groups = (dist.new_group(), dist.new_group())
+        _overlap_groups = (dist.new_group(timeout=collective_timeout()), dist.new_group(timeout=collective_timeout()))
     return _overlap_groups
 
 

@@ -73,7 +73,7 @@ def test_bench_gpus_2_self_launches_two_ranks(launch_ranks):
     HIP): two ranks share the one GPU of the box, gloo carries the collectives.  The JSON line must say n_gpus = 2 =
     ranks_seen and carry the exchange report with every form timed."""
     rc, out = launch_ranks([sys.executable, BENCH, "--gpus", "2", "--gaussians", "20000", "--width", "640", "--height", "480",
-                            "--steps", "4", "--warmup", "1", "--no-cpu-baseline"], 1,
+                            "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--steady-steps", "20"], 1,
                            env={"GSR_DIST_BACKEND": "gloo"}, timeout=900, raw=True)
     assert rc == [0], out[0]
     line = [ln for ln in out[0].splitlines() if ln.startswith("{")][-1]
@@ -81,9 +81,96 @@ def test_bench_gpus_2_self_launches_two_ranks(launch_ranks):
     assert rep["n_gpus"] == 2 and rep["ranks_seen"] == 2
     assert rep["config"]["launch"].startswith("self-launched")
     ex = rep["exchange"]
-    assert set(ex["forms"]) == {"factored+overlap", "factored", "plain"}
+    assert set(ex["forms"]) == {"factored+overlap", "factored", "plain"}  # each from its own fresh rank group
+    assert all(f.get("ms_per_step", 0) > 0 for f in ex["forms"].values()), ex["forms"]
+    assert ex["headline_form"] == ex["library_default_form"] == "factored+overlap"
+    assert rep["steady_state"]["steps"] == 5 and rep["untimed_steps_total"] == 1 + 15 + 5
     assert ex["bytes_per_gpu"] == int(2 * 0.5 * 11 * 20000 * 4 + 1 * 3 * 20000 * 4)
     assert ex["forms"]["plain"]["bytes_per_gpu"] == int(2 * 0.5 * 59 * 20000 * 4)
     assert ex["ms"] > 0 and ex["backend"] == "gloo"
     # gloo with device tensors cannot keep two communicators in flight: the line must say which form really ran
     assert ex["overlap"] is False and "sequential" in ex["form"]
+
+
+# ---- the supervisor (round-3 verdict "Next #1"): sections in fresh children, timeouts, merge -------------------------------
+def _fake(argv, timeout=300, **env):
+    p = subprocess.run([sys.executable, BENCH] + argv, env=_env(GSR_BENCH_FAKE=env.pop("GSR_BENCH_FAKE", "1"), **env),
+                       capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None), lines
+
+
+def test_supervisor_n1_merges_sections_into_one_line():
+    p, rep, lines = _fake(["--steps", "3", "--warmup", "1"])
+    assert p.returncode == 0 and len(lines) == 1, p.stderr
+    assert rep["ms_per_step"] == 1.5 and rep["cpu_baseline"]["kind"] == "port" and "config2" in rep["extra_configs"]
+
+
+def test_a_failing_or_hanging_extra_section_never_costs_the_headline():
+    p, rep, _ = _fake(["--steps", "3", "--warmup", "1", "--section-timeout", "3"], GSR_BENCH_FAIL_FORM="extras")
+    assert p.returncode == 0 and rep["ms_per_step"] == 1.5 and "error" in rep["extras_error"]
+    assert rep["cpu_baseline"]["kind"] == "port"
+    p, rep, _ = _fake(["--steps", "3", "--warmup", "1", "--section-timeout", "2"], GSR_BENCH_HANG_FORM="cpu_baseline")
+    assert p.returncode == 0 and rep["cpu_baseline"] == {"timeout": 2.0, "wall_s": rep["cpu_baseline"]["wall_s"]}
+    assert "extra_configs" in rep
+    p, rep, _ = _fake(["--steps", "3", "--warmup", "1"], GSR_BENCH_FAIL_FORM="headline")
+    assert p.returncode != 0 and rep is None
+
+
+@pytest.mark.parametrize("hang", ["factored", "factored+overlap"])
+def test_a_hanging_exchange_form_is_recorded_and_the_line_survives(hang):
+    p, rep, lines = _fake(["--gpus", "2", "--steps", "3", "--warmup", "1", "--section-timeout", "3"], GSR_BENCH_HANG_FORM=hang)
+    assert p.returncode == 0 and len(lines) == 1, p.stderr
+    forms = rep["exchange"]["forms"]
+    assert forms[hang] == {"timeout": 3.0, "wall_s": forms[hang]["wall_s"]}
+    assert forms["plain"]["ms_per_step"] == 3.0
+    # headline: the library default when its group completed, else the best completed form
+    assert rep["exchange"]["headline_form"] == ("factored+overlap" if hang == "factored" else "factored")
+    assert rep["n_gpus"] == 2 and "timed out" in p.stderr
+
+
+def test_a_failing_plain_form_is_recorded_and_all_forms_failing_fails():
+    p, rep, _ = _fake(["--gpus", "2", "--steps", "3", "--warmup", "1"], GSR_BENCH_FAIL_FORM="plain")
+    assert p.returncode == 0 and "error" in rep["exchange"]["forms"]["plain"] and rep["exchange"]["headline_form"] == "factored+overlap"
+    p, rep, _ = _fake(["--gpus", "2", "--steps", "3", "--warmup", "1", "--section-timeout", "2"],
+                      GSR_BENCH_FAKE="hang-all")
+    assert p.returncode != 0 and rep is None and "rank(s) failed" in p.stderr
+
+
+def test_rank0_stdout_larger_than_a_pipe_does_not_block_the_launch():
+    """rank 0's pipe was only read after every rank had exited (64 KB of NCCL_DEBUG output = deadlock)."""
+    p, rep, lines = _fake(["--gpus", "2", "--steps", "3", "--warmup", "1"], timeout=120, GSR_BENCH_FAKE_NOISE="300000")
+    assert p.returncode == 0 and len(lines) == 1 and rep["n_gpus"] == 2
+
+
+def test_supervisors_under_torchrun_rendezvous_each_form_on_a_fresh_port():
+    """The driver's launch: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`.  Every torchrun worker is a
+    supervisor; each form's rank group does a REAL gloo rendezvous + all-reduce on the port rank 0 published (the agent's own
+    store and its TORCHELASTIC_* variables must not leak into the children)."""
+    from bench import _free_port
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=_env(GSR_BENCH_FAKE="dist"), capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, p.stderr[-3000:]
+    rep = json.loads(lines[0])
+    assert rep["n_gpus"] == 2 and set(rep["exchange"]["forms"]) == {"plain", "factored", "factored+overlap"}
+    assert all("ms_per_step" in f for f in rep["exchange"]["forms"].values())
+
+
+def test_guarded_extras_record_errors_instead_of_raising(monkeypatch):
+    import bench
+
+    class FakeWl:
+        def __init__(self, *a, **kw): self.kw = kw
+        def measure(self, steps, warmup): return {"steps": steps}
+        def summary(self, m): return {"ms_per_step": 1.0}
+        def close(self): pass
+
+    monkeypatch.setattr(bench, "Workload", FakeWl)
+    monkeypatch.setenv("GSR_BENCH_FAIL_EXTRA", "config5")
+    args = bench.parse_args([])
+    out = bench.extra_configs(None, None, args)
+    assert out["config2"]["ms_per_step"] == 1.0 and "error" in out["config5"] and out["rgbd"]["ms_per_step"] == 1.0
+    assert set(out["trainer_step"]) == {"tail_step", "tail_in_backward"}
+    assert bench.guarded(lambda: 1 / 0)["error"].startswith("ZeroDivisionError")

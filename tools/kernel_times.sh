@@ -7,7 +7,7 @@ for lib in default $GSR_AB_LIBS; do
   tag=$(basename "$lib" .so)
   out=gpurun_out/ktimes_$tag
   rm -rf "$out"; mkdir -p "$out"
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o st -- python3 bench.py --no-extra --no-cpu-baseline --no-other-lists "$@" > "$out/bench.json" 2> "$out/err.log"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o st -- python3 bench.py --in-process --no-extra --no-cpu-baseline --no-other-lists "$@" > "$out/bench.json" 2> "$out/err.log"
   f=$(find "$out" -name "*kernel_stats.csv" | head -1)
   echo "== $lib"
   python3 - "$f" <<'PY'

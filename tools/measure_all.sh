@@ -15,7 +15,7 @@ cp profiles/pmc_traffic.json $O/pmc_traffic.json
 python bench.py > $O/bench_driver_line.json 2> $O/bench_driver_line.err
 # the same command under the profiler: per-kernel average durations to set against the line's HIP-event times
 # (--no-extra --no-other-lists: only config 3's kernels in the default list mode, so that the averages are the headline's)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 bench.py --no-cpu-baseline --no-extra --no-other-lists > $O/prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 bench.py --in-process --no-cpu-baseline --no-extra --no-other-lists > $O/prof.log 2>&1
 python3 tools/short_kernel_stats.py $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 find $O/prof -name "*kernel_trace.csv" -delete; find $O/prof -name "*agent_info.csv" -delete
 # two ranks on this one GPU, gloo carrying the collectives: the N > 1 code path of bench.py and its `exchange` object

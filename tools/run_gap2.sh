@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/gap2; rm -rf $O; mkdir -p $O
-timeout 600 rocprofv3 --kernel-trace --hip-runtime-trace --output-format csv -d $O/prof -o bench -- python3 bench.py --no-cpu-baseline --no-other-lists --steps 12 --warmup 3 > $O/prof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --hip-runtime-trace --output-format csv -d $O/prof -o bench -- python3 bench.py --in-process --no-cpu-baseline --no-other-lists --steps 12 --warmup 3 > $O/prof.log 2>&1
 ls $O/prof
 python3 - <<'PY'
 import csv, glob, re

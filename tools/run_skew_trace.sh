@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/skewtrace; rm -rf $O; mkdir -p $O
 for k in hot:8000 hot:32000; do
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof_${k/:/_} -o bench -- python3 bench.py --no-cpu-baseline --no-other-lists --no-loss --steps 5 --warmup 2 --skew $k > $O/log_${k/:/_}.txt 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof_${k/:/_} -o bench -- python3 bench.py --in-process --no-cpu-baseline --no-other-lists --no-loss --steps 5 --warmup 2 --skew $k > $O/log_${k/:/_}.txt 2>&1
 python3 - $O/prof_${k/:/_} <<'PY'
 import csv,glob,re,sys
 k=glob.glob(sys.argv[1]+"/*kernel_trace.csv")[0]

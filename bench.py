@@ -490,7 +490,7 @@ SURVEY_STEPS = 5   # untimed steps of the stage survey
 class Workload:
     def __init__(self, pkg, dev, rank, world, *, n, width, height, sh_degree, seed, mode="rgb", no_loss=False,
                  reference_lists=False, with_optimizer=False, unfused_tail=False, tail_in_backward=False, views=8,
-                 skew=None, order="random", ply=None, exchange_form=None):
+                 skew=None, order="random", ply=None, exchange_form=None, forward_only=False):
         import numpy as np
         import torch
         self.pkg, self.dev, self.rank, self.world = pkg, dev, rank, world
@@ -513,6 +513,7 @@ class Workload:
         self.K = K = s.shs.shape[1]
         self.mode, self.no_loss, self.reference_lists = mode, no_loss, reference_lists
         self.seed, self.ply, self.skew, self.order = seed, ply, skew, order
+        self.forward_only = forward_only  # GSR_FORWARD_ONLY renders (the reference's non-AD branch): a step = one forward
         self.view = view = rank % views
         self.views = views
         if world == 1:
@@ -613,6 +614,9 @@ class Workload:
             ev[1].record()
             params[0], params[4] = raw[0], raw[5]
             tail["n_steps"] += 1
+        if self.forward_only:
+            rast.forward_raw(*params, self.cam, self.deg, self.bg, forward_only=True)
+            return
         img = rast.forward_raw(*params, self.cam, self.deg, self.bg)
         if self.no_loss:
             vp = self.vpix_fixed
@@ -740,6 +744,8 @@ class Workload:
         # (tools/pmc_workload.py + tools/pmc_parse.py under rocprofv3 --pmc, committed per round) is reported
         key = (config_key(N, W, H, deg, self.mode, not self.reference_lists, not self.no_loss)
                if self.ply is None and not self.skew and self.order == "random" else None)
+        if key is not None and self.forward_only:
+            key = key.rsplit("_", 1)[0] + "_fwdonly"
         traffic, valu, pmc_src = None, None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if key is not None and os.path.exists(tpath) and self.tail is None:
@@ -782,7 +788,7 @@ class Workload:
                "ms_per_step_median": round(per[len(per) // 2], 4) if per else None,
                "value": round(self.world * self.W * self.H / (m["dt"] / m["steps"]) / 1e6, 3), "unit": "Mpixels/s",
                "steps": m["steps"], "n_gaussians": self.N, "resolution": [self.W, self.H], "mode": self.mode,
-               "loss": not self.no_loss, "visible": int(self.rast.stats.n_visible),
+               "loss": not self.no_loss and not self.forward_only, "visible": int(self.rast.stats.n_visible),
                "tile_instances": int(self.rast.stats.n_rendered),
                "dominant_kernel": r["kernel"], "dominant_ms": r["avg_launch_ms"],
                "roofline": {"bound": "hbm", "frac": r["frac"], "achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -792,6 +798,10 @@ class Workload:
                "stages_ms": r["stages_ms"]}
         if self.tail is not None and self.tail["n"]:
             out["trainer_tail"] = {k: round(self.tail[k] / self.tail["n"], 4) for k in ("prologue_fwd", "prologue_bwd", "adam")}
+        if self.forward_only:
+            out["metric"] = "forward-only (GSR_FORWARD_ONLY) Mpixels/s: one render per step, no backward state kept"
+            out["roofline"]["note"] = ("algorithmic bytes are SURVEY.md §8(d)'s forward figures (they count the sorted lists the "
+                                       "reference writes; this path never stores them)")
         return out
 
 
@@ -852,6 +862,10 @@ EXTRA_SPECS = [
      "config5: 5M Gaussians, SH deg 3, 3840x2160, fwd+bwd (random cotangent)"),
     ("rgbd", dict(n=1_000_000, width=1920, height=1080, sh_degree=3, seed=1003, mode="rgbd"),
      "N=1M SH3 1920x1080 :rgbd (the reference's default training mode), fwd + L1/0.2*DSSIM loss + bwd"),
+    ("forward_only.config3", dict(n=1_000_000, width=1920, height=1080, sh_degree=3, seed=1003, forward_only=True),
+     "config3 scene, forward only with GSR_FORWARD_ONLY (validate / GUI / render-views: rasterizer.jl:214-248)"),
+    ("forward_only.config5", dict(n=5_000_000, width=3840, height=2160, sh_degree=3, seed=1005, forward_only=True),
+     "config5 scene (5M @ 4K), forward only with GSR_FORWARD_ONLY"),
     ("trainer_step.tail_step", dict(n=1_000_000, width=1920, height=1080, sh_degree=3, seed=1003, with_optimizer=True),
      "config3 + prologue + Adam: gsr_backward then gsr_trainer_tail_step"),
     ("trainer_step.tail_in_backward", dict(n=1_000_000, width=1920, height=1080, sh_degree=3, seed=1003,

@@ -15,8 +15,9 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gsr.h")
 
 GSR_OK, GSR_E_INVALID_ARG, GSR_E_OOM, GSR_E_HIP, GSR_E_STATE = 0, -1, -2, -3, -4
 MODES = {"rgb": 3, "rgbd": 5, "rgbdn": 8}
+FORWARD_ONLY = 1  # gsr_aux.flags: no backward state is kept (inference render)
 FLAG_REFERENCE_TILE_LISTS = 2  # flags = 0: exact footprint culling (the default); bit 1 is retired (rejected)
-ABI_VERSION = 3  # GSR_ABI_VERSION of the include/gsr.h this mirror was written against
+ABI_VERSION = 4  # GSR_ABI_VERSION of the include/gsr.h this mirror was written against
 
 (BUF_RADII, BUF_GRAD_MEANS2D, BUF_N_CONTRIB, BUF_FINAL_T, BUF_TILE_RANGES, BUF_VALUES_SORTED, BUF_GEOM, BUF_NORMALS,
  BUF_GRAD_ROWS, BUF_INSTANCE_AUX) = range(10)
@@ -46,7 +47,8 @@ class CameraS(C.Structure):
 
 
 class Aux(C.Structure):
-    _fields_ = [("covisibilities", C.c_void_p), ("uncertainties", C.c_void_p), ("radii", C.c_void_p)]
+    _fields_ = [("covisibilities", C.c_void_p), ("uncertainties", C.c_void_p), ("radii", C.c_void_p),
+                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Stats(C.Structure):

@@ -229,7 +229,9 @@ __global__ __launch_bounds__(64) void composite_fwd_strip_kernel(int W, int H, i
 // BEFORE the host has read the scan's totals, like the sort's main pass was: every workgroup checks the totals against
 // the capacity of the buffers and leaves everything untouched when this view needs more (the host then runs the
 // separate sort and forward launches).
-template <int C, bool AUX>
+// KEEP = false (GSR_FORWARD_ONLY, the reference's non-AD branch rasterizer.jl:214-248): the emitted chunk lives in LDS only —
+// the 52-68 bytes per instance of stream + id that nothing but the backward reads are not stored.
+template <int C, bool AUX, bool KEEP>
 // (8 waves per SIMD: the sort needs 66 VGPRs left to itself; at 64 it does not spill and an eighth workgroup fits the CU)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void sort_composite_fwd_kernel(int W, int H, int grid_x,
                                                                  const uint32_t* __restrict__ tile_start,
@@ -284,10 +286,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void s
             if (i < n) {
                 const uint32_t id = ids[i];
                 const gsr_sort::InstanceVals v = gsr_sort::instance_vals<C>(id, X0, Y0, geom);
-                const uint32_t pos = start + i;
-                values_sorted[pos] = id;
-                stream.s0[pos] = v.v0; stream.s1[pos] = v.v1; stream.s2[pos] = v.v2;
-                if (C > 3) stream.s3[pos] = v.v3;
+                if (KEEP) {
+                    const uint32_t pos = start + i;
+                    values_sorted[pos] = id;
+                    stream.s0[pos] = v.v0; stream.s1[pos] = v.v1; stream.s2[pos] = v.v2;
+                    if (C > 3) stream.s3[pos] = v.v3;
+                }
                 e(0, tid) = v.v0; e(1, tid) = v.v1;
                 // LDS copy: (third colour, 1-based list position, depth | :rgb blend threshold, footprint masks)
                 e(2, tid) = make_float4(v.v2.x, __uint_as_float(i + 1u), v.v2.z, v.v2.w);
@@ -628,18 +632,21 @@ void gsr_launch_sort_composite_fwd(hipStream_t s, int channels, GsrCam cam, cons
                                    const uint32_t* tile_order, uint32_t* tile_count, const uint64_t* bins, uint32_t bin_cap,
                                    GsrGeom geom, GsrStream stream, const float* background, float* image,
                                    uint32_t* n_contrib, float* final_T, uint32_t* values_sorted, uint32_t* ranges,
-                                   uint8_t* covis, float* uncert, const uint32_t* totals, uint32_t cap_instances) {
+                                   uint8_t* covis, float* uncert, const uint32_t* totals, uint32_t cap_instances,
+                                   bool keep_backward_state) {
     dim3 grid(cam.grid_x * cam.grid_y), block(256);
     Bg bg = make_bg(background, channels);
     const bool aux = covis || uncert;
-#define LAUNCH(CC, AA)                                                                                             \
-    hipLaunchKernelGGL((sort_composite_fwd_kernel<CC, AA>), grid, block, 0, s, cam.width, cam.height, cam.grid_x,  \
-                       tile_start, tile_order, tile_count, bins, bin_cap, geom, stream, bg, image, n_contrib,      \
+#define LAUNCH2(CC, AA, KK)                                                                                            \
+    hipLaunchKernelGGL((sort_composite_fwd_kernel<CC, AA, KK>), grid, block, 0, s, cam.width, cam.height, cam.grid_x,  \
+                       tile_start, tile_order, tile_count, bins, bin_cap, geom, stream, bg, image, n_contrib,          \
                        final_T, values_sorted, ranges, covis, uncert, totals, cap_instances)
+#define LAUNCH(CC, AA) do { if (keep_backward_state) LAUNCH2(CC, AA, true); else LAUNCH2(CC, AA, false); } while (0)
     if (channels == 3) { if (aux) LAUNCH(3, true); else LAUNCH(3, false); }
     else if (channels == 5) { if (aux) LAUNCH(5, true); else LAUNCH(5, false); }
     else { if (aux) LAUNCH(8, true); else LAUNCH(8, false); }
 #undef LAUNCH
+#undef LAUNCH2
 }
 
 void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,

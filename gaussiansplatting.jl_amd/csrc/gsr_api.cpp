@@ -210,6 +210,7 @@ struct gsr_handle {
     hipStream_t aux_stream = nullptr;  // the four-wave backward of those tiles runs here, next to the main launch
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool fwd_valid = false, bwd_valid = false;
+    bool fwd_only = false;         // the last forward was GSR_FORWARD_ONLY: no stream / ids / row storage behind it
     bool inputs_consumed = false;  // gsr_backward_trainer_tail updated the forward's inputs in place
     uint64_t generation = 0;             // ordinal of the last gsr_forward (gsr_stats.generation)
     int32_t* radii_cur = nullptr;        // gstate.radii of the last forward: caller's (gsr_aux.radii) or h->radii
@@ -366,7 +367,7 @@ extern "C" {
 const char* gsr_last_error_string(void) { return g_err; }
 #define GSR_STR2(x) #x
 #define GSR_STR(x) GSR_STR2(x)
-const char* gsr_version(void) { return "gsr-hip 0.3 abi " GSR_STR(GSR_ABI_VERSION) " (gfx950)"; }
+const char* gsr_version(void) { return "gsr-hip 0.4 abi " GSR_STR(GSR_ABI_VERSION) " (gfx950)"; }
 int gsr_abi_version(void) { return GSR_ABI_VERSION; }
 
 int gsr_host_wait_policy(int spin_us, int yield_us, int sleep_us) {
@@ -480,12 +481,16 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     int rc = check_inputs(h, in, cam);
     if (rc) return rc;
     if (!image_out) return fail(GSR_E_INVALID_ARG, "null image_out");
+    if (aux && ((aux->flags & ~(uint32_t)GSR_FORWARD_ONLY) || aux->reserved))
+        return fail(GSR_E_INVALID_ARG, "unknown gsr_aux.flags 0x%x / reserved 0x%x", aux->flags, aux->reserved);
+    const bool fwd_only = aux && (aux->flags & GSR_FORWARD_ONLY);
     hipStream_t s = (hipStream_t)stream_v;
     const int C = h->cfg.mode, n = in->n;
     const size_t P = (size_t)h->cfg.width * h->cfg.height, T = (size_t)h->n_tiles;
     h->fwd_valid = false;
     h->bwd_valid = false;
     h->inputs_consumed = false;
+    h->fwd_only = fwd_only;
 
     const size_t nn = n > 0 ? (size_t)n : 1;
     const int n_blocks = (n + 255) / 256;
@@ -544,6 +549,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     uint64_t cap_instances = std::min(std::min(h->values_sorted.cap / 4, h->s0.cap / 16), std::min(h->s1.cap / 16, h->s2.cap / 16));
     if (C > 3) cap_instances = std::min<uint64_t>(cap_instances, h->s3.cap / 16);
     cap_instances = std::min<uint64_t>(cap_instances, 0xFFFFFFFFull);
+    if (fwd_only) cap_instances = 0xFFFFFFFFull;  // nothing is stored per instance: no capacity to respect
     static const bool no_fused = [] { const char* e = getenv("GSR_NO_FUSED_FWD"); return e && e[0] == '1'; }();  // A/B only
     const bool spec = use_bins && cap_instances > 0 && !no_fused;
     if (spec) {
@@ -553,7 +559,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
                                       stream_of(h), in->background, image_out, h->n_contrib.as<uint32_t>(),
                                       h->final_T.as<float>(), h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>(),
                                       aux ? aux->covisibilities : nullptr, aux ? aux->uncertainties : nullptr, totals,
-                                      (uint32_t)cap_instances);
+                                      (uint32_t)cap_instances, /*keep_backward_state=*/!fwd_only);
         sc3.close();
     }
     if ((rc = wait_totals(h, seq, s))) return rc;
@@ -598,18 +604,22 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
         return GSR_OK;
     }
     const float slack = 1.25f;  // instance count drifts slowly between training steps
-    if ((rc = h->values_sorted.ensure(D * 4, slack)) ||
-        (rc = h->rows.ensure(D_slots * 64, slack)) ||
-        (rc = h->s0.ensure(D * 16, slack)) || (rc = h->s1.ensure(D * 16, slack)) ||
-        (rc = h->s2.ensure(D * 16, slack)) || (C > 3 && (rc = h->s3.ensure(D * 16, slack))))
+    const uint32_t n_mid4 = h->host_totals[3], n_mid8 = h->host_totals[6];
+    const bool long_tiles = (n_mid4 | n_mid8 | n_big) != 0u;
+    // forward-only and everything composited by the fused launch: no per-instance storage at all (the rare paths below —
+    // tier lists, compact binning — still hand their instances over through the stream)
+    const bool need_stream = !(fwd_only && fused_done && !long_tiles);
+    if (need_stream &&
+        ((rc = h->values_sorted.ensure(D * 4, slack)) ||
+         (rc = h->s0.ensure(D * 16, slack)) || (rc = h->s1.ensure(D * 16, slack)) ||
+         (rc = h->s2.ensure(D * 16, slack)) || (C > 3 && (rc = h->s3.ensure(D * 16, slack)))))
         return rc;
+    if (!fwd_only && (rc = h->rows.ensure(D_slots * 64, slack))) return rc;
     size_t slab_stride = 0;
     if (n_big > 0) {  // lists beyond the LDS sort: two merge slabs per listed tile
         slab_stride = ((size_t)max_tile + 63) & ~(size_t)63;
         if ((rc = h->big_scratch.ensure((size_t)n_big * 2 * slab_stride * 8))) return rc;
     }
-    const uint32_t n_mid4 = h->host_totals[3], n_mid8 = h->host_totals[6];
-    const bool long_tiles = (n_mid4 | n_mid8 | n_big) != 0u;
     if (!fused_done || long_tiles) {
         StageScope sc4(h->prof, ST_SORT, s);
         const uint64_t* keys = h->bins.as<uint64_t>();
@@ -683,6 +693,8 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
     if (!vpixels || !g) return fail(GSR_E_INVALID_ARG, "null vpixels / grads");
     if (!h->fwd_valid || h->last_n != in->n)
         return fail(GSR_E_STATE, "gsr_backward without a matching gsr_forward on this handle");
+    if (h->fwd_only)
+        return fail(GSR_E_STATE, "the handle's last forward was GSR_FORWARD_ONLY: it kept no backward state");
     if (h->inputs_consumed)
         return fail(GSR_E_STATE, "the inputs of the handle's last forward were updated in place by "
                     "gsr_backward_trainer_tail; run gsr_forward again");
@@ -738,11 +750,11 @@ static int buffer_lookup(const gsr_handle* h, int which, const void** dev_ptr, s
         case GSR_BUF_N_CONTRIB: b = &h->n_contrib; sz = P * 4; break;
         case GSR_BUF_FINAL_T: b = &h->final_T; sz = P * 4; break;
         case GSR_BUF_TILE_RANGES: b = &h->ranges; sz = 2 * T * 4; break;
-        case GSR_BUF_VALUES_SORTED: b = &h->values_sorted; sz = D * 4; break;
+        case GSR_BUF_VALUES_SORTED: b = &h->values_sorted; sz = h->fwd_only ? 0 : D * 4; break;
         case GSR_BUF_GEOM: b = &h->geo; sz = n * 64; break;
         case GSR_BUF_NORMALS: b = &h->gnormal; sz = h->cfg.mode > 5 ? n * 16 : 0; break;
         case GSR_BUF_GRAD_ROWS: b = &h->rows; sz = (size_t)h->last_slots * 16 * GSR_ROW_F4(h->cfg.mode); break;
-        case GSR_BUF_INSTANCE_AUX: b = &h->s2; sz = D * 16; break;
+        case GSR_BUF_INSTANCE_AUX: b = &h->s2; sz = h->fwd_only ? 0 : D * 16; break;
         default: return fail(GSR_E_INVALID_ARG, "unknown buffer id %d", which);
     }
     if (sz > b->cap) sz = 0;  // not produced yet
@@ -964,6 +976,8 @@ int gsr_backward_trainer_tail(gsr_handle* h, const gsr_inputs* in, const gsr_cam
     if (!vpixels || !st) return fail(GSR_E_INVALID_ARG, "null vpixels / tail state");
     if (!h->fwd_valid || h->last_n != in->n)
         return fail(GSR_E_STATE, "gsr_backward_trainer_tail without a matching gsr_forward on this handle");
+    if (h->fwd_only)
+        return fail(GSR_E_STATE, "the handle's last forward was GSR_FORWARD_ONLY: it kept no backward state");
     if (h->inputs_consumed)
         return fail(GSR_E_STATE, "the inputs of the handle's last forward were updated in place by "
                     "gsr_backward_trainer_tail; run gsr_forward again");

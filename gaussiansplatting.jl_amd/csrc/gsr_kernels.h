@@ -134,7 +134,8 @@ void gsr_launch_sort_composite_fwd(hipStream_t s, int channels, GsrCam cam, cons
                                    const uint32_t* tile_order, uint32_t* tile_count, const uint64_t* bins, uint32_t bin_cap,
                                    GsrGeom geom, GsrStream stream, const float* background, float* image,
                                    uint32_t* n_contrib, float* final_T, uint32_t* values_sorted, uint32_t* ranges,
-                                   uint8_t* covis, float* uncert, const uint32_t* totals, uint32_t cap_instances);
+                                   uint8_t* covis, float* uncert, const uint32_t* totals, uint32_t cap_instances,
+                                   bool keep_backward_state /* false (GSR_FORWARD_ONLY): the sorted stream and ids are not stored */);
 void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
                               const uint32_t* tile_order, GsrStream stream,
                               const float* background, const float* vpixels, const uint32_t* n_contrib,

@@ -292,14 +292,17 @@ class GaussianRasterizer:
         return cs
 
     def forward_raw(self, means_3d, shs, opacities, scales, rotations, camera, sh_degree, background, R_w2c=None,
-                    t_w2c=None, covisibilities=None, uncertainties=None, image_out=None):
+                    t_w2c=None, covisibilities=None, uncertainties=None, image_out=None, forward_only: bool = False):
+        """`rasterize` (rasterizer.jl:255-408).  forward_only=True (GSR_FORWARD_ONLY): the render of the reference's non-AD
+        branch (rasterizer.jl:214-248: `validate`, GUI, render-views) — same image bit for bit, no backward state kept
+        (a third of the forward's HBM traffic); `backward_raw` after it raises GSR_E_STATE."""
         inp = self._inputs(means_3d, shs, opacities, scales, rotations, sh_degree, background)
         cs = self._camera(camera, R_w2c, t_w2c)
         img = self.image if image_out is None else _chk(image_out, "image_out", (self.height, self.width, self.channels))
         self.gstate.ensure(inp.n)  # rasterizer.jl:275-278
         aux = L.Aux(None if covisibilities is None else covisibilities.data_ptr(),
                     None if uncertainties is None else uncertainties.data_ptr(),
-                    self.gstate._radii.data_ptr() if inp.n else None)
+                    self.gstate._radii.data_ptr() if inp.n else None, L.FORWARD_ONLY if forward_only else 0, 0)
         with torch.cuda.device(self.device):
             L.check(self._lib.gsr_forward(self._h, C.byref(inp), C.byref(cs), _ptr(img), C.byref(aux), _stream(),
                                           C.byref(self.stats)))
@@ -475,7 +478,16 @@ def rasterize(means_3d, shs, opacities, scales, rotations, R_w2c=None, t_w2c=Non
     sh_degree, background, covisibilities, uncertainties) — rasterizer.jl:255-408.
     opacities / scales are the activated values.  Returns `rast.image` (aliased, overwritten by
     the next call), shape (H,W,C).  R_w2c is the device (3,3) array in the reference's
-    column-major order, i.e. the transpose of a row-major torch matrix."""
+    column-major order, i.e. the transpose of a row-major torch matrix.
+    Outside AD — `torch.no_grad()`, or no argument requires a gradient; the reference's `within_gradient` test,
+    rasterizer.jl:214-215 — the render keeps no backward state (GSR_FORWARD_ONLY)."""
+    diff = (means_3d, shs, opacities, scales, rotations, R_w2c, t_w2c)
+    if not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in diff)):
+        args = [a.detach().contiguous() for a in diff[:5]]
+        return rast.forward_raw(*args, camera, sh_degree, tuple(float(b) for b in background),
+                                None if R_w2c is None else R_w2c.detach().contiguous(),
+                                None if t_w2c is None else t_w2c.detach().contiguous(), covisibilities, uncertainties,
+                                forward_only=True)
     return _Rasterize.apply(means_3d, shs, opacities, scales, rotations, R_w2c, t_w2c, rast, camera, sh_degree,
                             tuple(float(b) for b in background), covisibilities, uncertainties)
 

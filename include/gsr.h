@@ -83,8 +83,10 @@ typedef struct gsr_config {
 /* ABI version of this header: bumped whenever a struct of this file changes size or a flag / enum value changes meaning.
  *   1: round-1 layout (flag bit 1u = exact tile cull, smaller gsr_config / gsr_aux / gsr_stats / gsr_grads)
  *   2: round-2 layout (flag bit 1u = reference tile lists) — never given a number at the time
- *   3: this layout (GSR_FLAG_REFERENCE_TILE_LISTS = 2u, bit 1u rejected, gsr_check_abi). */
-#define GSR_ABI_VERSION 3
+ *   3: round-3 layout (GSR_FLAG_REFERENCE_TILE_LISTS = 2u, bit 1u rejected, gsr_check_abi)
+ *   4: this layout: gsr_aux grew by `flags` (GSR_FORWARD_ONLY) + `reserved`;
+ *      gsr_sh_grad_from_views_tail. */
+#define GSR_ABI_VERSION 4
 
 /* Positional arguments of `rasterize(means_3d, shs, opacities, scales, rotations, ...)`
  * (rasterizer.jl:255-267).  opacities / scales are the ACTIVATED values, as the
@@ -125,7 +127,20 @@ typedef struct gsr_aux {
      * handle-owned memory, so the caller's own GeometryState stays truthful; the array must stay valid
      * until the matching gsr_backward (which re-reads it).  NULL: handle-owned (GSR_BUF_RADII). */
     int32_t* radii;
+    /* GSR_FORWARD_*.  New in ABI 4.  The reference's functor has a branch for rendering outside AD (rasterizer.jl:214-248,
+     * `within_gradient`), used by `validate` (training.jl:501-504), the GUI (gui/worker.jl:654-657) and
+     * scripts/render-views.jl: the same `rasterize`, whose backward state nobody will read. */
+    uint32_t flags;
+    uint32_t reserved; /* 0 */
 } gsr_aux;
+/* gsr_aux.flags — GSR_FORWARD_ONLY: this forward will not be differentiated.  The image, final_T, n_contrib, radii, tile ranges
+ * and the geometry records are produced as always (image / final_T bit-identical to a training forward), but the sorted
+ * splat stream and the sorted ids — 52-68 bytes per tile instance that only gsr_backward reads, a third of the fused
+ * forward's HBM traffic — are not written and no gradient-row storage is reserved: GSR_BUF_VALUES_SORTED and
+ * GSR_BUF_INSTANCE_AUX report 0 bytes, and gsr_backward / gsr_backward_trainer_tail / gsr_update_stats after such a forward
+ * fail with GSR_E_STATE.  (Tiles with more than 1024 instances, and views binned in compact mode, still go through the
+ * stream: they are the rare path.) */
+#define GSR_FORWARD_ONLY 1u
 
 typedef struct gsr_stats {
     int64_t n_rendered;         /* D: tile instances (rasterizer.jl:337) */

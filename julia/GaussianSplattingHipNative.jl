@@ -13,9 +13,13 @@
 #     enabled too — fall through to the reference kernels via `invoke`;
 #   * NO dispatch on keyword arguments (Julia has none): the two methods below are more specific than the
 #     reference's only in their POSITIONAL types (ROCArray instead of AbstractArray), and branch on the side table;
-#   * only `rasterize` and `∇rasterize` are overridden.  The reference's `ChainRulesCore.rrule`
-#     (rasterizer.jl:552-573) calls exactly these two generics, so the rrule, Zygote and the functor prologue are
-#     the reference's own code;
+#   * `rasterize` and `∇rasterize` are overridden; the reference's `ChainRulesCore.rrule` (rasterizer.jl:552-573) calls
+#     exactly these two generics, so Zygote and the functor prologue are the reference's own code.  ONE rrule method is added
+#     (same body as the reference's, ROCArray positional types): it tells the forward that a pullback will follow.  A
+#     `rasterize` that is called directly — the reference's non-AD branch (rasterizer.jl:214-248): `validate`
+#     (training.jl:501-504), the GUI (gui/worker.jl:654-657), scripts/render-views.jl — passes GSR_FORWARD_ONLY: same image,
+#     no backward state written (a third of the forward's HBM traffic).  `enable_hip_native!(rast;
+#     forward_only_outside_ad=false)` keeps the state for callers that run `∇rasterize` by hand after a bare `rasterize`;
 #   * the library writes `radii` and `∇means_2d` straight into `rast.gstate` (gsr_aux.radii / gsr_grads.vmeans2d) and
 #     the image into `rast.image`, so the reference's state object stays truthful.
 #
@@ -27,6 +31,8 @@ import KernelAbstractions as KA
 import GPUArrays
 import GaussianSplatting
 import GaussianSplatting: GaussianRasterizer, GeometryState, Camera, resolution, n_color_features, rasterize, ∇rasterize
+import ChainRulesCore
+import ChainRulesCore: NoTangent, unthunk
 
 const LIB = get(ENV, "GSR_HIP_LIB", "libgsr_hip.so")
 
@@ -46,7 +52,8 @@ struct GsrCamera
     principal::NTuple{2, Float32}; camera_center::NTuple{3, Float32}
     R_dev::Ptr{Float32}; t_dev::Ptr{Float32}
 end
-struct GsrAux; covisibilities::Ptr{UInt8}; uncertainties::Ptr{Float32}; radii::Ptr{Int32}; end
+struct GsrAux; covisibilities::Ptr{UInt8}; uncertainties::Ptr{Float32}; radii::Ptr{Int32}; flags::UInt32; reserved::UInt32; end
+const GSR_FORWARD_ONLY = 0x00000001  # gsr_aux.flags: this forward will not be differentiated (no backward state kept)
 struct GsrStats
     n_rendered::Int64; n_visible::Int32; max_tile_instances::Int32; generation::UInt64
     bins_bytes::Int64; compact_binning::Int32; reserved::Int32
@@ -63,7 +70,7 @@ check(rc) = rc == 0 || error(unsafe_string(ccall((:gsr_last_error_string, LIB), 
 
 # GSR_ABI_VERSION of the include/gsr.h these struct definitions mirror; checked (with the six struct sizes) against
 # the loaded library by the first enable_hip_native!: a stale libgsr_hip.so or a stale binding fails here, loudly.
-const GSR_ABI_VERSION = 3
+const GSR_ABI_VERSION = 4
 const ABI_CHECKED = Ref(false)
 function check_abi()
     ABI_CHECKED[] && return
@@ -79,25 +86,28 @@ hipstream() = Ptr{Cvoid}(UInt(AMDGPU.stream().stream))  # the task-local stream 
 mutable struct NativeState
     handle::Ptr{Cvoid}
     generation::UInt64
+    forward_only_outside_ad::Bool  # a bare `rasterize` (no rrule around it) keeps no backward state
+    pullback_follows::Bool         # set by the rrule below for the forward it is about to run
 end
 const NATIVE = WeakKeyDict{GaussianRasterizer, NativeState}()
 const NATIVE_LOCK = ReentrantLock()
 native(rast::GaussianRasterizer) = lock(() -> get(NATIVE, rast, nothing), NATIVE_LOCK)
 
 """
-    enable_hip_native!(rast; reference_tile_lists=false)
+    enable_hip_native!(rast; reference_tile_lists=false, forward_only_outside_ad=true)
 
 Route `rasterize` / `∇rasterize` on this rasterizer through libgsr_hip.so.  Width / height / mode / near / far
-are the rasterizer's own (rasterizer.jl:60-90).  Returns `rast`.
+are the rasterizer's own (rasterizer.jl:60-90).  `forward_only_outside_ad`: a `rasterize` that is not being
+differentiated (no `rrule` around it) is rendered with GSR_FORWARD_ONLY — `∇rasterize` after it is an error.  Returns `rast`.
 """
-function enable_hip_native!(rast::GaussianRasterizer; reference_tile_lists::Bool = false)
+function enable_hip_native!(rast::GaussianRasterizer; reference_tile_lists::Bool = false, forward_only_outside_ad::Bool = true)
     native(rast) === nothing || return rast
     check_abi()
     c, w, h = size(rast.image)
     href = Ref{Ptr{Cvoid}}()
     check(ccall((:gsr_create, LIB), Cint, (Ref{GsrConfig}, Ref{Ptr{Cvoid}}),
         GsrConfig(w, h, c, rast.near_plane, rast.far_plane, 3, 0.3f0, reference_tile_lists ? 0x2 : 0x0, 0), href))
-    st = NativeState(href[], 0)
+    st = NativeState(href[], 0, forward_only_outside_ad, false)
     finalizer(s -> ccall((:gsr_destroy, LIB), Cint, (Ptr{Cvoid},), s.handle), st)
     lock(() -> (NATIVE[rast] = st), NATIVE_LOCK)
     return rast
@@ -140,7 +150,10 @@ function GaussianSplatting.rasterize(means_3d::RM, shs::R3, opacities::RM, scale
         rast.gstate = GPUArrays.@uncached GeometryState(KA.get_backend(rast), n; n_features=n_color_features(rast.mode))
     end
     inp, cam = _structs(means_3d, shs, opacities, scales, rotations, R_w2c, t_w2c, camera, sh_degree, background)
-    aux = GsrAux(dptr(UInt8, covisibilities), dptr(uncertainties), dptr(Int32, rast.gstate.radii))
+    keep = st.pullback_follows || !st.forward_only_outside_ad
+    st.pullback_follows = false
+    aux = GsrAux(dptr(UInt8, covisibilities), dptr(uncertainties), dptr(Int32, rast.gstate.radii),
+        keep ? 0x00000000 : GSR_FORWARD_ONLY, 0x00000000)
     stats = Ref(GsrStats(0, 0, 0, 0, 0, 0, 0))
     check(ccall((:gsr_forward, LIB), Cint,
         (Ptr{Cvoid}, Ref{GsrInputs}, Ref{GsrCamera}, Ptr{Float32}, Ref{GsrAux}, Ptr{Cvoid}, Ref{GsrStats}),
@@ -169,6 +182,39 @@ function GaussianSplatting.∇rasterize(vpixels::R3, means_3d::RM, shs::R3, scal
         (Ptr{Cvoid}, Ref{GsrInputs}, Ref{GsrCamera}, Ptr{Float32}, Ref{GsrGrads}, Ptr{Cvoid}),
         st.handle, inp, cam, dptr(vpixels), g, hipstream()))
     return vmeans, vshs, vopac, vscales, vrot, vR, vt
+end
+
+# The pullback hands over `unthunk(vpixels)` (rasterizer.jl:567): under Zygote that can be a `FillArrays.Fill`, a
+# `Base.ReshapedArray` or a CPU array instead of a ROCArray.  Without this method dispatch would quietly fall through to the
+# reference's kernels for an ENABLED rasterizer (correct, but an invisible performance cliff — and on a forward that kept its
+# state in the library, not in rast.bstate, a wrong one).  Materialise the cotangent once and say so.
+function GaussianSplatting.∇rasterize(vpixels::AbstractArray{Float32, 3}, means_3d::RM, shs::R3, scales::RM, rotations::RM,
+        opacities::RM, radii::ROCVector{Int32}, R_w2c = nothing, t_w2c = nothing;
+        rast::GaussianRasterizer, camera::Camera, sh_degree::Int, background::SVector{3, Float32})
+    native(rast) === nothing && return invoke(∇rasterize, REF_BWD_SIG, vpixels, means_3d, shs, scales, rotations, opacities,
+        radii, R_w2c, t_w2c; rast, camera, sh_degree, background)
+    @warn "GaussianSplattingHipNative: cotangent of type $(typeof(vpixels)) copied into a ROCArray for the native ∇rasterize" maxlog=1
+    vp = similar(rast.image)
+    vp .= vpixels
+    return ∇rasterize(vp, means_3d, shs, scales, rotations, opacities, radii, R_w2c, t_w2c; rast, camera, sh_degree, background)
+end
+
+# rrule(rasterize, ...) — the reference's own (rasterizer.jl:552-573) with ROCArray positional types: the only addition is the
+# note to the forward that this render WILL be differentiated (a bare `rasterize` is rendered forward-only).
+function ChainRulesCore.rrule(::typeof(rasterize), means_3d::RM, shs::R3, opacities::RM, scales::RM, rotations::RM,
+        R_w2c = nothing, t_w2c = nothing;
+        rast::GaussianRasterizer, camera::Camera, sh_degree::Int, background::SVector{3, Float32},
+        covisibilities = nothing, uncertainties = nothing)
+    st = native(rast)
+    st === nothing || (st.pullback_follows = true)
+    image = rasterize(means_3d, shs, opacities, scales, rotations, R_w2c, t_w2c;
+        rast, camera, sh_degree, background, covisibilities, uncertainties)
+    function _pullback(vpixels)
+        ∇ = ∇rasterize(unthunk(vpixels), means_3d, shs, scales, rotations, opacities,
+            rast.gstate.radii, R_w2c, t_w2c; rast, camera, sh_degree, background)
+        return (NoTangent(), ∇...)
+    end
+    return image, _pullback
 end
 
 # release_scene_buffers!(rast) (rasterizer.jl:111-123) also has to drop the library's scene-sized scratch

@@ -27,22 +27,25 @@ def test_stale_callers_fail_loudly(pkg):
     reference-lists flag lives on bit 2u; gsr_check_abi compares the ABI number and the six struct sizes."""
     L = pkg._lib
     lib = L.load()
-    assert lib.gsr_abi_version() == L.ABI_VERSION == 3
-    assert b"abi 3" in lib.gsr_version()
+    assert lib.gsr_abi_version() == L.ABI_VERSION == 4
+    assert b"abi 4" in lib.gsr_version()
     hdr = open(L.HEADER_PATH).read()
-    assert re.search(r"#define\s+GSR_ABI_VERSION\s+3\b", hdr) and re.search(r"#define\s+GSR_FLAG_REFERENCE_TILE_LISTS\s+2u", hdr)
+    assert re.search(r"#define\s+GSR_ABI_VERSION\s+4\b", hdr) and re.search(r"#define\s+GSR_FLAG_REFERENCE_TILE_LISTS\s+2u", hdr)
     h = C.c_void_p()
     cfg = L.Config(64, 48, 3, 0.2, 1000.0, 3, 0.3, 1, 0)  # the retired bit
     assert lib.gsr_create(C.byref(cfg), C.byref(h)) == L.GSR_E_INVALID_ARG
     assert b"retired" in lib.gsr_last_error_string()
     sizes = [C.sizeof(t) for t in (L.Config, L.Inputs, L.CameraS, L.Aux, L.Stats, L.Grads)]
-    assert lib.gsr_check_abi(3, *sizes) == 0
+    assert lib.gsr_check_abi(4, *sizes) == 0
+    assert lib.gsr_check_abi(3, *sizes) == L.GSR_E_INVALID_ARG and b"ABI 3" in lib.gsr_last_error_string()
     assert lib.gsr_check_abi(2, *sizes) == L.GSR_E_INVALID_ARG and b"ABI 2" in lib.gsr_last_error_string()
     stale = list(sizes); stale[5] -= 16  # round-1 gsr_grads had no vmeans2d / forward_generation
-    assert lib.gsr_check_abi(3, *stale) == L.GSR_E_INVALID_ARG and b"gsr_grads" in lib.gsr_last_error_string()
+    assert lib.gsr_check_abi(4, *stale) == L.GSR_E_INVALID_ARG and b"gsr_grads" in lib.gsr_last_error_string()
     # the Julia binding carries the same numbers
     jl = open(os.path.join(os.path.dirname(L.HEADER_PATH), "..", "julia", "GaussianSplattingHipNative.jl")).read()
-    assert "const GSR_ABI_VERSION = 3" in jl and "reference_tile_lists ? 0x2 : 0x0" in jl and ":gsr_check_abi" in jl
+    stale = list(sizes); stale[3] -= 8  # ABI 3's gsr_aux had no flags / reserved
+    assert lib.gsr_check_abi(4, *stale) == L.GSR_E_INVALID_ARG and b"gsr_aux" in lib.gsr_last_error_string()
+    assert "const GSR_ABI_VERSION = 4" in jl and "reference_tile_lists ? 0x2 : 0x0" in jl and ":gsr_check_abi" in jl
 
 
 def test_struct_sizes_match_header(pkg):
@@ -53,7 +56,7 @@ def test_struct_sizes_match_header(pkg):
     assert C.sizeof(L.CameraS) == (9 + 3 + 2 + 2 + 3) * 4 + 4 + 16
     assert C.sizeof(L.Stats) == 40
     assert C.sizeof(L.Grads) == 80
-    assert C.sizeof(L.Aux) == 24
+    assert C.sizeof(L.Aux) == 32
     assert C.sizeof(L.TailState) == 248
 
 

@@ -32,6 +32,7 @@ ap.add_argument("--seed", type=int, default=1003)
 ap.add_argument("--mode", default="rgb")
 ap.add_argument("--no-loss", action="store_true")
 ap.add_argument("--reference-lists", action="store_true")
+ap.add_argument("--forward-only", action="store_true", help="GSR_FORWARD_ONLY renders (a step = one forward)")
 ap.add_argument("--steps", type=int, default=4)
 ap.add_argument("--meta", default=os.path.join(ROOT, "gpurun_out", "pmc_meta.json"))
 args = ap.parse_args()
@@ -57,11 +58,16 @@ vpf = to(pkg.synthetic.make_vpixels(W, H, C, seed))
 rast = pkg.rasterizer.GaussianRasterizer(W, H, mode=args.mode, device=dev, exact_tile_cull=not args.reference_lists)
 arena = torch.empty(pkg.distributed.arena_numel(N, s.shs.shape[1]), device=dev)
 for _ in range(args.steps):
+    if args.forward_only:
+        rast.forward_raw(*params, cam, deg, (0.0, 0.0, 0.0), forward_only=True)
+        continue
     img = rast.forward_raw(*params, cam, deg, (0.0, 0.0, 0.0))
     vp = vpf if args.no_loss else pkg.fused_ssim.l1_ssim_loss(rast, img, target)[1]
     rast.backward_raw(vp, *params, cam, deg, (0.0, 0.0, 0.0), arena=arena)
 torch.cuda.synchronize()
 key = bench.config_key(N, W, H, deg, args.mode, not args.reference_lists, not args.no_loss)
+if args.forward_only:
+    key = key.rsplit("_", 1)[0] + "_fwdonly"
 meta = {"key": key, "tile_instances": int(rast.stats.n_rendered), "n_visible": int(rast.stats.n_visible), "steps": args.steps}
 os.makedirs(os.path.dirname(args.meta), exist_ok=True)
 json.dump(meta, open(args.meta, "w"))

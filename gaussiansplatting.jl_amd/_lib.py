@@ -96,6 +96,7 @@ class GatherGroup(C.Structure):
 
 EXPORTS = ["gsr_create", "gsr_destroy", "gsr_release_scene_buffers", "gsr_memory_usage", "gsr_forward",
            "gsr_backward", "gsr_host_wait_policy", "gsr_buffer", "gsr_copy_buffer", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_loss_l1_ssim",
+           "gsr_ssim_precision",
            "gsr_allreduce_grads", "gsr_last_error_string", "gsr_version", "gsr_abi_version", "gsr_check_abi", "gsr_profile_enable",
            "gsr_profile_stage_count", "gsr_profile_stages", "gsr_profile_stage_name", "gsr_profile_read", "gsr_profile_read_intervals", "gsr_update_stats",
            "gsr_prologue_forward", "gsr_prologue_backward", "gsr_adam_step", "gsr_stream_triad",
@@ -108,7 +109,9 @@ _lib = None
 
 
 def build(verbose: bool = False) -> str:
-    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU).  The product only: the native
+    test program of tests/test_gpu_host_wait.py is `build_tools()` (a link failure of a test tool must not read
+    as 'building libgsr_hip.so failed')."""
     cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or r.returncode != 0:
@@ -116,6 +119,15 @@ def build(verbose: bool = False) -> str:
     if r.returncode != 0:
         raise RuntimeError("building libgsr_hip.so failed")
     return LIB_PATH
+
+
+def build_tools(verbose: bool = False) -> bool:
+    """`make tools`: host_wait_threads (host code through the C ABI).  Returns False — with the compiler's words on stdout —
+    when it does not build; never raises."""
+    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "tools"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-2000:], r.stderr[-2000:])
+    return r.returncode == 0
 
 
 def load():
@@ -165,6 +177,7 @@ def load():
                                           C.POINTER(f32), C.POINTER(C.c_uint32), f32, f32, f32, vp, vp, vp, vp]
     lib.gsr_backward_trainer_tail.argtypes = [vp, C.POINTER(Inputs), C.POINTER(CameraS), vp, C.POINTER(TailState), vp]
     lib.gsr_stream_triad.argtypes = [vp, vp, vp, C.c_size_t, f32, vp]
+    lib.gsr_ssim_precision.argtypes = [i32]
     lib.gsr_profile_enable.argtypes = [vp, i32]
     lib.gsr_profile_stages.argtypes = [vp, C.c_uint32]
     lib.gsr_profile_stage_name.argtypes = [i32]

@@ -276,6 +276,10 @@ static inline void cpu_relax() {
 struct WaitPolicy { int spin_us = 30, yield_us = 0, sleep_us = 0; };
 WaitPolicy g_wait;
 
+// gsr_ssim_precision: 0 = the contracted build of ssim.hip (default), 1 = its bit-exact twin.  GSR_SSIM_EXACT=1 in the
+// environment starts a process in exact mode (A/B runs of unmodified callers).
+int g_ssim_exact = [] { const char* e = getenv("GSR_SSIM_EXACT"); return e && e[0] == '1' ? 1 : 0; }();
+
 // Wait until tile_scan of forward `seq` has published its totals (a word of pinned host memory).
 // A wait that lasts longer than any sane queue depth (50 ms) starts polling the stream, so that a failed launch or a
 // faulted kernel ends with an error instead of hanging the caller — not earlier: hipStreamQuery puts a marker packet on
@@ -373,6 +377,12 @@ int gsr_abi_version(void) { return GSR_ABI_VERSION; }
 int gsr_host_wait_policy(int spin_us, int yield_us, int sleep_us) {
     if (spin_us < 0 || yield_us < 0 || sleep_us < 0) return fail(GSR_E_INVALID_ARG, "negative wait time");
     g_wait.spin_us = spin_us; g_wait.yield_us = yield_us; g_wait.sleep_us = sleep_us;
+    return GSR_OK;
+}
+
+int gsr_ssim_precision(int exact) {
+    if (exact != 0 && exact != 1) return fail(GSR_E_INVALID_ARG, "gsr_ssim_precision: 0 (fast) or 1 (exact)");
+    g_ssim_exact = exact;
     return GSR_OK;
 }
 
@@ -785,8 +795,8 @@ int gsr_ssim_forward(int W, int H, int CH, int B, const float* img, const float*
     if (!img || !ref || !ssim_map) return fail(GSR_E_INVALID_ARG, "null SSIM array");
     if (train && (!dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12)) return fail(GSR_E_INVALID_ARG, "train needs the 3 partial maps");
     if ((size_t)CH * B > 65535) return fail(GSR_E_INVALID_ARG, "CH*B too large");
-    gsr_launch_ssim_fwd((hipStream_t)stream, W, H, CH, B, img, ref, C1, C2, train, ssim_map, dm_dmu1, dm_dsigma1_sq,
-                        dm_dsigma12);
+    (g_ssim_exact ? gsr_launch_ssim_fwd_exact : gsr_launch_ssim_fwd_fast)((hipStream_t)stream, W, H, CH, B, img, ref, C1, C2, train,
+                                                                          ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12);
     HIPCHK(hipGetLastError());
     return GSR_OK;
 }
@@ -798,8 +808,8 @@ int gsr_ssim_backward(int W, int H, int CH, int B, const float* img, const float
     if (!img || !ref || !dL_dmap || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg)
         return fail(GSR_E_INVALID_ARG, "null SSIM array");
     if ((size_t)CH * B > 65535) return fail(GSR_E_INVALID_ARG, "CH*B too large");
-    gsr_launch_ssim_bwd((hipStream_t)stream, W, H, CH, B, img, ref, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
-                        dL_dimg);
+    (g_ssim_exact ? gsr_launch_ssim_bwd_exact : gsr_launch_ssim_bwd_fast)((hipStream_t)stream, W, H, CH, B, img, ref, dL_dmap, dm_dmu1,
+                                                                          dm_dsigma1_sq, dm_dsigma12, dL_dimg);
     HIPCHK(hipGetLastError());
     return GSR_OK;
 }
@@ -816,12 +826,13 @@ int gsr_loss_l1_ssim(gsr_handle* h, const float* image, const float* target, flo
         return rc;
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;  // fused_ssim.jl:374
     StageScope sc9(h->prof, ST_LOSS_FWD, s);
-    gsr_launch_loss_fwd(s, W, H, C, image, target, C1, C2, h->d0.as<float>(), h->d1.as<float>(), h->d2.as<float>(),
-                        h->partial.as<float>());
+    (g_ssim_exact ? gsr_launch_loss_fwd_exact : gsr_launch_loss_fwd_fast)(s, W, H, C, image, target, C1, C2, h->d0.as<float>(),
+                                                                          h->d1.as<float>(), h->d2.as<float>(), h->partial.as<float>());
     sc9.close();
     StageScope sc10(h->prof, ST_LOSS_BWD, s);
-    gsr_launch_loss_bwd(s, W, H, C, image, target, lambda_dssim, h->d0.as<float>(), h->d1.as<float>(),
-                        h->d2.as<float>(), h->partial.as<float>(), loss_out, vpixels);
+    (g_ssim_exact ? gsr_launch_loss_bwd_exact : gsr_launch_loss_bwd_fast)(s, W, H, C, image, target, lambda_dssim, h->d0.as<float>(),
+                                                                          h->d1.as<float>(), h->d2.as<float>(), h->partial.as<float>(),
+                                                                          loss_out, vpixels);
     sc10.close();
     HIPCHK(hipGetLastError());
     return GSR_OK;

@@ -184,14 +184,19 @@ void gsr_launch_nonfinite_scan(hipStream_t s, int n_groups, const float* const* 
 void gsr_launch_ply_rows(hipStream_t s, bool pack, long long n, int kr, float* points, float* dc, float* rest, float* opac,
                          float* scales, float* rots, float* rows);
 
-// ---- ssim.hip ----
-void gsr_launch_ssim_fwd(hipStream_t s, int W, int H, int CH, int B, const float* img, const float* ref, float C1,
-                         float C2, int train, float* ssim_map, float* d0, float* d1, float* d2);
-void gsr_launch_ssim_bwd(hipStream_t s, int W, int H, int CH, int B, const float* img, const float* ref,
-                         const float* dL_dmap, const float* d0, const float* d1, const float* d2, float* dL_dimg);
-// fused loss head: image (C,W,H) vs target (W,H,3)
-void gsr_launch_loss_fwd(hipStream_t s, int W, int H, int C, const float* image, const float* target, float C1,
-                         float C2, float* d0, float* d1, float* d2, float* partial /* [3T][2]: per-workgroup sum|x-y|, sum ssim */);
-void gsr_launch_loss_bwd(hipStream_t s, int W, int H, int C, const float* image, const float* target, float lambda,
-                         const float* d0, const float* d1, const float* d2, const float* partial, float* loss_out,
-                         float* vpixels);
+// ---- ssim.hip (compiled twice: *_exact = -ffp-contract=off + IEEE divisions, bit-exact vs the oracle; *_fast = contracted
+// multiply-adds + hardware reciprocals, the default path; gsr_ssim_precision selects) ----
+#define GSR_SSIM_DECL(SUF)                                                                                              \
+    void gsr_launch_ssim_fwd_##SUF(hipStream_t s, int W, int H, int CH, int B, const float* img, const float* ref, float C1, \
+                                   float C2, int train, float* ssim_map, float* d0, float* d1, float* d2);             \
+    void gsr_launch_ssim_bwd_##SUF(hipStream_t s, int W, int H, int CH, int B, const float* img, const float* ref,      \
+                                   const float* dL_dmap, const float* d0, const float* d1, const float* d2, float* dL_dimg); \
+    /* fused loss head: image (C,W,H) vs target (W,H,3); partial: [3T][2] per-workgroup sum|x-y|, sum ssim */          \
+    void gsr_launch_loss_fwd_##SUF(hipStream_t s, int W, int H, int C, const float* image, const float* target, float C1, \
+                                   float C2, float* d0, float* d1, float* d2, float* partial);                         \
+    void gsr_launch_loss_bwd_##SUF(hipStream_t s, int W, int H, int C, const float* image, const float* target, float lambda, \
+                                   const float* d0, const float* d1, const float* d2, const float* partial, float* loss_out, \
+                                   float* vpixels);
+GSR_SSIM_DECL(exact)
+GSR_SSIM_DECL(fast)
+#undef GSR_SSIM_DECL

@@ -4,11 +4,27 @@
 //
 // 16x16 output tile + 5-pixel halo staged in LDS, separable 11-tap Gaussian:
 // horizontal pass into LDS, vertical pass in registers.  Accumulation order follows the
-// reference (symmetric pairs d = 1..5 with weight GAUSS[5-d], centre tap last) and this
-// file is compiled with -ffp-contract=off, so the maps are bit-reproducible against the
-// CPU oracle.  grid.z enumerates (channel, batch) planes for the generic entry points; the
-// loss head loops the three channels inside one workgroup, as the reference does.
+// reference (symmetric pairs d = 1..5 with weight GAUSS[5-d], centre tap last).  grid.z enumerates
+// (channel, batch) planes for the generic entry points; the loss head loops the three channels inside
+// one workgroup, as the reference does.
+//
+// This file is compiled TWICE into the library (csrc/Makefile):
+//   SSIM_EXACT = 1, -ffp-contract=off: every fp32 operation as written, IEEE divisions — the maps are
+//       bit-reproducible against the CPU oracle (the oracle's twin; gsr_ssim_precision(1) selects it);
+//   SSIM_EXACT = 0 (the default path), -ffp-contract=fast: the same expressions with the multiply-adds fused
+//       and the six divisions of the SSIM formula replaced by two hardware reciprocals — what any GPU compiler
+//       makes of the reference's source ("contraction order unspecified, LLVM may fuse FMAs");
+//       parity at the stated fp32 tolerance instead of bit for bit; −46 % VALU instructions per pixel.
 #include "gsr_kernels.h"
+
+#ifndef SSIM_EXACT
+#define SSIM_EXACT 1
+#endif
+#if SSIM_EXACT
+#define SSIM_NAME(x) x##_exact
+#else
+#define SSIM_NAME(x) x##_fast
+#endif
 
 namespace {
 
@@ -143,8 +159,9 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(Src src, int W, int H, fl
         const float sigma1_sq = o[1] - mu1_sq, sigma2_sq = o[3] - mu2_sq, sigma12 = o[4] - mu1 * mu2;
         const float A = mu1_sq + mu2_sq + C1, Bv = sigma1_sq + sigma2_sq + C2;
         const float Cv = 2.0f * mu1 * mu2 + C1, Dv = 2.0f * sigma12 + C2;
-        const float val = (Cv * Dv) / (A * Bv);
         const size_t oi = (size_t)px + (size_t)W * py + (size_t)W * H * plane;
+#if SSIM_EXACT
+        const float val = (Cv * Dv) / (A * Bv);
         if (!LOSS) ssim_map[oi] = val;
         if (train) {
             d0[oi] = ((mu2 * 2.0f * Dv) / (A * Bv) - (mu2 * 2.0f * Cv) / (A * Bv) -
@@ -152,6 +169,17 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(Src src, int W, int H, fl
             d1[oi] = (-Cv * Dv) / (A * Bv * Bv);
             d2[oi] = (2.0f * Cv) / (A * Bv);
         }
+#else
+        // the same four quotients (fused_ssim.jl:219-233) over two reciprocals: 1/(AB) = rA·rB, 1/(A²B) = rA·rAB, 1/(AB²) = rB·rAB
+        const float rA = __builtin_amdgcn_rcpf(A), rB = __builtin_amdgcn_rcpf(Bv), rAB = rA * rB;
+        const float val = (Cv * Dv) * rAB;
+        if (!LOSS) ssim_map[oi] = val;
+        if (train) {
+            d0[oi] = 2.0f * (mu2 * (Dv - Cv) * rAB + mu1 * val * (rB - rA));
+            d1[oi] = -val * rB;
+            d2[oi] = 2.0f * Cv * rAB;
+        }
+#endif
         if (LOSS) {
             sv += val;
             l1 += fabsf(sx[ty + HALO][tx + HALO] - sy[ty + HALO][tx + HALO]);
@@ -284,28 +312,28 @@ static dim3 ssim_grid(int W, int H, int planes) {
     return dim3(8 * ((n + 7) / 8), 1, planes);
 }
 
-void gsr_launch_ssim_fwd(hipStream_t s, int W, int H, int CH, int B, const float* img, const float* ref, float C1,
+void SSIM_NAME(gsr_launch_ssim_fwd)(hipStream_t s, int W, int H, int CH, int B, const float* img, const float* ref, float C1,
                          float C2, int train, float* ssim_map, float* d0, float* d1, float* d2) {
     PlanarSrc src{img, ref, W, H};
     hipLaunchKernelGGL((ssim_fwd_kernel<PlanarSrc, false, 1>), ssim_grid(W, H, CH * B), dim3(256), 0, s, src, W, H, C1,
                        C2, train, ssim_map, d0, d1, d2, (float*)nullptr);
 }
 
-void gsr_launch_ssim_bwd(hipStream_t s, int W, int H, int CH, int B, const float* img, const float* ref,
+void SSIM_NAME(gsr_launch_ssim_bwd)(hipStream_t s, int W, int H, int CH, int B, const float* img, const float* ref,
                          const float* dL_dmap, const float* d0, const float* d1, const float* d2, float* dL_dimg) {
     PlanarSrc src{img, ref, W, H};
     hipLaunchKernelGGL((ssim_bwd_kernel<PlanarSrc, false, 1>), ssim_grid(W, H, CH * B), dim3(256), 0, s, src, W, H,
                        dL_dmap, 0.0f, 0.0f, d0, d1, d2, dL_dimg, 0, (const float*)nullptr, 0, 0.0f, 0.0f, (float*)nullptr);
 }
 
-void gsr_launch_loss_fwd(hipStream_t s, int W, int H, int C, const float* image, const float* target, float C1,
+void SSIM_NAME(gsr_launch_loss_fwd)(hipStream_t s, int W, int H, int C, const float* image, const float* target, float C1,
                          float C2, float* d0, float* d1, float* d2, float* partial) {
     RasterSrc src{image, target, W, H, C};
     hipLaunchKernelGGL((ssim_fwd_kernel<RasterSrc, true, 3>), ssim_grid(W, H, 1), dim3(256), 0, s, src, W, H, C1, C2, 1,
                        (float*)nullptr, d0, d1, d2, partial);
 }
 
-void gsr_launch_loss_bwd(hipStream_t s, int W, int H, int C, const float* image, const float* target, float lambda,
+void SSIM_NAME(gsr_launch_loss_bwd)(hipStream_t s, int W, int H, int C, const float* image, const float* target, float lambda,
                          const float* d0, const float* d1, const float* d2, const float* partial, float* loss_out,
                          float* vpixels) {
     RasterSrc src{image, target, W, H, C};

@@ -15,6 +15,23 @@ C1_DEFAULT = 0.01 ** 2
 C2_DEFAULT = 0.03 ** 2
 
 
+class exact_arithmetic:
+    """`with fused_ssim.exact_arithmetic():` — gsr_ssim_precision(1) inside the block: every fp32 operation of the three SSIM
+    entry points as written (no FMA contraction, IEEE divisions), bit-identical to the CPU oracle.  Outside it the library's
+    default (contracted multiply-adds, two reciprocals for the formula's six divisions) applies.  Process-wide switch."""
+
+    def __init__(self, on: bool = True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        L.check(L.load().gsr_ssim_precision(1 if self.on else 0))
+        return self
+
+    def __exit__(self, *exc):
+        L.check(L.load().gsr_ssim_precision(0))
+        return False
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 

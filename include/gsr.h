@@ -271,6 +271,15 @@ GSR_API int gsr_ssim_backward(int W, int H, int CH, int B, const float* img, con
                               const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
                               float* dL_dimg, void* stream);
 
+/* Arithmetic of the three SSIM entry points (gsr_ssim_forward / gsr_ssim_backward / gsr_loss_l1_ssim).  Process-wide.
+ *   0 (default): multiply-adds contracted to FMAs and the six divisions of the SSIM formula (fused_ssim.jl:219-233) taken over
+ *      two hardware reciprocals — what a GPU compiler makes of the reference's own source; results agree with the
+ *      fp32-as-written evaluation to ~1e-6 relative (the loss to 1e-6 absolute, its pullback to 1e-5 relative L2);
+ *   1: every fp32 operation as written, IEEE divisions: bit-identical to the CPU oracle (the parity tests' twin), ~35 us
+ *      slower per 1080p loss evaluation.
+ * GSR_SSIM_EXACT=1 in the environment starts the process in mode 1. */
+GSR_API int gsr_ssim_precision(int exact);
+
 /* The photometric loss head of Trainer.step! — src/training.jl:656,684-694:
  *   image = features[1:3,:,:]; permute to (W,H,3,1);
  *   L = (1-lambda)*mean|image-target| + lambda*(1-mean(fused_ssim(image; ref=target)))

@@ -3,7 +3,7 @@ polite"): eight handles driven by eight host threads — the shape of an 8-rank 
 with the default policy (30 us spin, then sched_yield polling) and with the opt-in adaptive sleep (100, 0, 50) as with a
 pure busy spin.
 
-The eight threads are NATIVE (tools/host_wait_threads.cpp, built next to the library by its Makefile, straight through
+The eight threads are NATIVE (tools/host_wait_threads.cpp, built next to the library by `make tools`, straight through
 the C ABI): the first version of this test drove the handles from eight Python threads and measured the GIL — 0.8 to
 2.2 ms per step for one and the same policy, a failure in one run of three on an idle box.  The native program repeats to
 0.2 % (1.106 .. 1.111 ms per step in every policy over six runs; 7.35 CPU-ms per step spinning, 0.77 with the sleep)."""
@@ -21,7 +21,7 @@ PROG = os.path.join(ROOT, "gaussiansplatting.jl_amd", "host_wait_threads")
 
 def test_eight_threads_step_time_unchanged_with_the_back_off(pkg):
     if not os.path.exists(PROG):
-        pkg._lib.build()  # (the Makefile's default target builds the program with the library)
+        pkg._lib.build_tools()  # (`make tools`: not part of the product build)
     assert os.path.exists(PROG), "gaussiansplatting.jl_amd/csrc/Makefile did not build host_wait_threads"
     out = subprocess.run([PROG, "8", "300", "3"], capture_output=True, text=True, timeout=600)
     print(out.stdout)

@@ -443,18 +443,45 @@ def test_k15_sky_dome(pkg, orc):
 # ---- SSIM + loss head ----
 @pytest.mark.parametrize("shape", [(2, 3, 128, 128), (1, 3, 37, 53), (1, 1, 16, 16)])
 def test_ssim_vs_oracle(pkg, orc, shape):
+    """The exact twin of ssim.hip (gsr_ssim_precision(1)): bit for bit the oracle's maps and pullback."""
+    rng = np.random.default_rng(5)
+    x = rng.uniform(size=shape).astype(np.float32)
+    y = rng.uniform(size=shape).astype(np.float32)
+    m, d0, d1, d2 = orc.ssim_forward(x, y, train=True)
+    F = pkg.fused_ssim
+    with F.exact_arithmetic():
+        hm, h0, h1, h2 = F._fused_ssim(dev(x), dev(y), train=True)
+        for a, b in ((hm, m), (h0, d0), (h1, d1), (h2, d2)):
+            assert np.array_equal(a.cpu().numpy(), b), "SSIM maps are bit-exact (no FMA contraction)"
+        dl = rng.standard_normal(shape).astype(np.float32)
+        g = orc.ssim_backward(x, y, dl, d0, d1, d2)
+        hg = F.fused_ssim_bwd(dev(x), dev(y), dev(dl), h0, h1, h2)
+        assert np.array_equal(hg.cpu().numpy(), g)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 128, 128), (1, 3, 37, 53), (1, 1, 16, 16)])
+def test_default_ssim_arithmetic_vs_oracle_at_fp32_tolerance(pkg, orc, shape):
+    """The library's DEFAULT SSIM path: multiply-adds contracted, the formula's six divisions over two reciprocals (what a GPU
+    compiler makes of fused_ssim.jl).  Against the oracle's fp32-as-written evaluation: the SSIM map to
+    2e-6 absolute (its values lie in [-1, 1]), the derivative maps and the pullback to 1e-5 of their L2 norm and element-wise
+    to 1e-4 relative + 1e-5 of the map's scale on 99.9 % of the values."""
     rng = np.random.default_rng(5)
     x = rng.uniform(size=shape).astype(np.float32)
     y = rng.uniform(size=shape).astype(np.float32)
     m, d0, d1, d2 = orc.ssim_forward(x, y, train=True)
     F = pkg.fused_ssim
     hm, h0, h1, h2 = F._fused_ssim(dev(x), dev(y), train=True)
-    for a, b in ((hm, m), (h0, d0), (h1, d1), (h2, d2)):
-        assert np.array_equal(a.cpu().numpy(), b), "SSIM maps are bit-exact (no FMA contraction)"
+    assert np.abs(hm.cpu().numpy() - m).max() <= 2e-6
+    for a, b in ((h0, d0), (h1, d1), (h2, d2)):
+        a = a.cpu().numpy()
+        assert rel_l2(a, b) <= 1e-5
+        assert frac_bad(a, b, 1e-4, 1e-5 * float(np.abs(b).max())) <= 1e-3
     dl = rng.standard_normal(shape).astype(np.float32)
     g = orc.ssim_backward(x, y, dl, d0, d1, d2)
-    hg = F.fused_ssim_bwd(dev(x), dev(y), dev(dl), h0, h1, h2)
-    assert np.array_equal(hg.cpu().numpy(), g)
+    hg = F.fused_ssim_bwd(dev(x), dev(y), dev(dl), h0, h1, h2).cpu().numpy()   # (its own derivative maps: the whole chain)
+    assert rel_l2(hg, g) <= 1e-5
+    assert frac_bad(hg, g, 1e-4, 1e-5 * float(np.abs(g).max())) <= 1e-3
+    assert not np.array_equal(hm.cpu().numpy(), m) or shape[-1] <= 16  # (it IS the other build: not bit-identical at size)
 
 
 def test_ssim_known_answers_and_autograd(pkg):
@@ -479,12 +506,17 @@ def test_loss_head_vs_oracle(pkg, orc, mode):
     tgt = pkg.synthetic.make_target(W, H, 77)
     loss, vp = orc.loss_head(st.image, tgt)
     run = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, 1, mode=mode)
-    # feed the oracle's image so only the loss head is compared
+    # feed the oracle's image so only the loss head is compared; default (contracted) arithmetic at tolerance, then the exact
+    # twin, whose pullback is the oracle's bit for bit
     hl, hv = pkg.fused_ssim.l1_ssim_loss(run.rast, dev(st.image), dev(tgt))
     torch.cuda.synchronize()
     assert abs(float(hl) - float(loss)) <= 1e-5 * max(1.0, abs(float(loss)))
     assert rel_l2(hv.cpu().numpy(), vp) <= 1e-5
     assert not hv.cpu().numpy()[:, :, 3:].any()
+    with pkg.fused_ssim.exact_arithmetic():
+        hl2, hv2 = pkg.fused_ssim.l1_ssim_loss(run.rast, dev(st.image), dev(tgt))
+        torch.cuda.synchronize()
+    assert abs(float(hl2) - float(loss)) <= 1e-6 and np.array_equal(hv2.cpu().numpy(), vp)
 
 
 def test_functor_autograd_end_to_end(pkg, orc):

@@ -340,7 +340,11 @@ constexpr int BWD_BATCH = GSR_BWD_BATCH;  // splats staged per round (LDS: one a
 // LISTED: the tiles of one tier list of the scan (lists longer than GSR_BWD_SPLIT_LEN) — launched with PPL = 1, four
 // waves per tile on a second stream next to the main PPL = 4 launch, which leaves those tiles out: one wave walking a
 // list of 30 k instances is milliseconds long (real captures have such tiles; config 3 has none).
-template <int C, int PPL, bool LISTED>
+// BG0: the background is exactly (0, 0, 0) — the reference's default (rasterizer.jl:209) and what a trainer without a sky
+// colour passes: the term -T_final/(1-α)·(bg·v) (render.jl:259) vanishes identically, and with it four registers of
+// per-pixel state and one FMA per active visit.  With the fy trick below that is what takes the :rgbd kernel (the
+// reference's default mode) from 88 to 80 VGPRs = from five to six waves per SIMD (:rgbdn 101 -> 94: four to five).
+template <int C, int PPL, bool LISTED, bool BG0>
 __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_kernel(int W, int H, int grid_x,
                                                                 const uint32_t* __restrict__ tile_start,
                                                                 const uint32_t* __restrict__ tile_order,
@@ -388,7 +392,10 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
     if (!LISTED && end - start > tiers.split_len) return;  // the four-wave launch over the tier lists owns this tile
 
     // per-pixel state (PPL pixels per lane: rows py0 and py0 + 4)
-    float fy[PPL], T[PPL], A[PPL], bgT[PPL], vp[PPL][C];
+    // (C > 3: the rows' y coordinates are rebuilt from the first one — fy0 + 4q, exact in fp32, so dy and sigma keep their
+    //  bits — instead of living in PPL registers: one more add per visited group, three registers less)
+    constexpr bool FY_REBUILD = C > 3 && PPL > 1;
+    float fy[FY_REBUILD ? 1 : PPL], T[PPL], A[PPL], bgT[BG0 ? 1 : PPL], vp[PPL][C];
     int last_contributor[PPL];
     int wave_last = 0;  // deepest list position any pixel of this wave blended
 #pragma unroll
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
         const int py = py0 + 4 * q;
         const bool inside = px < W && py < H;
         const size_t pi = (size_t)px + (size_t)W * py;
-        fy[q] = (float)py;
+        if (!FY_REBUILD || q == 0) fy[FY_REBUILD ? 0 : q] = (float)py;
         const float T_final = inside ? final_T[pi] : 0.0f;
         T[q] = T_final;
         last_contributor[q] = inside ? (int)n_contrib[pi] : 0;
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
             vp[q][c] = inside ? vpixels[(size_t)C * pi + c] : 0.0f;
             bg_dot += bg.v[c] * vp[q][c];
         }
-        bgT[q] = -T_final * bg_dot;
+        if (!BG0) bgT[BG0 ? 0 : q] = -T_final * bg_dot;
         // The reference carries accum_rec[c], last_color[c], last_alpha per channel and forms
         //   vα = Σ_c (color[c] - accum_rec[c])·v[c]            (render.jl:245-252).
         // Only the dot product with the pixel cotangent is ever used, so the state is folded to
@@ -484,7 +491,8 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
                 // merges behind it — the ballot accumulator —, is scalar; without it the test and `any_active` were VALU)
                 if (PPL > 1 && __builtin_amdgcn_readfirstlane((int)((rowbits >> (4 * q)) & 0xFu)) == 0) continue;
 #endif
-                const float dy = a.y - fy[q], dy2 = __fmul_rn(dy, dy);
+                const float fyq = FY_REBUILD ? fy[0] + (float)(4 * q) : fy[FY_REBUILD ? 0 : q];
+                const float dy = a.y - fyq, dy2 = __fmul_rn(dy, dy);
                 const float sigma = sigma_of(sx, b.x, dy, dy2);
                 // the blend test is one unsigned compare of sigma against the instance's threshold; exp and alpha are only
                 // computed for the lanes that pass (they run under EXEC = active)
@@ -504,7 +512,7 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
 #pragma unroll
                     for (int c = 1; c < C; c++) cv += f[c] * vp[q][c];
                     const float d = cv - A[q];                 // (color - accum_rec)·v
-                    const float valpha = d * T[q] + bgT[q] * rinv;
+                    const float valpha = BG0 ? d * T[q] : d * T[q] + bgT[BG0 ? 0 : q] * rinv;
                     A[q] = A[q] + alpha * d;                   // α·cv + (1-α)·A for the next (nearer) splat
                     const float t = G * valpha;
                     P += t;
@@ -600,6 +608,15 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
     }
 }
 
+// exactly zero (either sign) in every channel: the kernels' BG0 specialisation; GSR_NO_BG0=1 disables it (A/B runs)
+bool bg_is_zero(const Bg& b) {
+    static const bool off = [] { const char* e = getenv("GSR_NO_BG0"); return e && e[0] == '1'; }();
+    if (off) return false;
+    for (int c = 0; c < 8; c++)
+        if (b.v[c] != 0.0f) return false;
+    return true;
+}
+
 Bg make_bg(const float* background, int channels) {
     Bg b;
     for (int c = 0; c < 8; c++) b.v[c] = (c < 3 && c < channels) ? background[c] : 0.0f;  // rasterizer.jl:411-414
@@ -657,13 +674,16 @@ void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uin
     Bg bg = make_bg(background, channels);
     GsrTierLists none{};
     none.split_len = split_len;
-#define LAUNCH(CC)                                                                                                 \
-    hipLaunchKernelGGL((composite_bwd_kernel<CC, GSR_BWD_PPL, false>), grid, block, 0, s, cam.width, cam.height,   \
+    const bool bg0 = bg_is_zero(bg);
+#define LAUNCH2(CC, ZZ)                                                                                                \
+    hipLaunchKernelGGL((composite_bwd_kernel<CC, GSR_BWD_PPL, false, ZZ>), grid, block, 0, s, cam.width, cam.height,   \
                        cam.grid_x, tile_start, tile_order, stream, bg, vpixels, n_contrib, final_T, inst, none)
+#define LAUNCH(CC) do { if (bg0) LAUNCH2(CC, true); else LAUNCH2(CC, false); } while (0)
     if (channels == 3) LAUNCH(3);
     else if (channels == 5) LAUNCH(5);
     else LAUNCH(8);
 #undef LAUNCH
+#undef LAUNCH2
 }
 
 void gsr_launch_composite_bwd_listed(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
@@ -674,7 +694,7 @@ void gsr_launch_composite_bwd_listed(hipStream_t s, int channels, GsrCam cam, co
     dim3 grid(n_listed), block(256);
     Bg bg = make_bg(background, channels);
 #define LAUNCH(CC)                                                                                                 \
-    hipLaunchKernelGGL((composite_bwd_kernel<CC, 1, true>), grid, block, 0, s, cam.width, cam.height, cam.grid_x,  \
+    hipLaunchKernelGGL((composite_bwd_kernel<CC, 1, true, false>), grid, block, 0, s, cam.width, cam.height, cam.grid_x,  \
                        tile_start, (const uint32_t*)nullptr, stream, bg, vpixels, n_contrib, final_T, inst, tiers)
     if (channels == 3) LAUNCH(3);
     else if (channels == 5) LAUNCH(5);

@@ -342,8 +342,11 @@ constexpr int BWD_BATCH = GSR_BWD_BATCH;  // splats staged per round (LDS: one a
 // list of 30 k instances is milliseconds long (real captures have such tiles; config 3 has none).
 // BG0: the background is exactly (0, 0, 0) — the reference's default (rasterizer.jl:209) and what a trainer without a sky
 // colour passes: the term -T_final/(1-α)·(bg·v) (render.jl:259) vanishes identically, and with it four registers of
-// per-pixel state and one FMA per active visit.  With the fy trick below that is what takes the :rgbd kernel (the
-// reference's default mode) from 88 to 80 VGPRs = from five to six waves per SIMD (:rgbdn 101 -> 94: four to five).
+// per-pixel state and one FMA per active visit.  With the fy trick below: :rgb 74 -> 70 VGPRs (6 -> 7 waves per SIMD),
+// :rgbd 88 -> 80 (5 -> 6), :rgbdn 101 -> 94 (4 -> 5).  Measured at config-3 size (profiles/r04/experiments/
+// bwd_occupancy_ab.txt, A/B in one run, two repetitions): :rgbdn 0.907 -> 0.876 ms — kept; :rgbd 0.7236 -> 0.770 ms and :rgb
+// 0.659 -> 0.676 ms — SLOWER with the extra wave (as round 3's forced-occupancy probes said: 789 / 735 / 677 / 695 us at 4 / 5 /
+// 6 / 7 waves), so the launcher only takes the BG0 kernel for C == 8 and the other two instantiations are never launched.
 template <int C, int PPL, bool LISTED, bool BG0>
 __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_kernel(int W, int H, int grid_x,
                                                                 const uint32_t* __restrict__ tile_start,
@@ -392,9 +395,9 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
     if (!LISTED && end - start > tiers.split_len) return;  // the four-wave launch over the tier lists owns this tile
 
     // per-pixel state (PPL pixels per lane: rows py0 and py0 + 4)
-    // (C > 3: the rows' y coordinates are rebuilt from the first one — fy0 + 4q, exact in fp32, so dy and sigma keep their
+    // (:rgbdn: the rows' y coordinates are rebuilt from the first one — fy0 + 4q, exact in fp32, so dy and sigma keep their
     //  bits — instead of living in PPL registers: one more add per visited group, three registers less)
-    constexpr bool FY_REBUILD = C > 3 && PPL > 1;
+    constexpr bool FY_REBUILD = C > 5 && PPL > 1;
     float fy[FY_REBUILD ? 1 : PPL], T[PPL], A[PPL], bgT[BG0 ? 1 : PPL], vp[PPL][C];
     int last_contributor[PPL];
     int wave_last = 0;  // deepest list position any pixel of this wave blended
@@ -666,24 +669,53 @@ void gsr_launch_sort_composite_fwd(hipStream_t s, int channels, GsrCam cam, cons
 #undef LAUNCH2
 }
 
+// Tiles order_first .. order_first + order_count - 1 of the launch order, `ppl` pixels per lane: 4 = one wave per tile (the main
+// launch), 1 = four waves per tile (the backfill of the launch's last, partial round: gsr_api.cpp launch_composite_bwd).
 void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
                               const uint32_t* tile_order, GsrStream stream, const float* background,
                               const float* vpixels, const uint32_t* n_contrib, const float* final_T, GsrInst inst,
-                              uint32_t split_len) {
-    dim3 grid(cam.grid_x * cam.grid_y), block(256 / GSR_BWD_PPL);
+                              uint32_t split_len, uint32_t order_first, uint32_t order_count, int ppl) {
+    if (order_count == 0) return;
+    dim3 grid(order_count), block(256 / ppl);
     Bg bg = make_bg(background, channels);
     GsrTierLists none{};
     none.split_len = split_len;
     const bool bg0 = bg_is_zero(bg);
-#define LAUNCH2(CC, ZZ)                                                                                                \
-    hipLaunchKernelGGL((composite_bwd_kernel<CC, GSR_BWD_PPL, false, ZZ>), grid, block, 0, s, cam.width, cam.height,   \
-                       cam.grid_x, tile_start, tile_order, stream, bg, vpixels, n_contrib, final_T, inst, none)
-#define LAUNCH(CC) do { if (bg0) LAUNCH2(CC, true); else LAUNCH2(CC, false); } while (0)
-    if (channels == 3) LAUNCH(3);
-    else if (channels == 5) LAUNCH(5);
-    else LAUNCH(8);
-#undef LAUNCH
+    const uint32_t* order = tile_order + order_first;
+#define LAUNCH2(CC, PP, ZZ)                                                                                            \
+    hipLaunchKernelGGL((composite_bwd_kernel<CC, PP, false, ZZ>), grid, block, 0, s, cam.width, cam.height,            \
+                       cam.grid_x, tile_start, order, stream, bg, vpixels, n_contrib, final_T, inst, none)
+    if (ppl == GSR_BWD_PPL) {
+        if (channels == 3) LAUNCH2(3, GSR_BWD_PPL, false);
+        else if (channels == 5) LAUNCH2(5, GSR_BWD_PPL, false);
+        else if (bg0) LAUNCH2(8, GSR_BWD_PPL, true);
+        else LAUNCH2(8, GSR_BWD_PPL, false);
+    } else if (ppl == 2) {
+        if (channels == 3) LAUNCH2(3, 2, false);
+        else if (channels == 5) LAUNCH2(5, 2, false);
+        else LAUNCH2(8, 2, false);
+    } else {
+        if (channels == 3) LAUNCH2(3, 1, false);
+        else if (channels == 5) LAUNCH2(5, 1, false);
+        else LAUNCH2(8, 1, false);
+    }
 #undef LAUNCH2
+}
+
+// Wave slots of the whole device for the main (one wave per tile) backward kernel of a render mode: resident workgroups per CU
+// (registers and LDS, from the runtime's occupancy calculator) x CUs.  The launch's last, partial round is what is left of
+// the tile count after whole multiples of this.
+uint32_t gsr_composite_bwd_wave_slots(int channels, bool zero_background) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return 0;
+    hipError_t e;
+    if (channels == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, composite_bwd_kernel<3, GSR_BWD_PPL, false, false>, 256 / GSR_BWD_PPL, 0);
+    else if (channels == 5) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, composite_bwd_kernel<5, GSR_BWD_PPL, false, false>, 256 / GSR_BWD_PPL, 0);
+    else if (zero_background) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, composite_bwd_kernel<8, GSR_BWD_PPL, false, true>, 256 / GSR_BWD_PPL, 0);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, composite_bwd_kernel<8, GSR_BWD_PPL, false, false>, 256 / GSR_BWD_PPL, 0);
+    if (e != hipSuccess || per_cu <= 0 || cus <= 0) return 0;
+    return (uint32_t)per_cu * (uint32_t)cus;
 }
 
 void gsr_launch_composite_bwd_listed(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,

@@ -49,14 +49,16 @@ def frac_bad(a, b, rtol, atol):
     return float((np.abs(a - b) > rtol * np.abs(b) + atol).mean())
 
 
-def blend_boundary_pixels(st, opacities, W, H, ulps=4):
+def blend_boundary_pixels(st, opacities, W, H, ulps=4, with_ids=False):
     """Pixels of the oracle state `st` at which some (pixel, splat) pair of the tile's list sits within `ulps` ulps of the
     blend-test boundary sigma = ln(255·o) (render.jl:92-95: alpha = 1/255 exactly).  There the decision depends on the last
     bit of the exp that produced alpha — two exp implementations disagree, and so may the kernels' single-compare test
     (tile_sort_device.h blend_threshold_bits) and the oracle's libm expf.  Small-image parity tests, where ONE pixel is
     already more than the 1e-4 outlier fraction, leave these pixels out of the count (measured case: seed 103, 80x64, pixel
-    (20, 31), sigma == tau bit for bit, alpha·255 == 1.0f).  Small images only (pure numpy over every tile list)."""
+    (20, 31), sigma == tau bit for bit, alpha·255 == 1.0f).  Small images only (pure numpy over every tile list).
+    with_ids=True: also the set of Gaussian ids that own such a pair."""
     mask = np.zeros((H, W), bool)
+    owners = set()
     tw = (W + 15) // 16
     op = np.asarray(opacities, np.float32).reshape(-1)
     for t, (a, b) in enumerate(np.asarray(st.ranges)):
@@ -74,4 +76,6 @@ def blend_boundary_pixels(st, opacities, W, H, ulps=4):
                + np.float32(0.5) * (con[:, 0][:, None, None] * dx * dx + con[:, 2][:, None, None] * dy * dy)).astype(np.float32)
         near = np.abs(sig - tau[:, None, None]) <= ulps * np.spacing(np.abs(tau))[:, None, None]
         mask[y0:y0 + 16, x0:x0 + 16] |= near.any(0)
-    return mask
+        if with_ids:
+            owners.update(int(i) for i in ids[near.reshape(len(ids), -1).any(1)])
+    return (mask, owners) if with_ids else mask

@@ -124,9 +124,9 @@ def test_hip_matches_golden_ssim(pkg):
         assert np.array_equal(g.cpu().numpy(), f["dL_dimg"])
     # the default (contracted) arithmetic: the same fixture at fp32 tolerance
     m, d0, d1, d2 = F._fused_ssim(dev(f["img"]), dev(f["ref"]), train=True)
-    assert np.abs(m.cpu().numpy() - f["ssim_map"]).max() <= 2e-6
+    assert np.abs(m.cpu().numpy() - f["ssim_map"]).max() <= 1e-5
     g = F.fused_ssim_bwd(dev(f["img"]), dev(f["ref"]), dev(f["dL_dmap"]), d0, d1, d2).cpu().numpy()
-    assert np.linalg.norm(g - f["dL_dimg"]) <= 1e-5 * np.linalg.norm(f["dL_dimg"])
+    assert np.linalg.norm(g - f["dL_dimg"]) <= 2e-5 * np.linalg.norm(f["dL_dimg"])
 
 
 def test_oracle_reproduces_golden_trainer_tail(orc):

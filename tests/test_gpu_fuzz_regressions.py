@@ -1,0 +1,132 @@
+"""-m gpu: the diagnosed failures of round 3's fuzz campaign (profiles/r03/fuzz_parity.txt: 20 of 9 000 randomised / deep
+scenes and 44 of 2 000 hostile ones missed a HIP-vs-oracle gradient criterion) as ASSERTIONS, arbitrated by the float64
+autograd model (tests/f64_model.py) — the only evidence independent of both fp32 evaluations while the oracle cannot be pinned
+on a live reference (runtests.jl:95-306 pins the adjoints with Float64 finite differences the same way).
+
+A gradient tensor of a recorded case must satisfy ONE of
+  (a) the suite's own criterion: rel-L2(HIP, oracle) <= 1e-4;
+  (b) conditioning: HIP is no farther from float64 than the fp32 oracle is — rel-L2(HIP, f64) <= 1.5 * rel-L2(oracle, f64)
+      (+ 2e-5): anisotropy beyond ~30 : 1 makes the fp32 rotation / scale adjoints ill-conditioned for ANY fp32 evaluation;
+  (c) one boundary pair: >= 80 % of ||HIP - oracle||^2 sits on ONE Gaussian that owns a (pixel, splat) pair within 4 ulps of
+      the blend boundary alpha = 1/255 (render.jl:95) — the pair is decided by the last bit of sigma / exp on either side —,
+      one of the two evaluations agrees with float64 (<= 5e-5), and without that Gaussian the tensor meets (a).
+Anything else — a difference spread over many Gaussians, or concentrated on one that is nowhere near the boundary and well
+conditioned — fails: that would be a kernel bug."""
+import numpy as np
+import pytest
+import torch
+
+import f64_model as fm
+import fuzz_scenes
+from hip_helpers import HipRun, blend_boundary_pixels
+
+pytestmark = pytest.mark.gpu
+DT = torch.float64
+NAMES = ("vmeans", "vshs", "vopacities", "vscales", "vrots")
+
+
+def _rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def three_way(pkg, orc, fs, exact_tile_cull=False):
+    """oracle, HIP and float64 gradients of one scene -> {tensor: (oracle, hip, f64) as (N, -1) float64 arrays}, oracle state."""
+    st = orc.forward(fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, background=fs.bg, mode=fs.mode)
+    vp = fs.cotangent()
+    g = orc.backward(st, vp, fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, background=fs.bg)
+    run = HipRun(pkg, fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, fs.bg, fs.mode, exact_tile_cull=exact_tile_cull)
+    run.forward()
+    out = [o.cpu().numpy() for o in run.backward(vp)[:5]]
+    tt = lambda a: torch.tensor(np.asarray(a, np.float64), dtype=DT, requires_grad=True)  # noqa: E731
+    leaves = [tt(fs.means), tt(fs.shs), tt(fs.opac), tt(fs.scales), tt(fs.rots)]
+    img = fm.render_dense(*leaves, fs.cam, fs.deg, np.asarray(fs.bg, np.float32), fs.mode, st.values_sorted, st.ranges, st.radii)
+    (img * torch.tensor(vp, dtype=DT)).sum().backward()
+    n = fs.means.shape[0]
+    ref = (g.vmeans, g.vshs, g.vopacities, g.vscales, g.vrots)
+    res = {}
+    for nm, o, r, leaf in zip(NAMES, out, ref, leaves):
+        res[nm] = tuple(np.asarray(x, np.float64).reshape(n, -1) for x in (r, o, leaf.grad.numpy()))
+    return res, st
+
+
+def arbitrate(res, st, fs):
+    """Apply (a) / (b) / (c) to every tensor; returns {tensor: verdict string}; raises AssertionError with the numbers."""
+    vis = st.radii > 0
+    W, H = fs.cam.width, fs.cam.height
+    owners = None
+    verdicts = {}
+    for nm, (orc_g, hip_g, f64_g) in res.items():
+        e_ho, e_o, e_h = _rel(hip_g[vis], orc_g[vis]), _rel(orc_g[vis], f64_g[vis]), _rel(hip_g[vis], f64_g[vis])
+        if e_ho <= 1e-4:
+            verdicts[nm] = f"(a) {e_ho:.1e}"
+            continue
+        if e_h <= 1.5 * e_o + 2e-5:
+            verdicts[nm] = f"(b) HIP-f64 {e_h:.1e} <= 1.5 x oracle-f64 {e_o:.1e}"
+            continue
+        d2 = ((hip_g - orc_g) ** 2).sum(1)
+        w = int(np.argmax(d2))
+        share = float(d2[w] / max(d2.sum(), 1e-300))
+        if owners is None:
+            owners = blend_boundary_pixels(st, fs.opac, W, H, with_ids=True)[1]
+        rest = vis.copy(); rest[w] = False
+        e_rest = _rel(hip_g[rest], orc_g[rest])
+        ok = share >= 0.8 and w in owners and min(e_o, e_h) <= 5e-5 and e_rest <= 1e-4
+        assert ok, (f"{nm}: HIP-oracle {e_ho:.2e}, oracle-f64 {e_o:.2e}, HIP-f64 {e_h:.2e}; {100 * share:.0f} % of the squared "
+                    f"difference on Gaussian {w} (owns a boundary pair: {w in owners}), without it {e_rest:.2e}")
+        verdicts[nm] = f"(c) Gaussian {w}: {100 * share:.0f} %, rest {e_rest:.1e}, oracle-f64 {e_o:.1e}, HIP-f64 {e_h:.1e}"
+    return verdicts
+
+
+# randomised sweep: the five cases tools/dbg_sweep3.py looked at in round 3 + the two of the first 2 000
+@pytest.mark.parametrize("case", [137, 1160, 3127, 5124, 6928, 3285, 4629])
+def test_sweep_failures_are_boundary_pairs_or_conditioning(pkg, orc, case):
+    fs = fuzz_scenes.sweep_scene(pkg, case)
+    res, st = three_way(pkg, orc, fs)
+    print(f"sweep {case}", arbitrate(res, st, fs))
+
+
+# hostile inputs: needles (27 : 1 stacked on screen-filling / scene spread: beyond 30 : 1) and one faint large Gaussian (1651)
+@pytest.mark.parametrize("case", [1518, 1575, 1651, 1847, 1959, 1981, 1990])
+def test_edge_failures_are_conditioning_or_boundary_pairs(pkg, orc, case):
+    fs = fuzz_scenes.edge_scene(pkg, case)
+    res, st = three_way(pkg, orc, fs)
+    print(f"edge {case}", arbitrate(res, st, fs))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_600_to_1_needles_hip_is_as_close_to_float64_as_the_oracle(pkg, orc, seed):
+    """No 1e-4 criterion between two fp32 evaluations holds on 600 : 1 needles (round 3: 2.2e-4 / 3.2e-4 / 4.7e-4); what must
+    hold is that the kernels are not the worse of the two."""
+    fs = fuzz_scenes.needle_scene(pkg, seed)
+    res, st = three_way(pkg, orc, fs)
+    print(f"needle {seed}", arbitrate(res, st, fs))
+    m = fs.note["needles"] & (st.radii > 0)
+    assert m.any()
+    for nm in ("vmeans", "vscales", "vrots"):   # the needles alone, where the conditioning bites
+        o, h, t = res[nm]
+        assert _rel(h[m], t[m]) <= 1.5 * _rel(o[m], t[m]) + 2e-5, nm
+
+
+def test_deep_case_523_differs_on_one_boundary_gaussian_only(pkg, orc):
+    """41 514 instances in one tile, opacity 0.0066: v_opacities was 1.2e-4 off from ONE pair on the boundary.  (No float64
+    arbitration here — the dense model of a 41 k list needs tens of GB — but the structure of the difference is asserted.)"""
+    fs = fuzz_scenes.deep_scene(pkg, 523)
+    st = orc.forward(fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, background=fs.bg, mode=fs.mode)
+    vp = fs.cotangent()
+    g = orc.backward(st, vp, fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, background=fs.bg)
+    run = HipRun(pkg, fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, fs.bg, fs.mode)
+    run.forward()
+    out = [o.cpu().numpy() for o in run.backward(vp)[:5]]
+    vis = st.radii > 0
+    owners = blend_boundary_pixels(st, fs.opac, fs.cam.width, fs.cam.height, with_ids=True)[1]
+    n = fs.means.shape[0]
+    for nm, o, r in zip(NAMES, out, (g.vmeans, g.vshs, g.vopacities, g.vscales, g.vrots)):
+        o, r = np.asarray(o, np.float64).reshape(n, -1), np.asarray(r, np.float64).reshape(n, -1)
+        e = _rel(o[vis], r[vis])
+        if e <= 1e-4:
+            continue
+        d2 = ((o - r) ** 2).sum(1)
+        w = int(np.argmax(d2))
+        rest = vis.copy(); rest[w] = False
+        assert d2[w] >= 0.8 * d2.sum() and w in owners and _rel(o[rest], r[rest]) <= 1e-4, (nm, e, w, w in owners)

@@ -35,85 +35,37 @@ import torch  # noqa: E402
 from hip_helpers import HipRun  # noqa: E402
 
 
-def deep_case(case):
-    rng = np.random.default_rng(77000 + case)
-    mode = ["rgb", "rgbd", "rgbdn"][case % 3]
-    deg = int(rng.integers(0, 3))
-    W, H = int(rng.integers(16, 49)), int(rng.integers(16, 49))
-    target = int(np.exp(rng.uniform(np.log(300), np.log(40000))))          # instances in the deepest tile, roughly
-    n = int(target * rng.uniform(1.0, 1.6))
-    s = pkg.synthetic.make_scene(n, W, H, deg, 77100 + case)
-    spread = float(rng.uniform(0.02, 0.3))
-    means = np.stack([rng.uniform(-spread, spread, n), rng.uniform(-spread, spread, n), rng.uniform(2, 8, n)], 1).astype(np.float32)
-    cam = orc.Camera(W, H, s.focal)
-    opac = np.full(n, float(rng.uniform(0.004, 0.05)), np.float32) * rng.uniform(0.5, 1.5, n).astype(np.float32)
-    scales = s.scales * float(rng.uniform(1.0, 3.0))
-    bg = tuple(float(x) for x in rng.uniform(0, 1, 3))
-    st = orc.forward(means, s.shs, opac, scales, s.rotations, cam, deg, background=bg, mode=mode)
-    run = HipRun(pkg, means, s.shs, opac, scales, s.rotations, cam, deg, bg, mode)
+import fuzz_scenes  # noqa: E402  (tests/fuzz_scenes.py: the seeded scene families, shared with the test suite)
+
+
+def _scene_case(fs):
+    """forward (every field, both list modes) + every gradient of one fuzz scene against the oracle."""
+    st = orc.forward(fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, background=fs.bg, mode=fs.mode)
+    run = HipRun(pkg, fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, fs.bg, fs.mode, pose_dev=fs.pose)
     img = run.forward().clone()
-    T._compare_forward(st, run, img, opac)
-    C = st.image.shape[2]
-    vp = rng.standard_normal((H, W, C)).astype(np.float32)
-    g = orc.backward(st, vp, means, s.shs, opac, scales, s.rotations, cam, deg, background=bg)
+    T._compare_forward(st, run, img, fs.opac)
+    vp = fs.cotangent()
+    g = orc.backward(st, vp, fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, background=fs.bg,
+                     **({"pose_grad": True} if fs.pose else {}))
     ok = st.n_rendered > 0 and np.linalg.norm(g.vmeans) > 0
     if ok:
-        T._compare_backward(g, run.backward(vp), st.radii > 0)
-    cul = HipRun(pkg, means, s.shs, opac, scales, s.rotations, cam, deg, bg, mode, exact_tile_cull=True)
+        vR, vt = T._compare_backward(g, run.backward(vp), st.radii > 0)
+        if fs.pose:
+            assert T.rel_l2(vR.reshape(-1), g.vR) <= 1e-4 and T.rel_l2(vt, g.vt) <= 1e-4
+    cul = HipRun(pkg, fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, fs.bg, fs.mode, exact_tile_cull=True)
     assert torch.equal(cul.forward(), img)
     if ok:
         T._compare_backward(g, cul.backward(vp), st.radii > 0)
+    return st
+
+
+def deep_case(case):
+    st = _scene_case(fuzz_scenes.deep_scene(pkg, case))
     return int((st.ranges[:, 1] - st.ranges[:, 0]).max())
 
 
 def edge_case(case):
-    rng = np.random.default_rng(55000 + case)
-    mode = ["rgb", "rgbd", "rgbdn"][case % 3]
-    deg = int(rng.integers(0, 4))
-    W, H = int(rng.integers(17, 150)), int(rng.integers(17, 120))
-    n = int(rng.integers(1, 1200))
-    s = pkg.synthetic.make_scene(n, W, H, deg, 55100 + case, sigma_px=float(rng.uniform(1.0, 12.0)))
-    means, scales, opac, shs = s.means.copy(), s.scales.copy(), s.opacities.copy(), s.shs.copy()
-    k = lambda frac: rng.random(n) < frac  # noqa: E731
-    opac = rng.uniform(0.0, 1.0, n).astype(np.float32)
-    opac[k(0.05)] = 0.0; opac[k(0.05)] = 1.0; opac[k(0.05)] = np.float32(0.995); opac[k(0.03)] = np.float32(1.0 / 255.0)
-    scales[k(0.08)] *= 0.02                     # sub-pixel: radius <= 3 -> culled
-    scales[k(0.03)] *= 6.0                      # screen-filling
-    scales[k(0.02)] *= -1.0                     # negative (activated) scales: only their squares matter
-    # needles, ~27 : 1.  (At 600 : 1 the fp32 gradients themselves are only good to 2e-4 .. 6e-2: against the float64
-    # autograd model the oracle is off by as much as the kernels are — tools/dbg_needle.py — and no 1e-4 criterion holds.)
-    m = k(0.08); scales[m, 0] *= 4.0; scales[m, 1] *= 0.15
-    means[k(0.04), 2] *= -1.0                   # behind the camera
-    means[k(0.03), 0] += 40.0                   # far off-screen
-    shs[k(0.1)] *= 8.0                          # clamping colours
-    fx = float(s.focal[0]) * float(rng.uniform(0.6, 1.6)); fy = float(s.focal[1]) * float(rng.uniform(0.6, 1.6))
-    ang = rng.uniform(-0.35, 0.35, 3)
-    cx, sx_, cy, sy_, cz, sz_ = np.cos(ang[0]), np.sin(ang[0]), np.cos(ang[1]), np.sin(ang[1]), np.cos(ang[2]), np.sin(ang[2])
-    Rx = np.array([[1, 0, 0], [0, cx, -sx_], [0, sx_, cx]]); Ry = np.array([[cy, 0, sy_], [0, 1, 0], [-sy_, 0, cy]])
-    Rz = np.array([[cz, -sz_, 0], [sz_, cz, 0], [0, 0, 1]])
-    Rm = (Rz @ Ry @ Rx).astype(np.float32)
-    t = rng.uniform(-0.5, 0.5, 3).astype(np.float32)
-    near, far = (0.2, 1000.0) if case % 4 else (float(rng.uniform(1.0, 4.0)), float(rng.uniform(6.0, 11.0)))
-    cam = orc.Camera(W, H, (np.float32(fx), np.float32(fy)), R=Rm, t=t, near_plane=near, far_plane=far,
-                     principal=(float(rng.uniform(0.3, 0.7)), float(rng.uniform(0.3, 0.7))))
-    bg = tuple(float(x) for x in rng.uniform(0, 1, 3))
-    st = orc.forward(means, shs, opac, scales, s.rotations, cam, deg, background=bg, mode=mode)
-    pose = bool(case & 2)
-    run = HipRun(pkg, means, shs, opac, scales, s.rotations, cam, deg, bg, mode, pose_dev=pose)
-    img = run.forward().clone()
-    T._compare_forward(st, run, img, opac)
-    C = st.image.shape[2]
-    vp = rng.standard_normal((H, W, C)).astype(np.float32)
-    g = orc.backward(st, vp, means, shs, opac, scales, s.rotations, cam, deg, background=bg, pose_grad=pose)
-    ok = st.n_rendered > 0 and np.linalg.norm(g.vmeans) > 0
-    if ok:
-        vR, vt = T._compare_backward(g, run.backward(vp), st.radii > 0)
-        if pose:
-            assert T.rel_l2(vR.reshape(-1), g.vR) <= 1e-4 and T.rel_l2(vt, g.vt) <= 1e-4
-    cul = HipRun(pkg, means, shs, opac, scales, s.rotations, cam, deg, bg, mode, exact_tile_cull=True)
-    assert torch.equal(cul.forward(), img)
-    if ok:
-        T._compare_backward(g, cul.backward(vp), st.radii > 0)
+    st = _scene_case(fuzz_scenes.edge_scene(pkg, case))
     return int((st.radii > 0).sum())
 
 
@@ -128,13 +80,14 @@ def ssim_case(case):
         y = x.copy()
     m, d0, d1, d2 = orc.ssim_forward(x, y, train=True)
     Fs = pkg.fused_ssim
-    hm, h0, h1, h2 = Fs._fused_ssim(dev(x), dev(y), train=True)
-    for a, b in ((hm, m), (h0, d0), (h1, d1), (h2, d2)):
-        assert np.array_equal(a.cpu().numpy(), b, equal_nan=True), ("ssim fwd", shape)
-    dl = rng.standard_normal(shape).astype(np.float32)
-    g = orc.ssim_backward(x, y, dl, d0, d1, d2)
-    hg = Fs.fused_ssim_bwd(dev(x), dev(y), dev(dl), h0, h1, h2)
-    assert np.array_equal(hg.cpu().numpy(), g, equal_nan=True), ("ssim bwd", shape)
+    with Fs.exact_arithmetic():  # the bit-exact twin of ssim.hip (the default build is compared at tolerance by the loss head below)
+        hm, h0, h1, h2 = Fs._fused_ssim(dev(x), dev(y), train=True)
+        for a, b in ((hm, m), (h0, d0), (h1, d1), (h2, d2)):
+            assert np.array_equal(a.cpu().numpy(), b, equal_nan=True), ("ssim fwd", shape)
+        dl = rng.standard_normal(shape).astype(np.float32)
+        g = orc.ssim_backward(x, y, dl, d0, d1, d2)
+        hg = Fs.fused_ssim_bwd(dev(x), dev(y), dev(dl), h0, h1, h2)
+        assert np.array_equal(hg.cpu().numpy(), g, equal_nan=True), ("ssim bwd", shape)
     # loss head on a ragged image
     W, H = int(rng.integers(16, 200)), int(rng.integers(16, 150))
     mode = ["rgb", "rgbd"][case % 2]

@@ -669,53 +669,24 @@ void gsr_launch_sort_composite_fwd(hipStream_t s, int channels, GsrCam cam, cons
 #undef LAUNCH2
 }
 
-// Tiles order_first .. order_first + order_count - 1 of the launch order, `ppl` pixels per lane: 4 = one wave per tile (the main
-// launch), 1 = four waves per tile (the backfill of the launch's last, partial round: gsr_api.cpp launch_composite_bwd).
 void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
                               const uint32_t* tile_order, GsrStream stream, const float* background,
                               const float* vpixels, const uint32_t* n_contrib, const float* final_T, GsrInst inst,
-                              uint32_t split_len, uint32_t order_first, uint32_t order_count, int ppl) {
-    if (order_count == 0) return;
-    dim3 grid(order_count), block(256 / ppl);
+                              uint32_t split_len) {
+    dim3 grid(cam.grid_x * cam.grid_y), block(256 / GSR_BWD_PPL);
     Bg bg = make_bg(background, channels);
     GsrTierLists none{};
     none.split_len = split_len;
     const bool bg0 = bg_is_zero(bg);
-    const uint32_t* order = tile_order + order_first;
-#define LAUNCH2(CC, PP, ZZ)                                                                                            \
-    hipLaunchKernelGGL((composite_bwd_kernel<CC, PP, false, ZZ>), grid, block, 0, s, cam.width, cam.height,            \
-                       cam.grid_x, tile_start, order, stream, bg, vpixels, n_contrib, final_T, inst, none)
-    if (ppl == GSR_BWD_PPL) {
-        if (channels == 3) LAUNCH2(3, GSR_BWD_PPL, false);
-        else if (channels == 5) LAUNCH2(5, GSR_BWD_PPL, false);
-        else if (bg0) LAUNCH2(8, GSR_BWD_PPL, true);
-        else LAUNCH2(8, GSR_BWD_PPL, false);
-    } else if (ppl == 2) {
-        if (channels == 3) LAUNCH2(3, 2, false);
-        else if (channels == 5) LAUNCH2(5, 2, false);
-        else LAUNCH2(8, 2, false);
-    } else {
-        if (channels == 3) LAUNCH2(3, 1, false);
-        else if (channels == 5) LAUNCH2(5, 1, false);
-        else LAUNCH2(8, 1, false);
-    }
+#define LAUNCH2(CC, ZZ)                                                                                                \
+    hipLaunchKernelGGL((composite_bwd_kernel<CC, GSR_BWD_PPL, false, ZZ>), grid, block, 0, s, cam.width, cam.height,   \
+                       cam.grid_x, tile_start, tile_order, stream, bg, vpixels, n_contrib, final_T, inst, none)
+    // (the zero-background kernel only where it pays: :rgbdn, 4 -> 5 waves per SIMD; profiles/r04/experiments/bwd_occupancy_ab.txt)
+    if (channels == 3) LAUNCH2(3, false);
+    else if (channels == 5) LAUNCH2(5, false);
+    else if (bg0) LAUNCH2(8, true);
+    else LAUNCH2(8, false);
 #undef LAUNCH2
-}
-
-// Wave slots of the whole device for the main (one wave per tile) backward kernel of a render mode: resident workgroups per CU
-// (registers and LDS, from the runtime's occupancy calculator) x CUs.  The launch's last, partial round is what is left of
-// the tile count after whole multiples of this.
-uint32_t gsr_composite_bwd_wave_slots(int channels, bool zero_background) {
-    int dev = 0, cus = 0, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        return 0;
-    hipError_t e;
-    if (channels == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, composite_bwd_kernel<3, GSR_BWD_PPL, false, false>, 256 / GSR_BWD_PPL, 0);
-    else if (channels == 5) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, composite_bwd_kernel<5, GSR_BWD_PPL, false, false>, 256 / GSR_BWD_PPL, 0);
-    else if (zero_background) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, composite_bwd_kernel<8, GSR_BWD_PPL, false, true>, 256 / GSR_BWD_PPL, 0);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, composite_bwd_kernel<8, GSR_BWD_PPL, false, false>, 256 / GSR_BWD_PPL, 0);
-    if (e != hipSuccess || per_cu <= 0 || cus <= 0) return 0;
-    return (uint32_t)per_cu * (uint32_t)cus;
 }
 
 void gsr_launch_composite_bwd_listed(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,

@@ -209,9 +209,6 @@ struct gsr_handle {
     uint32_t tier_n[3] = {0, 0, 0};    // tiles of the last forward with lists in (1024, 4096], (4096, 8192], > 8192
     hipStream_t aux_stream = nullptr;  // the four-wave backward of those tiles runs here, next to the main launch
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipStream_t tail_stream = nullptr; // the backward of the main launch's last partial round (launch_composite_bwd)
-    hipEvent_t ev_join_tail = nullptr;
-    uint32_t bwd_slots[2] = {0, 0};    // wave slots of the device for the main backward kernel ([1]: zero background), 0 = unknown
     bool fwd_valid = false, bwd_valid = false;
     bool fwd_only = false;         // the last forward was GSR_FORWARD_ONLY: no stream / ids / row storage behind it
     bool inputs_consumed = false;  // gsr_backward_trainer_tail updated the forward's inputs in place
@@ -440,8 +437,6 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join_tail, hipEventDisableTiming);
     if (e != hipSuccess) {
         gsr_destroy(h);
         return fail(GSR_E_HIP, "pinned memory / stream / event creation failed: %s", hipGetErrorString(e));
@@ -460,8 +455,6 @@ int gsr_destroy(gsr_handle* h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
-    if (h->ev_join_tail) (void)hipEventDestroy(h->ev_join_tail);
-    if (h->tail_stream) (void)hipStreamDestroy(h->tail_stream);
     h->prof.destroy();
     delete h;
     return GSR_OK;
@@ -690,43 +683,15 @@ static int launch_composite_bwd(gsr_handle* h, hipStream_t s, int C, const GsrCa
         tiers.split_len = cut[t];
     }
     if (n == 0) tiers.split_len = 0xFFFFFFFFu;  // nothing to split (or the deepest tier alone is already plentiful)
-    // The main launch's last, partial round.  One wave per tile and T tiles on S wave slots (registers: 6 waves per SIMD in :rgb
-    // mode, 6144 slots; config 3 has 8160 tiles of nearly equal length): after the first S tiles every SIMD is left with
-    // T/S - 1 of a round, i.e. two waves instead of six for the last quarter of the work — and this kernel hides its latencies
-    // only from about five waves up (round 3: 789 / 735 / 677 us at 4 / 5 / 6 waves).  So the T mod S shortest tiles — the end
-    // of the launch order — are walked by `tail_ppl`-pixel lanes (1: four waves per tile, 2: two) in a second launch on a
-    // stream of its own, which the hardware backfills into the slots the main launch leaves free: the round fills up again,
-    // at the price of the per-strip reductions (~20 % more work on those tiles).  Only when the remainder is at most half a
-    // round; GSR_BWD_TAIL=0 turns it off, GSR_BWD_TAIL=<ppl> selects 1 / 2 (A/B runs).
-    static const int tail_ppl = [] { const char* e = getenv("GSR_BWD_TAIL"); return e ? atoi(e) : 1; }();
-    const uint32_t T = (uint32_t)h->n_tiles;
-    uint32_t n_tail = 0;
-    if (tail_ppl == 1 || tail_ppl == 2) {
-        const bool bg0 = background[0] == 0.0f && background[1] == 0.0f && background[2] == 0.0f;
-        uint32_t& slots = h->bwd_slots[bg0 ? 1 : 0];
-        if (slots == 0) slots = gsr_composite_bwd_wave_slots(C, bg0);
-        static const int slots_env = [] { const char* e = getenv("GSR_BWD_SLOTS"); return e ? atoi(e) : 0; }();
-        const uint32_t S = slots_env > 0 ? (uint32_t)slots_env : slots;
-        if (S > 0 && T > S && T % S <= S / 2) n_tail = T % S;
-    }
-    if (n > 0 || n_tail > 0) HIPCHK(hipEventRecord(h->ev_fork, s));
     if (n > 0) {
+        HIPCHK(hipEventRecord(h->ev_fork, s));
         HIPCHK(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
         gsr_launch_composite_bwd_listed(h->aux_stream, C, k, h->tile_start.as<uint32_t>(), tiers, stream_of(h), background,
                                         vpixels, h->n_contrib.as<uint32_t>(), h->final_T.as<float>(), inst_of(h));
         HIPCHK(hipEventRecord(h->ev_join, h->aux_stream));
     }
     gsr_launch_composite_bwd(s, C, k, h->tile_start.as<uint32_t>(), h->tile_order.as<uint32_t>(), stream_of(h), background,
-                             vpixels, h->n_contrib.as<uint32_t>(), h->final_T.as<float>(), inst_of(h), tiers.split_len,
-                             0u, T - n_tail, 4);
-    if (n_tail > 0) {
-        HIPCHK(hipStreamWaitEvent(h->tail_stream, h->ev_fork, 0));
-        gsr_launch_composite_bwd(h->tail_stream, C, k, h->tile_start.as<uint32_t>(), h->tile_order.as<uint32_t>(), stream_of(h),
-                                 background, vpixels, h->n_contrib.as<uint32_t>(), h->final_T.as<float>(), inst_of(h),
-                                 tiers.split_len, T - n_tail, n_tail, tail_ppl);
-        HIPCHK(hipEventRecord(h->ev_join_tail, h->tail_stream));
-        HIPCHK(hipStreamWaitEvent(s, h->ev_join_tail, 0));
-    }
+                             vpixels, h->n_contrib.as<uint32_t>(), h->final_T.as<float>(), inst_of(h), tiers.split_len);
     if (n > 0) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
     return GSR_OK;
 }

@@ -140,10 +140,7 @@ void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uin
                               const uint32_t* tile_order, GsrStream stream,
                               const float* background, const float* vpixels, const uint32_t* n_contrib,
                               const float* final_T, GsrInst inst,
-                              uint32_t split_len /* tiles with a longer list are left to the listed launch */,
-                              uint32_t order_first, uint32_t order_count /* slice of the launch order */,
-                              int ppl /* pixels per lane: 4 = one wave per tile, 2 / 1 = two / four waves per tile */);
-uint32_t gsr_composite_bwd_wave_slots(int channels, bool zero_background);
+                              uint32_t split_len /* tiles with a longer list are left to the listed launch */);
 void gsr_launch_composite_bwd_listed(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
                                      GsrTierLists tiers, GsrStream stream, const float* background,
                                      const float* vpixels, const uint32_t* n_contrib, const float* final_T, GsrInst inst);

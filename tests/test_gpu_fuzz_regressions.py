@@ -7,9 +7,10 @@ A gradient tensor of a recorded case must satisfy ONE of
   (a) the suite's own criterion: rel-L2(HIP, oracle) <= 1e-4;
   (b) conditioning: HIP is no farther from float64 than the fp32 oracle is — rel-L2(HIP, f64) <= 1.5 * rel-L2(oracle, f64)
       (+ 2e-5): anisotropy beyond ~30 : 1 makes the fp32 rotation / scale adjoints ill-conditioned for ANY fp32 evaluation;
-  (c) one boundary pair: >= 80 % of ||HIP - oracle||^2 sits on ONE Gaussian that owns a (pixel, splat) pair within 4 ulps of
-      the blend boundary alpha = 1/255 (render.jl:95) — the pair is decided by the last bit of sigma / exp on either side —,
-      one of the two evaluations agrees with float64 (<= 5e-5), and without that Gaussian the tensor meets (a).
+  (c) boundary pairs: >= 80 % of ||HIP - oracle||^2 sits on at most FOUR Gaussians, each of which owns a (pixel, splat) pair
+      within 4 ulps of the blend boundary alpha = 1/255 (render.jl:95) — such a pair is decided by the last bit of sigma / exp
+      on either side —, one of the two evaluations agrees with float64 (<= 5e-5), and without those Gaussians the tensor
+      meets (a).
 Anything else — a difference spread over many Gaussians, or concentrated on one that is nowhere near the boundary and well
 conditioned — fails: that would be a kernel bug."""
 import numpy as np
@@ -65,16 +66,21 @@ def arbitrate(res, st, fs):
             verdicts[nm] = f"(b) HIP-f64 {e_h:.1e} <= 1.5 x oracle-f64 {e_o:.1e}"
             continue
         d2 = ((hip_g - orc_g) ** 2).sum(1)
-        w = int(np.argmax(d2))
-        share = float(d2[w] / max(d2.sum(), 1e-300))
         if owners is None:
             owners = blend_boundary_pixels(st, fs.opac, W, H, with_ids=True)[1]
-        rest = vis.copy(); rest[w] = False
-        e_rest = _rel(hip_g[rest], orc_g[rest])
-        ok = share >= 0.8 and w in owners and min(e_o, e_h) <= 5e-5 and e_rest <= 1e-4
-        assert ok, (f"{nm}: HIP-oracle {e_ho:.2e}, oracle-f64 {e_o:.2e}, HIP-f64 {e_h:.2e}; {100 * share:.0f} % of the squared "
-                    f"difference on Gaussian {w} (owns a boundary pair: {w in owners}), without it {e_rest:.2e}")
-        verdicts[nm] = f"(c) Gaussian {w}: {100 * share:.0f} %, rest {e_rest:.1e}, oracle-f64 {e_o:.1e}, HIP-f64 {e_h:.1e}"
+        top = [int(w) for w in np.argsort(-d2)[:4]]
+        taken, rest, e_rest, share = [], vis.copy(), e_ho, 0.0
+        for w in top:               # peel boundary-pair owners off the top of the difference until the rest meets (a)
+            if w not in owners or e_rest <= 1e-4:
+                break
+            taken.append(w)
+            rest[w] = False
+            e_rest = _rel(hip_g[rest], orc_g[rest])
+            share = float(d2[taken].sum() / max(d2.sum(), 1e-300))
+        ok = bool(taken) and share >= 0.8 and min(e_o, e_h) <= 5e-5 and e_rest <= 1e-4
+        assert ok, (f"{nm}: HIP-oracle {e_ho:.2e}, oracle-f64 {e_o:.2e}, HIP-f64 {e_h:.2e}; top contributors {top} (own a boundary "
+                    f"pair: {[w in owners for w in top]}), {100 * share:.0f} % on {taken}, without them {e_rest:.2e}")
+        verdicts[nm] = f"(c) Gaussians {taken}: {100 * share:.0f} %, rest {e_rest:.1e}, oracle-f64 {e_o:.1e}, HIP-f64 {e_h:.1e}"
     return verdicts
 
 

@@ -588,6 +588,13 @@ class Workload:
     def _exchange(self):
         D, pkg, N, K = self.D, self.pkg, self.N, self.K
         p = self.params
+        if self.factored and self.tail is not None and not self.unfused_tail:
+            # trainer step: the ∇shs rebuild happens INSIDE the tail (gsr_sh_grad_from_views_tail): only the collectives here
+            if self.overlap:
+                vc_all = D.exchange_factored_overlapped(self.arena, N, self.gathered, lambda v: v)
+                self.overlap_ran = bool(D.last_exchange_overlapped())
+                return vc_all
+            return D.exchange_factored(self.arena, N, self.gathered)
         if self.factored and self.overlap:
             # all-gather(vc) || all-reduce(11·N): the ∇shs rebuild runs while the all-reduce is in flight
             ran = D.exchange_factored_overlapped(self.arena, N, self.gathered, lambda vc_all: pkg.rasterizer.sh_grad_from_views(
@@ -630,20 +637,26 @@ class Workload:
             tail["_last"] = (ev[0], ev[1], ev[2], ev[3], e4)
             return
         rast.backward_raw(vp, *params, self.cam, self.deg, self.bg, arena=self.arena, factored_sh=self.factored)
+        exchanged = None
         if self.dist_on:
             if self.exchange_events is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                self._exchange()
+                exchanged = self._exchange()
                 e1.record()
                 self.exchange_events.append((e0, e1))
             else:
-                self._exchange()
+                exchanged = self._exchange()
         if tail is not None:
             g = (D.split_arena(self.arena, N, K) if not self.factored else
                  dict(D.split_factored_arena(self.arena, N), vshs=self.vshs_sum))
             ev[2].record()
-            if self.unfused_tail:
+            if self.factored and not self.unfused_tail:
+                # multi-GPU trainer step, self-contained: rebuild of Σ_v basis x vc + prologue pullback + Adam + next prologue
+                ev[3].record()
+                pkg.optim.sh_views_tail_step(self.opt_map, self.raw_map, dict(g, vopacities=g["vopacities"].view(-1, 1)),
+                                             exchanged.view(-1, N, 3), self.centers_d, self.deg, params[1], params[2], params[3])
+            elif self.unfused_tail:
                 vdc, vrest, vo, vs = pkg.rasterizer.prologue_backward(params[2], params[3], g["vshs"],
                                                                       g["vopacities"].view(-1, 1), g["vscales"], 3)
                 ev[3].record()
@@ -1024,6 +1037,8 @@ def run_section(args, section):
         out["trainer_tail"]["algorithmic_bytes"] = {"prologue_fwd": 2 * 4 * (3 * K + 4) * N, "prologue_bwd": 2 * 4 * (3 * K + 4) * N + 16 * N,
                                                     "adam": 7 * 4 * (3 * K + 11) * N}
         out["trainer_tail"]["form"] = ("three kernels" if args.unfused_tail else
+                                       "multi-view: gsr_sh_grad_from_views_tail after the factored exchange (rebuild of the SH gradient + "
+                                       "prologue pullback + Adam + next prologue in ONE pass: 'adam' is that pass)" if wl.factored else
                                        "inside the backward (gsr_backward_trainer_tail: 'adam' = composite_bwd + per-Gaussian backward + tail)"
                                        if args.tail_in_backward else "fused (gsr_trainer_tail_step: 'adam' is the whole tail)")
         out["config"]["workload"] += " + prologue + Adam (trainer tail, not the headline metric)"

@@ -100,7 +100,7 @@ EXPORTS = ["gsr_create", "gsr_destroy", "gsr_release_scene_buffers", "gsr_memory
            "gsr_allreduce_grads", "gsr_last_error_string", "gsr_version", "gsr_abi_version", "gsr_check_abi", "gsr_profile_enable",
            "gsr_profile_stage_count", "gsr_profile_stages", "gsr_profile_stage_name", "gsr_profile_read", "gsr_profile_read_intervals", "gsr_update_stats",
            "gsr_prologue_forward", "gsr_prologue_backward", "gsr_adam_step", "gsr_stream_triad",
-           "gsr_mask_findall_scratch_bytes", "gsr_mask_findall", "gsr_gather_rows", "gsr_sh_grad_from_views", "gsr_trainer_tail_step",
+           "gsr_mask_findall_scratch_bytes", "gsr_mask_findall", "gsr_gather_rows", "gsr_sh_grad_from_views", "gsr_sh_grad_from_views_tail", "gsr_trainer_tail_step",
            "gsr_backward_trainer_tail",
            "gsr_densify_grad_mean", "gsr_densify_mask", "gsr_compose_rows", "gsr_split_transform", "gsr_reset_opacity",
            "gsr_ply_pack_rows", "gsr_ply_unpack_rows", "gsr_count_nonfinite"]
@@ -173,6 +173,7 @@ def load():
     lib.gsr_ply_pack_rows.argtypes = [i64, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_ply_unpack_rows.argtypes = [i64, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_sh_grad_from_views.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.gsr_sh_grad_from_views_tail.argtypes = [i32, i32, i32, i32, vp, vp, C.POINTER(TailGrads), C.POINTER(TailState), vp]
     lib.gsr_trainer_tail_step.argtypes = [i32, i32, i32, C.POINTER(TailGrads), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                           C.POINTER(f32), C.POINTER(C.c_uint32), f32, f32, f32, vp, vp, vp, vp]
     lib.gsr_backward_trainer_tail.argtypes = [vp, C.POINTER(Inputs), C.POINTER(CameraS), vp, C.POINTER(TailState), vp]

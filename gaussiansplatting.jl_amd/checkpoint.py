@@ -142,20 +142,29 @@ def read_adam(opt, ckpt: Checkpoint, prefix: str, numel=None) -> None:
     opt.current_step = ckpt.read_scalar(f"{prefix}.current_step")
 
 
-def save_state(filename: str, gaussians, optimizers: Dict[str, object], step: int) -> None:
-    """The Gaussian + optimizer part of `save_state` (training.jl:418-445)."""
+def save_state(filename: str, gaussians, optimizers: Dict[str, object], step: int, strategy=None) -> None:
+    """The Gaussian + optimizer part of `save_state` (training.jl:418-445).  `strategy` (a densification.DefaultStrategy):
+    its split-noise position is added as two metadata scalars (`strategy.split_seed_base`, `strategy.split_rounds`) —
+    keys the reference's reader never asks for, so the file stays a valid reference checkpoint; the reference itself draws
+    split noise from the backend's RNG and has nothing to save there (densification.jl:128)."""
     tensors, meta = {}, {}
     write_gaussians(tensors, meta, "gaussians", gaussians)
     for name in OPTIMIZER_NAMES:
         write_adam(tensors, meta, f"optimizers.{name}", optimizers[name], shape=tuple(_host(getattr(gaussians, name)).shape))
     meta["step"] = str(int(step))
+    if strategy is not None:
+        for k, v in strategy.state_dict().items():
+            meta[f"strategy.{k}"] = str(int(v))
     save_checkpoint(filename, tensors, meta)
 
 
-def load_state(filename: str, optimizers: Dict[str, object]):
-    """Counterpart (training.jl:447-470): returns (GaussianModel, step); optimizers are filled in place."""
+def load_state(filename: str, optimizers: Dict[str, object], strategy=None):
+    """Counterpart (training.jl:447-470): returns (GaussianModel, step); optimizers are filled in place, and so is
+    `strategy`'s split-noise position when the file carries one."""
     ckpt = load_checkpoint(filename)
     g = read_gaussians(ckpt, "gaussians")
     for name in OPTIMIZER_NAMES:
         read_adam(optimizers[name], ckpt, f"optimizers.{name}", numel=int(np.asarray(getattr(g, name)).size))
+    if strategy is not None and "strategy.split_rounds" in ckpt.meta:
+        strategy.load_state_dict({k: ckpt.read_scalar(f"strategy.{k}") for k in ("split_seed_base", "split_rounds")})
     return g, ckpt.read_scalar("step")

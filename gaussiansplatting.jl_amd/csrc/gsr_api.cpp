@@ -1185,6 +1185,32 @@ int gsr_sh_grad_from_views(int32_t n, int32_t n_coeffs, int32_t sh_degree, int32
     return GSR_OK;
 }
 
+int gsr_sh_grad_from_views_tail(int32_t n, int32_t n_coeffs, int32_t sh_degree, int32_t n_views, const float* camera_centers,
+                                const float* vcolors_all, const gsr_tail_grads* small, const gsr_tail_state* st, void* stream) {
+    if (n < 0 || n_views < 1 || sh_degree < 0 || sh_degree > 3 || n_coeffs < (sh_degree + 1) * (sh_degree + 1) || n_coeffs > 16)
+        return fail(GSR_E_INVALID_ARG, "bad sizes: n=%d views=%d degree=%d K=%d", n, n_views, sh_degree, n_coeffs);
+    if (n == 0) return GSR_OK;
+    if (!camera_centers || !vcolors_all || !small || !st) return fail(GSR_E_INVALID_ARG, "null argument");
+    if (!small->vmeans || !small->vopacities || !small->vscales || !small->vrotations)
+        return fail(GSR_E_INVALID_ARG, "null gradient (vmeans / vopacities / vscales / vrotations; vshs is not read)");
+    if (st->scale_dims != 1 && st->scale_dims != 3) return fail(GSR_E_INVALID_ARG, "scale_dims must be 1 or 3");
+    if (!st->shs || !st->opacities_act || !st->scales_act) return fail(GSR_E_INVALID_ARG, "null activated copy");
+    float lr_t[6];
+    for (int g = 0; g < 6; g++) {
+        if (g == 2 && n_coeffs == 1) { lr_t[g] = 0.0f; continue; }  // empty features_rest (training.jl:770)
+        if (!st->theta[g] || !st->mu[g] || !st->nu[g]) return fail(GSR_E_INVALID_ARG, "group %d: null array", g);
+        if (st->current_step[g] == 0) return fail(GSR_E_INVALID_ARG, "group %d: current_step counts from 1", g);
+        const float t = (float)st->current_step[g];
+        lr_t[g] = st->lr[g] * sqrtf(1.0f - powf(st->beta2, t)) / (1.0f - powf(st->beta1, t));
+    }
+    const gsr::TailState S = gsr_make_tail_state(st->theta, st->mu, st->nu, lr_t, st->beta1, st->beta2, st->eps,
+                                                 st->scale_dims, st->shs, st->opacities_act, st->scales_act);
+    gsr_launch_sh_views_tail((hipStream_t)stream, n, n_coeffs, sh_degree, n_views, camera_centers, vcolors_all, small->vmeans,
+                             small->vopacities, small->vscales, small->vrotations, S);
+    HIPCHK(hipGetLastError());
+    return GSR_OK;
+}
+
 int gsr_stream_triad(float* a, const float* b, const float* c, size_t count, float q, void* stream) {
     if (!a || !b || !c) return fail(GSR_E_INVALID_ARG, "null array");
     if (count % 4 != 0 || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) != 0)

@@ -84,6 +84,10 @@ void gsr_launch_pergauss_bwd_tail(hipStream_t s, int n, int K, int degree, int c
                                   GsrInst inst, float2* vmean2d, const gsr::TailState& S);
 void gsr_launch_sh_grad_views(hipStream_t s, int n, int K, int degree, int n_views, const float* centers,
                               const float* means, const float* vc_all, float* vshs);
+// the same rebuild with the trainer tail applied in place of the ∇shs store (multi-GPU trainer step; S.points = the means)
+void gsr_launch_sh_views_tail(hipStream_t s, int n, int K, int degree, int n_views, const float* centers,
+                              const float* vc_all, const float* vmeans, const float* vopac_act, const float* vscales_act,
+                              const float* vrot, const gsr::TailState& S);
 
 void gsr_launch_update_stats(hipStream_t s, int n, const int32_t* radii, const float2* vmean2d, int width, int height,
                              int32_t* max_radii, float* accum, float* denom);

@@ -495,6 +495,47 @@ __global__ __launch_bounds__(256) void emit_compact_kernel(int n, GsrCam cam, Gs
     }
 }
 
+// One SH optimizer group (features_dc: R = 3, k0 = 0; features_rest: R = 3 (K-1), k0 = 1) of the cnt Gaussians of a
+// workgroup starting at i0, updated element-major by the whole workgroup so that θ, μ, ν stream as full cache lines
+// (float4); grad(il, k, c) supplies the gradient of Gaussian il (0-based inside the workgroup), band k, channel c.  The
+// updated coefficient is also written into the hcat copy `shs` the next forward reads (rasterizer.jl:218-228).  Shared by
+// the backward's fused epilogue and by the multi-view tail (sh_views_tail_kernel): one definition, identical bits.
+template <class Grad>
+__device__ __forceinline__ void tail_sh_group(const gsr::TailState& TS, int i0, int cnt, int K3, float* __restrict__ th,
+                                              float* __restrict__ mu, float* __restrict__ nu, int R, int k0,
+                                              const gsr::AdamHyper& hy, Grad grad) {
+    const size_t base = (size_t)i0 * R;
+    const int total = cnt * R;
+    const uint32_t inv = (1u << 20) / (uint32_t)R + 1u;  // e / R == (e * inv) >> 20 for e < 2^20 / R (R <= 45, e < 256 R)
+    th += base; mu += base; nu += base;
+    const bool aligned = ((((uintptr_t)th) | ((uintptr_t)mu) | ((uintptr_t)nu)) & 15) == 0;
+    const int total4 = aligned ? total >> 2 : 0;
+    auto element = [&](int e, float& t, float& m, float& v) {
+        const int il = (int)(((uint32_t)e * inv) >> 20);
+        const int j = e - il * R;
+        const int kb = j / 3, c = j - 3 * kb, k = k0 + kb;
+        const float g = grad(il, k, c);
+        t = gsr::adam_update(t, g, m, v, hy);
+        TS.shs[(size_t)(i0 + il) * K3 + 3 * k0 + j] = t;  // hcat(sh_color, sh_remainder) of the next forward
+    };
+    for (int f = threadIdx.x; f < total4; f += 256) {
+        float4 t4 = reinterpret_cast<float4*>(th)[f], m4 = reinterpret_cast<float4*>(mu)[f],
+               v4 = reinterpret_cast<float4*>(nu)[f];
+        element(4 * f, t4.x, m4.x, v4.x);
+        element(4 * f + 1, t4.y, m4.y, v4.y);
+        element(4 * f + 2, t4.z, m4.z, v4.z);
+        element(4 * f + 3, t4.w, m4.w, v4.w);
+        reinterpret_cast<float4*>(th)[f] = t4;
+        reinterpret_cast<float4*>(mu)[f] = m4;
+        reinterpret_cast<float4*>(nu)[f] = v4;
+    }
+    for (int e = 4 * total4 + threadIdx.x; e < total; e += 256) {
+        float t = th[e], m = mu[e], v = nu[e];
+        element(e, t, m, v);
+        th[e] = t; mu[e] = m; nu[e] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // fused ∇project! (projection.jl:170-256) + ∇spherical_harmonics!
 // (spherical_harmonics.jl:32-37,76-181).  Every output element is written exactly
@@ -947,40 +988,10 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
     if constexpr (FUSED) {
         if (i < n) gsr::tail_gauss_apply(TS, i, f_vmean, f_vopac, f_vs, f_vq);
         __syncthreads();
-        // one SH group of the workgroup's Gaussians, element-major: R floats per Gaussian starting at band k0
+        // (g(il, k, c): the SH-coefficient gradient of Gaussian il of the workgroup, band k, channel c)
+        auto grad = [&](int il, int k, int c) { return k < tail_nb[il] ? tail_b[il][k] * tail_vc[il][c] : 0.0f; };
         auto sh_group = [&](float* __restrict__ th, float* __restrict__ mu, float* __restrict__ nu, int R, int k0,
-                            const gsr::AdamHyper& hy) {
-            const size_t base = (size_t)i0 * R;
-            const int total = cnt * R;
-            const uint32_t inv = (1u << 20) / (uint32_t)R + 1u;  // e / R == (e * inv) >> 20 for e < 2^20 / R (R <= 45, e < 256 R)
-            th += base; mu += base; nu += base;
-            const bool aligned = ((((uintptr_t)th) | ((uintptr_t)mu) | ((uintptr_t)nu)) & 15) == 0;
-            const int total4 = aligned ? total >> 2 : 0;
-            auto element = [&](int e, float& t, float& m, float& v) {
-                const int il = (int)(((uint32_t)e * inv) >> 20);
-                const int j = e - il * R;
-                const int kb = j / 3, c = j - 3 * kb, k = k0 + kb;
-                const float g = k < tail_nb[il] ? tail_b[il][k] * tail_vc[il][c] : 0.0f;
-                t = gsr::adam_update(t, g, m, v, hy);
-                TS.shs[(size_t)(i0 + il) * K3 + 3 * k0 + j] = t;  // hcat(sh_color, sh_remainder) of the next forward
-            };
-            for (int f = threadIdx.x; f < total4; f += 256) {
-                float4 t4 = reinterpret_cast<float4*>(th)[f], m4 = reinterpret_cast<float4*>(mu)[f],
-                       v4 = reinterpret_cast<float4*>(nu)[f];
-                element(4 * f, t4.x, m4.x, v4.x);
-                element(4 * f + 1, t4.y, m4.y, v4.y);
-                element(4 * f + 2, t4.z, m4.z, v4.z);
-                element(4 * f + 3, t4.w, m4.w, v4.w);
-                reinterpret_cast<float4*>(th)[f] = t4;
-                reinterpret_cast<float4*>(mu)[f] = m4;
-                reinterpret_cast<float4*>(nu)[f] = v4;
-            }
-            for (int e = 4 * total4 + threadIdx.x; e < total; e += 256) {
-                float t = th[e], m = mu[e], v = nu[e];
-                element(e, t, m, v);
-                th[e] = t; mu[e] = m; nu[e] = v;
-            }
-        };
+                            const gsr::AdamHyper& hy) { tail_sh_group(TS, i0, cnt, K3, th, mu, nu, R, k0, hy, grad); };
         sh_group(TS.dc, TS.dc_mu, TS.dc_nu, 3, 0, TS.h_dc);
         if (K > 1) sh_group(TS.rest, TS.rest_mu, TS.rest_nu, 3 * (K - 1), 1, TS.h_rest);
     }
@@ -1057,6 +1068,60 @@ __global__ __launch_bounds__(256) void sh_grad_views_kernel(int n, int K, int n_
     for (int f = threadIdx.x; f < total4; f += 256)
         reinterpret_cast<float4*>(dst)[f] = make_float4(value(4 * f), value(4 * f + 1), value(4 * f + 2), value(4 * f + 3));
     for (int e = 4 * total4 + threadIdx.x; e < total; e += 256) dst[e] = value(e);
+}
+
+// The multi-GPU trainer step made self-contained (training.jl:768-779): after the exchange of the
+// factored arena — the 11·N small gradients all-reduced, the per-view colour cotangents all-gathered — ONE pass rebuilds
+// Σ_v basis(dir_v) ⊗ vc_v per Gaussian (as sh_grad_views_kernel), keeps it in LDS instead of writing the 3K·N-float
+// ∇shs, and applies the trainer tail right there: pullback of the functor prologue + the six NU.Adam updates + the
+// activated copies of the next forward (adam_math.h / tail_sh_group: the definitions gsr_trainer_tail_step and the
+// backward's fused epilogue use).  Bit-identical θ, μ, ν to gsr_sh_grad_from_views followed by gsr_trainer_tail_step;
+// 192 B/Gaussian of gradient writes and reads less.  `S.points` are the means the directions are taken from; they are
+// read before they are updated (same thread).
+template <int DEG>
+__global__ __launch_bounds__(256) void sh_views_tail_kernel(int n, int K, int n_views, const float* __restrict__ centers,
+                                                            const float* __restrict__ vc_all,
+                                                            const float* __restrict__ vmeans,
+                                                            const float* __restrict__ vopac_act,
+                                                            const float* __restrict__ vscales_act,
+                                                            const float* __restrict__ vrot, gsr::TailState S) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    constexpr int ST = 3 * NB + 1;                 // odd stride: conflict-free
+    __shared__ float stage[256 * ST];
+    float acc[3 * NB];
+#pragma unroll
+    for (int k = 0; k < 3 * NB; k++) acc[k] = 0.0f;
+    if (i < n) {
+        const float p[3] = {S.points[3 * (size_t)i], S.points[3 * (size_t)i + 1], S.points[3 * (size_t)i + 2]};
+        for (int v = 0; v < n_views; v++) {
+            const float* vcp = vc_all + ((size_t)v * n + i) * 3;
+            const float vc[3] = {vcp[0], vcp[1], vcp[2]};
+            if (vc[0] == 0.0f && vc[1] == 0.0f && vc[2] == 0.0f) continue;  // culled in this view (or zero cotangent)
+            float d0[3] = {p[0] - centers[3 * v], p[1] - centers[3 * v + 1], p[2] - centers[3 * v + 2]};
+            float inv = 1.0f / sqrtf(d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2]);
+            const float dir[3] = {d0[0] * inv, d0[1] * inv, d0[2] * inv};
+            float b[16];
+            sh_basis<DEG>(dir, b);
+#pragma unroll
+            for (int k = 0; k < NB; k++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) acc[3 * k + c] = acc[3 * k + c] + b[k] * vc[c];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3 * NB; k++) stage[threadIdx.x * ST + k] = acc[k];
+    if (i < n) {
+        const float vm[3] = {vmeans[3 * (size_t)i], vmeans[3 * (size_t)i + 1], vmeans[3 * (size_t)i + 2]};
+        const float vs[3] = {vscales_act[3 * (size_t)i], vscales_act[3 * (size_t)i + 1], vscales_act[3 * (size_t)i + 2]};
+        const float vq[4] = {vrot[4 * (size_t)i], vrot[4 * (size_t)i + 1], vrot[4 * (size_t)i + 2], vrot[4 * (size_t)i + 3]};
+        gsr::tail_gauss_apply(S, i, vm, vopac_act[i], vs, vq);
+    }
+    __syncthreads();
+    const int i0 = blockIdx.x * 256, cnt = min(256, n - i0), K3 = 3 * K;
+    auto grad = [&](int il, int k, int c) { return k < NB ? stage[il * ST + 3 * k + c] : 0.0f; };  // bands above the degree: 0
+    tail_sh_group(S, i0, cnt, K3, S.dc, S.dc_mu, S.dc_nu, 3, 0, S.h_dc, grad);
+    if (K > 1) tail_sh_group(S, i0, cnt, K3, S.rest, S.rest_mu, S.rest_nu, 3 * (K - 1), 1, S.h_rest, grad);
 }
 
 // _update_stats! (src/strategy.jl:118-136): densification statistics from the side outputs of
@@ -1141,6 +1206,22 @@ void gsr_launch_pergauss_bwd_tail(hipStream_t s, int n, int K, int degree, int c
                        r4, (const float*)nullptr, cam, geom, inst, vmean2d, (float*)nullptr, (float*)nullptr,       \
                        (float*)nullptr, (float*)nullptr, (float4*)nullptr, (float*)nullptr, (float*)nullptr,        \
                        (float*)nullptr, S)
+    switch (degree) {
+        case 0: LAUNCH(0); break;
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        default: LAUNCH(3); break;
+    }
+#undef LAUNCH
+}
+
+void gsr_launch_sh_views_tail(hipStream_t s, int n, int K, int degree, int n_views, const float* centers,
+                              const float* vc_all, const float* vmeans, const float* vopac_act, const float* vscales_act,
+                              const float* vrot, const gsr::TailState& S) {
+    if (n <= 0) return;
+    dim3 grid((n + 255) / 256), block(256);
+#define LAUNCH(D) hipLaunchKernelGGL(sh_views_tail_kernel<D>, grid, block, 0, s, n, K, n_views, centers, vc_all, vmeans, \
+                                     vopac_act, vscales_act, vrot, S)
     switch (degree) {
         case 0: LAUNCH(0); break;
         case 1: LAUNCH(1); break;

@@ -79,15 +79,21 @@ PARAMS = ("points", "features_dc", "features_rest", "scales", "rotations", "opac
 class GaussianModel:
     """The six parameter arrays of `GaussianModel` (gaussians.jl:2-20) as HIP device tensors, Gaussian index first:
     points (N,3), features_dc (N,1,3), features_rest (N,K-1,3) (may be empty), scales (N,3) or (N,1), rotations (N,4),
-    opacities (N,1) — all raw (pre-activation)."""
+    opacities (N,1) — all raw (pre-activation).  `ids`: the optional Int32 (N) label array of the reference's model
+    (`use_ids`, gaussians.jl:14,25,46): not a parameter, no optimizer — carried through clone / split / prune like one
+    (densification.jl:47,90,185-188,253-257)."""
 
-    def __init__(self, points, features_dc, features_rest, scales, rotations, opacities):
+    def __init__(self, points, features_dc, features_rest, scales, rotations, opacities, ids=None):
         self.points, self.features_dc, self.features_rest = points, features_dc, features_rest
         self.scales, self.rotations, self.opacities = scales, rotations, opacities
+        self.ids = ids
         for k in PARAMS:
             t = getattr(self, k)
             if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
                 raise ValueError(f"{k} must be a contiguous float32 HIP device tensor (no CPU path)")
+        if ids is not None and not (ids.is_cuda and ids.dtype == torch.int32 and ids.is_contiguous()
+                                    and tuple(ids.shape) == (points.shape[0],)):
+            raise ValueError("ids must be a contiguous int32 HIP device tensor of N elements")
 
     def __len__(self):
         return int(self.points.shape[0])
@@ -97,7 +103,8 @@ class DefaultStrategy:
     """DefaultStrategy (strategy.jl:28-66): per-Gaussian statistics + hyper-parameters."""
 
     def __init__(self, gs: GaussianModel, dense_percent=1e-2, densify_from_iter=500, densify_until_iter=15_000,
-                 densification_interval=100, densify_grad_threshold=2e-4, opacity_reset_interval=3_000, min_opacity=0.005):
+                 densification_interval=100, densify_grad_threshold=2e-4, opacity_reset_interval=3_000, min_opacity=0.005,
+                 seed: int = 0):
         n, dev = len(gs), gs.points.device
         self.max_radii = torch.zeros(n, dtype=torch.int32, device=dev)
         self.accum_grad_means_2d = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -107,9 +114,21 @@ class DefaultStrategy:
         self.opacity_reset_interval, self.min_opacity = int(opacity_reset_interval), float(min_opacity)
         # Split noise is a pure function of (seed, appended row, draw): the seed MUST differ between densification rounds
         # or appended row i would get the same normal triple every round (the reference draws fresh randn each time,
-        # densification.jl:121-135).  `split_seed_base` identifies the run; `split_rounds` advances on every split.
-        self.split_seed_base = 0
+        # densification.jl:121-135).  `split_seed_base` identifies the run — the trainer's RNG seed (`seed`), the same on
+        # every rank of a multi-GPU job so that the replicas split identically —, `split_rounds` advances on every split;
+        # both travel in checkpoints (state_dict / checkpoint.save_state(strategy=...)), so a resumed run continues the
+        # noise sequence instead of replaying it from round 1.
+        self.split_seed_base = int(seed) & 0xFFFFFFFF
         self.split_rounds = 0
+
+    def state_dict(self) -> dict:
+        """What a checkpoint must hold for `next_split_seed` to continue where it stopped (scalars only: the per-Gaussian
+        statistics restart from zero at every densification anyway, densification.jl:203-209)."""
+        return {"split_seed_base": int(self.split_seed_base), "split_rounds": int(self.split_rounds)}
+
+    def load_state_dict(self, d: dict):
+        self.split_seed_base = int(d["split_seed_base"]) & 0xFFFFFFFF
+        self.split_rounds = int(d["split_rounds"])
 
     def next_split_seed(self) -> int:
         """Seed for the next split when the caller gives none: distinct for every round of this strategy object."""
@@ -148,11 +167,17 @@ def _compose(gs: GaussianModel, optimizers, keep_idx, n_keep, sel_idx, n_sel, re
         groups += [L.ComposeGroup(x.data_ptr(), y.data_ptr(), rw, 0), L.ComposeGroup(opt.mu.data_ptr(), mu.data_ptr(), rw, 1),
                    L.ComposeGroup(opt.nu.data_ptr(), nu.data_ptr(), rw, 1)]
         outs.append((k, y, mu, nu))
+    new_ids = None
+    if gs.ids is not None:  # gs.ids[mask] / repeat(gs.ids[mask], 2) / gs.ids[valid_mask] (densification.jl:47,90,185-188)
+        new_ids = torch.empty(rows, device=gs.ids.device, dtype=torch.int32)
+        groups.append(L.ComposeGroup(gs.ids.data_ptr(), new_ids.data_ptr(), 1, 0))
     arr = (L.ComposeGroup * len(groups))(*groups)
     L.check(L.load().gsr_compose_rows(arr, len(groups), _ptr(keep_idx), n_keep, _ptr(sel_idx), n_sel, reps, _stream()))
     for k, y, mu, nu in outs:
         setattr(gs, k, y)
         optimizers[k].mu, optimizers[k].nu = mu, nu
+    if new_ids is not None:
+        gs.ids = new_ids
 
 
 def _reset_stats(strategy: DefaultStrategy, n, dev):

@@ -153,6 +153,30 @@ def fused_backward_tail_step(rast, vpixels, opts, raw, shs, opacities_act, scale
         o.current_step += 1
 
 
+def sh_views_tail_step(opts, raw, small_grads, vcolors_all, camera_centers, sh_degree: int, shs, opacities_act, scales_act):
+    """The multi-GPU `step!` after the gradient exchange, self-contained (gsr_sh_grad_from_views_tail): rebuild
+    Σ_views basis x vc from the all-gathered colour cotangents `vcolors_all` (V,N,3) and apply prologue pullback + the six
+    `NU.step!` + the next prologue in the same pass — the (N,K,3) ∇shs is never written.  `small_grads`: dict with vmeans,
+    vopacities, vscales, vrot of the all-reduced block (distributed.split_factored_arena).  Same results, bit for bit, as
+    `rasterizer.sh_grad_from_views(...)` followed by `trainer_tail_step(...)`."""
+    n = raw["points"].shape[0]
+    K = int(shs.shape[1])
+    V = int(vcolors_all.shape[0])
+    for t, nm, shape in ((vcolors_all, "vcolors_all", (V, n, 3)), (camera_centers, "camera_centers", (V, 3))):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == shape):
+            raise ValueError(f"{nm} must be a contiguous float32 HIP device tensor of shape {shape}")
+    for k in ("vmeans", "vopacities", "vscales", "vrot"):
+        if not (small_grads[k].is_cuda and small_grads[k].dtype == torch.float32 and small_grads[k].is_contiguous()):
+            raise ValueError(f"{k} must be a contiguous float32 HIP device tensor")
+    st, bump = tail_state(opts, raw, shs, opacities_act, scales_act)
+    tg = L.TailGrads(small_grads["vmeans"].data_ptr(), None, small_grads["vopacities"].data_ptr(),
+                     small_grads["vscales"].data_ptr(), small_grads["vrot"].data_ptr())
+    L.check(L.load().gsr_sh_grad_from_views_tail(n, K, int(sh_degree), V, camera_centers.data_ptr(), vcolors_all.data_ptr(),
+                                                 C.byref(tg), C.byref(st), _stream()))
+    for o in bump:  # committed only after validation and a successful launch
+        o.current_step += 1
+
+
 def nonfinite_gradient_report(names, grads, n: int):
     """The GSP_DEBUG guard of `step!` + the per-parameter part of `nonfinite_gradient_report` (training.jl:534-552,772-777):
     for gradient arrays `grads` (each with the Gaussian index first, n rows; empty ones are skipped) returns

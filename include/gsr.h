@@ -475,6 +475,21 @@ GSR_API int gsr_sh_grad_from_views(int32_t n, int32_t n_coeffs, int32_t sh_degre
                                    const float* camera_centers, const float* means, const float* vcolors_all,
                                    float* vshs, void* stream);
 
+/* New in ABI 4 (SURVEY.md §8f-1 for the multi-GPU step; training.jl:768-779): gsr_sh_grad_from_views with the trainer tail in
+ * place of the ∇shs store.  After the factored exchange — the 11·N small gradients all-reduced, the per-view colour
+ * cotangents all-gathered — ONE pass rebuilds Σ_v basis(dir_v) x vc_v per Gaussian, keeps it on chip, and applies the
+ * pullback of the functor prologue + the six NU.Adam updates + the activated copies of the next forward.  Equivalent to
+ *     gsr_sh_grad_from_views(n, K, deg, V, centers, st->theta[0], vcolors_all, vshs, stream);
+ *     gsr_trainer_tail_step(n, K-1, st->scale_dims, {small..., vshs}, st->theta, st->mu, st->nu, ..., stream);
+ * with bit-identical θ, μ, ν and activated copies, without the 3K·N-float ∇shs ever being written or read.
+ *   small : vmeans, vopacities, vscales, vrotations of the all-reduced block (w.r.t. the ACTIVATED opacity / scale);
+ *           small->vshs is not read (may be NULL)
+ *   st    : as for gsr_backward_trainer_tail (theta[0] = the points the view directions are taken from; vmeans2d and
+ *           forward_generation are not used). */
+GSR_API int gsr_sh_grad_from_views_tail(int32_t n, int32_t n_coeffs, int32_t sh_degree, int32_t n_views,
+                                        const float* camera_centers, const float* vcolors_all,
+                                        const gsr_tail_grads* small, const gsr_tail_state* st, void* stream);
+
 /* New (no reference counterpart): sum the per-view gradient arena over
  * the ranks of an RCCL communicator (ncclComm_t passed as void*).  librccl is resolved
  * lazily with dlopen, so single-GPU users need not have it. */

@@ -61,6 +61,31 @@ def main():
     torch.cuda.synchronize()
     np.save(os.path.join(out_dir, f"fact_small_{rank}.npy"), farena[:11 * N].cpu().numpy())
     np.save(os.path.join(out_dir, f"fact_vshs_{rank}.npy"), vshs.cpu().numpy())
+    # the trainer step made self-contained (gsr_sh_grad_from_views_tail): from the SAME exchanged data, rebuild + Adam in one
+    # pass must leave the parameters where rebuild -> gsr_trainer_tail_step leaves them (bit for bit, on every rank)
+    O = pkg.optim
+    lrs = dict(points=1.6e-4, features_dc=2.5e-3, features_rest=2.5e-3 / 20, opacities=2.5e-2, scales=5e-3, rotations=1e-3)
+
+    def trainer():
+        raw = dict(points=p[0].clone(), features_dc=p[1][:, :1].contiguous(), features_rest=p[1][:, 1:].contiguous(),
+                   opacities=to(s.opacities_raw.reshape(-1, 1)), scales=to(s.scales_raw), rotations=p[4].clone())
+        opts = {k: O.Adam(raw[k], lrs[k], eps=1e-15) for k in O.GROUPS}
+        act = list(pkg.rasterizer.prologue_forward(raw["features_dc"], raw["features_rest"], raw["opacities"], raw["scales"]))
+        return raw, opts, act
+
+    g = D.split_factored_arena(farena, N)
+    small = dict(vmeans=g["vmeans"], vopacities=g["vopacities"].view(-1, 1), vscales=g["vscales"], vrot=g["vrot"])
+    vc_all = gathered.view(world, N, 3)
+    raw_a, opt_a, act_a = trainer()
+    raw_b, opt_b, act_b = trainer()
+    O.sh_views_tail_step(opt_a, raw_a, small, vc_all, centers_d, DEG, *act_a)
+    O.trainer_tail_step(opt_b, raw_b, dict(small, vshs=vshs), *act_b)
+    torch.cuda.synchronize()
+    same = all(torch.equal(raw_a[k], raw_b[k]) and torch.equal(opt_a[k].mu, opt_b[k].mu) and torch.equal(opt_a[k].nu, opt_b[k].nu)
+               for k in O.GROUPS) and all(torch.equal(a, b) for a, b in zip(act_a, act_b))
+    moved = float((raw_a["features_rest"] - p[1][:, 1:]).abs().max()) > 0
+    np.save(os.path.join(out_dir, f"tail_{rank}.npy"), np.array([int(same), int(moved)]))
+    np.save(os.path.join(out_dir, f"tail_points_{rank}.npy"), raw_a["points"].cpu().numpy())
     # per-view side outputs stay local (they feed per-view densification statistics)
     np.save(os.path.join(out_dir, f"radii_{rank}.npy"), rast.gstate.radii.cpu().numpy())
     if torch.distributed.is_initialized():

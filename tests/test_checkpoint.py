@@ -44,6 +44,34 @@ def test_state_roundtrip_names_and_metadata(pkg, tmp_path):
         assert fresh[k].current_step == opts[k].current_step
 
 
+def test_strategy_split_noise_position_travels_in_the_metadata(pkg, tmp_path):
+    """`split_rounds` / `split_seed_base` of the DefaultStrategy are saved as two extra metadata scalars (the
+    reference's reader never asks for them) and restored, so a resumed run does not replay its split noise from round 1."""
+    ck = pkg.checkpoint
+
+    class _Strat:
+        def __init__(self): self.split_seed_base, self.split_rounds = 0, 0
+        def state_dict(self): return {"split_seed_base": self.split_seed_base, "split_rounds": self.split_rounds}
+        def load_state_dict(self, d): self.split_seed_base, self.split_rounds = int(d["split_seed_base"]), int(d["split_rounds"])
+
+    g = _model(pkg)
+    sizes = dict(points=33, features_dc=33, features_rest=11 * 45, opacities=11, scales=33, rotations=44)
+    opts = {k: _Opt(v, i) for i, (k, v) in enumerate(sizes.items())}
+    st = _Strat(); st.split_seed_base, st.split_rounds = 4242, 17
+    path = str(tmp_path / "state.safetensors")
+    ck.save_state(path, g, opts, step=5, strategy=st)
+    c = ck.load_checkpoint(path)
+    assert c.meta["strategy.split_rounds"] == "17" and c.meta["strategy.split_seed_base"] == "4242"
+    st2 = _Strat()
+    ck.load_state(path, {k: _Opt(v, 9) for k, v in sizes.items()}, strategy=st2)
+    assert (st2.split_seed_base, st2.split_rounds) == (4242, 17)
+    # a file without the keys (a reference-written checkpoint) leaves the strategy alone
+    ck.save_state(path, g, opts, step=5)
+    st3 = _Strat(); st3.split_rounds = 3
+    ck.load_state(path, {k: _Opt(v, 9) for k, v in sizes.items()}, strategy=st3)
+    assert st3.split_rounds == 3
+
+
 def test_foreign_safetensors_is_rejected(pkg, tmp_path):
     from safetensors.numpy import save_file
     path = str(tmp_path / "other.safetensors")

@@ -39,6 +39,10 @@ def test_densify_and_prune_matches_oracle(pkg, scale_dims, k_rest, mss):
     for k in dz.PARAMS:
         opt_o[k]["mu"][:] = rng.normal(size=opt_o[k]["mu"].shape); opt_o[k]["nu"][:] = rng.uniform(size=opt_o[k]["nu"].shape)
     gs_d = to_device(pkg, gs_o)
+    # `gs.ids` (use_ids, gaussians.jl:14,46): labels that ride along — here the original index, so the result says where
+    # every surviving row came from
+    ids0 = np.arange(n, dtype=np.int32) * 3 + 1
+    gs_d.ids = dev(ids0, torch.int32)
     opt_d = device_optimizers(pkg, gs_d, opt_o)
     st_d = Dz.DefaultStrategy(gs_d)
     st_d.max_radii, st_d.accum_grad_means_2d, st_d.denom = dev(st_o.max_radii, torch.int32), dev(st_o.accum_grad_means_2d), dev(st_o.denom)
@@ -67,6 +71,16 @@ def test_densify_and_prune_matches_oracle(pkg, scale_dims, k_rest, mss):
         assert np.array_equal(opt_d[k].nu.cpu().numpy(), opt_o[k]["nu"]), k
     assert np.array_equal(st_d.max_radii.cpu().numpy(), st_o.max_radii) and st_d.denom.shape[0] == len(gs_o)
     assert not st_d.accum_grad_means_2d.any()
+    # ids through the three steps, restated from the reference: clone appends gs.ids[mask] (densification.jl:47,253-257), split
+    # appends repeat(gs.ids[mask], 2) and prunes the originals (:90,105-111), prune keeps gs.ids[valid_mask] (:185-188)
+    ids = np.concatenate([ids0, ids0[masks_o["clone"]]])
+    sp = masks_o["split"]
+    ids = np.concatenate([ids[~sp], np.tile(ids[sp], 2)])
+    ids = ids[masks_o["valid"]]
+    got = gs_d.ids.cpu().numpy()
+    assert got.dtype == np.int32 and np.array_equal(got, ids)
+    with pytest.raises(ValueError):
+        Dz.GaussianModel(*[getattr(gs_d, k) for k in dz.PARAMS], ids=gs_d.ids[:-1].contiguous())
 
 
 def test_reset_opacity_matches_oracle(pkg):
@@ -164,3 +178,11 @@ def test_default_split_seed_differs_between_rounds(pkg):
     c, d = one_round(st_d, 7), one_round(st_d, 7)
     assert np.array_equal(c, d), "an explicit seed is reproducible"
     assert st_d.split_rounds == 2, "explicit seeds do not advance the counter"
+    # the seed base comes from the trainer's RNG seed and the round counter survives a checkpoint — a resumed run
+    # continues the noise sequence instead of replaying it
+    s1 = Dz.DefaultStrategy(to_device(pkg, gs_o), seed=1234)
+    s2 = Dz.DefaultStrategy(to_device(pkg, gs_o), seed=1235)
+    assert s1.next_split_seed() != s2.next_split_seed()
+    s3 = Dz.DefaultStrategy(to_device(pkg, gs_o))
+    s3.load_state_dict(s1.state_dict())
+    assert s3.split_rounds == 1 and s3.next_split_seed() == s1.next_split_seed()

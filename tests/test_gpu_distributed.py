@@ -69,6 +69,9 @@ def _ranks_vs_sequential(tmp_path, pkg, launch_ranks, world, extra_env):
         vshs = np.load(tmp_path / f"fact_vshs_{r}.npy")
         assert rel_l2(vshs.reshape(-1), ref["vshs"].cpu().numpy().reshape(-1)) <= 1e-6
         assert np.array_equal(np.load(tmp_path / f"radii_{r}.npy"), radii[r]), "per-view side outputs stay local"
+        # the multi-GPU trainer step in one pass == rebuild -> gsr_trainer_tail_step, and every rank ends on the same parameters
+        assert list(np.load(tmp_path / f"tail_{r}.npy")) == [1, 1]
+        assert np.array_equal(np.load(tmp_path / f"tail_points_{r}.npy"), np.load(tmp_path / "tail_points_0.npy"))
 
 
 class _NcclId(C.Structure):

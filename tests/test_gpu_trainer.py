@@ -230,6 +230,57 @@ def test_fused_trainer_tail_equals_the_three_kernels_and_the_oracle(pkg, orc, kr
         assert opt_a["features_rest"].current_step == 0   # empty group skipped (training.jl:770)
 
 
+@pytest.mark.parametrize("kr,iso,deg,V", [(15, False, 3, 3), (15, False, 1, 2), (0, False, 0, 4), (3, True, 1, 1)])
+def test_multi_view_tail_equals_rebuild_then_tail_step(pkg, kr, iso, deg, V):
+    """gsr_sh_grad_from_views_tail (the multi-GPU trainer step after the factored exchange) ==
+    gsr_sh_grad_from_views + gsr_trainer_tail_step: θ, μ, ν and the activated copies bit-identical over 3 steps — the
+    (N,K,3) ∇shs is never materialised on the fused side.  Views with culled Gaussians (zero cotangents), an active degree
+    below the stored one, isotropic scales, no higher bands."""
+    r = np.random.default_rng(43)
+    n, K = 1031, 1 + kr
+    O, R = pkg.optim, pkg.rasterizer
+    shapes = dict(points=(n, 3), features_dc=(n, 1, 3), features_rest=(n, kr, 3), opacities=(n, 1),
+                  scales=(n, 1 if iso else 3), rotations=(n, 4))
+    lrs = dict(points=1.6e-4, features_dc=2.5e-3, features_rest=2.5e-3 / 20, opacities=2.5e-2, scales=5e-3, rotations=1e-3)
+    host = {k: r.normal(size=s).astype(np.float32) for k, s in shapes.items()}
+    host["points"][:, 2] += 6.0
+    raw_a = {k: dev(v) for k, v in host.items()}          # fused: rebuild + tail in one pass
+    raw_b = {k: dev(v) for k, v in host.items()}          # rebuild, then gsr_trainer_tail_step
+    opt_a = {k: O.Adam(raw_a[k], lrs[k], eps=1e-15) for k in O.GROUPS}
+    opt_b = {k: O.Adam(raw_b[k], lrs[k], eps=1e-15) for k in O.GROUPS}
+    rest = lambda d: d["features_rest"] if kr else None  # noqa: E731
+    act_a = list(R.prologue_forward(raw_a["features_dc"], rest(raw_a), raw_a["opacities"], raw_a["scales"]))
+    act_b = list(R.prologue_forward(raw_b["features_dc"], rest(raw_b), raw_b["opacities"], raw_b["scales"]))
+    centers = dev(r.normal(size=(V, 3)).astype(np.float32))
+    for step in range(1, 4):
+        vc = r.normal(size=(V, n, 3)).astype(np.float32)
+        vc[r.random((V, n)) < 0.2] = 0.0                  # culled in that view
+        small = dict(vmeans=r.normal(size=(n, 3)), vopacities=r.normal(size=(n, 1)), vscales=r.normal(size=(n, 3)),
+                     vrot=r.normal(size=(n, 4)))
+        small = {k: dev(v.astype(np.float32)) for k, v in small.items()}
+        vcd = dev(vc)
+        vshs = R.sh_grad_from_views(raw_b["points"], vcd, centers, K, deg)
+        O.trainer_tail_step(opt_b, raw_b, dict(small, vshs=vshs), *act_b)
+        O.sh_views_tail_step(opt_a, raw_a, small, vcd, centers, deg, *act_a)
+        torch.cuda.synchronize()
+        for k in O.GROUPS:
+            if not raw_a[k].numel():
+                continue
+            assert torch.equal(raw_a[k], raw_b[k]), (k, step)
+            assert torch.equal(opt_a[k].mu, opt_b[k].mu) and torch.equal(opt_a[k].nu, opt_b[k].nu), (k, step)
+            assert opt_a[k].current_step == step
+        for a, b in zip(act_a, act_b):
+            assert torch.equal(a, b), step
+    assert float((raw_a["features_dc"] - dev(host["features_dc"])).abs().max()) > 0
+    # argument checking: a null gradient is an error, not a crash
+    import ctypes as C
+    L = pkg._lib
+    st, _ = O.tail_state(opt_a, raw_a, *act_a)
+    tg = L.TailGrads(None, None, None, None, None)
+    assert L.load().gsr_sh_grad_from_views_tail(n, K, deg, V, centers.data_ptr(), vcd.data_ptr(), C.byref(tg), C.byref(st),
+                                                None) == L.GSR_E_INVALID_ARG
+
+
 def test_end_to_end_fit_reduces_the_loss(pkg):
     """The whole chain a trainer step runs — functor prologue, rasterize, L1/DSSIM loss head, ∇rasterize,
     fused trainer tail — fits a perturbed scene back towards the image it was rendered from."""

@@ -1,6 +1,6 @@
 #!/bin/bash
 # On the GPU box: step time and host CPU time per step of bench.py under different gsr_host_wait_policy settings
-# (config 2 = 0.23 ms steps, config 3 = 1.5 ms steps).   tools/host_wait_ab.sh
+# (config 2 = 0.23 ms steps, config 3 = 1.5 ms steps).   tools/experiments/host_wait_ab.sh
 cd "$GRAFT_REPO_ROOT"
 for hw in default 1000000,0,0 default 20,0,20 300,0,50; do
   for cfg in "--gaussians 100000 --no-loss --seed 1002" ""; do

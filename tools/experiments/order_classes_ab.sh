@@ -1,5 +1,9 @@
 #!/bin/bash
 # On the GPU box: launch-order length classes (GSR_ORDER_CLASSES) vs HBM reads of the fused forward and kernel times.
+# the knob GSR_ORDER_CLASSES only exists in profiles/r03/experiments/tile_order_classes.patch — without that patch
+# applied and the variant library built, every "class" below would measure the same binary.  Refuse to run then.
+grep -q GSR_ORDER_CLASSES gaussiansplatting.jl_amd/csrc/*.hip gaussiansplatting.jl_amd/csrc/*.cpp 2>/dev/null || {
+  echo "order_classes_ab.sh: GSR_ORDER_CLASSES is not in this tree: apply profiles/r03/experiments/tile_order_classes.patch and rebuild first" >&2; exit 2; }
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for c in "$@"; do
   export GSR_ORDER_CLASSES=$c

@@ -1,6 +1,6 @@
 #!/bin/bash
 # On the GPU box: SQ counters of one kernel for each library in GSR_AB_LIBS (and the default build).
-#   GSR_AB_LIBS="tools/bin/a.so tools/bin/b.so" tools/sq_ab.sh <kernel substring> [pmc_workload flags ...]
+#   GSR_AB_LIBS="tools/bin/a.so tools/bin/b.so" tools/experiments/sq_ab.sh <kernel substring> [pmc_workload flags ...]
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 K=${1:-composite_bwd}; shift
 for lib in default $GSR_AB_LIBS; do

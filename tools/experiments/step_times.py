@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """On the GPU box: the launch-to-launch interval of every step of bench.py's timed region, in order (is the mean above the
-median because of the first steps, or of scattered ones?).   python tools/step_times.py [steps = 40] [warmup = 3]"""
+median because of the first steps, or of scattered ones?).   python tools/experiments/step_times.py [steps = 40] [warmup = 3]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 import torch  # noqa: E402

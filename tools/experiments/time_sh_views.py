@@ -1,6 +1,6 @@
-"""Time gsr_sh_grad_from_views at config 3's size for V views:  python tools/time_sh_views.py [V]"""
+"""Time gsr_sh_grad_from_views at config 3's size for V views:  python tools/experiments/time_sh_views.py [V]"""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np, torch
 import gsr_pkg
 pkg = gsr_pkg.load()

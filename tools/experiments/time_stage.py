@@ -1,7 +1,7 @@
 """Stage times of the forward on config 3's scene for A/B builds (GSR_HIP_LIB selects the library):
-    python tools/time_stage.py [stage ...]"""
+    python tools/experiments/time_stage.py [stage ...]"""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np, torch
 import gsr_pkg
 pkg = gsr_pkg.load()

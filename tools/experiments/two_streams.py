@@ -1,7 +1,7 @@
 """Do two independent views on two streams overlap on one MI355X?  (memory- / atomic-bound stages of one view under the
-VALU-bound compositing of the other)   python tools/two_streams.py"""
+VALU-bound compositing of the other)   python tools/experiments/two_streams.py"""
 import os, sys, threading, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np, torch
 import gsr_pkg
 pkg = gsr_pkg.load()

@@ -189,7 +189,7 @@ struct gsr_handle {
     // ImageState (states.jl:99-111) + tile bookkeeping
     DevBuf ranges, n_contrib, final_T, tile_count, tile_start, tile_order, totals;
     // GeometryState (states.jl:2-47), repacked as one 64-byte record per Gaussian
-    DevBuf geo, gnormal, radii, bsum, bpre, bvis;
+    DevBuf geo, gnormal, radii, bsum, bpre, bvis, shjac;
     // BinningState (states.jl:66-85): unsorted keys (per-tile bins of bin_cap slots), sorted ids, sorted splat stream
     uint32_t bin_cap = 0;           // capacity (keys per tile) the NEXT fast-mode view will use; 0 = none chosen yet
     uint32_t bin_cap_view = 0;      // capacity the bins were filled with in the current view
@@ -211,6 +211,8 @@ struct gsr_handle {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool fwd_valid = false, bwd_valid = false;
     bool fwd_only = false;         // the last forward was GSR_FORWARD_ONLY: no stream / ids / row storage behind it
+    bool fwd_jac = false;          // the last forward left d colour / d direction in shjac (training forward, degree > 0)
+    int fwd_degree = -1;           // its active SH degree
     bool inputs_consumed = false;  // gsr_backward_trainer_tail updated the forward's inputs in place
     uint64_t generation = 0;             // ordinal of the last gsr_forward (gsr_stats.generation)
     int32_t* radii_cur = nullptr;        // gstate.radii of the last forward: caller's (gsr_aux.radii) or h->radii
@@ -244,7 +246,7 @@ GsrCam make_cam(const gsr_handle* h, const gsr_camera* c) {
 
 GsrGeom geom_of(const gsr_handle* h) {
     return GsrGeom{h->geo.as<GsrGeoRec>(), h->gnormal.as<float4>(), h->radii_cur, h->bsum.as<uint32_t>(),
-                   h->bpre.as<uint32_t>()};
+                   h->bpre.as<uint32_t>(), h->fwd_jac ? h->shjac.as<float>() : nullptr};
 }
 GsrStream stream_of(const gsr_handle* h) {
     return GsrStream{h->s0.as<float4>(), h->s1.as<float4>(), h->s2.as<float4>(), h->s3.as<float4>()};
@@ -419,7 +421,7 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
     DevBuf* list[] = {&h->ranges, &h->n_contrib, &h->final_T, &h->tile_count, &h->tile_start, &h->tile_order, &h->totals,
                       &h->geo, &h->gnormal, &h->radii, &h->bsum, &h->bpre, &h->bvis, &h->bins, &h->values_sorted, &h->s0,
                       &h->s1, &h->s2, &h->s3, &h->big_scratch, &h->rows, &h->vmean2d, &h->d0, &h->d1,
-                      &h->d2, &h->partial, &h->keys_compact, &h->big_list};
+                      &h->d2, &h->partial, &h->keys_compact, &h->big_list, &h->shjac};
     for (DevBuf* b : list) h->all[h->n_all++] = b;
     const size_t P = (size_t)cfg->width * cfg->height, T = (size_t)h->n_tiles;
     int rc = GSR_OK;
@@ -463,7 +465,7 @@ int gsr_destroy(gsr_handle* h) {
 int gsr_release_scene_buffers(gsr_handle* h) {
     if (!h) return fail(GSR_E_INVALID_ARG, "null handle");
     DevBuf* scene[] = {&h->geo, &h->gnormal, &h->radii, &h->bsum, &h->bpre, &h->bvis, &h->bins, &h->values_sorted, &h->s0, &h->s1,
-                       &h->s2, &h->s3, &h->big_scratch, &h->rows, &h->vmean2d, &h->keys_compact};
+                       &h->s2, &h->s3, &h->big_scratch, &h->rows, &h->vmean2d, &h->keys_compact, &h->shjac};
     h->bin_cap = 0;
     h->compact_sticky = false;
     for (DevBuf* b : scene) {
@@ -509,6 +511,10 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
         (rc = h->bsum.ensure((size_t)(n_blocks + 1) * 4)) || (rc = h->bpre.ensure((size_t)(n_blocks + 1) * 4)) || (rc = h->bvis.ensure((size_t)(n_blocks + 1) * 4)) ||
         (C > 5 && (rc = h->gnormal.ensure(nn * 16))))
         return rc;
+    // d colour / d direction for the backward (9 floats per Gaussian): only a forward that will be differentiated pays for it
+    h->fwd_jac = !fwd_only && in->sh_degree > 0;
+    h->fwd_degree = in->sh_degree;
+    if (h->fwd_jac && (rc = h->shjac.ensure(nn * 36))) return rc;
     h->radii_cur = own_radii ? h->radii.as<int32_t>() : aux->radii;
     h->vmean2d_cur = nullptr;
     h->generation++;
@@ -705,6 +711,8 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
         return fail(GSR_E_STATE, "gsr_backward without a matching gsr_forward on this handle");
     if (h->fwd_only)
         return fail(GSR_E_STATE, "the handle's last forward was GSR_FORWARD_ONLY: it kept no backward state");
+    if (in->sh_degree != h->fwd_degree)
+        return fail(GSR_E_STATE, "gsr_backward with sh_degree %d after a forward with sh_degree %d", in->sh_degree, h->fwd_degree);
     if (h->inputs_consumed)
         return fail(GSR_E_STATE, "the inputs of the handle's last forward were updated in place by "
                     "gsr_backward_trainer_tail; run gsr_forward again");
@@ -989,6 +997,9 @@ int gsr_backward_trainer_tail(gsr_handle* h, const gsr_inputs* in, const gsr_cam
         return fail(GSR_E_STATE, "gsr_backward_trainer_tail without a matching gsr_forward on this handle");
     if (h->fwd_only)
         return fail(GSR_E_STATE, "the handle's last forward was GSR_FORWARD_ONLY: it kept no backward state");
+    if (in->sh_degree != h->fwd_degree)
+        return fail(GSR_E_STATE, "gsr_backward_trainer_tail with sh_degree %d after a forward with sh_degree %d", in->sh_degree,
+                    h->fwd_degree);
     if (h->inputs_consumed)
         return fail(GSR_E_STATE, "the inputs of the handle's last forward were updated in place by "
                     "gsr_backward_trainer_tail; run gsr_forward again");

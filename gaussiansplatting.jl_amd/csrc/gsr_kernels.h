@@ -43,6 +43,8 @@ struct GsrGeom {
     int32_t* radii;
     uint32_t* bsum;   // per 256-Gaussian block: sum of tile-rect areas (scanned into bpre by tile_scan)
     uint32_t* bpre;
+    float* shjac;     // 9 planes of N floats: d(colour c)/d(direction x, y, z) of the SH expansion (plane 3·axis + c), written by
+                      // preprocess for visible Gaussians of a training forward with degree > 0, read by pergauss_bwd; or nullptr
 };
 
 // Sorted per-instance splat stream written by tile_sort (planes of float4, coalesced).

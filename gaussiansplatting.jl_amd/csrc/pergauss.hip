@@ -202,12 +202,65 @@ __device__ __forceinline__ void gaussian_normal(const M33& Rw, const M33& Rg, co
     for (int r = 0; r < 3; r++) n[r] = sign * nc[r];
 }
 
+// d(colour)/d(direction) of the SH expansion (spherical_harmonics.jl:76-173): dcx[c] = Σ_k ∂basis_k/∂x · sh[k][c] etc., for the
+// bands k >= 1 (`sh` points at band 1: SHC(k, c) = sh[3 (k-1) + c]).  ONE definition, evaluated by preprocess (which has the
+// coefficients in flight anyway and leaves the nine numbers in geom.shjac) and, as written here, what ∇spherical_harmonics!
+// needs of the 180 higher-band bytes: the per-Gaussian backward reads 36 bytes instead (round 4).
+template <int DEG>
+__device__ __forceinline__ void sh_dir_jacobian(const float* __restrict__ sh, float dirx, float diry, float dirz, float dcx[3],
+                                                float dcy[3], float dcz[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) { dcx[c] = 0.0f; dcy[c] = 0.0f; dcz[c] = 0.0f; }
+#define SHC(k_, c_) sh[3 * ((k_) - 1) + (c_)]
+    if (DEG > 0) {
+        const float x = dirx, y = diry, z = dirz;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            dcx[c] = -SH1 * SHC(3, c); dcy[c] = -SH1 * SHC(1, c); dcz[c] = SH1 * SHC(2, c);
+        }
+        // (band by band: left to itself the scheduler issues all 45 coefficient loads first and keeps them live — 20 VGPRs
+        //  and a wave per SIMD of the preprocess kernel)
+        __builtin_amdgcn_sched_barrier(0);
+        if (DEG > 1) {
+            float x2 = x * x, y2 = y * y, z2 = z * z, xy = x * y, xz = x * z, yz = y * z;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                dcx[c] = dcx[c] + SH2C1 * y * SHC(4, c) + SH2C3 * 2.0f * -x * SHC(6, c) +
+                         SH2C4 * z * SHC(7, c) + SH2C5 * 2.0f * x * SHC(8, c);
+                dcy[c] = dcy[c] + SH2C1 * x * SHC(4, c) + SH2C2 * z * SHC(5, c) +
+                         SH2C3 * 2.0f * -y * SHC(6, c) + SH2C5 * 2.0f * -y * SHC(8, c);
+                dcz[c] = dcz[c] + SH2C2 * y * SHC(5, c) + SH2C3 * 4.0f * z * SHC(6, c) + SH2C4 * x * SHC(7, c);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (DEG > 2) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    dcx[c] = dcx[c] + SH3C1 * SHC(9, c) * 3.0f * 2.0f * xy + SH3C2 * SHC(10, c) * yz +
+                             SH3C3 * SHC(11, c) * -2.0f * xy + SH3C4 * SHC(12, c) * -3.0f * 2.0f * xz +
+                             SH3C5 * SHC(13, c) * (-3.0f * x2 + 4.0f * z2 - y2) +
+                             SH3C6 * SHC(14, c) * 2.0f * xz + SH3C7 * SHC(15, c) * 3.0f * (x2 - y2);
+                    dcy[c] = dcy[c] + SH3C1 * SHC(9, c) * 3.0f * (x2 - y2) + SH3C2 * SHC(10, c) * xz +
+                             SH3C3 * SHC(11, c) * (-3.0f * y2 + 4.0f * z2 - x2) +
+                             SH3C4 * SHC(12, c) * -3.0f * 2.0f * yz + SH3C5 * SHC(13, c) * -2.0f * xy +
+                             SH3C6 * SHC(14, c) * -2.0f * yz + SH3C7 * SHC(15, c) * -3.0f * 2.0f * xy;
+                    dcz[c] = dcz[c] + SH3C2 * SHC(10, c) * xy + SH3C3 * SHC(11, c) * 4.0f * 2.0f * yz +
+                             SH3C4 * SHC(12, c) * 3.0f * (2.0f * z2 - x2 - y2) +
+                             SH3C5 * SHC(13, c) * 4.0f * 2.0f * xz + SH3C6 * SHC(14, c) * (x2 - y2);
+                    __builtin_amdgcn_sched_barrier(0);  // (channel by channel: seven coefficients in flight, not twenty-one)
+                }
+            }
+        }
+    }
+#undef SHC
+}
+
 // ---------------------------------------------------------------------------------
 // preprocess: project! (projection.jl:69-129) + spherical_harmonics!
 // (spherical_harmonics.jl:12-17,41-74) + count_tiles_per_gaussian! (utils.jl:131-141),
 // and the per-tile occupancy histogram that replaces cumsum!/duplicate/sort-by-tile.
 // ---------------------------------------------------------------------------------
-template <int DEG>
+// JAC: also leave d(colour)/d(direction) in geom.shjac for the backward (training forwards; not GSR_FORWARD_ONLY renders)
+template <int DEG, bool JAC>
 __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int channels, const float* __restrict__ means,
                                                          const float* __restrict__ scales,
                                                          const float4* __restrict__ rots,
@@ -300,6 +353,21 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
                 res = res + 0.5f + 1.1920929e-7f;
                 if (res < 0.0f) clamp_bits |= 1u << c;
                 rgb[c] = fmaxf(0.0f, res);
+            }
+            if (JAC && DEG > 0) {
+                // (the coefficients are read a second time — from L1/L2, the lines were touched a few instructions ago —
+                //  through a pointer the optimiser cannot see through: kept live from the colour sum to here they cost
+                //  20 VGPRs and the kernel a wave per SIMD, 134 instead of 114)
+                const float* sh2 = sh + 3;
+                asm volatile("" : "+v"(sh2));
+                float dcx[3], dcy[3], dcz[3];
+                sh_dir_jacobian<DEG>(sh2, d[0], d[1], d[2], dcx, dcy, dcz);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    geom.shjac[(size_t)c * n + i] = dcx[c];
+                    geom.shjac[(size_t)(3 + c) * n + i] = dcy[c];
+                    geom.shjac[(size_t)(6 + c) * n + i] = dcz[c];
+                }
             }
             if (channels > 5) {
                 float nn[3]; int k; float sg;
@@ -866,8 +934,6 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
             }
 
             // ---- ∇SH ----
-            // coefficients of band k >= 1 (band 0 has no directional gradient)
-            const float* sh = FUSED ? TS.rest + (size_t)3 * (K - 1) * i : shs + (size_t)3 * K * i + 3;
             const uint32_t clamp_bits = __float_as_uint(g2.y);
             float vc[3] = {a0.x * (1.0f - (float)(clamp_bits & 1u)), a0.y * (1.0f - (float)((clamp_bits >> 1) & 1u)),
                            a0.z * (1.0f - (float)((clamp_bits >> 2) & 1u))};
@@ -898,43 +964,18 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
 #pragma unroll
                 for (int k = 0; k < NB; k++) f_b[k] = b[k];
             }
+            // d(colour)/d(direction): the nine numbers preprocess left in geom.shjac (sh_dir_jacobian: same expressions, same
+            // translation unit — the bits the in-place evaluation from the 180 bytes of higher bands used to give); nine
+            // coalesced plane loads
             float dcx[3] = {0, 0, 0}, dcy[3] = {0, 0, 0}, dcz[3] = {0, 0, 0};
-#define SHC(k_, c_) sh[3 * ((k_) - 1) + (c_)]
             if (DEG > 0) {
-                const float x = dx, y = dy, z = dz;
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    dcx[c] = -SH1 * SHC(3, c); dcy[c] = -SH1 * SHC(1, c); dcz[c] = SH1 * SHC(2, c);
-                }
-                if (DEG > 1) {
-                    float x2 = x * x, y2 = y * y, z2 = z * z, xy = x * y, xz = x * z, yz = y * z;
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        dcx[c] = dcx[c] + SH2C1 * y * SHC(4, c) + SH2C3 * 2.0f * -x * SHC(6, c) +
-                                 SH2C4 * z * SHC(7, c) + SH2C5 * 2.0f * x * SHC(8, c);
-                        dcy[c] = dcy[c] + SH2C1 * x * SHC(4, c) + SH2C2 * z * SHC(5, c) +
-                                 SH2C3 * 2.0f * -y * SHC(6, c) + SH2C5 * 2.0f * -y * SHC(8, c);
-                        dcz[c] = dcz[c] + SH2C2 * y * SHC(5, c) + SH2C3 * 4.0f * z * SHC(6, c) + SH2C4 * x * SHC(7, c);
-                    }
-                    if (DEG > 2) {
-#pragma unroll
-                        for (int c = 0; c < 3; c++) {
-                            dcx[c] = dcx[c] + SH3C1 * SHC(9, c) * 3.0f * 2.0f * xy + SH3C2 * SHC(10, c) * yz +
-                                     SH3C3 * SHC(11, c) * -2.0f * xy + SH3C4 * SHC(12, c) * -3.0f * 2.0f * xz +
-                                     SH3C5 * SHC(13, c) * (-3.0f * x2 + 4.0f * z2 - y2) +
-                                     SH3C6 * SHC(14, c) * 2.0f * xz + SH3C7 * SHC(15, c) * 3.0f * (x2 - y2);
-                            dcy[c] = dcy[c] + SH3C1 * SHC(9, c) * 3.0f * (x2 - y2) + SH3C2 * SHC(10, c) * xz +
-                                     SH3C3 * SHC(11, c) * (-3.0f * y2 + 4.0f * z2 - x2) +
-                                     SH3C4 * SHC(12, c) * -3.0f * 2.0f * yz + SH3C5 * SHC(13, c) * -2.0f * xy +
-                                     SH3C6 * SHC(14, c) * -2.0f * yz + SH3C7 * SHC(15, c) * -3.0f * 2.0f * xy;
-                            dcz[c] = dcz[c] + SH3C2 * SHC(10, c) * xy + SH3C3 * SHC(11, c) * 4.0f * 2.0f * yz +
-                                     SH3C4 * SHC(12, c) * 3.0f * (2.0f * z2 - x2 - y2) +
-                                     SH3C5 * SHC(13, c) * 4.0f * 2.0f * xz + SH3C6 * SHC(14, c) * (x2 - y2);
-                        }
-                    }
+                    dcx[c] = geom.shjac[(size_t)c * n + i];
+                    dcy[c] = geom.shjac[(size_t)(3 + c) * n + i];
+                    dcz[c] = geom.shjac[(size_t)(6 + c) * n + i];
                 }
             }
-#undef SHC
             float vdir[3];
             vdir[0] = dcx[0] * vc[0] + dcx[1] * vc[1] + dcx[2] * vc[2];
             vdir[1] = dcy[0] * vc[0] + dcy[1] * vc[1] + dcy[2] * vc[2];
@@ -1157,16 +1198,19 @@ void gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels
     if (n <= 0) return;
     dim3 grid((n + 255) / 256), block(256);
     const float4* r4 = reinterpret_cast<const float4*>(rots);
-#define LAUNCH(D)                                                                                                  \
-    hipLaunchKernelGGL(preprocess_kernel<D>, grid, block, 0, s, n, K, channels, means, scales, r4, opac, shs, cam, \
+    // geom.shjac given: a training forward (the backward will want d colour / d direction); NULL: GSR_FORWARD_ONLY or degree 0
+#define LAUNCH2(D, J)                                                                                                    \
+    hipLaunchKernelGGL((preprocess_kernel<D, J>), grid, block, 0, s, n, K, channels, means, scales, r4, opac, shs, cam, \
                        geom, tile_count, n_visible, bins, bin_cap)
+#define LAUNCH(D) do { if (geom.shjac) LAUNCH2(D, true); else LAUNCH2(D, false); } while (0)
     switch (degree) {
-        case 0: LAUNCH(0); break;
+        case 0: LAUNCH2(0, false); break;
         case 1: LAUNCH(1); break;
         case 2: LAUNCH(2); break;
         default: LAUNCH(3); break;
     }
 #undef LAUNCH
+#undef LAUNCH2
 }
 
 void gsr_launch_emit_compact(hipStream_t s, int n, GsrCam cam, GsrGeom geom, const uint32_t* tile_start, uint32_t* tile_fill,

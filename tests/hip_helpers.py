@@ -56,9 +56,12 @@ def blend_boundary_pixels(st, opacities, W, H, ulps=4, with_ids=False):
     (tile_sort_device.h blend_threshold_bits) and the oracle's libm expf.  Small-image parity tests, where ONE pixel is
     already more than the 1e-4 outlier fraction, leave these pixels out of the count (measured case: seed 103, 80x64, pixel
     (20, 31), sigma == tau bit for bit, alpha·255 == 1.0f).  Small images only (pure numpy over every tile list).
-    with_ids=True: also the set of Gaussian ids that own such a pair."""
+    with_ids=True: also the set of Gaussian ids that own such a pair, and the set of ALL Gaussians that blend into one of
+    those pixels (alpha >= half the threshold): a flipped pair changes the transmittance of everything behind it and the
+    `accum_rec` recursion of everything in front of it at that pixel (render.jl:237-258), so that is where two evaluations
+    that decide the pair differently may legitimately differ."""
     mask = np.zeros((H, W), bool)
-    owners = set()
+    owners, touched = set(), set()
     tw = (W + 15) // 16
     op = np.asarray(opacities, np.float32).reshape(-1)
     for t, (a, b) in enumerate(np.asarray(st.ranges)):
@@ -76,6 +79,11 @@ def blend_boundary_pixels(st, opacities, W, H, ulps=4, with_ids=False):
                + np.float32(0.5) * (con[:, 0][:, None, None] * dx * dx + con[:, 2][:, None, None] * dy * dy)).astype(np.float32)
         near = np.abs(sig - tau[:, None, None]) <= ulps * np.spacing(np.abs(tau))[:, None, None]
         mask[y0:y0 + 16, x0:x0 + 16] |= near.any(0)
-        if with_ids:
+        if with_ids and near.any():
             owners.update(int(i) for i in ids[near.reshape(len(ids), -1).any(1)])
-    return (mask, owners) if with_ids else mask
+            px = near.any(0)                                             # boundary pixels of this tile
+            with np.errstate(over="ignore"):
+                alpha = o[:, None, None] * np.exp(-sig)
+            blends = (sig >= 0) & (alpha >= 0.5 / 255.0) & px[None]
+            touched.update(int(i) for i in ids[blends.reshape(len(ids), -1).any(1)])
+    return (mask, owners, touched) if with_ids else mask

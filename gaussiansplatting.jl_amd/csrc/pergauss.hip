@@ -337,11 +337,36 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
         geom.radii[i] = radius;
         if (radius > 0) {
             visible = true;
+            // (the normal first: it is the last reader of R, Rg, s and mc — 24 registers that would otherwise stay allocated
+            //  across the SH stage, the kernel's register peak, whatever the render mode)
+            if (channels > 5) {
+                float nn[3]; int k; float sg;
+                gaussian_normal(R, Rg, s, mc, nn, k, sg);
+                geom.normal[i] = make_float4(nn[0], nn[1], nn[2], 0.0f);
+            }
             // SH colour
             const float* sh = shs + (size_t)3 * K * i;
             float d[3] = {p[0] - cam.center[0], p[1] - cam.center[1], p[2] - cam.center[2]};
             float inv = 1.0f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
             d[0] *= inv; d[1] *= inv; d[2] *= inv;
+            if (JAC && DEG > 0) {
+                // d(colour)/d(direction) for the backward, BEFORE the colour sum and stored at once, so that its nine results and
+                // temporaries are dead when the sixteen basis values and the coefficient loads of the colour are live (computed
+                // after it the kernel needs 134 VGPRs instead of 114: three waves per SIMD instead of four, +26 us)
+                // (its coefficient loads are its own — through a pointer the optimiser cannot see through; the colour sum
+                //  below re-reads the lines from L1/L2 — or the 45 values would stay live across both)
+                const float* sh2 = sh + 3;
+                asm volatile("" : "+v"(sh2));
+                float dcx[3], dcy[3], dcz[3];
+                sh_dir_jacobian<DEG>(sh2, d[0], d[1], d[2], dcx, dcy, dcz);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    geom.shjac[(size_t)c * n + i] = dcx[c];
+                    geom.shjac[(size_t)(3 + c) * n + i] = dcy[c];
+                    geom.shjac[(size_t)(6 + c) * n + i] = dcz[c];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             float b[16];
             sh_basis<DEG>(d, b);
             constexpr int NB = (DEG + 1) * (DEG + 1);
@@ -353,26 +378,6 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
                 res = res + 0.5f + 1.1920929e-7f;
                 if (res < 0.0f) clamp_bits |= 1u << c;
                 rgb[c] = fmaxf(0.0f, res);
-            }
-            if (JAC && DEG > 0) {
-                // (the coefficients are read a second time — from L1/L2, the lines were touched a few instructions ago —
-                //  through a pointer the optimiser cannot see through: kept live from the colour sum to here they cost
-                //  20 VGPRs and the kernel a wave per SIMD, 134 instead of 114)
-                const float* sh2 = sh + 3;
-                asm volatile("" : "+v"(sh2));
-                float dcx[3], dcy[3], dcz[3];
-                sh_dir_jacobian<DEG>(sh2, d[0], d[1], d[2], dcx, dcy, dcz);
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    geom.shjac[(size_t)c * n + i] = dcx[c];
-                    geom.shjac[(size_t)(3 + c) * n + i] = dcy[c];
-                    geom.shjac[(size_t)(6 + c) * n + i] = dcz[c];
-                }
-            }
-            if (channels > 5) {
-                float nn[3]; int k; float sg;
-                gaussian_normal(R, Rg, s, mc, nn, k, sg);
-                geom.normal[i] = make_float4(nn[0], nn[1], nn[2], 0.0f);
             }
             get_rect(m2[0], m2[1], radius, cam.grid_x, cam.grid_y, rmin, rmax);
             area = (uint32_t)((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]));

@@ -218,9 +218,6 @@ __device__ __forceinline__ void sh_dir_jacobian(const float* __restrict__ sh, fl
         for (int c = 0; c < 3; c++) {
             dcx[c] = -SH1 * SHC(3, c); dcy[c] = -SH1 * SHC(1, c); dcz[c] = SH1 * SHC(2, c);
         }
-        // (band by band: left to itself the scheduler issues all 45 coefficient loads first and keeps them live — 20 VGPRs
-        //  and a wave per SIMD of the preprocess kernel)
-        __builtin_amdgcn_sched_barrier(0);
         if (DEG > 1) {
             float x2 = x * x, y2 = y * y, z2 = z * z, xy = x * y, xz = x * z, yz = y * z;
 #pragma unroll
@@ -231,7 +228,6 @@ __device__ __forceinline__ void sh_dir_jacobian(const float* __restrict__ sh, fl
                          SH2C3 * 2.0f * -y * SHC(6, c) + SH2C5 * 2.0f * -y * SHC(8, c);
                 dcz[c] = dcz[c] + SH2C2 * y * SHC(5, c) + SH2C3 * 4.0f * z * SHC(6, c) + SH2C4 * x * SHC(7, c);
             }
-            __builtin_amdgcn_sched_barrier(0);
             if (DEG > 2) {
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
@@ -246,7 +242,6 @@ __device__ __forceinline__ void sh_dir_jacobian(const float* __restrict__ sh, fl
                     dcz[c] = dcz[c] + SH3C2 * SHC(10, c) * xy + SH3C3 * SHC(11, c) * 4.0f * 2.0f * yz +
                              SH3C4 * SHC(12, c) * 3.0f * (2.0f * z2 - x2 - y2) +
                              SH3C5 * SHC(13, c) * 4.0f * 2.0f * xz + SH3C6 * SHC(14, c) * (x2 - y2);
-                    __builtin_amdgcn_sched_barrier(0);  // (channel by channel: seven coefficients in flight, not twenty-one)
                 }
             }
         }
@@ -352,7 +347,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
             if (JAC && DEG > 0) {
                 // d(colour)/d(direction) for the backward, BEFORE the colour sum and stored at once, so that its nine results and
                 // temporaries are dead when the sixteen basis values and the coefficient loads of the colour are live (computed
-                // after it the kernel needs 134 VGPRs instead of 114: three waves per SIMD instead of four, +26 us)
+                // after it the kernel needed 134 VGPRs: three waves per SIMD instead of four).  No scheduling barriers: they
+                // held the registers at 110 but turned the stage into five dependent memory round trips (+25 us)
                 // (its coefficient loads are its own — through a pointer the optimiser cannot see through; the colour sum
                 //  below re-reads the lines from L1/L2 — or the 45 values would stay live across both)
                 const float* sh2 = sh + 3;
@@ -365,7 +361,6 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
                     geom.shjac[(size_t)(3 + c) * n + i] = dcy[c];
                     geom.shjac[(size_t)(6 + c) * n + i] = dcz[c];
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
             float b[16];
             sh_basis<DEG>(d, b);

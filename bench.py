@@ -214,6 +214,7 @@ class SyncDir:
 
     def __init__(self, rank, world):
         self.rank, self.world = rank, world
+        self.t0 = time.time()
         self.path = os.environ.get("GSR_BENCH_SYNC_DIR") or os.path.join(
             "/tmp", f"gsr_bench_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}")
         if world > 1:
@@ -235,11 +236,16 @@ class SyncDir:
             self._put(name, str(p))
             return p
         t_end = time.time() + timeout
+        path = os.path.join(self.path, name)
         while time.time() < t_end:
             try:
-                return int(open(os.path.join(self.path, name)).read())
+                # (a file older than this run — left behind by a killed run that happened to share the launcher PID and the
+                #  port — is not rank 0's word)
+                if os.path.getmtime(path) >= self.t0 - 300.0:
+                    return int(open(path).read())
             except (OSError, ValueError):
-                time.sleep(0.05)
+                pass
+            time.sleep(0.05)
         return None
 
     def done(self, i, deadline):
@@ -247,8 +253,14 @@ class SyncDir:
         if self.world == 1:
             return
         self._put(f"done_{i}_{self.rank}", "1")
+
+        def fresh(r):
+            try:
+                return os.path.getmtime(os.path.join(self.path, f"done_{i}_{r}")) >= self.t0 - 300.0
+            except OSError:
+                return False
         while time.time() < deadline:
-            if all(os.path.exists(os.path.join(self.path, f"done_{i}_{r}")) for r in range(self.world)):
+            if all(fresh(r) for r in range(self.world)):
                 return
             time.sleep(0.05)
 

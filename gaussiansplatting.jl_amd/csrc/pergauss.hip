@@ -349,10 +349,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
                 // temporaries are dead when the sixteen basis values and the coefficient loads of the colour are live (computed
                 // after it the kernel needed 134 VGPRs: three waves per SIMD instead of four).  No scheduling barriers: they
                 // held the registers at 110 but turned the stage into five dependent memory round trips (+25 us)
-                // (its coefficient loads are its own — through a pointer the optimiser cannot see through; the colour sum
-                //  below re-reads the lines from L1/L2 — or the 45 values would stay live across both)
+                // (the coefficient loads are shared with the colour sum below: 122 VGPRs, still four waves per SIMD; reading
+                //  them a second time through a laundered pointer held the kernel at 100 VGPRs but cost as much L2 traffic in
+                //  this memory-pipeline-bound kernel as the backward saved: +19 us here for -19 us there)
                 const float* sh2 = sh + 3;
-                asm volatile("" : "+v"(sh2));
                 float dcx[3], dcy[3], dcz[3];
                 sh_dir_jacobian<DEG>(sh2, d[0], d[1], d[2], dcx, dcy, dcz);
 #pragma unroll

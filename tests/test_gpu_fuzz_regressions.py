@@ -14,8 +14,9 @@ A gradient tensor of a recorded case must satisfy ONE of
       boundary alpha = 1/255 (render.jl:95) — such a pair is decided by the last bit of sigma / exp on either side —, at least
       80 % of the squared difference sits on the Gaussians that blend into those boundary pixels (a flipped pair changes the
       transmittance of everything behind it and the accum_rec recursion of everything in front of it AT THAT PIXEL,
-      render.jl:237-258), those are at most half of the visible Gaussians, one of the two evaluations agrees with float64
-      (<= 5e-5), and without them the tensor meets (a).
+      render.jl:237-258), the boundary pixels are a handful (<= max(4, 2 % of the image), the bound of the suite's image
+      comparison), one of the two evaluations agrees with float64 (<= 1e-4: it meets (a) against the float64 model), and
+      without those Gaussians the tensor meets (a).
 Anything else — a difference spread over many Gaussians, or concentrated on one that is nowhere near the boundary and well
 conditioned — fails: that would be a kernel bug."""
 import numpy as np
@@ -61,6 +62,7 @@ def arbitrate(res, st, fs):
     vis = st.radii > 0
     W, H = fs.cam.width, fs.cam.height
     owners = touched = None
+    few_pixels = False
     verdicts = {}
     for nm, (orc_g, hip_g, f64_g) in res.items():
         e_ho, e_o, e_h = _rel(hip_g[vis], orc_g[vis]), _rel(orc_g[vis], f64_g[vis]), _rel(hip_g[vis], f64_g[vis])
@@ -78,7 +80,8 @@ def arbitrate(res, st, fs):
             continue
         d2 = ((hip_g - orc_g) ** 2).sum(1)
         if owners is None:
-            _, owners, touched = blend_boundary_pixels(st, fs.opac, W, H, with_ids=True)
+            bmask, owners, touched = blend_boundary_pixels(st, fs.opac, W, H, with_ids=True)
+            few_pixels = int(bmask.sum()) <= max(4, 0.02 * W * H)
         top = int(np.argmax(d2))
         sel = np.zeros(vis.shape[0], bool)
         sel[list(touched)] = True
@@ -86,7 +89,7 @@ def arbitrate(res, st, fs):
         rest = vis & ~sel
         e_rest = _rel(hip_g[rest], orc_g[rest])
         frac = sel[vis].mean()
-        ok = top in owners and share >= 0.8 and frac <= 0.5 and min(e_o, e_h) <= 5e-5 and e_rest <= 1e-4
+        ok = top in owners and share >= 0.8 and few_pixels and min(e_o, e_h) <= 1e-4 and e_rest <= 1e-4
         assert ok, (f"{nm}: HIP-oracle {e_ho:.2e}, oracle-f64 {e_o:.2e}, HIP-f64 {e_h:.2e}; largest contributor {top} (owns a "
                     f"boundary pair: {top in owners}); {100 * share:.0f} % of the squared difference on the {int(sel.sum())} Gaussians "
                     f"({100 * frac:.0f} % of the visible ones) that blend into the boundary pixels, the rest {e_rest:.2e}")

@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from isa_loop import blocks, cost  # noqa: E402
 
-KERNEL = "composite_bwd_kernelILi3ELi4ELb0E"
+KERNEL = "composite_bwd_kernelILi3ELi4ELb0ELb0E"  # <C = 3, PPL = 4, LISTED = false, BG0 = false>: the kernel the :rgb launch takes
 N_SIMD = 1024
 
 

@@ -209,10 +209,12 @@ struct gsr_handle {
     uint32_t tier_n[3] = {0, 0, 0};    // tiles of the last forward with lists in (1024, 4096], (4096, 8192], > 8192
     hipStream_t aux_stream = nullptr;  // the four-wave backward of those tiles runs here, next to the main launch
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t jac_stream = nullptr;  // sh_jacobian_kernel streams here, under composite_bwd (launch_sh_jacobian)
+    hipEvent_t ev_jac_fork = nullptr, ev_jac_join = nullptr;
     bool fwd_valid = false, bwd_valid = false;
     bool fwd_only = false;         // the last forward was GSR_FORWARD_ONLY: no stream / ids / row storage behind it
-    bool fwd_jac = false;          // the last forward left d colour / d direction in shjac (training forward, degree > 0)
-    int fwd_degree = -1;           // its active SH degree
+    bool fwd_jac = false;          // shjac holds d colour / d direction of the current backward (degree > 0)
+    int fwd_degree = -1;           // active SH degree of the last forward
     bool inputs_consumed = false;  // gsr_backward_trainer_tail updated the forward's inputs in place
     uint64_t generation = 0;             // ordinal of the last gsr_forward (gsr_stats.generation)
     int32_t* radii_cur = nullptr;        // gstate.radii of the last forward: caller's (gsr_aux.radii) or h->radii
@@ -439,6 +441,9 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->jac_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_jac_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_jac_join, hipEventDisableTiming);
     if (e != hipSuccess) {
         gsr_destroy(h);
         return fail(GSR_E_HIP, "pinned memory / stream / event creation failed: %s", hipGetErrorString(e));
@@ -457,6 +462,9 @@ int gsr_destroy(gsr_handle* h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
+    if (h->ev_jac_fork) (void)hipEventDestroy(h->ev_jac_fork);
+    if (h->ev_jac_join) (void)hipEventDestroy(h->ev_jac_join);
+    if (h->jac_stream) (void)hipStreamDestroy(h->jac_stream);
     h->prof.destroy();
     delete h;
     return GSR_OK;
@@ -511,10 +519,8 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
         (rc = h->bsum.ensure((size_t)(n_blocks + 1) * 4)) || (rc = h->bpre.ensure((size_t)(n_blocks + 1) * 4)) || (rc = h->bvis.ensure((size_t)(n_blocks + 1) * 4)) ||
         (C > 5 && (rc = h->gnormal.ensure(nn * 16))))
         return rc;
-    // d colour / d direction for the backward (9 floats per Gaussian): only a forward that will be differentiated pays for it
-    h->fwd_jac = !fwd_only && in->sh_degree > 0;
+    h->fwd_jac = false;
     h->fwd_degree = in->sh_degree;
-    if (h->fwd_jac && (rc = h->shjac.ensure(nn * 36))) return rc;
     h->radii_cur = own_radii ? h->radii.as<int32_t>() : aux->radii;
     h->vmean2d_cur = nullptr;
     h->generation++;
@@ -702,6 +708,26 @@ static int launch_composite_bwd(gsr_handle* h, hipStream_t s, int C, const GsrCa
     return GSR_OK;
 }
 
+// d(colour)/d(direction) of the SH expansion for ∇spherical_harmonics! (degree > 0): a register-light streaming kernel that
+// depends on the inputs only, forked onto the handle's own stream so that it runs UNDER the VALU-bound composite_bwd (which
+// leaves 32 VGPRs per SIMD lane and two wave slots free); the caller's stream joins it before pergauss_bwd reads the nine planes.
+static int fork_sh_jacobian(gsr_handle* h, hipStream_t s, const gsr_inputs* in, const GsrCam& k, const float* means) {
+    h->fwd_jac = false;
+    if (in->sh_degree <= 0 || in->n <= 0) return GSR_OK;
+    int rc = h->shjac.ensure((size_t)in->n * 36);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(h->ev_jac_fork, s));
+    HIPCHK(hipStreamWaitEvent(h->jac_stream, h->ev_jac_fork, 0));
+    gsr_launch_sh_jacobian(h->jac_stream, in->n, in->n_coeffs, in->sh_degree, means, in->shs, k, h->radii_cur, h->shjac.as<float>());
+    HIPCHK(hipEventRecord(h->ev_jac_join, h->jac_stream));
+    h->fwd_jac = true;
+    return GSR_OK;
+}
+static int join_sh_jacobian(gsr_handle* h, hipStream_t s) {
+    if (h->fwd_jac) HIPCHK(hipStreamWaitEvent(s, h->ev_jac_join, 0));
+    return GSR_OK;
+}
+
 int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, const float* vpixels,
                  const gsr_grads* g, void* stream_v) {
     int rc = check_inputs(h, in, cam);
@@ -738,9 +764,11 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
         sc6.close();
     }
     GsrCam k = make_cam(h, cam);
+    if ((rc = fork_sh_jacobian(h, s, in, k, in->means))) return rc;
     StageScope sc7(h->prof, ST_COMPOSITE_BWD, s);
     if (h->last_D > 0 && (rc = launch_composite_bwd(h, s, C, k, in->background, vpixels))) return rc;
     sc7.close();
+    if ((rc = join_sh_jacobian(h, s))) return rc;
     StageScope sc8(h->prof, ST_PERGAUSS_BWD, s);
     gsr_launch_pergauss_bwd(s, n, in->n_coeffs, in->sh_degree, C, in->means, in->scales, in->rotations, in->shs, k,
                             geom_of(h), inst_of(h), h->vmean2d_cur, g->vmeans, g->vshs, g->vopacities,
@@ -1028,9 +1056,11 @@ int gsr_backward_trainer_tail(gsr_handle* h, const gsr_inputs* in, const gsr_cam
     if (!st->vmeans2d && (rc = h->vmean2d.ensure((size_t)n * 8))) return rc;
     h->vmean2d_cur = st->vmeans2d ? reinterpret_cast<float2*>(st->vmeans2d) : h->vmean2d.as<float2>();
     GsrCam k = make_cam(h, cam);
+    if ((rc = fork_sh_jacobian(h, s, in, k, st->theta[0]))) return rc;  // (the higher bands are read through in->shs == st->shs)
     StageScope sc11(h->prof, ST_COMPOSITE_BWD, s);
     if (h->last_D > 0 && (rc = launch_composite_bwd(h, s, C, k, in->background, vpixels))) return rc;
     sc11.close();
+    if ((rc = join_sh_jacobian(h, s))) return rc;
     StageScope sc12(h->prof, ST_PERGAUSS_BWD, s);
     const gsr::TailState S = gsr_make_tail_state(st->theta, st->mu, st->nu, lr_t, st->beta1, st->beta2, st->eps,
                                                  st->scale_dims, st->shs, st->opacities_act, st->scales_act);

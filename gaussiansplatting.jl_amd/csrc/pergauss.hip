@@ -203,9 +203,10 @@ __device__ __forceinline__ void gaussian_normal(const M33& Rw, const M33& Rg, co
 }
 
 // d(colour)/d(direction) of the SH expansion (spherical_harmonics.jl:76-173): dcx[c] = Σ_k ∂basis_k/∂x · sh[k][c] etc., for the
-// bands k >= 1 (`sh` points at band 1: SHC(k, c) = sh[3 (k-1) + c]).  ONE definition, evaluated by preprocess (which has the
-// coefficients in flight anyway and leaves the nine numbers in geom.shjac) and, as written here, what ∇spherical_harmonics!
-// needs of the 180 higher-band bytes: the per-Gaussian backward reads 36 bytes instead (round 4).
+// bands k >= 1 (`sh` points at band 1: SHC(k, c) = sh[3 (k-1) + c]) — all that ∇spherical_harmonics! needs of the 180 bytes
+// of higher bands.  Evaluated by sh_jacobian_kernel, a register-light streaming kernel that gsr_backward launches on a stream of
+// its own NEXT TO composite_bwd (it depends on the inputs only); the per-Gaussian backward then reads 36 bytes per Gaussian
+// instead of 180 (round 4).
 template <int DEG>
 __device__ __forceinline__ void sh_dir_jacobian(const float* __restrict__ sh, float dirx, float diry, float dirz, float dcx[3],
                                                 float dcy[3], float dcz[3]) {
@@ -254,8 +255,7 @@ __device__ __forceinline__ void sh_dir_jacobian(const float* __restrict__ sh, fl
 // (spherical_harmonics.jl:12-17,41-74) + count_tiles_per_gaussian! (utils.jl:131-141),
 // and the per-tile occupancy histogram that replaces cumsum!/duplicate/sort-by-tile.
 // ---------------------------------------------------------------------------------
-// JAC: also leave d(colour)/d(direction) in geom.shjac for the backward (training forwards; not GSR_FORWARD_ONLY renders)
-template <int DEG, bool JAC>
+template <int DEG>
 __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int channels, const float* __restrict__ means,
                                                          const float* __restrict__ scales,
                                                          const float4* __restrict__ rots,
@@ -344,24 +344,6 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
             float d[3] = {p[0] - cam.center[0], p[1] - cam.center[1], p[2] - cam.center[2]};
             float inv = 1.0f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
             d[0] *= inv; d[1] *= inv; d[2] *= inv;
-            if (JAC && DEG > 0) {
-                // d(colour)/d(direction) for the backward, BEFORE the colour sum and stored at once, so that its nine results and
-                // temporaries are dead when the sixteen basis values and the coefficient loads of the colour are live (computed
-                // after it the kernel needed 134 VGPRs: three waves per SIMD instead of four).  No scheduling barriers: they
-                // held the registers at 110 but turned the stage into five dependent memory round trips (+25 us)
-                // (the coefficient loads are shared with the colour sum below: 122 VGPRs, still four waves per SIMD; reading
-                //  them a second time through a laundered pointer held the kernel at 100 VGPRs but cost as much L2 traffic in
-                //  this memory-pipeline-bound kernel as the backward saved: +19 us here for -19 us there)
-                const float* sh2 = sh + 3;
-                float dcx[3], dcy[3], dcz[3];
-                sh_dir_jacobian<DEG>(sh2, d[0], d[1], d[2], dcx, dcy, dcz);
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    geom.shjac[(size_t)c * n + i] = dcx[c];
-                    geom.shjac[(size_t)(3 + c) * n + i] = dcy[c];
-                    geom.shjac[(size_t)(6 + c) * n + i] = dcz[c];
-                }
-            }
             float b[16];
             sh_basis<DEG>(d, b);
             constexpr int NB = (DEG + 1) * (DEG + 1);
@@ -560,6 +542,31 @@ __global__ __launch_bounds__(256) void emit_compact_kernel(int n, GsrCam cam, Gs
                 keys[tile_start[t] + atomicAdd(tile_fill + t, 1u)] = bkey;
             }
         }
+    }
+}
+
+// d(colour)/d(direction) of every visible Gaussian into nine coalesced planes (plane 3·axis + channel).  What makes this a kernel
+// of its own: it needs nothing the backward computes, it streams (180 B read, 36 B written per Gaussian), and it is built to fit
+// the registers composite_bwd leaves free — six compositing waves hold 480 of a SIMD's 512 VGPRs — so that the hardware runs it
+// UNDER the VALU-bound compositing (profiles/r04/experiments/pergauss_under_composite_overlap.txt: a 0.75 GB stream beside the
+// backward costs 6 us instead of 131).  Same expressions, same translation unit as the in-place evaluation it replaces: same bits.
+template <int DEG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) void sh_jacobian_kernel(
+    int n, int K, const float* __restrict__ means, const float* __restrict__ shs, GsrCam cam,
+    const int32_t* __restrict__ radii, float* __restrict__ shjac) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || radii[i] <= 0) return;
+    const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+    float d0[3] = {p[0] - cam.center[0], p[1] - cam.center[1], p[2] - cam.center[2]};
+    float inv = 1.0f / sqrtf(d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2]);
+    const float dx = d0[0] * inv, dy = d0[1] * inv, dz = d0[2] * inv;
+    float dcx[3], dcy[3], dcz[3];
+    sh_dir_jacobian<DEG>(shs + (size_t)3 * K * i + 3, dx, dy, dz, dcx, dcy, dcz);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        shjac[(size_t)c * n + i] = dcx[c];
+        shjac[(size_t)(3 + c) * n + i] = dcy[c];
+        shjac[(size_t)(6 + c) * n + i] = dcz[c];
     }
 }
 
@@ -1198,19 +1205,29 @@ void gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels
     if (n <= 0) return;
     dim3 grid((n + 255) / 256), block(256);
     const float4* r4 = reinterpret_cast<const float4*>(rots);
-    // geom.shjac given: a training forward (the backward will want d colour / d direction); NULL: GSR_FORWARD_ONLY or degree 0
-#define LAUNCH2(D, J)                                                                                                    \
-    hipLaunchKernelGGL((preprocess_kernel<D, J>), grid, block, 0, s, n, K, channels, means, scales, r4, opac, shs, cam, \
+#define LAUNCH(D)                                                                                                  \
+    hipLaunchKernelGGL(preprocess_kernel<D>, grid, block, 0, s, n, K, channels, means, scales, r4, opac, shs, cam, \
                        geom, tile_count, n_visible, bins, bin_cap)
-#define LAUNCH(D) do { if (geom.shjac) LAUNCH2(D, true); else LAUNCH2(D, false); } while (0)
     switch (degree) {
-        case 0: LAUNCH2(0, false); break;
+        case 0: LAUNCH(0); break;
         case 1: LAUNCH(1); break;
         case 2: LAUNCH(2); break;
         default: LAUNCH(3); break;
     }
 #undef LAUNCH
-#undef LAUNCH2
+}
+
+void gsr_launch_sh_jacobian(hipStream_t s, int n, int K, int degree, const float* means, const float* shs, GsrCam cam,
+                            const int32_t* radii, float* shjac) {
+    if (n <= 0 || degree <= 0) return;
+    dim3 grid((n + 255) / 256), block(256);
+#define LAUNCH(D) hipLaunchKernelGGL(sh_jacobian_kernel<D>, grid, block, 0, s, n, K, means, shs, cam, radii, shjac)
+    switch (degree) {
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        default: LAUNCH(3); break;
+    }
+#undef LAUNCH
 }
 
 void gsr_launch_emit_compact(hipStream_t s, int n, GsrCam cam, GsrGeom geom, const uint32_t* tile_start, uint32_t* tile_fill,

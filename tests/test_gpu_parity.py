@@ -494,7 +494,7 @@ def test_ssim_known_answers_and_autograd(pkg):
     F = pkg.fused_ssim
     ones, zeros = torch.ones(1, 3, 16, 16).cuda(), torch.zeros(1, 3, 16, 16).cuda()
     assert abs(float(F.fused_ssim(ones, zeros).mean())) < 1e-4
-    assert abs(float(F.fused_ssim(ones, ones).mean()) - 1) < 1e-6
+    assert abs(float(F.fused_ssim(ones, ones).mean()) - 1) < 1e-5   # (runtests.jl:496-520 asks for ≈, i.e. 3e-4)
     x = torch.zeros(1, 3, 16, 16)
     x[:, :, 0:4, 0:4] = 0.25; x[:, :, 0:4, 4:8] = 0.5; x[:, :, 12:16, 8:12] = 0.75; x[:, :, 12:16, 12:16] = 1.0
     assert abs(float(F.fused_ssim(x.cuda(), ones).mean()) - 0.1035) < 1e-3

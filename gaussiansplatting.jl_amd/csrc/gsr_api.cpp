@@ -189,7 +189,7 @@ struct gsr_handle {
     // ImageState (states.jl:99-111) + tile bookkeeping
     DevBuf ranges, n_contrib, final_T, tile_count, tile_start, tile_order, totals;
     // GeometryState (states.jl:2-47), repacked as one 64-byte record per Gaussian
-    DevBuf geo, gnormal, radii, bsum, bpre, bvis, shjac;
+    DevBuf geo, gnormal, radii, bsum, bpre, bvis;
     // BinningState (states.jl:66-85): unsorted keys (per-tile bins of bin_cap slots), sorted ids, sorted splat stream
     uint32_t bin_cap = 0;           // capacity (keys per tile) the NEXT fast-mode view will use; 0 = none chosen yet
     uint32_t bin_cap_view = 0;      // capacity the bins were filled with in the current view
@@ -209,12 +209,8 @@ struct gsr_handle {
     uint32_t tier_n[3] = {0, 0, 0};    // tiles of the last forward with lists in (1024, 4096], (4096, 8192], > 8192
     hipStream_t aux_stream = nullptr;  // the four-wave backward of those tiles runs here, next to the main launch
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipStream_t jac_stream = nullptr;  // sh_jacobian_kernel streams here, under composite_bwd (launch_sh_jacobian)
-    hipEvent_t ev_jac_fork = nullptr, ev_jac_join = nullptr;
     bool fwd_valid = false, bwd_valid = false;
     bool fwd_only = false;         // the last forward was GSR_FORWARD_ONLY: no stream / ids / row storage behind it
-    bool fwd_jac = false;          // shjac holds d colour / d direction of the current backward (degree > 0)
-    int fwd_degree = -1;           // active SH degree of the last forward
     bool inputs_consumed = false;  // gsr_backward_trainer_tail updated the forward's inputs in place
     uint64_t generation = 0;             // ordinal of the last gsr_forward (gsr_stats.generation)
     int32_t* radii_cur = nullptr;        // gstate.radii of the last forward: caller's (gsr_aux.radii) or h->radii
@@ -248,7 +244,7 @@ GsrCam make_cam(const gsr_handle* h, const gsr_camera* c) {
 
 GsrGeom geom_of(const gsr_handle* h) {
     return GsrGeom{h->geo.as<GsrGeoRec>(), h->gnormal.as<float4>(), h->radii_cur, h->bsum.as<uint32_t>(),
-                   h->bpre.as<uint32_t>(), h->fwd_jac ? h->shjac.as<float>() : nullptr};
+                   h->bpre.as<uint32_t>()};
 }
 GsrStream stream_of(const gsr_handle* h) {
     return GsrStream{h->s0.as<float4>(), h->s1.as<float4>(), h->s2.as<float4>(), h->s3.as<float4>()};
@@ -423,7 +419,7 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
     DevBuf* list[] = {&h->ranges, &h->n_contrib, &h->final_T, &h->tile_count, &h->tile_start, &h->tile_order, &h->totals,
                       &h->geo, &h->gnormal, &h->radii, &h->bsum, &h->bpre, &h->bvis, &h->bins, &h->values_sorted, &h->s0,
                       &h->s1, &h->s2, &h->s3, &h->big_scratch, &h->rows, &h->vmean2d, &h->d0, &h->d1,
-                      &h->d2, &h->partial, &h->keys_compact, &h->big_list, &h->shjac};
+                      &h->d2, &h->partial, &h->keys_compact, &h->big_list};
     for (DevBuf* b : list) h->all[h->n_all++] = b;
     const size_t P = (size_t)cfg->width * cfg->height, T = (size_t)h->n_tiles;
     int rc = GSR_OK;
@@ -441,9 +437,6 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->jac_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_jac_fork, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_jac_join, hipEventDisableTiming);
     if (e != hipSuccess) {
         gsr_destroy(h);
         return fail(GSR_E_HIP, "pinned memory / stream / event creation failed: %s", hipGetErrorString(e));
@@ -462,9 +455,6 @@ int gsr_destroy(gsr_handle* h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
-    if (h->ev_jac_fork) (void)hipEventDestroy(h->ev_jac_fork);
-    if (h->ev_jac_join) (void)hipEventDestroy(h->ev_jac_join);
-    if (h->jac_stream) (void)hipStreamDestroy(h->jac_stream);
     h->prof.destroy();
     delete h;
     return GSR_OK;
@@ -473,7 +463,7 @@ int gsr_destroy(gsr_handle* h) {
 int gsr_release_scene_buffers(gsr_handle* h) {
     if (!h) return fail(GSR_E_INVALID_ARG, "null handle");
     DevBuf* scene[] = {&h->geo, &h->gnormal, &h->radii, &h->bsum, &h->bpre, &h->bvis, &h->bins, &h->values_sorted, &h->s0, &h->s1,
-                       &h->s2, &h->s3, &h->big_scratch, &h->rows, &h->vmean2d, &h->keys_compact, &h->shjac};
+                       &h->s2, &h->s3, &h->big_scratch, &h->rows, &h->vmean2d, &h->keys_compact};
     h->bin_cap = 0;
     h->compact_sticky = false;
     for (DevBuf* b : scene) {
@@ -519,8 +509,6 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
         (rc = h->bsum.ensure((size_t)(n_blocks + 1) * 4)) || (rc = h->bpre.ensure((size_t)(n_blocks + 1) * 4)) || (rc = h->bvis.ensure((size_t)(n_blocks + 1) * 4)) ||
         (C > 5 && (rc = h->gnormal.ensure(nn * 16))))
         return rc;
-    h->fwd_jac = false;
-    h->fwd_degree = in->sh_degree;
     h->radii_cur = own_radii ? h->radii.as<int32_t>() : aux->radii;
     h->vmean2d_cur = nullptr;
     h->generation++;
@@ -708,26 +696,6 @@ static int launch_composite_bwd(gsr_handle* h, hipStream_t s, int C, const GsrCa
     return GSR_OK;
 }
 
-// d(colour)/d(direction) of the SH expansion for ∇spherical_harmonics! (degree > 0): a register-light streaming kernel that
-// depends on the inputs only, forked onto the handle's own stream so that it runs UNDER the VALU-bound composite_bwd (which
-// leaves 32 VGPRs per SIMD lane and two wave slots free); the caller's stream joins it before pergauss_bwd reads the nine planes.
-static int fork_sh_jacobian(gsr_handle* h, hipStream_t s, const gsr_inputs* in, const GsrCam& k, const float* means) {
-    h->fwd_jac = false;
-    if (in->sh_degree <= 0 || in->n <= 0) return GSR_OK;
-    int rc = h->shjac.ensure((size_t)in->n * 36);
-    if (rc) return rc;
-    HIPCHK(hipEventRecord(h->ev_jac_fork, s));
-    HIPCHK(hipStreamWaitEvent(h->jac_stream, h->ev_jac_fork, 0));
-    gsr_launch_sh_jacobian(h->jac_stream, in->n, in->n_coeffs, in->sh_degree, means, in->shs, k, h->radii_cur, h->shjac.as<float>());
-    HIPCHK(hipEventRecord(h->ev_jac_join, h->jac_stream));
-    h->fwd_jac = true;
-    return GSR_OK;
-}
-static int join_sh_jacobian(gsr_handle* h, hipStream_t s) {
-    if (h->fwd_jac) HIPCHK(hipStreamWaitEvent(s, h->ev_jac_join, 0));
-    return GSR_OK;
-}
-
 int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, const float* vpixels,
                  const gsr_grads* g, void* stream_v) {
     int rc = check_inputs(h, in, cam);
@@ -737,8 +705,6 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
         return fail(GSR_E_STATE, "gsr_backward without a matching gsr_forward on this handle");
     if (h->fwd_only)
         return fail(GSR_E_STATE, "the handle's last forward was GSR_FORWARD_ONLY: it kept no backward state");
-    if (in->sh_degree != h->fwd_degree)
-        return fail(GSR_E_STATE, "gsr_backward with sh_degree %d after a forward with sh_degree %d", in->sh_degree, h->fwd_degree);
     if (h->inputs_consumed)
         return fail(GSR_E_STATE, "the inputs of the handle's last forward were updated in place by "
                     "gsr_backward_trainer_tail; run gsr_forward again");
@@ -764,11 +730,9 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
         sc6.close();
     }
     GsrCam k = make_cam(h, cam);
-    if ((rc = fork_sh_jacobian(h, s, in, k, in->means))) return rc;
     StageScope sc7(h->prof, ST_COMPOSITE_BWD, s);
     if (h->last_D > 0 && (rc = launch_composite_bwd(h, s, C, k, in->background, vpixels))) return rc;
     sc7.close();
-    if ((rc = join_sh_jacobian(h, s))) return rc;
     StageScope sc8(h->prof, ST_PERGAUSS_BWD, s);
     gsr_launch_pergauss_bwd(s, n, in->n_coeffs, in->sh_degree, C, in->means, in->scales, in->rotations, in->shs, k,
                             geom_of(h), inst_of(h), h->vmean2d_cur, g->vmeans, g->vshs, g->vopacities,
@@ -1025,9 +989,6 @@ int gsr_backward_trainer_tail(gsr_handle* h, const gsr_inputs* in, const gsr_cam
         return fail(GSR_E_STATE, "gsr_backward_trainer_tail without a matching gsr_forward on this handle");
     if (h->fwd_only)
         return fail(GSR_E_STATE, "the handle's last forward was GSR_FORWARD_ONLY: it kept no backward state");
-    if (in->sh_degree != h->fwd_degree)
-        return fail(GSR_E_STATE, "gsr_backward_trainer_tail with sh_degree %d after a forward with sh_degree %d", in->sh_degree,
-                    h->fwd_degree);
     if (h->inputs_consumed)
         return fail(GSR_E_STATE, "the inputs of the handle's last forward were updated in place by "
                     "gsr_backward_trainer_tail; run gsr_forward again");
@@ -1056,11 +1017,9 @@ int gsr_backward_trainer_tail(gsr_handle* h, const gsr_inputs* in, const gsr_cam
     if (!st->vmeans2d && (rc = h->vmean2d.ensure((size_t)n * 8))) return rc;
     h->vmean2d_cur = st->vmeans2d ? reinterpret_cast<float2*>(st->vmeans2d) : h->vmean2d.as<float2>();
     GsrCam k = make_cam(h, cam);
-    if ((rc = fork_sh_jacobian(h, s, in, k, st->theta[0]))) return rc;  // (the higher bands are read through in->shs == st->shs)
     StageScope sc11(h->prof, ST_COMPOSITE_BWD, s);
     if (h->last_D > 0 && (rc = launch_composite_bwd(h, s, C, k, in->background, vpixels))) return rc;
     sc11.close();
-    if ((rc = join_sh_jacobian(h, s))) return rc;
     StageScope sc12(h->prof, ST_PERGAUSS_BWD, s);
     const gsr::TailState S = gsr_make_tail_state(st->theta, st->mu, st->nu, lr_t, st->beta1, st->beta2, st->eps,
                                                  st->scale_dims, st->shs, st->opacities_act, st->scales_act);

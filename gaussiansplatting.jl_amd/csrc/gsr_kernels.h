@@ -43,9 +43,6 @@ struct GsrGeom {
     int32_t* radii;
     uint32_t* bsum;   // per 256-Gaussian block: sum of tile-rect areas (scanned into bpre by tile_scan)
     uint32_t* bpre;
-    float* shjac;     // 9 planes of N floats: d(colour c)/d(direction x, y, z) of the SH expansion (plane 3·axis + c), written by
-                      // sh_jacobian_kernel (launched by the backward next to composite_bwd) for visible Gaussians when the
-                      // degree is > 0, read by pergauss_bwd; or nullptr
 };
 
 // Sorted per-instance splat stream written by tile_sort (planes of float4, coalesced).
@@ -73,9 +70,6 @@ void gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels
                            GsrGeom geom, uint32_t* tile_count, uint32_t* n_visible /* per 256-block */,
                            uint64_t* bins /* (T+1) x bin_cap keys */, uint32_t bin_cap);
 // compact binning mode: scatter the keys to tile_start[t] + arrival rank (tile_fill zeroed by the caller)
-// d(colour)/d(direction) of the SH expansion for the backward (degree > 0): streams next to composite_bwd on its own stream
-void gsr_launch_sh_jacobian(hipStream_t s, int n, int K, int degree, const float* means, const float* shs, GsrCam cam,
-                            const int32_t* radii, float* shjac /* 9 planes of n floats */);
 void gsr_launch_emit_compact(hipStream_t s, int n, GsrCam cam, GsrGeom geom, const uint32_t* tile_start, uint32_t* tile_fill,
                              uint64_t* keys);
 void gsr_launch_pergauss_bwd(hipStream_t s, int n, int K, int degree, int channels, const float* means,

@@ -202,54 +202,6 @@ __device__ __forceinline__ void gaussian_normal(const M33& Rw, const M33& Rg, co
     for (int r = 0; r < 3; r++) n[r] = sign * nc[r];
 }
 
-// d(colour)/d(direction) of the SH expansion (spherical_harmonics.jl:76-173): dcx[c] = Σ_k ∂basis_k/∂x · sh[k][c] etc., for the
-// bands k >= 1 (`sh` points at band 1: SHC(k, c) = sh[3 (k-1) + c]) — all that ∇spherical_harmonics! needs of the 180 bytes
-// of higher bands.  Evaluated by sh_jacobian_kernel, a register-light streaming kernel that gsr_backward launches on a stream of
-// its own NEXT TO composite_bwd (it depends on the inputs only); the per-Gaussian backward then reads 36 bytes per Gaussian
-// instead of 180 (round 4).
-template <int DEG>
-__device__ __forceinline__ void sh_dir_jacobian(const float* __restrict__ sh, float dirx, float diry, float dirz, float dcx[3],
-                                                float dcy[3], float dcz[3]) {
-#pragma unroll
-    for (int c = 0; c < 3; c++) { dcx[c] = 0.0f; dcy[c] = 0.0f; dcz[c] = 0.0f; }
-#define SHC(k_, c_) sh[3 * ((k_) - 1) + (c_)]
-    if (DEG > 0) {
-        const float x = dirx, y = diry, z = dirz;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            dcx[c] = -SH1 * SHC(3, c); dcy[c] = -SH1 * SHC(1, c); dcz[c] = SH1 * SHC(2, c);
-        }
-        if (DEG > 1) {
-            float x2 = x * x, y2 = y * y, z2 = z * z, xy = x * y, xz = x * z, yz = y * z;
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                dcx[c] = dcx[c] + SH2C1 * y * SHC(4, c) + SH2C3 * 2.0f * -x * SHC(6, c) +
-                         SH2C4 * z * SHC(7, c) + SH2C5 * 2.0f * x * SHC(8, c);
-                dcy[c] = dcy[c] + SH2C1 * x * SHC(4, c) + SH2C2 * z * SHC(5, c) +
-                         SH2C3 * 2.0f * -y * SHC(6, c) + SH2C5 * 2.0f * -y * SHC(8, c);
-                dcz[c] = dcz[c] + SH2C2 * y * SHC(5, c) + SH2C3 * 4.0f * z * SHC(6, c) + SH2C4 * x * SHC(7, c);
-            }
-            if (DEG > 2) {
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    dcx[c] = dcx[c] + SH3C1 * SHC(9, c) * 3.0f * 2.0f * xy + SH3C2 * SHC(10, c) * yz +
-                             SH3C3 * SHC(11, c) * -2.0f * xy + SH3C4 * SHC(12, c) * -3.0f * 2.0f * xz +
-                             SH3C5 * SHC(13, c) * (-3.0f * x2 + 4.0f * z2 - y2) +
-                             SH3C6 * SHC(14, c) * 2.0f * xz + SH3C7 * SHC(15, c) * 3.0f * (x2 - y2);
-                    dcy[c] = dcy[c] + SH3C1 * SHC(9, c) * 3.0f * (x2 - y2) + SH3C2 * SHC(10, c) * xz +
-                             SH3C3 * SHC(11, c) * (-3.0f * y2 + 4.0f * z2 - x2) +
-                             SH3C4 * SHC(12, c) * -3.0f * 2.0f * yz + SH3C5 * SHC(13, c) * -2.0f * xy +
-                             SH3C6 * SHC(14, c) * -2.0f * yz + SH3C7 * SHC(15, c) * -3.0f * 2.0f * xy;
-                    dcz[c] = dcz[c] + SH3C2 * SHC(10, c) * xy + SH3C3 * SHC(11, c) * 4.0f * 2.0f * yz +
-                             SH3C4 * SHC(12, c) * 3.0f * (2.0f * z2 - x2 - y2) +
-                             SH3C5 * SHC(13, c) * 4.0f * 2.0f * xz + SH3C6 * SHC(14, c) * (x2 - y2);
-                }
-            }
-        }
-    }
-#undef SHC
-}
-
 // ---------------------------------------------------------------------------------
 // preprocess: project! (projection.jl:69-129) + spherical_harmonics!
 // (spherical_harmonics.jl:12-17,41-74) + count_tiles_per_gaussian! (utils.jl:131-141),
@@ -333,7 +285,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
         if (radius > 0) {
             visible = true;
             // (the normal first: it is the last reader of R, Rg, s and mc — 24 registers that would otherwise stay allocated
-            //  across the SH stage, the kernel's register peak, whatever the render mode)
+            //  across the SH stage, the kernel's register peak, whatever the render mode: 114 -> 100 VGPRs)
             if (channels > 5) {
                 float nn[3]; int k; float sg;
                 gaussian_normal(R, Rg, s, mc, nn, k, sg);
@@ -542,31 +494,6 @@ __global__ __launch_bounds__(256) void emit_compact_kernel(int n, GsrCam cam, Gs
                 keys[tile_start[t] + atomicAdd(tile_fill + t, 1u)] = bkey;
             }
         }
-    }
-}
-
-// d(colour)/d(direction) of every visible Gaussian into nine coalesced planes (plane 3·axis + channel).  What makes this a kernel
-// of its own: it needs nothing the backward computes, it streams (180 B read, 36 B written per Gaussian), and it is built to fit
-// the registers composite_bwd leaves free — six compositing waves hold 480 of a SIMD's 512 VGPRs — so that the hardware runs it
-// UNDER the VALU-bound compositing (profiles/r04/experiments/pergauss_under_composite_overlap.txt: a 0.75 GB stream beside the
-// backward costs 6 us instead of 131).  Same expressions, same translation unit as the in-place evaluation it replaces: same bits.
-template <int DEG>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) void sh_jacobian_kernel(
-    int n, int K, const float* __restrict__ means, const float* __restrict__ shs, GsrCam cam,
-    const int32_t* __restrict__ radii, float* __restrict__ shjac) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n || radii[i] <= 0) return;
-    const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
-    float d0[3] = {p[0] - cam.center[0], p[1] - cam.center[1], p[2] - cam.center[2]};
-    float inv = 1.0f / sqrtf(d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2]);
-    const float dx = d0[0] * inv, dy = d0[1] * inv, dz = d0[2] * inv;
-    float dcx[3], dcy[3], dcz[3];
-    sh_dir_jacobian<DEG>(shs + (size_t)3 * K * i + 3, dx, dy, dz, dcx, dcy, dcz);
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        shjac[(size_t)c * n + i] = dcx[c];
-        shjac[(size_t)(3 + c) * n + i] = dcy[c];
-        shjac[(size_t)(6 + c) * n + i] = dcz[c];
     }
 }
 
@@ -941,6 +868,8 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
             }
 
             // ---- ∇SH ----
+            // coefficients of band k >= 1 (band 0 has no directional gradient)
+            const float* sh = FUSED ? TS.rest + (size_t)3 * (K - 1) * i : shs + (size_t)3 * K * i + 3;
             const uint32_t clamp_bits = __float_as_uint(g2.y);
             float vc[3] = {a0.x * (1.0f - (float)(clamp_bits & 1u)), a0.y * (1.0f - (float)((clamp_bits >> 1) & 1u)),
                            a0.z * (1.0f - (float)((clamp_bits >> 2) & 1u))};
@@ -971,18 +900,43 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
 #pragma unroll
                 for (int k = 0; k < NB; k++) f_b[k] = b[k];
             }
-            // d(colour)/d(direction): the nine numbers preprocess left in geom.shjac (sh_dir_jacobian: same expressions, same
-            // translation unit — the bits the in-place evaluation from the 180 bytes of higher bands used to give); nine
-            // coalesced plane loads
             float dcx[3] = {0, 0, 0}, dcy[3] = {0, 0, 0}, dcz[3] = {0, 0, 0};
+#define SHC(k_, c_) sh[3 * ((k_) - 1) + (c_)]
             if (DEG > 0) {
+                const float x = dx, y = dy, z = dz;
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    dcx[c] = geom.shjac[(size_t)c * n + i];
-                    dcy[c] = geom.shjac[(size_t)(3 + c) * n + i];
-                    dcz[c] = geom.shjac[(size_t)(6 + c) * n + i];
+                    dcx[c] = -SH1 * SHC(3, c); dcy[c] = -SH1 * SHC(1, c); dcz[c] = SH1 * SHC(2, c);
+                }
+                if (DEG > 1) {
+                    float x2 = x * x, y2 = y * y, z2 = z * z, xy = x * y, xz = x * z, yz = y * z;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        dcx[c] = dcx[c] + SH2C1 * y * SHC(4, c) + SH2C3 * 2.0f * -x * SHC(6, c) +
+                                 SH2C4 * z * SHC(7, c) + SH2C5 * 2.0f * x * SHC(8, c);
+                        dcy[c] = dcy[c] + SH2C1 * x * SHC(4, c) + SH2C2 * z * SHC(5, c) +
+                                 SH2C3 * 2.0f * -y * SHC(6, c) + SH2C5 * 2.0f * -y * SHC(8, c);
+                        dcz[c] = dcz[c] + SH2C2 * y * SHC(5, c) + SH2C3 * 4.0f * z * SHC(6, c) + SH2C4 * x * SHC(7, c);
+                    }
+                    if (DEG > 2) {
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            dcx[c] = dcx[c] + SH3C1 * SHC(9, c) * 3.0f * 2.0f * xy + SH3C2 * SHC(10, c) * yz +
+                                     SH3C3 * SHC(11, c) * -2.0f * xy + SH3C4 * SHC(12, c) * -3.0f * 2.0f * xz +
+                                     SH3C5 * SHC(13, c) * (-3.0f * x2 + 4.0f * z2 - y2) +
+                                     SH3C6 * SHC(14, c) * 2.0f * xz + SH3C7 * SHC(15, c) * 3.0f * (x2 - y2);
+                            dcy[c] = dcy[c] + SH3C1 * SHC(9, c) * 3.0f * (x2 - y2) + SH3C2 * SHC(10, c) * xz +
+                                     SH3C3 * SHC(11, c) * (-3.0f * y2 + 4.0f * z2 - x2) +
+                                     SH3C4 * SHC(12, c) * -3.0f * 2.0f * yz + SH3C5 * SHC(13, c) * -2.0f * xy +
+                                     SH3C6 * SHC(14, c) * -2.0f * yz + SH3C7 * SHC(15, c) * -3.0f * 2.0f * xy;
+                            dcz[c] = dcz[c] + SH3C2 * SHC(10, c) * xy + SH3C3 * SHC(11, c) * 4.0f * 2.0f * yz +
+                                     SH3C4 * SHC(12, c) * 3.0f * (2.0f * z2 - x2 - y2) +
+                                     SH3C5 * SHC(13, c) * 4.0f * 2.0f * xz + SH3C6 * SHC(14, c) * (x2 - y2);
+                        }
+                    }
                 }
             }
+#undef SHC
             float vdir[3];
             vdir[0] = dcx[0] * vc[0] + dcx[1] * vc[1] + dcx[2] * vc[2];
             vdir[1] = dcy[0] * vc[0] + dcy[1] * vc[1] + dcy[2] * vc[2];
@@ -1210,19 +1164,6 @@ void gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels
                        geom, tile_count, n_visible, bins, bin_cap)
     switch (degree) {
         case 0: LAUNCH(0); break;
-        case 1: LAUNCH(1); break;
-        case 2: LAUNCH(2); break;
-        default: LAUNCH(3); break;
-    }
-#undef LAUNCH
-}
-
-void gsr_launch_sh_jacobian(hipStream_t s, int n, int K, int degree, const float* means, const float* shs, GsrCam cam,
-                            const int32_t* radii, float* shjac) {
-    if (n <= 0 || degree <= 0) return;
-    dim3 grid((n + 255) / 256), block(256);
-#define LAUNCH(D) hipLaunchKernelGGL(sh_jacobian_kernel<D>, grid, block, 0, s, n, K, means, shs, cam, radii, shjac)
-    switch (degree) {
         case 1: LAUNCH(1); break;
         case 2: LAUNCH(2); break;
         default: LAUNCH(3); break;

@@ -174,3 +174,20 @@ def test_guarded_extras_record_errors_instead_of_raising(monkeypatch):
     assert out["config2"]["ms_per_step"] == 1.0 and "error" in out["config5"] and out["rgbd"]["ms_per_step"] == 1.0
     assert set(out["trainer_step"]) == {"tail_step", "tail_in_backward"}
     assert bench.guarded(lambda: 1 / 0)["error"].startswith("ZeroDivisionError")
+
+
+@pytest.mark.gpu
+def test_bench_one_rank_rccl_runs_every_form_in_its_own_process(launch_ranks):
+    """GSR_DIST_FORCE=1: the collectives run on a ONE-rank "nccl" (= RCCL) communicator — the only way to push the real RCCL code
+    path of every exchange form (communicator creation with a timeout, the two extra communicators of the overlapped form, async
+    work handles, stream joins) through the supervisor on a one-GPU box: three sections, three fresh processes, one line."""
+    rc, out = launch_ranks([sys.executable, BENCH, "--gpus", "1", "--gaussians", "20000", "--width", "640", "--height", "480",
+                            "--steps", "4", "--warmup", "1", "--steady-steps", "20"], 1,
+                           env={"GSR_DIST_FORCE": "1"}, timeout=900, raw=True)
+    assert rc == [0], out[0]
+    rep = json.loads([ln for ln in out[0].splitlines() if ln.startswith("{")][-1])
+    ex = rep["exchange"]
+    assert ex["backend"] == "nccl" and set(ex["forms"]) == {"plain", "factored", "factored+overlap"}
+    assert all(f.get("ms_per_step", 0) > 0 for f in ex["forms"].values()), ex["forms"]
+    assert ex["headline_form"] == "factored+overlap" and ex["overlap"] is True
+    assert rep["n_gpus"] == 1 and rep["ranks_seen"] == 1

@@ -13,6 +13,8 @@ forward, every gradient).  Prints the failing cases with their assertion; exit c
       off-screen, SH values that clamp; pose gradients from device-resident poses
   python tools/fuzz_parity.py ssim [N = 300] [first case = 0]    fused SSIM forward / backward (bit-exact) on random
       (B, C, H, W) from 1 x 1 x 1 x 1 up, and the L1 + DSSIM loss head on ragged resolutions
+  python tools/fuzz_parity.py arbitrate sweep|edge CASE ...      failing cases of a campaign against the float64 autograd model:
+      which of the suite's criteria — (a) tolerance, (b) conditioning, (c) a boundary pair — explains each gradient tensor
   python tools/fuzz_parity.py trainer [N = 40] [first case = 0]  the bit-exact trainer-tail / compaction tests of
       tests/test_gpu_trainer.py and the densification test of tests/test_gpu_densify.py at random sizes, SH degrees,
       isotropic / anisotropic scales and render modes (their data seeds are fixed inside the tests)
@@ -121,7 +123,28 @@ def trainer_case(case):
         TD.test_densify_and_prune_matches_oracle(pkg, 1 if iso else 3, kr, int(rng.choice([0, 20])))
 
 
+def arbitrate_cases(family, cases):
+    """`python tools/fuzz_parity.py arbitrate sweep|edge CASE ...`: the float64 arbitration of the suite
+    (tests/test_gpu_fuzz_regressions.py: criteria (a) / (b) / (c)) on failing cases of a campaign — oracle, HIP kernels and the
+    float64 autograd model on the same scene; prints the verdict per gradient tensor, or the assertion that none applies."""
+    import test_gpu_fuzz_regressions as R
+    build = {"sweep": fuzz_scenes.sweep_scene, "edge": fuzz_scenes.edge_scene}[family]
+    bad = 0
+    for case in cases:
+        fs = build(pkg, case)
+        try:
+            res, st = R.three_way(pkg, orc, fs)
+            print(family, case, R.arbitrate(res, st, fs), flush=True)
+        except AssertionError as e:
+            bad += 1
+            print(family, case, "NOT EXPLAINED:", str(e)[:400], flush=True)
+    print(f"{len(cases) - bad} / {len(cases)} failing {family} cases explained by criteria (a) / (b) / (c)")
+    sys.exit(min(bad, 100))
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "arbitrate":
+        return arbitrate_cases(sys.argv[2], [int(a) for a in sys.argv[3:]])
     deep = len(sys.argv) > 1 and sys.argv[1] == "deep"
     edge = len(sys.argv) > 1 and sys.argv[1] == "edge"
     ssim = len(sys.argv) > 1 and sys.argv[1] == "ssim"

@@ -682,8 +682,13 @@ void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uin
     hipLaunchKernelGGL((composite_bwd_kernel<CC, GSR_BWD_PPL, false, ZZ>), grid, block, 0, s, cam.width, cam.height,   \
                        cam.grid_x, tile_start, tile_order, stream, bg, vpixels, n_contrib, final_T, inst, none)
     // (the zero-background kernel only where it pays: :rgbdn, 4 -> 5 waves per SIMD; profiles/r04/experiments/bwd_occupancy_ab.txt)
+    // (the zero-background kernels where they pay — profiles/r04/experiments/bwd_occupancy_ab.txt: :rgbdn 101 -> 94 VGPRs, four ->
+    //  five waves per SIMD, -3.4 %; :rgbd WITHOUT the rebuilt row coordinates 88 -> 83 VGPRs, five waves as before, one FMA per
+    //  active visit less: -1 %; with them (80 VGPRs, six waves) it is 6 % slower)
+    // (:rgb: 74 -> 70 VGPRs = seven waves per SIMD, 0.659 -> 0.676 ms; capped at six waves with 1.25 KB of unused dynamic LDS per
+    //  workgroup the same kernel takes 0.738 ms: it is the code generated under the tighter budget, not the occupancy)
     if (channels == 3) LAUNCH2(3, false);
-    else if (channels == 5) LAUNCH2(5, false);
+    else if (channels == 5) { if (bg0) LAUNCH2(5, true); else LAUNCH2(5, false); }
     else if (bg0) LAUNCH2(8, true);
     else LAUNCH2(8, false);
 #undef LAUNCH2

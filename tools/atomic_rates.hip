@@ -20,6 +20,25 @@ __global__ __launch_bounds__(256) void atomics_coalesced_kernel(unsigned long lo
     if (acc == 0xdeadbeefcafeull) sink[0] = acc;
 }
 
+
+// lanes of a wave on L random 128-byte LINES of the counter array, random words inside them: what grouping a workgroup's
+// requests by cache line (a counting sort in LDS) would give the binning atomics
+template <int L>
+__global__ __launch_bounds__(256) void atomics_lines_kernel(unsigned long long* words, uint32_t n_words, int rounds,
+                                                            unsigned long long* sink) {
+    const uint32_t tid = blockIdx.x * 256 + threadIdx.x, lane = tid & 63u;
+    const uint32_t n_lines = n_words / 16u;
+    unsigned long long acc = 0, old[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const uint32_t line = mix((tid >> 6) * 977u + (uint32_t)r * 0x9e3779b9u + (lane % L) * 0x85ebca6bu) % n_lines;
+        const uint32_t w = line * 16u + (mix(tid * 31u + r) & 15u);
+        old[r] = atomicAdd(words + w, 1ull);
+    }
+    acc = old[0] + old[1] + old[2];
+    if (acc == 0xdeadbeefcafeull) sink[0] = acc;
+}
+
 template <int INFLIGHT>
 __global__ __launch_bounds__(256) void atomics_kernel(unsigned long long* words, uint32_t n_words, uint32_t stride_words,
                                                       int rounds, unsigned long long* sink) {
@@ -73,5 +92,14 @@ int main() {
         float ms; hipEventElapsedTime(&ms, a, b);
         if (rep == 2) printf("words 4080, lanes of a wave on 64 consecutive words: %.3f ms = %.1f G/s\n", ms, threads * 3.0 / ms * 1e-6);
     }
+#define LINES(Lv)                                                                                                       \
+    for (int rep = 0; rep < 3; rep++) {                                                                                 \
+        hipEventRecord(a);                                                                                              \
+        atomics_lines_kernel<Lv><<<threads / 256, 256>>>(buf, 4080, 1, sink);                                           \
+        hipEventRecord(b); hipEventSynchronize(b);                                                                      \
+        float ms; hipEventElapsedTime(&ms, a, b);                                                                       \
+        if (rep == 2) printf("words 4080, lanes of a wave on %d random lines (random words inside): %.3f ms = %.1f G/s\n", Lv, ms, threads * 3.0 / ms * 1e-6); \
+    }
+    LINES(4) LINES(8) LINES(16) LINES(32) LINES(64)
     return 0;
 }

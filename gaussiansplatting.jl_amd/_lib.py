@@ -96,7 +96,7 @@ class GatherGroup(C.Structure):
 
 EXPORTS = ["gsr_create", "gsr_destroy", "gsr_release_scene_buffers", "gsr_memory_usage", "gsr_forward",
            "gsr_backward", "gsr_host_wait_policy", "gsr_buffer", "gsr_copy_buffer", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_loss_l1_ssim",
-           "gsr_ssim_precision",
+           "gsr_ssim_precision", "gsr_preprocess_form",
            "gsr_allreduce_grads", "gsr_last_error_string", "gsr_version", "gsr_abi_version", "gsr_check_abi", "gsr_profile_enable",
            "gsr_profile_stage_count", "gsr_profile_stages", "gsr_profile_stage_name", "gsr_profile_read", "gsr_profile_read_intervals", "gsr_update_stats",
            "gsr_prologue_forward", "gsr_prologue_backward", "gsr_adam_step", "gsr_stream_triad",
@@ -179,6 +179,7 @@ def load():
     lib.gsr_backward_trainer_tail.argtypes = [vp, C.POINTER(Inputs), C.POINTER(CameraS), vp, C.POINTER(TailState), vp]
     lib.gsr_stream_triad.argtypes = [vp, vp, vp, C.c_size_t, f32, vp]
     lib.gsr_ssim_precision.argtypes = [i32]
+    lib.gsr_preprocess_form.argtypes = [i32]
     lib.gsr_profile_enable.argtypes = [vp, i32]
     lib.gsr_profile_stages.argtypes = [vp, C.c_uint32]
     lib.gsr_profile_stage_name.argtypes = [i32]

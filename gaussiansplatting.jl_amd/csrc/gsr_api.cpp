@@ -386,6 +386,12 @@ int gsr_ssim_precision(int exact) {
     return GSR_OK;
 }
 
+int gsr_preprocess_form(int form) {
+    if (form < -1 || form > 1) return fail(GSR_E_INVALID_ARG, "gsr_preprocess_form: -1 (by size), 0 (direct) or 1 (aggregating)");
+    g_preprocess_form = form;
+    return GSR_OK;
+}
+
 int gsr_check_abi(int abi_version, size_t sizeof_config, size_t sizeof_inputs, size_t sizeof_camera, size_t sizeof_aux,
                   size_t sizeof_stats, size_t sizeof_grads) {
     if (abi_version != GSR_ABI_VERSION)
@@ -541,7 +547,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     StageScope sc1(h->prof, ST_PREPROCESS, s);
     gsr_launch_preprocess(s, n, in->n_coeffs, in->sh_degree, C, in->means, in->scales, in->rotations, in->opacities,
                           in->shs, k, geom_of(h), h->tile_count.as<uint32_t>(), h->bvis.as<uint32_t>(),
-                          h->bins.as<uint64_t>(), h->bin_cap_view /* 0: count only */);
+                          h->bins.as<uint64_t>(), h->bin_cap_view /* 0: count only */, h->n_tiles);
     sc1.close();
     const uint32_t seq = ++h->totals_seq ? h->totals_seq : ++h->totals_seq;  // never 0
     StageScope sc2(h->prof, ST_SCAN, s);

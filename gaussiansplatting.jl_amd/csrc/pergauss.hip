@@ -20,6 +20,9 @@
 namespace {
 
 constexpr uint32_t EMIT_COOP = 48;  // tiles per rect above which the wave emits cooperatively
+constexpr int kAggThreads = 512;           // workgroup of preprocess_kernel's aggregating form
+constexpr size_t kAggLdsMax = 52 * 1024;   // ... its dynamic LDS (the counter words): three workgroups per CU, below the 64 KB default limit
+constexpr int kAggMinGaussians = 400000;   // ... and the scene size from which it is the default (measured: DESIGN.md §4)
 // Gradient-row slots of a Gaussian (Gaussian-major, gsr_kernels.h): rects of at most DENSE_RECT tiles get one slot per
 // EMITTED tile — preprocess keeps the bit mask of the rect's tiles that passed the footprint test in the record, the
 // sort's emit ranks a tile by a popcount below its bit, the per-Gaussian backward sums popcount(mask) contiguous rows
@@ -207,20 +210,60 @@ __device__ __forceinline__ void gaussian_normal(const M33& Rw, const M33& Rg, co
 // (spherical_harmonics.jl:12-17,41-74) + count_tiles_per_gaussian! (utils.jl:131-141),
 // and the per-tile occupancy histogram that replaces cumsum!/duplicate/sort-by-tile.
 // ---------------------------------------------------------------------------------
-template <int DEG>
-__global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int channels, const float* __restrict__ means,
-                                                         const float* __restrict__ scales,
-                                                         const float4* __restrict__ rots,
-                                                         const float* __restrict__ opac,
-                                                         const float* __restrict__ shs, GsrCam cam, GsrGeom geom,
-                                                         uint32_t* __restrict__ tile_count,
-                                                         uint32_t* __restrict__ n_visible,
-                                                         uint64_t* __restrict__ bins, uint32_t bin_cap) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+//   Two forms of the binning.  DIRECT (AGG_NT == 0): one returning global atomic per instance pair, as described below.
+// AGGREGATING (large scenes on grids whose counter words fit the LDS three times per CU): what the global atomics cost on
+// this part is the number of memory transactions a wave instruction makes (tools/atomic_rates.hip: 64 lanes on 64 random
+// counter words run at 24 G atomics/s, on 64 consecutive words at 130 G/s), and one Gaussian per lane in the scene's
+// order means 64 random words per instruction.  A workgroup of AGG_NT Gaussians therefore (1) adds its requests up per
+// counter word in LDS (one 64-bit word per aligned tile pair, the global counters' packing), (2) issues ONE returning
+// global atomic per word it counted in — consecutive lanes on consecutive words; the LDS word then holds the bin
+// positions this workgroup's instances start at (config 3, 512 Gaussians: ~1 500 requests on ~1 250 of the 4 081 words,
+// 16 % fewer global atomics, in address order), (3) re-walks its rects, the footprint tests replayed from the emitted
+// mask, every instance taking its position with a returning LDS atomic, and stores the keys.  Three workgroups per CU in
+// several rounds, so that the phases of different workgroups overlap (1024 Gaussians per workgroup aggregate better and
+// were measured slower: 0.19 ms against 0.15; so was one resident wave of persistent workgroups).  The order inside a
+// bin differs from the direct form's (it is arbitrary in both; the tile sort fixes it); everything else is bit-identical.
+//   n_words: 64-bit words of the counter array = LDS words of the AGG form ((T + 2) / 2).
+template <int DEG, int AGG_NT /* 0: direct form, 256 threads; else the threads of the aggregating workgroup */>
+__global__ __launch_bounds__(AGG_NT ? AGG_NT : 256, AGG_NT ? 3 * AGG_NT / 256 : 1) void preprocess_kernel(int n, int K, int channels,
+                                                                      const float* __restrict__ means,
+                                                                      const float* __restrict__ scales,
+                                                                      const float4* __restrict__ rots,
+                                                                      const float* __restrict__ opac,
+                                                                      const float* __restrict__ shs, GsrCam cam,
+                                                                      GsrGeom geom, uint32_t* __restrict__ tile_count,
+                                                                      uint32_t* __restrict__ n_visible,
+                                                                      uint64_t* __restrict__ bins, uint32_t bin_cap,
+                                                                      int n_words) {
+    constexpr bool AGG = AGG_NT != 0;
+    constexpr int NT = AGG ? AGG_NT : 256;
+    extern __shared__ unsigned long long agg[];  // AGG: per counter word, this workgroup's counts, then its bin positions
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (AGG)
+        for (int w = threadIdx.x; w < n_words; w += NT) agg[w] = 0ull;
     bool visible = false;
     uint32_t area = 0, clamp_bits = 0, emitted = 0;  // emitted: bit k = tile k of the rect (row-major) got an instance
     float m2[2] = {0, 0}, conic[3] = {0, 0, 0}, rgb[3] = {0, 0, 0}, mc_z = 0.0f, tau = 0.0f, opac_v = 0.0f;
     int rmin[2] = {0, 0}, rmax[2] = {0, 0};
+    // SH colour of Gaussian i at world position p (spherical_harmonics.jl:12-17,41-74)
+    auto sh_colour = [&](const float p[3]) {
+        const float* sh = shs + (size_t)3 * K * i;
+        float d[3] = {p[0] - cam.center[0], p[1] - cam.center[1], p[2] - cam.center[2]};
+        float inv = 1.0f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        d[0] *= inv; d[1] *= inv; d[2] *= inv;
+        float b[16];
+        sh_basis<DEG>(d, b);
+        constexpr int NB = (DEG + 1) * (DEG + 1);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float res = b[0] * sh[c];
+#pragma unroll
+            for (int k = 1; k < NB; k++) res = res + b[k] * sh[3 * k + c];
+            res = res + 0.5f + 1.1920929e-7f;
+            if (res < 0.0f) clamp_bits |= 1u << c;
+            rgb[c] = fmaxf(0.0f, res);
+        }
+    };
     if (i < n) {
         M33 R; float t[3];
         load_pose(cam, R, t);
@@ -291,86 +334,114 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
                 gaussian_normal(R, Rg, s, mc, nn, k, sg);
                 geom.normal[i] = make_float4(nn[0], nn[1], nn[2], 0.0f);
             }
-            // SH colour
-            const float* sh = shs + (size_t)3 * K * i;
-            float d[3] = {p[0] - cam.center[0], p[1] - cam.center[1], p[2] - cam.center[2]};
-            float inv = 1.0f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-            d[0] *= inv; d[1] *= inv; d[2] *= inv;
-            float b[16];
-            sh_basis<DEG>(d, b);
-            constexpr int NB = (DEG + 1) * (DEG + 1);
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                float res = b[0] * sh[c];
-#pragma unroll
-                for (int k = 1; k < NB; k++) res = res + b[k] * sh[3 * k + c];
-                res = res + 0.5f + 1.1920929e-7f;
-                if (res < 0.0f) clamp_bits |= 1u << c;
-                rgb[c] = fmaxf(0.0f, res);
-            }
+            sh_colour(p);
             get_rect(m2[0], m2[1], radius, cam.grid_x, cam.grid_y, rmin, rmax);
             area = (uint32_t)((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]));
             tau = footprint_tau(opac_in);
-            // duplicate_with_keys! (utils.jl:85-120) restated per tile, fused into this kernel: the
-            // instance takes the next free position of its tile's BIN (a fixed-capacity segment of
-            // `bins`, capacity from the previous view) with a returning atomic on the tile's counter
-            // and stores its (depth bits << 32 | id) key there — the counters end up holding the
-            // reference's per-tile counts, and no separate count / scan / scatter pass over the
-            // instances exists.  Horizontally adjacent tiles are consecutive 32-bit counters, so an
-            // aligned pair is served by ONE 64-bit atomic; up to 8 are kept in flight before their
-            // keys are stored (a returning device-scope atomic is a ~2 us round trip to the memory
-            // side).  A position >= bin_cap is not stored: the host sees max count > capacity in the
-            // scan's totals, grows the bins and repeats the pass (first view / a much denser view).
-            // exact-cull mode: a tile none of whose pixels can reach alpha >= 1/255 gets no
-            // instance (the reference keeps it and skips it pixel by pixel, render.jl:95).
-            const uint64_t key = ((uint64_t)__float_as_uint(mc_z) << 32) | (uint32_t)i;
-            constexpr int PEND = 8;
-            uint32_t kk = 0u;
-            uint32_t pend_t[PEND], pend_c[PEND];
-            int np = 0;
-            auto flush = [&]() {
-                unsigned long long old[PEND];
-#pragma unroll
-                for (int k = 0; k < PEND; k++)
-                    if (k < np)
-                        old[k] = atomicAdd(reinterpret_cast<unsigned long long*>(tile_count + pend_t[k]),
-                                           (unsigned long long)(pend_c[k] & 1u) | ((unsigned long long)(pend_c[k] >> 1) << 32));
-#pragma unroll
-                for (int k = 0; k < PEND; k++)
-                    if (k < np) {
-                        const uint32_t p0 = (uint32_t)old[k], p1 = (uint32_t)(old[k] >> 32);
-                        if ((pend_c[k] & 1u) && p0 < bin_cap) bins[(size_t)pend_t[k] * bin_cap + p0] = key;
-                        if ((pend_c[k] & 2u) && p1 < bin_cap) bins[(size_t)(pend_t[k] + 1) * bin_cap + p1] = key;
-                    }
-                np = 0;
-            };
-            // (rects of more than EMIT_COOP tiles are emitted by the whole wave below)
-            for (int y = rmin[1]; y < rmax[1] && area <= EMIT_COOP; y++) {
-                int x = rmin[0];
-                while (x < rmax[0]) {
-                    const int t = y * cam.grid_x + x;
-                    const bool odd = t & 1;
-                    const bool pair = !odd && x + 1 < rmax[0];
-                    const uint32_t c0 = (!cam.exact_cull || tile_may_touch(m2[0], m2[1], conic[0], conic[1], conic[2],
-                                                                         tau, x * GSR_TILE, y * GSR_TILE)) ? 1u : 0u;
-                    uint32_t c1 = 0u;
+        }
+    }
+    // duplicate_with_keys! (utils.jl:85-120) restated per tile, fused into this kernel: the
+    // instance takes the next free position of its tile's BIN (a fixed-capacity segment of
+    // `bins`, capacity from the previous view) with a returning atomic on the tile's counter
+    // and stores its (depth bits << 32 | id) key there — the counters end up holding the
+    // reference's per-tile counts, and no separate count / scan / scatter pass over the
+    // instances exists.  Horizontally adjacent tiles are consecutive 32-bit counters, so an
+    // aligned pair is served by ONE 64-bit atomic; up to 8 are kept in flight before their
+    // keys are stored (a returning device-scope atomic is a ~2 us round trip to the memory
+    // side).  A position >= bin_cap is not stored: the host sees max count > capacity in the
+    // scan's totals, grows the bins and repeats the pass (first view / a much denser view).
+    // exact-cull mode: a tile none of whose pixels can reach alpha >= 1/255 gets no
+    // instance (the reference keeps it and skips it pixel by pixel, render.jl:95).
+    const uint64_t key = ((uint64_t)__float_as_uint(mc_z) << 32) | (uint32_t)i;
+    // the rect's aligned tile pairs in row-major order: visit(even tile index, bit 0: even tile emitted, bit 1: odd tile)
+    // (rects of more than EMIT_COOP tiles are emitted by the whole wave below)
+    auto walk = [&](auto&& visit, bool set_emitted) {
+        uint32_t kk = 0u;
+        for (int y = rmin[1]; y < rmax[1]; y++) {
+            int x = rmin[0];
+            while (x < rmax[0]) {
+                const int t = y * cam.grid_x + x;
+                const bool odd = t & 1;
+                const bool pair = !odd && x + 1 < rmax[0];
+                uint32_t c0, c1 = 0u;
+                if (!set_emitted && area <= 32u) {  // the second walk of the AGG form: the first one's results
+                    c0 = (emitted >> (kk & 31u)) & 1u;
+                    if (pair) c1 = (emitted >> ((kk + 1u) & 31u)) & 1u;
+                } else {
+                    c0 = (!cam.exact_cull || tile_may_touch(m2[0], m2[1], conic[0], conic[1], conic[2], tau, x * GSR_TILE,
+                                                            y * GSR_TILE)) ? 1u : 0u;
                     if (pair)
                         c1 = (!cam.exact_cull || tile_may_touch(m2[0], m2[1], conic[0], conic[1], conic[2], tau,
                                                                (x + 1) * GSR_TILE, y * GSR_TILE)) ? 1u : 0u;
-                    // (bit kk = the rect's row-major tile index: the walk visits the tiles in exactly that order; only read
-                    //  back when area <= DENSE_RECT)
-                    emitted |= (c0 | (c1 << 1)) << (kk & 31u);
-                    kk += pair ? 2u : 1u;
-                    if (c0 | c1) {
-                        pend_t[np] = (uint32_t)(t & ~1);                 // aligned pair
-                        pend_c[np] = odd ? (c0 << 1) : (c0 | (c1 << 1));  // bit 0: even tile, bit 1: odd tile
-                        if (++np == PEND) flush();
-                    }
-                    x += pair ? 2 : 1;
                 }
+                // (bit kk = the rect's row-major tile index: the walk visits the tiles in exactly that order; only read
+                //  back when area <= DENSE_RECT)
+                if (set_emitted) emitted |= (c0 | (c1 << 1)) << (kk & 31u);
+                kk += pair ? 2u : 1u;
+                if (c0 | c1) visit((uint32_t)(t & ~1) /* aligned pair */, odd ? (c0 << 1) : (c0 | (c1 << 1)));
+                x += pair ? 2 : 1;
             }
+        }
+    };
+    const bool walks = visible && area <= EMIT_COOP;
+    if (!AGG) {
+        constexpr int PEND = 8;
+        uint32_t pend_t[PEND], pend_c[PEND];
+        int np = 0;
+        auto flush = [&]() {
+            unsigned long long old[PEND];
+#pragma unroll
+            for (int k = 0; k < PEND; k++)
+                if (k < np)
+                    old[k] = atomicAdd(reinterpret_cast<unsigned long long*>(tile_count + pend_t[k]),
+                                       (unsigned long long)(pend_c[k] & 1u) | ((unsigned long long)(pend_c[k] >> 1) << 32));
+#pragma unroll
+            for (int k = 0; k < PEND; k++)
+                if (k < np) {
+                    const uint32_t p0 = (uint32_t)old[k], p1 = (uint32_t)(old[k] >> 32);
+                    if ((pend_c[k] & 1u) && p0 < bin_cap) bins[(size_t)pend_t[k] * bin_cap + p0] = key;
+                    if ((pend_c[k] & 2u) && p1 < bin_cap) bins[(size_t)(pend_t[k] + 1) * bin_cap + p1] = key;
+                }
+            np = 0;
+        };
+        if (walks) {
+            walk([&](uint32_t t, uint32_t c) {
+                pend_t[np] = t;
+                pend_c[np] = c;  // bit 0: even tile, bit 1: odd tile
+                if (++np == PEND) flush();
+            }, true);
             flush();
         }
+    } else {
+        __syncthreads();  // agg zeroed
+        if (walks)
+            walk([&](uint32_t t, uint32_t c) {
+                atomicAdd(&agg[t >> 1], (unsigned long long)(c & 1u) | ((unsigned long long)(c >> 1) << 32));
+            }, true);
+        __syncthreads();
+        // one global atomic per word this workgroup counted in; the word then holds the bin positions its instances start at
+        unsigned long long* tc64 = reinterpret_cast<unsigned long long*>(tile_count);
+        for (int w0 = threadIdx.x; w0 < n_words; w0 += 4 * NT) {  // four in flight per lane
+            unsigned long long old[4];
+            uint32_t any = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned long long c = w0 + k * NT < n_words ? agg[w0 + k * NT] : 0ull;
+                if (c) { old[k] = atomicAdd(tc64 + w0 + k * NT, c); any |= 1u << k; }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (any & (1u << k)) agg[w0 + k * NT] = old[k];
+        }
+        __syncthreads();
+        if (walks && bin_cap > 0u)
+            walk([&](uint32_t t, uint32_t c) {
+                const unsigned long long old =
+                    atomicAdd(&agg[t >> 1], (unsigned long long)(c & 1u) | ((unsigned long long)(c >> 1) << 32));
+                const uint32_t p0 = (uint32_t)old, p1 = (uint32_t)(old >> 32);
+                if ((c & 1u) && p0 < bin_cap) bins[(size_t)t * bin_cap + p0] = key;
+                if ((c & 2u) && p1 < bin_cap) bins[(size_t)(t + 1) * bin_cap + p1] = key;
+            }, false);
     }
     // Large footprints: one thread walking hundreds of tiles serialises the wave (the reference's
     // duplicate_with_keys! has exactly this loop, utils.jl:96-119).  Rects of more than EMIT_COOP
@@ -388,7 +459,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
             const int bx0 = __shfl(rmin[0], src), by0 = __shfl(rmin[1], src);
             const int bx1 = __shfl(rmax[0], src), by1 = __shfl(rmax[1], src);
             const uint32_t bz = __shfl(__float_as_uint(mc_z), src);
-            const uint64_t bkey = ((uint64_t)bz << 32) | (uint32_t)(blockIdx.x * 256 + (threadIdx.x & ~63) + src);
+            const uint64_t bkey = ((uint64_t)bz << 32) | (uint32_t)(blockIdx.x * NT + (threadIdx.x & ~63) + src);
             const int w = bx1 - bx0, total = w * (by1 - by0);
             for (int e = lane; e < total; e += 64) {
                 const int ry = e / w, rx = e - ry * w;
@@ -405,8 +476,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
     // gives every Gaussian the offset of its instance slots (gradient rows) — the reference's
     // cumsum!(tiles_touched) (rasterizer.jl:333-335), restated hierarchically.
     {
-        __shared__ uint32_t wsum[4];
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        // (blocks of 256 Gaussians whatever the workgroup size: bpre[i >> 8] is what the readers index)
+        __shared__ uint32_t wsum[NT / 64];
+        __shared__ uint32_t wvis[NT / 64];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wave0 = wave & ~3;
         // gradient-row slots of this Gaussian: one per emitted tile (small rects), one per tile of the rect otherwise
         const uint32_t slots = area <= DENSE_RECT ? (uint32_t)__popc(emitted) : area;
         uint32_t x = slots;
@@ -415,18 +488,17 @@ __global__ __launch_bounds__(256) void preprocess_kernel(int n, int K, int chann
             uint32_t y = __shfl_up(x, off);
             if (lane >= off) x += y;
         }
-        __shared__ uint32_t wvis[4];
         const unsigned long long vm = __ballot(visible);
         if (lane == 63) { wsum[wave] = x; wvis[wave] = (uint32_t)__popcll(vm); }
         __syncthreads();
         uint32_t woff = 0;
-        for (int w = 0; w < wave; w++) woff += wsum[w];
+        for (int w = wave0; w < wave; w++) woff += wsum[w];
         const uint32_t lpre = woff + x - slots;
-        if (threadIdx.x == 255) {
-            geom.bsum[blockIdx.x] = lpre + slots;
+        if ((threadIdx.x & 255) == 255 && i - 255 < n) {
+            geom.bsum[i >> 8] = lpre + slots;
             // visible count per block, summed by tile_scan (15 k same-address atomics would
             // serialise at ~12 ns each: 0.19 ms — the "fanin" price of MI355X_MICROARCH.md)
-            n_visible[blockIdx.x] = wvis[0] + wvis[1] + wvis[2] + wvis[3];
+            n_visible[i >> 8] = wvis[wave0] + wvis[wave0 + 1] + wvis[wave0 + 2] + wvis[wave0 + 3];
         }
         if (visible) {
             GsrGeoRec rec;
@@ -1153,15 +1225,30 @@ void gsr_launch_update_stats(hipStream_t s, int n, const int32_t* radii, const f
 }
 
 
+// -1: by scene and grid size (default), 0: direct form, 1: aggregating form wherever its LDS fits (gsr_preprocess_form)
+int g_preprocess_form = [] { const char* e = getenv("GSR_PREPROCESS_AGG"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+
 void gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels, const float* means,
                            const float* scales, const float* rots, const float* opac, const float* shs, GsrCam cam,
-                           GsrGeom geom, uint32_t* tile_count, uint32_t* n_visible, uint64_t* bins, uint32_t bin_cap) {
+                           GsrGeom geom, uint32_t* tile_count, uint32_t* n_visible, uint64_t* bins, uint32_t bin_cap,
+                           int n_tiles) {
     if (n <= 0) return;
-    dim3 grid((n + 255) / 256), block(256);
     const float4* r4 = reinterpret_cast<const float4*>(rots);
-#define LAUNCH(D)                                                                                                  \
-    hipLaunchKernelGGL(preprocess_kernel<D>, grid, block, 0, s, n, K, channels, means, scales, r4, opac, shs, cam, \
-                       geom, tile_count, n_visible, bins, bin_cap)
+    // The aggregating form wants its counter words in LDS three times per CU (8 B per tile pair: 33 KB at 1080p) and a
+    // scene of several rounds of 512-Gaussian workgroups; smaller scenes and larger grids take the direct form.
+    const int n_words = (n_tiles + 2) / 2;
+    const size_t lds = (size_t)n_words * 8;
+    const bool agg = lds <= kAggLdsMax && (g_preprocess_form >= 0 ? g_preprocess_form != 0 : n >= kAggMinGaussians);
+#define LAUNCH(D)                                                                                                          \
+    do {                                                                                                                   \
+        if (agg)                                                                                                           \
+            hipLaunchKernelGGL((preprocess_kernel<D, kAggThreads>), dim3((n + kAggThreads - 1) / kAggThreads),             \
+                               dim3(kAggThreads), lds, s, n, K, channels, means, scales, r4, opac, shs, cam, geom,         \
+                               tile_count, n_visible, bins, bin_cap, n_words);                                             \
+        else                                                                                                               \
+            hipLaunchKernelGGL((preprocess_kernel<D, 0>), dim3((n + 255) / 256), dim3(256), 0, s, n, K, channels, means,   \
+                               scales, r4, opac, shs, cam, geom, tile_count, n_visible, bins, bin_cap, n_words);           \
+    } while (0)
     switch (degree) {
         case 0: LAUNCH(0); break;
         case 1: LAUNCH(1); break;

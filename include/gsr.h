@@ -280,6 +280,17 @@ GSR_API int gsr_ssim_backward(int W, int H, int CH, int B, const float* img, con
  * GSR_SSIM_EXACT=1 in the environment starts the process in mode 1. */
 GSR_API int gsr_ssim_precision(int exact);
 
+/* Form of the binning inside gsr_forward's first kernel (preprocess: projection.jl:69-129 + spherical_harmonics! +
+ * utils.jl:85-142 fused).  Process-wide; outputs are identical in every form (only the arbitrary order of the unsorted
+ * keys inside a tile's bin differs), this is a performance switch and the tests' handle on both code paths.
+ *  -1 (default): chosen per call — the aggregating form for scenes of >= 400 000 Gaussians on grids whose counter words
+ *      fit the LDS three times per CU (up to ~13 000 tiles: 1080p yes, 4K no), else the direct form;
+ *   0: always the direct form (one returning global atomic per instance pair);
+ *   1: the aggregating form wherever its LDS fits (a workgroup adds its requests up per counter word in LDS and issues
+ *      one global atomic per word, in address order).
+ * GSR_PREPROCESS_AGG=0/1 in the environment starts the process in mode 0 / 1. */
+GSR_API int gsr_preprocess_form(int form);
+
 /* The photometric loss head of Trainer.step! — src/training.jl:656,684-694:
  *   image = features[1:3,:,:]; permute to (W,H,3,1);
  *   L = (1-lambda)*mean|image-target| + lambda*(1-mean(fused_ssim(image; ref=target)))

@@ -1,0 +1,93 @@
+"""-m gpu: the two forms of preprocess's binning (gsr_preprocess_form) — direct (one returning global atomic per instance
+pair) and aggregating (a workgroup of 512 Gaussians adds its requests up per counter word in LDS, one global atomic per word
+in address order; the default for large scenes).  Only the arbitrary order of the unsorted keys inside a tile's bin may differ:
+records, sorted lists, ranges, image, final T, radii and every gradient must be bit-identical, on every binning path
+(fixed-capacity bins, first view, bin overflow -> compact, forced compact, wave-emitted large rects, odd grids, both cull modes)."""
+import contextlib
+
+import numpy as np
+import pytest
+import torch
+
+from hip_helpers import HipRun
+
+pytestmark = pytest.mark.gpu
+
+
+@contextlib.contextmanager
+def form(pkg, f):
+    L = pkg._lib
+    L.check(L.load().gsr_preprocess_form(f))
+    try:
+        yield
+    finally:
+        L.check(L.load().gsr_preprocess_form(-1))
+
+
+def _views(pkg, orc, s, W, H, deg, mode, exact, f, n_views=3, vp_seed=3, **kw):
+    """n_views forward + backward passes on one handle under form f; returns everything comparable per view."""
+    cam = orc.Camera(W, H, s.focal)
+    out = []
+    with form(pkg, f):
+        run = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, (0.1, 0.3, 0.2), mode,
+                     exact_tile_cull=exact, **kw)
+        C = run.rast.channels
+        vp = np.random.default_rng(vp_seed).standard_normal((H, W, C)).astype(np.float32)
+        for _ in range(n_views):
+            img = run.forward().clone()
+            st = run.rast.stats
+            rec = dict(img=img, T=run.rast.accum_alpha.clone(), nc=run.rast.n_contrib.clone(), radii=run.rast.radii.clone(),
+                       ranges=run.rast.ranges.clone(), ids=run.rast.values_sorted.clone(),
+                       stats=(st.n_rendered, st.n_visible, st.max_tile_instances, st.compact_binning))
+            rec["grads"] = [g.clone() for g in run.backward(vp)[:5]]
+            out.append(rec)
+        run.rast.close()
+    return out
+
+
+def _assert_same(a, b):
+    assert len(a) == len(b)
+    for va, vb in zip(a, b):
+        assert va["stats"] == vb["stats"]
+        for k in ("img", "T", "nc", "radii", "ranges", "ids"):
+            assert torch.equal(va[k], vb[k]), k
+        for ga, gb in zip(va["grads"], vb["grads"]):
+            assert torch.equal(ga, gb)
+
+
+@pytest.mark.parametrize("mode", ["rgb", "rgbdn"])
+@pytest.mark.parametrize("exact", [True, False])
+def test_both_forms_give_identical_lists_images_and_gradients(pkg, orc, mode, exact):
+    W, H, n, deg = 328, 200, 30000, 2   # 21 x 13 tiles: odd grid, the last tile pair is half outside the counters' pairs
+    s = pkg.synthetic.make_scene(n, W, H, deg, 5100, sigma_px=5.0)
+    _assert_same(_views(pkg, orc, s, W, H, deg, mode, exact, 0), _views(pkg, orc, s, W, H, deg, mode, exact, 1))
+
+
+def test_forms_agree_on_large_rects_hot_tiles_and_compact_binning(pkg, orc):
+    W, H, deg = 256, 160, 1
+    base = pkg.synthetic.make_scene(20000, W, H, deg, 5200, sigma_px=4.0)
+    # one tile beyond 4096 instances (tier sorts), and Gaussians whose rects exceed the per-thread walk (wave-emitted)
+    s = pkg.synthetic.add_skew(base, "hot:6000", seed=5201)
+    import dataclasses
+    big = s.scales_raw.copy()
+    big[:40] += np.log(30.0).astype(np.float32)   # rects of hundreds of tiles: beyond the per-thread walk
+    s = dataclasses.replace(s, scales_raw=big)
+    a = _views(pkg, orc, s, W, H, deg, "rgb", True, 0)
+    b = _views(pkg, orc, s, W, H, deg, "rgb", True, 1)
+    _assert_same(a, b)
+    assert a[-1]["stats"][2] > 4096
+    # compact binning (count -> scan -> scatter) forced by a 1-byte bins budget: the aggregating form only counts
+    a = _views(pkg, orc, s, W, H, deg, "rgb", True, 0, n_views=2, bins_budget_bytes=1)
+    b = _views(pkg, orc, s, W, H, deg, "rgb", True, 1, n_views=2, bins_budget_bytes=1)
+    _assert_same(a, b)
+    assert a[-1]["stats"][3] == 1
+
+
+def test_default_form_by_size_and_argument_check(pkg, orc):
+    L = pkg._lib
+    lib = L.load()
+    assert lib.gsr_preprocess_form(2) == L.GSR_E_INVALID_ARG and lib.gsr_preprocess_form(-2) == L.GSR_E_INVALID_ARG
+    # 500 k Gaussians at 640 x 360: the default picks the aggregating form; same outputs as the direct form forced
+    W, H, n, deg = 640, 360, 500_000, 1
+    s = pkg.synthetic.make_scene(n, W, H, deg, 5300, sigma_px=1.5)
+    _assert_same(_views(pkg, orc, s, W, H, deg, "rgb", True, -1, n_views=2), _views(pkg, orc, s, W, H, deg, "rgb", True, 0, n_views=2))

@@ -50,7 +50,7 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                  (plain all-reduce / factored / factored+overlap), each from its own fresh rank group of the same run;
   steady_state — wall-clock mean of `--steady-steps` (2000) further steps after the timed region: a 3 s corroboration of
                  the K-step number that does not depend on HIP events;
-  untimed_steps_total — W + 15 settle + 5 survey steps run before the timed region (`warmup` is the CLI's W).
+  untimed_steps_total — W + 15 settle + 5 survey + 5 re-settle steps run before the timed region (`warmup` is the CLI's W).
 `value` / `ms_per_step` follow the driver contract (K steps between two barriers+synchronize, total / K);
 `ms_per_step_median` is the median of the K-1 launch-to-launch intervals of the dominant stage's HIP events
 inside the timed region.
@@ -497,6 +497,7 @@ def guarded(fn, *a, **kw):
 # ------------------------------------------------------------------------------------------------------------------
 SETTLE_STEPS = 15  # untimed steps in front of the stage survey (Workload.measure)
 SURVEY_STEPS = 5   # untimed steps of the stage survey
+RESETTLE_STEPS = 5  # untimed steps between the survey's bookkeeping and the timed region (no idle device in front of it)
 
 
 class Workload:
@@ -693,6 +694,13 @@ class Workload:
             self.torch.distributed.barrier()
         self.torch.cuda.synchronize()
 
+    def spin_until_idle(self):
+        """Busy-wait until everything queued on the current stream has run (event query, no blocking call)."""
+        ev = self.torch.cuda.Event()
+        ev.record()
+        while not ev.query():
+            pass
+
     def max_over_ranks(self, dt):
         if self.dist_on:
             tt = self.torch.tensor([dt], device=self.dev, dtype=self.torch.float64)
@@ -723,6 +731,10 @@ class Workload:
         after 25 + 5 (tools/step_times.py) — and a training loop runs thousands: the timed region, like the stage survey,
         should see the steady state."""
         rast = self.rast
+        import gc
+        gc_was = gc.isenabled()
+        gc.collect()
+        gc.disable()   # (until the timed region is over: see there)
         for _ in range(warmup + settle_steps):
             self.step()
         self.sync()
@@ -736,13 +748,28 @@ class Workload:
         survey = {k: (ms / max(c, 1), c) for k, (ms, c) in rast.profile_read().items() if c > 0}
         dom = max(survey, key=lambda k: survey[k][0] * survey[k][1])
         rast.profile(True, stages=[dom])
+        # Nothing of the host's may land inside the timed region, and no idle time right in front of it: Python's cyclic
+        # collector is paused (a generation-2 pass over the interpreter's objects is a millisecond — 5 % of K = 20 steps — and
+        # the forward waits for the host once per step); the survey's bookkeeping above left the device idle for a moment,
+        # and even a few milliseconds of idle cost the following steps 3-7 % (measured: K = 20 right after a gc.collect()
+        # 1.54 ms against 1.44 ms at steady state — the clocks ramp), so a few more untimed steps run up to the region's
+        # opening barrier + synchronize; the closing synchronize finds the device already idle (a spin on an event: a
+        # blocking wait's wake-up latency is not GPU time).  The bracket itself is the contract's.
+        for _ in range(RESETTLE_STEPS):
+            self.step()
+        self.spin_until_idle()
+        rast.profile_read()   # (reset: the dominant stage's records of the re-settle steps are not the timed region's)
+        self.sync()
         t0 = time.perf_counter()
         for _ in range(steps):
             self.step()
+        self.spin_until_idle()
         self.sync()
         dt = time.perf_counter() - t0
         # per-step times = launch-to-launch intervals of the dominant stage's own event pairs (a separate per-step
         # marker would be one more ~6 us bubble on the stream, tools/gap_report.py): K-1 samples
+        if gc_was:
+            gc.enable()
         per_step = sorted(rast.profile_intervals(dom))
         self.tail_collect()
         prof = rast.profile_read()
@@ -796,7 +823,7 @@ class Workload:
             "algorithmic_bytes": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
             "avg_launch_ms_source": f"HIP events around {dom} on the launch stream, {live[dom][1]} launches inside the timed region",
             "stages_ms": {k: round(v[0], 4) for k, v in stages.items()},
-            "untimed_steps": {"warmup": "W (--warmup)", "settle": SETTLE_STEPS, "stage_survey": SURVEY_STEPS},
+            "untimed_steps": {"warmup": "W (--warmup)", "settle": SETTLE_STEPS, "stage_survey": SURVEY_STEPS, "resettle": RESETTLE_STEPS},
             "stages_ms_source": "5-step survey with every stage timed, just before the timed region (all stages timed "
                                 "inside it would slow the step by 3 %, so these may sum to more than ms_per_step); the "
                                 "dominant stage: the timed region",
@@ -887,6 +914,8 @@ EXTRA_SPECS = [
      "config5: 5M Gaussians, SH deg 3, 3840x2160, fwd+bwd (random cotangent)"),
     ("rgbd", dict(n=1_000_000, width=1920, height=1080, sh_degree=3, seed=1003, mode="rgbd"),
      "N=1M SH3 1920x1080 :rgbd (the reference's default training mode), fwd + L1/0.2*DSSIM loss + bwd"),
+    ("morton_order", dict(n=1_000_000, width=1920, height=1080, sh_degree=3, seed=1003, order="morton"),
+     "config3 with its Gaussians sorted along a 3-D Morton curve (densification.reorder_spatially): NOT the headline configuration"),
     ("forward_only.config3", dict(n=1_000_000, width=1920, height=1080, sh_degree=3, seed=1003, forward_only=True),
      "config3 scene, forward only with GSR_FORWARD_ONLY (validate / GUI / render-views: rasterizer.jl:214-248)"),
     ("forward_only.config5", dict(n=5_000_000, width=3840, height=2160, sh_degree=3, seed=1005, forward_only=True),
@@ -1014,7 +1043,7 @@ def run_section(args, section):
     else:
         par = (f"view-parallel x{world}, 1 all-reduce of {wl.arena.numel() * 4 / 1e6:.0f} MB" if wl.dist_on else
                "single GPU, one view (no collective)")
-    untimed = args.warmup + SETTLE_STEPS + SURVEY_STEPS
+    untimed = args.warmup + SETTLE_STEPS + SURVEY_STEPS + RESETTLE_STEPS
     out = {
         "metric": "fwd+bwd Mpixels/s @1920x1080, 1M Gaussians SH=3",
         "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps,

@@ -102,7 +102,7 @@ EXPORTS = ["gsr_create", "gsr_destroy", "gsr_release_scene_buffers", "gsr_memory
            "gsr_prologue_forward", "gsr_prologue_backward", "gsr_adam_step", "gsr_stream_triad",
            "gsr_mask_findall_scratch_bytes", "gsr_mask_findall", "gsr_gather_rows", "gsr_sh_grad_from_views", "gsr_sh_grad_from_views_tail", "gsr_trainer_tail_step",
            "gsr_backward_trainer_tail",
-           "gsr_densify_grad_mean", "gsr_densify_mask", "gsr_compose_rows", "gsr_split_transform", "gsr_reset_opacity",
+           "gsr_densify_grad_mean", "gsr_densify_mask", "gsr_compose_rows", "gsr_split_transform", "gsr_reset_opacity", "gsr_morton_codes",
            "gsr_ply_pack_rows", "gsr_ply_unpack_rows", "gsr_count_nonfinite"]
 
 _lib = None
@@ -169,6 +169,7 @@ def load():
     lib.gsr_compose_rows.argtypes = [C.POINTER(ComposeGroup), C.c_int32, vp, i64, vp, i64, C.c_int32, vp]
     lib.gsr_split_transform.argtypes = [i64, C.c_int32, vp, vp, vp, C.c_uint32, vp]
     lib.gsr_reset_opacity.argtypes = [i64, vp, vp]
+    lib.gsr_morton_codes.argtypes = [i64, vp, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp]
     lib.gsr_count_nonfinite.argtypes = [C.POINTER(vp), C.POINTER(C.c_int32), C.c_int32, i64, vp, vp, vp]
     lib.gsr_ply_pack_rows.argtypes = [i64, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_ply_unpack_rows.argtypes = [i64, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]

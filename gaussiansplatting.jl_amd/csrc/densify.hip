@@ -209,6 +209,34 @@ __global__ __launch_bounds__(256) void nonfinite_scan_kernel(ScanGroups G, long 
     }
 }
 
+// Morton (Z-order) code of every Gaussian's position inside the box [lo, lo + 1/inv_extent): 21 bits per axis, x in the
+// lowest bit of each triple.  Not a reference function: the key of the optional spatial re-sort after a densification
+// (densification.py reorder_spatially) — neighbours in the arrays become neighbours on screen, which is what the
+// aggregating preprocess and the record gathers of the tile sort like.
+__device__ __forceinline__ unsigned long long spread21(unsigned int v) {
+    unsigned long long x = v & 0x1FFFFFu;
+    x = (x | (x << 32)) & 0x1F00000000FFFFull;
+    x = (x | (x << 16)) & 0x1F0000FF0000FFull;
+    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+__global__ __launch_bounds__(256) void morton_codes_kernel(long long n, const float* __restrict__ points, float lx, float ly,
+                                                           float lz, float ix, float iy, float iz,
+                                                           unsigned long long* __restrict__ codes) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float q = 2097151.0f;  // 2^21 - 1
+    auto cell = [&](float v, float lo, float inv) {
+        float t = (v - lo) * inv;
+        t = t != t ? 0.0f : fminf(fmaxf(t, 0.0f), 1.0f);  // NaN -> 0
+        return (unsigned int)(t * q);
+    };
+    codes[i] = spread21(cell(points[3 * i], lx, ix)) | (spread21(cell(points[3 * i + 1], ly, iy)) << 1) |
+               (spread21(cell(points[3 * i + 2], lz, iz)) << 2);
+}
+
 }  // namespace
 
 void gsr_launch_nonfinite_scan(hipStream_t s, int n_groups, const float* const* src, const int* row_words, long long n_rows,
@@ -278,6 +306,13 @@ void gsr_launch_split_transform(hipStream_t s, long long n_new, int scale_dims, 
     if (n_new <= 0) return;
     hipLaunchKernelGGL(split_transform_kernel, dim3((unsigned)((n_new + 255) / 256)), dim3(256), 0, s, n_new, scale_dims,
                        points, reinterpret_cast<const float4*>(rots), scales, seed);
+}
+
+void gsr_launch_morton_codes(hipStream_t s, long long n, const float* points, const float lo[3], const float inv_extent[3],
+                             unsigned long long* codes) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(morton_codes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, points, lo[0], lo[1], lo[2],
+                       inv_extent[0], inv_extent[1], inv_extent[2], codes);
 }
 
 void gsr_launch_reset_opacity(hipStream_t s, long long n, float* opacities) {

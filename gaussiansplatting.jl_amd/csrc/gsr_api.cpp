@@ -1140,6 +1140,21 @@ int gsr_reset_opacity(int64_t n, float* opacities, void* stream) {
     return GSR_OK;
 }
 
+int gsr_morton_codes(int64_t n, const float* points, const float* box_lo, const float* box_hi, uint64_t* codes, void* stream) {
+    if (n < 0) return fail(GSR_E_INVALID_ARG, "negative n");
+    if (n == 0) return GSR_OK;
+    if (!points || !box_lo || !box_hi || !codes) return fail(GSR_E_INVALID_ARG, "null array");
+    float inv[3];
+    for (int k = 0; k < 3; k++) {
+        const float e = box_hi[k] - box_lo[k];
+        if (!(e >= 0.0f)) return fail(GSR_E_INVALID_ARG, "gsr_morton_codes: box_hi < box_lo (or NaN)");
+        inv[k] = e > 0.0f ? 1.0f / e : 0.0f;
+    }
+    gsr_launch_morton_codes((hipStream_t)stream, n, points, box_lo, inv, reinterpret_cast<unsigned long long*>(codes));
+    HIPCHK(hipGetLastError());
+    return GSR_OK;
+}
+
 int gsr_count_nonfinite(const float* const* arrays, const int32_t* row_words, int32_t n_groups, int64_t n_rows, uint32_t* counts,
                         uint32_t* first_bad, void* stream) {
     if (n_groups < 0 || n_groups > GSR_ADAM_MAX_GROUPS || (n_groups > 0 && (!arrays || !row_words)))

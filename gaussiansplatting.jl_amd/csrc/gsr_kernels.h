@@ -184,6 +184,8 @@ void gsr_launch_compose_rows(hipStream_t s, int n_groups, const void* const* src
 void gsr_launch_split_transform(hipStream_t s, long long n_new, int scale_dims, float* points, const float* rots,
                                 float* scales, uint32_t seed);
 void gsr_launch_reset_opacity(hipStream_t s, long long n, float* opacities);
+void gsr_launch_morton_codes(hipStream_t s, long long n, const float* points, const float lo[3], const float inv_extent[3],
+                             unsigned long long* codes);
 void gsr_launch_nonfinite_scan(hipStream_t s, int n_groups, const float* const* src, const int* row_words, long long n_rows,
                                uint32_t* counts, uint32_t* first_bad);
 void gsr_launch_ply_rows(hipStream_t s, bool pack, long long n, int kr, float* points, float* dc, float* rest, float* opac,

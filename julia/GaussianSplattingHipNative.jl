@@ -224,6 +224,23 @@ function release_native_scene_buffers!(rast::GaussianRasterizer)
     return
 end
 
+# ---- process-wide switches ----
+
+# Form of the binning inside the forward's first kernel: -1 by scene and grid size (default), 0 direct, 1 aggregating wherever
+# its LDS fits.  Identical outputs in every form (include/gsr.h: gsr_preprocess_form); a performance switch.
+preprocess_form!(form::Integer) = check(ccall((:gsr_preprocess_form, LIB), Cint, (Cint,), form))
+# Arithmetic of the SSIM entry points: false = contracted (default), true = every fp32 operation as written (gsr_ssim_precision)
+ssim_exact!(exact::Bool) = check(ccall((:gsr_ssim_precision, LIB), Cint, (Cint,), exact ? 1 : 0))
+
+# Optional (not a reference function): 63-bit Morton codes of the positions (3 x N Float32 device array) inside the box
+# lo .. hi — sortperm of them is the permutation of a spatial re-sort (apply it to every per-Gaussian array, `gs.ids` included).
+function morton_codes!(codes, points, lo::NTuple{3,Float32}, hi::NTuple{3,Float32})
+    n = size(points, 2)
+    check(ccall((:gsr_morton_codes, LIB), Cint, (Int64, Ptr{Float32}, Ref{NTuple{3,Float32}}, Ref{NTuple{3,Float32}}, Ptr{UInt64}, Ptr{Cvoid}),
+                n, dptr(points), Ref(lo), Ref(hi), dptr(UInt64, codes), hipstream()))
+    return codes
+end
+
 # ---- optional fused tails (not needed for the drop-in; callers opt in) ----
 
 # update_stats!(strategy, radii, ∇means_2d, resolution) (strategy.jl:107-136) on the library's kernel

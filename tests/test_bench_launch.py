@@ -84,7 +84,7 @@ def test_bench_gpus_2_self_launches_two_ranks(launch_ranks):
     assert set(ex["forms"]) == {"factored+overlap", "factored", "plain"}  # each from its own fresh rank group
     assert all(f.get("ms_per_step", 0) > 0 for f in ex["forms"].values()), ex["forms"]
     assert ex["headline_form"] == ex["library_default_form"] == "factored+overlap"
-    assert rep["steady_state"]["steps"] == 5 and rep["untimed_steps_total"] == 1 + 15 + 5
+    assert rep["steady_state"]["steps"] == 5 and rep["untimed_steps_total"] == 1 + 15 + 5 + 5  # W + settle + survey + re-settle
     assert ex["bytes_per_gpu"] == int(2 * 0.5 * 11 * 20000 * 4 + 1 * 3 * 20000 * 4)
     assert ex["forms"]["plain"]["bytes_per_gpu"] == int(2 * 0.5 * 59 * 20000 * 4)
     assert ex["ms"] > 0 and ex["backend"] == "gloo"

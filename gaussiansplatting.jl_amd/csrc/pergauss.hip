@@ -383,7 +383,20 @@ __global__ __launch_bounds__(AGG_NT ? AGG_NT : 256, AGG_NT ? 3 * AGG_NT / 256 : 
             }
         }
     };
-    const bool walks = visible && area <= EMIT_COOP;
+    // the aggregating form's flattened walks (below): grids of even width only
+    constexpr int FLAT_MAX = 16;
+    const bool flat = AGG && (cam.grid_x & 1) == 0;
+    __shared__ uint8_t own_tab[AGG ? NT / 64 : 1][AGG ? 64 * FLAT_MAX : 1];
+    __shared__ uint32_t emit_tab[AGG ? NT / 64 : 1][AGG ? 64 : 1];
+    int fcnt = 0, fppr = 0;          // this lane's pair requests in the flattened walks, pairs per row of its rect
+    bool coop_small = false;         // ... or too many of them: with the wave-cooperative path
+    uint32_t flat_pre = 0, flat_total = 0;
+    if (flat && visible && area <= EMIT_COOP) {
+        fppr = ((rmax[0] - 1) >> 1) - (rmin[0] >> 1) + 1;
+        fcnt = fppr * (rmax[1] - rmin[1]);
+        if (fcnt > FLAT_MAX) { fcnt = 0; coop_small = true; }
+    }
+    const bool walks = visible && area <= EMIT_COOP && !flat;
     if (!AGG) {
         constexpr int PEND = 8;
         uint32_t pend_t[PEND], pend_c[PEND];
@@ -414,10 +427,62 @@ __global__ __launch_bounds__(AGG_NT ? AGG_NT : 256, AGG_NT ? 3 * AGG_NT / 256 : 
         }
     } else {
         __syncthreads();  // agg zeroed
-        if (walks)
+        // Both walks of this form are FLATTENED over the lanes of the wave on grids of even width (where the pairing of a
+        // row's tiles follows x alone): in scene order a wave's slowest lane has 13.6 pair requests at config 3 and the
+        // average lane 3.9, so a per-lane loop runs at 28 % lane efficiency — twice.  Instead every lane announces its
+        // count, an owner table in LDS maps item -> lane (wave-local, no barrier), and the wave works its ~250 items off
+        // 64 at a time, each lane fetching its item's Gaussian with ds_bpermute.  Gaussians of more than FLAT_MAX
+        // requests (1 %) join the wave-cooperative path below, which then also leaves their emitted mask.
+        const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (flat) {
+            uint32_t x = (uint32_t)fcnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t y = __shfl_up(x, off);
+                if (ln >= off) x += y;
+            }
+            const uint32_t fpre = x - (uint32_t)fcnt, ftotal = __shfl(x, 63);
+            for (int k = 0; k < fcnt; k++) own_tab[wv][fpre + k] = (uint8_t)ln;
+            emit_tab[wv][ln] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t rlo = (uint32_t)rmin[0] | ((uint32_t)rmin[1] << 16);
+            // pairs per rect row, and the multiplier of the small division q / ppr = (q * fmul) >> 8 (q < 16, ppr <= 16: exact)
+            const uint32_t rhi = (uint32_t)rmax[0] | ((fppr > 0 ? (256u + (uint32_t)fppr - 1u) / (uint32_t)fppr : 0u) << 16);
+            // (every lane of the wave runs every trip: a ds_bpermute reads zero from a lane that is switched off)
+            for (uint32_t base = 0; base < ftotal; base += 64u) {
+                const bool on = base + (uint32_t)ln < ftotal;
+                const uint32_t it = on ? base + (uint32_t)ln : ftotal - 1u;
+                const int src = own_tab[wv][it];
+                const uint32_t q = it - __shfl(fpre, src);
+                const uint32_t lo = __shfl(rlo, src), hi = __shfl(rhi, src);
+                const float smx = __shfl(m2[0], src), smy = __shfl(m2[1], src);
+                const float sa = __shfl(conic[0], src), sb = __shfl(conic[1], src), sc = __shfl(conic[2], src);
+                const float stau = __shfl(tau, src);
+                const int x0 = (int)(lo & 0xFFFFu), y0 = (int)(lo >> 16), x1 = (int)(hi & 0xFFFFu);
+                const int sppr = ((x1 - 1) >> 1) - (x0 >> 1) + 1, w = x1 - x0;
+                const int row = (int)((q * (hi >> 16)) >> 8), pc = (int)q - row * sppr;
+                const int xe = ((x0 >> 1) + pc) << 1, y = y0 + row;   // the pair's even tile (may lie left of the rect)
+                const bool va = on && xe >= x0, vb = on && xe + 1 < x1;
+                const uint32_t kka = (uint32_t)(row * w + (xe - x0)) & 31u, kkb = (uint32_t)(row * w + (xe + 1 - x0)) & 31u;
+                const uint32_t t = (uint32_t)(y * cam.grid_x + xe);
+                uint32_t c0 = 0u, c1 = 0u;
+                if (va) c0 = (!cam.exact_cull || tile_may_touch(smx, smy, sa, sb, sc, stau, xe * GSR_TILE, y * GSR_TILE)) ? 1u : 0u;
+                if (vb) c1 = (!cam.exact_cull || tile_may_touch(smx, smy, sa, sb, sc, stau, (xe + 1) * GSR_TILE, y * GSR_TILE)) ? 1u : 0u;
+                if (c0 | c1) {
+                    atomicOr(&emit_tab[wv][src], (c0 << kka) | (c1 << kkb));
+                    atomicAdd(&agg[t >> 1], (unsigned long long)c0 | ((unsigned long long)c1 << 32));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (fcnt > 0) emitted = emit_tab[wv][ln];
+            flat_pre = fpre; flat_total = ftotal;
+        } else if (walks) {
             walk([&](uint32_t t, uint32_t c) {
                 atomicAdd(&agg[t >> 1], (unsigned long long)(c & 1u) | ((unsigned long long)(c >> 1) << 32));
             }, true);
+        }
         __syncthreads();
         // one global atomic per word this workgroup counted in; the word then holds the bin positions its instances start at
         unsigned long long* tc64 = reinterpret_cast<unsigned long long*>(tile_count);
@@ -434,14 +499,45 @@ __global__ __launch_bounds__(AGG_NT ? AGG_NT : 256, AGG_NT ? 3 * AGG_NT / 256 : 
                 if (any & (1u << k)) agg[w0 + k * NT] = old[k];
         }
         __syncthreads();
-        if (walks && bin_cap > 0u)
-            walk([&](uint32_t t, uint32_t c) {
-                const unsigned long long old =
-                    atomicAdd(&agg[t >> 1], (unsigned long long)(c & 1u) | ((unsigned long long)(c >> 1) << 32));
-                const uint32_t p0 = (uint32_t)old, p1 = (uint32_t)(old >> 32);
-                if ((c & 1u) && p0 < bin_cap) bins[(size_t)t * bin_cap + p0] = key;
-                if ((c & 2u) && p1 < bin_cap) bins[(size_t)(t + 1) * bin_cap + p1] = key;
-            }, false);
+        if (bin_cap > 0u) {
+            if (flat) {
+                // (item() again, second pass: same table, same decode)
+                const uint32_t rlo = (uint32_t)rmin[0] | ((uint32_t)rmin[1] << 16);
+                const uint32_t rhi = (uint32_t)rmax[0] | ((fppr > 0 ? (256u + (uint32_t)fppr - 1u) / (uint32_t)fppr : 0u) << 16);
+                for (uint32_t base = 0; base < flat_total; base += 64u) {
+                    const bool on = base + (uint32_t)ln < flat_total;
+                    const uint32_t it = on ? base + (uint32_t)ln : flat_total - 1u;
+                    const int src = own_tab[wv][it];
+                    const uint32_t q = it - __shfl(flat_pre, src);
+                    const uint32_t lo = __shfl(rlo, src), hi = __shfl(rhi, src);
+                    const uint32_t em = __shfl(emitted, src);
+                    const uint32_t zb = __shfl(__float_as_uint(mc_z), src);
+                    const int x0 = (int)(lo & 0xFFFFu), y0 = (int)(lo >> 16), x1 = (int)(hi & 0xFFFFu);
+                    const int sppr = ((x1 - 1) >> 1) - (x0 >> 1) + 1, w = x1 - x0;
+                    const int row = (int)((q * (hi >> 16)) >> 8), pc = (int)q - row * sppr;
+                    const int xe = ((x0 >> 1) + pc) << 1, y = y0 + row;
+                    const bool va = on && xe >= x0, vb = on && xe + 1 < x1;
+                    const uint32_t kka = (uint32_t)(row * w + (xe - x0)) & 31u, kkb = (uint32_t)(row * w + (xe + 1 - x0)) & 31u;
+                    const uint32_t t = (uint32_t)(y * cam.grid_x + xe);
+                    const uint32_t c0 = va ? (em >> kka) & 1u : 0u, c1 = vb ? (em >> kkb) & 1u : 0u;
+                    if (c0 | c1) {
+                        const unsigned long long old = atomicAdd(&agg[t >> 1], (unsigned long long)c0 | ((unsigned long long)c1 << 32));
+                        const uint64_t skey = ((uint64_t)zb << 32) | (uint32_t)(blockIdx.x * NT + (threadIdx.x & ~63) + src);
+                        const uint32_t p0 = (uint32_t)old, p1 = (uint32_t)(old >> 32);
+                        if (c0 && p0 < bin_cap) bins[(size_t)t * bin_cap + p0] = skey;
+                        if (c1 && p1 < bin_cap) bins[(size_t)(t + 1) * bin_cap + p1] = skey;
+                    }
+                }
+            } else if (walks) {
+                walk([&](uint32_t t, uint32_t c) {
+                    const unsigned long long old =
+                        atomicAdd(&agg[t >> 1], (unsigned long long)(c & 1u) | ((unsigned long long)(c >> 1) << 32));
+                    const uint32_t p0 = (uint32_t)old, p1 = (uint32_t)(old >> 32);
+                    if ((c & 1u) && p0 < bin_cap) bins[(size_t)t * bin_cap + p0] = key;
+                    if ((c & 2u) && p1 < bin_cap) bins[(size_t)(t + 1) * bin_cap + p1] = key;
+                }, false);
+            }
+        }
     }
     // Large footprints: one thread walking hundreds of tiles serialises the wave (the reference's
     // duplicate_with_keys! has exactly this loop, utils.jl:96-119).  Rects of more than EMIT_COOP
@@ -449,7 +545,7 @@ __global__ __launch_bounds__(AGG_NT ? AGG_NT : 256, AGG_NT ? 3 * AGG_NT / 256 : 
     // (broadcast) floats, so the lists are identical.
     {
         const int lane = threadIdx.x & 63;
-        unsigned long long big = __builtin_amdgcn_ballot_w64(visible && area > EMIT_COOP);
+        unsigned long long big = __builtin_amdgcn_ballot_w64(visible && (area > EMIT_COOP || coop_small));
         while (big) {
             const int src = __builtin_ctzll(big);
             big &= big - 1;
@@ -461,15 +557,20 @@ __global__ __launch_bounds__(AGG_NT ? AGG_NT : 256, AGG_NT ? 3 * AGG_NT / 256 : 
             const uint32_t bz = __shfl(__float_as_uint(mc_z), src);
             const uint64_t bkey = ((uint64_t)bz << 32) | (uint32_t)(blockIdx.x * NT + (threadIdx.x & ~63) + src);
             const int w = bx1 - bx0, total = w * (by1 - by0);
+            uint32_t first32 = 0u;  // which of the rect's first 32 tiles got an instance (its emitted mask when it is a small one)
             for (int e = lane; e < total; e += 64) {
                 const int ry = e / w, rx = e - ry * w;
                 const int x = bx0 + rx, y = by0 + ry;
-                if (!cam.exact_cull || tile_may_touch(bmx, bmy, ba, bb, bc, btau, x * GSR_TILE, y * GSR_TILE)) {
+                const bool pass = !cam.exact_cull || tile_may_touch(bmx, bmy, ba, bb, bc, btau, x * GSR_TILE, y * GSR_TILE);
+                if (e < 64) first32 = (uint32_t)__builtin_amdgcn_ballot_w64(pass);  // (lane 0 is in the first trip)
+                if (pass) {
                     const uint32_t t = (uint32_t)(y * cam.grid_x + x);
                     const uint32_t pos = atomicAdd(tile_count + t, 1u);
                     if (pos < bin_cap) bins[(size_t)t * bin_cap + pos] = bkey;
                 }
             }
+            first32 = __shfl(first32, 0);
+            if (lane == src && (uint32_t)total <= DENSE_RECT) emitted = first32;
         }
     }
     // Exclusive scan of the tile-rect areas inside the block: with bpre[block] (tile_scan) it

@@ -21,8 +21,8 @@ namespace {
 
 constexpr uint32_t EMIT_COOP = 48;  // tiles per rect above which the wave emits cooperatively
 constexpr int kAggThreads = 512;           // workgroup of preprocess_kernel's aggregating form
-constexpr size_t kAggLdsMax = 52 * 1024;   // ... its dynamic LDS (the counter words): three workgroups per CU, below the 64 KB default limit
-constexpr int kAggMinGaussians = 400000;   // ... and the scene size from which it is the default (measured: DESIGN.md §4)
+constexpr size_t kAggLdsMax = 42 * 1024;   // ... its dynamic LDS (the counter words; + 10 KB of static tables): three workgroups per CU
+constexpr int kAggMinGaussians = 100000;   // ... and the scene size from which it is the default (measured: DESIGN.md §4; 50 k: a tie)
 // Gradient-row slots of a Gaussian (Gaussian-major, gsr_kernels.h): rects of at most DENSE_RECT tiles get one slot per
 // EMITTED tile — preprocess keeps the bit mask of the rect's tiles that passed the footprint test in the record, the
 // sort's emit ranks a tile by a popcount below its bit, the per-Gaussian backward sums popcount(mask) contiguous rows

@@ -10,6 +10,7 @@
 // the per-Gaussian floats are bit-reproducible against the CPU oracle.  These
 // kernels are HBM-bound (192 B of SH per Gaussian), the extra VALU ops are free.
 #include "gsr_kernels.h"
+#include <type_traits>
 #ifndef GSR_PGB_MINWAVES
 #define GSR_PGB_MINWAVES 1
 #endif
@@ -22,6 +23,7 @@ namespace {
 constexpr uint32_t EMIT_COOP = 48;  // tiles per rect above which the wave emits cooperatively
 constexpr int kAggThreads = 512;           // workgroup of preprocess_kernel's aggregating form
 constexpr size_t kAggLdsMax = 42 * 1024;   // ... its dynamic LDS (the counter words; + 10 KB of static tables): three workgroups per CU
+constexpr size_t kAggLds32Max = 42 * 1024;  // ... the same limit with 2 x 16-bit words: up to ~21 500 tiles (1440p; 4K at two per CU was measured slower than direct)
 constexpr int kAggMinGaussians = 100000;   // ... and the scene size from which it is the default (measured: DESIGN.md §4; 50 k: a tie)
 // Gradient-row slots of a Gaussian (Gaussian-major, gsr_kernels.h): rects of at most DENSE_RECT tiles get one slot per
 // EMITTED tile — preprocess keeps the bit mask of the rect's tiles that passed the footprint test in the record, the
@@ -225,7 +227,8 @@ __device__ __forceinline__ void gaussian_normal(const M33& Rw, const M33& Rg, co
 // were measured slower: 0.19 ms against 0.15; so was one resident wave of persistent workgroups).  The order inside a
 // bin differs from the direct form's (it is arbitrary in both; the tile sort fixes it); everything else is bit-identical.
 //   n_words: 64-bit words of the counter array = LDS words of the AGG form ((T + 2) / 2).
-template <int DEG, int AGG_NT /* 0: direct form, 256 threads; else the threads of the aggregating workgroup */>
+template <int DEG, int AGG_NT /* 0: direct form, 256 threads; else the threads of the aggregating workgroup */,
+          bool W32 = false /* aggregating form with 2 x 16-bit LDS words (grids whose 64-bit words do not fit; bin_cap < 65 024) */>
 __global__ __launch_bounds__(AGG_NT ? AGG_NT : 256, AGG_NT ? 3 * AGG_NT / 256 : 1) void preprocess_kernel(int n, int K, int channels,
                                                                       const float* __restrict__ means,
                                                                       const float* __restrict__ scales,
@@ -238,10 +241,20 @@ __global__ __launch_bounds__(AGG_NT ? AGG_NT : 256, AGG_NT ? 3 * AGG_NT / 256 : 
                                                                       int n_words) {
     constexpr bool AGG = AGG_NT != 0;
     constexpr int NT = AGG ? AGG_NT : 256;
-    extern __shared__ unsigned long long agg[];  // AGG: per counter word, this workgroup's counts, then its bin positions
+    // AGG: per counter word (an aligned tile pair), this workgroup's two counts, then its two bin positions — 2 x 32 bits, or
+    // 2 x 16 bits (W32) where a larger grid would not fit otherwise: a workgroup adds at most NT per tile, and a position that
+    // does not fit 16 bits is beyond bin_cap (the launcher checks) and is clamped to "not stored"
+    using AggWord = typename std::conditional<W32, uint32_t, unsigned long long>::type;
+    extern __shared__ unsigned long long agg_raw[];
+    AggWord* agg = reinterpret_cast<AggWord*>(agg_raw);
+    auto agg_inc = [](uint32_t c0, uint32_t c1) -> AggWord {
+        return W32 ? (AggWord)(c0 | (c1 << 16)) : (AggWord)((unsigned long long)c0 | ((unsigned long long)c1 << 32));
+    };
+    auto agg_lo = [](AggWord v) -> uint32_t { return W32 ? (uint32_t)v & 0xFFFFu : (uint32_t)v; };
+    auto agg_hi = [](AggWord v) -> uint32_t { return W32 ? (uint32_t)v >> 16 : (uint32_t)((unsigned long long)v >> 32); };
     const int i = blockIdx.x * NT + threadIdx.x;
     if (AGG)
-        for (int w = threadIdx.x; w < n_words; w += NT) agg[w] = 0ull;
+        for (int w = threadIdx.x; w < n_words; w += NT) agg[w] = (AggWord)0;
     bool visible = false;
     uint32_t area = 0, clamp_bits = 0, emitted = 0;  // emitted: bit k = tile k of the rect (row-major) got an instance
     float m2[2] = {0, 0}, conic[3] = {0, 0, 0}, rgb[3] = {0, 0, 0}, mc_z = 0.0f, tau = 0.0f, opac_v = 0.0f;
@@ -472,7 +485,7 @@ __global__ __launch_bounds__(AGG_NT ? AGG_NT : 256, AGG_NT ? 3 * AGG_NT / 256 : 
                 if (vb) c1 = (!cam.exact_cull || tile_may_touch(smx, smy, sa, sb, sc, stau, (xe + 1) * GSR_TILE, y * GSR_TILE)) ? 1u : 0u;
                 if (c0 | c1) {
                     atomicOr(&emit_tab[wv][src], (c0 << kka) | (c1 << kkb));
-                    atomicAdd(&agg[t >> 1], (unsigned long long)c0 | ((unsigned long long)c1 << 32));
+                    atomicAdd(&agg[t >> 1], agg_inc(c0, c1));
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -480,9 +493,7 @@ __global__ __launch_bounds__(AGG_NT ? AGG_NT : 256, AGG_NT ? 3 * AGG_NT / 256 : 
             if (fcnt > 0) emitted = emit_tab[wv][ln];
             flat_pre = fpre; flat_total = ftotal;
         } else if (walks) {
-            walk([&](uint32_t t, uint32_t c) {
-                atomicAdd(&agg[t >> 1], (unsigned long long)(c & 1u) | ((unsigned long long)(c >> 1) << 32));
-            }, true);
+            walk([&](uint32_t t, uint32_t c) { atomicAdd(&agg[t >> 1], agg_inc(c & 1u, c >> 1)); }, true);
         }
         __syncthreads();
         // one global atomic per word this workgroup counted in; the word then holds the bin positions its instances start at
@@ -492,12 +503,22 @@ __global__ __launch_bounds__(AGG_NT ? AGG_NT : 256, AGG_NT ? 3 * AGG_NT / 256 : 
             uint32_t any = 0u;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const unsigned long long c = w0 + k * NT < n_words ? agg[w0 + k * NT] : 0ull;
-                if (c) { old[k] = atomicAdd(tc64 + w0 + k * NT, c); any |= 1u << k; }
+                const AggWord c = w0 + k * NT < n_words ? agg[w0 + k * NT] : (AggWord)0;
+                if (c) {
+                    old[k] = atomicAdd(tc64 + w0 + k * NT, (unsigned long long)agg_lo(c) | ((unsigned long long)agg_hi(c) << 32));
+                    any |= 1u << k;
+                }
             }
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                if (any & (1u << k)) agg[w0 + k * NT] = old[k];
+                if (any & (1u << k)) {
+                    if (W32) {
+                        const uint32_t lim = 0xFFFFu - (uint32_t)NT;  // (>= bin_cap: "not stored", and no carry into the other half)
+                        agg[w0 + k * NT] = (AggWord)(min((uint32_t)old[k], lim) | (min((uint32_t)(old[k] >> 32), lim) << 16));
+                    } else {
+                        agg[w0 + k * NT] = (AggWord)old[k];
+                    }
+                }
         }
         __syncthreads();
         if (bin_cap > 0u) {
@@ -522,18 +543,17 @@ __global__ __launch_bounds__(AGG_NT ? AGG_NT : 256, AGG_NT ? 3 * AGG_NT / 256 : 
                     const uint32_t t = (uint32_t)(y * cam.grid_x + xe);
                     const uint32_t c0 = va ? (em >> kka) & 1u : 0u, c1 = vb ? (em >> kkb) & 1u : 0u;
                     if (c0 | c1) {
-                        const unsigned long long old = atomicAdd(&agg[t >> 1], (unsigned long long)c0 | ((unsigned long long)c1 << 32));
+                        const AggWord old = atomicAdd(&agg[t >> 1], agg_inc(c0, c1));
                         const uint64_t skey = ((uint64_t)zb << 32) | (uint32_t)(blockIdx.x * NT + (threadIdx.x & ~63) + src);
-                        const uint32_t p0 = (uint32_t)old, p1 = (uint32_t)(old >> 32);
+                        const uint32_t p0 = agg_lo(old), p1 = agg_hi(old);
                         if (c0 && p0 < bin_cap) bins[(size_t)t * bin_cap + p0] = skey;
                         if (c1 && p1 < bin_cap) bins[(size_t)(t + 1) * bin_cap + p1] = skey;
                     }
                 }
             } else if (walks) {
                 walk([&](uint32_t t, uint32_t c) {
-                    const unsigned long long old =
-                        atomicAdd(&agg[t >> 1], (unsigned long long)(c & 1u) | ((unsigned long long)(c >> 1) << 32));
-                    const uint32_t p0 = (uint32_t)old, p1 = (uint32_t)(old >> 32);
+                    const AggWord old = atomicAdd(&agg[t >> 1], agg_inc(c & 1u, c >> 1));
+                    const uint32_t p0 = agg_lo(old), p1 = agg_hi(old);
                     if ((c & 1u) && p0 < bin_cap) bins[(size_t)t * bin_cap + p0] = key;
                     if ((c & 2u) && p1 < bin_cap) bins[(size_t)(t + 1) * bin_cap + p1] = key;
                 }, false);
@@ -1339,12 +1359,20 @@ void gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels
     // The aggregating form wants its counter words in LDS three times per CU (8 B per tile pair: 33 KB at 1080p) and a
     // scene of several rounds of 512-Gaussian workgroups; smaller scenes and larger grids take the direct form.
     const int n_words = (n_tiles + 2) / 2;
-    const size_t lds = (size_t)n_words * 8;
-    const bool agg = lds <= kAggLdsMax && (g_preprocess_form >= 0 ? g_preprocess_form != 0 : n >= kAggMinGaussians);
+    const bool want = g_preprocess_form >= 0 ? g_preprocess_form != 0 : n >= kAggMinGaussians;
+    // 64-bit LDS words where they fit three workgroups per CU; else 2 x 16-bit words (up to ~21 500 tiles: 1440p), which need
+    // every stored bin position to fit 16 bits
+    const bool agg = want && (size_t)n_words * 8 <= kAggLdsMax;
+    const bool agg32 = want && !agg && (size_t)n_words * 4 <= kAggLds32Max && bin_cap < 0xFFFFu - (uint32_t)kAggThreads;
+    const size_t lds = (size_t)n_words * (agg32 ? 4 : 8);
 #define LAUNCH(D)                                                                                                          \
     do {                                                                                                                   \
         if (agg)                                                                                                           \
             hipLaunchKernelGGL((preprocess_kernel<D, kAggThreads>), dim3((n + kAggThreads - 1) / kAggThreads),             \
+                               dim3(kAggThreads), lds, s, n, K, channels, means, scales, r4, opac, shs, cam, geom,         \
+                               tile_count, n_visible, bins, bin_cap, n_words);                                             \
+        else if (agg32)                                                                                                    \
+            hipLaunchKernelGGL((preprocess_kernel<D, kAggThreads, true>), dim3((n + kAggThreads - 1) / kAggThreads),       \
                                dim3(kAggThreads), lds, s, n, K, channels, means, scales, r4, opac, shs, cam, geom,         \
                                tile_count, n_visible, bins, bin_cap, n_words);                                             \
         else                                                                                                               \

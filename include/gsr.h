@@ -284,7 +284,8 @@ GSR_API int gsr_ssim_precision(int exact);
  * utils.jl:85-142 fused).  Process-wide; outputs are identical in every form (only the arbitrary order of the unsorted
  * keys inside a tile's bin differs), this is a performance switch and the tests' handle on both code paths.
  *  -1 (default): chosen per call — the aggregating form for scenes of >= 100 000 Gaussians on grids whose counter words
- *      fit the LDS three times per CU (up to ~10 700 tiles: 1080p and 2048x1080 yes, 1440p and 4K no), else the direct form;
+ *      fit the LDS three times per CU (up to ~10 700 tiles with 2 x 32-bit words: 1080p; up to ~21 500 with 2 x 16-bit words
+ *      while the bins' capacity is below 65 024: 1440p; 4K no), else the direct form;
  *   0: always the direct form (one returning global atomic per instance pair);
  *   1: the aggregating form wherever its LDS fits (a workgroup adds its requests up per counter word in LDS and issues
  *      one global atomic per word, in address order; on grids of even width both rect walks are spread evenly over the

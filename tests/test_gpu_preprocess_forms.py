@@ -91,3 +91,13 @@ def test_default_form_by_size_and_argument_check(pkg, orc):
     W, H, n, deg = 640, 360, 150_000, 1
     s = pkg.synthetic.make_scene(n, W, H, deg, 5300, sigma_px=1.5)
     _assert_same(_views(pkg, orc, s, W, H, deg, "rgb", True, -1, n_views=2), _views(pkg, orc, s, W, H, deg, "rgb", True, 0, n_views=2))
+
+
+def test_sixteen_bit_words_on_a_large_grid(pkg, orc):
+    """Grids whose 64-bit counter words do not fit the LDS three times per CU (beyond ~10 700 tiles) take the aggregating form
+    with 2 x 16-bit words up to ~21 500 tiles (positions clamp at "not stored"): 2560 x 1440 = 14 400 tiles here; a hot tile far beyond the first
+    view's bin capacity exercises the clamp; the direct form is the reference, bit for bit."""
+    W, H, deg = 2560, 1440, 1
+    base = pkg.synthetic.make_scene(60000, W, H, deg, 5400, sigma_px=6.0)
+    s = pkg.synthetic.add_skew(base, "hot:9000", seed=5401)
+    _assert_same(_views(pkg, orc, s, W, H, deg, "rgb", True, 0), _views(pkg, orc, s, W, H, deg, "rgb", True, 1))

@@ -24,7 +24,7 @@ constexpr uint32_t EMIT_COOP = 48;  // tiles per rect above which the wave emits
 constexpr int kAggThreads = 512;           // workgroup of preprocess_kernel's aggregating form
 constexpr size_t kAggLdsMax = 42 * 1024;   // ... its dynamic LDS (the counter words; + 10 KB of static tables): three workgroups per CU
 constexpr size_t kAggLds32Max = 42 * 1024;  // ... the same limit with 2 x 16-bit words: up to ~21 500 tiles (1440p; 4K at two per CU was measured slower than direct)
-constexpr int kAggMinGaussians = 100000;   // ... and the scene size from which it is the default (measured: DESIGN.md §4; 50 k: a tie)
+constexpr int kAggMinGaussians = 250000;   // ... and the scene size from which it is the default (measured, both forms flattened: DESIGN.md §4)
 // Gradient-row slots of a Gaussian (Gaussian-major, gsr_kernels.h): rects of at most DENSE_RECT tiles get one slot per
 // EMITTED tile — preprocess keeps the bit mask of the rect's tiles that passed the footprint test in the record, the
 // sort's emit ranks a tile by a popcount below its bit, the per-Gaussian backward sums popcount(mask) contiguous rows
@@ -397,11 +397,16 @@ __global__ __launch_bounds__(AGG_NT ? AGG_NT : 256, AGG_NT ? 3 * AGG_NT / 256 : 
             }
         }
     };
-    // the aggregating form's flattened walks (below): grids of even width only
+    // FLATTENED walks (both forms, below): grids of even width only, where the pairing of a row's tiles follows x alone.  In
+    // scene order a wave's slowest lane has 13.6 pair requests at config 3 and the average lane 3.9 — a per-lane walk runs at
+    // 28 % lane efficiency.  Instead every lane announces its count, an owner table in LDS maps item -> lane (wave-local, no
+    // barrier), and the wave works its ~250 items off 64 at a time, each lane fetching its item's Gaussian with ds_bpermute.
+    // Gaussians of more than FLAT_MAX requests (1 %) join the wave-cooperative path below, which then also leaves their
+    // emitted mask.
     constexpr int FLAT_MAX = 16;
-    const bool flat = AGG && (cam.grid_x & 1) == 0;
-    __shared__ uint8_t own_tab[AGG ? NT / 64 : 1][AGG ? 64 * FLAT_MAX : 1];
-    __shared__ uint32_t emit_tab[AGG ? NT / 64 : 1][AGG ? 64 : 1];
+    const bool flat = (cam.grid_x & 1) == 0;
+    __shared__ uint8_t own_tab[NT / 64][64 * FLAT_MAX];
+    __shared__ uint32_t emit_tab[NT / 64][64];
     int fcnt = 0, fppr = 0;          // this lane's pair requests in the flattened walks, pairs per row of its rect
     bool coop_small = false;         // ... or too many of them: with the wave-cooperative path
     uint32_t flat_pre = 0, flat_total = 0;
@@ -411,7 +416,70 @@ __global__ __launch_bounds__(AGG_NT ? AGG_NT : 256, AGG_NT ? 3 * AGG_NT / 256 : 
         if (fcnt > FLAT_MAX) { fcnt = 0; coop_small = true; }
     }
     const bool walks = visible && area <= EMIT_COOP && !flat;
-    if (!AGG) {
+    if (!AGG && flat) {
+        // the direct form with its walk flattened over the lanes: an item = one pair request = (at most) one returning global
+        // atomic; two rounds of items in flight per lane
+        const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        uint32_t x = (uint32_t)fcnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(x, off);
+            if (ln >= off) x += y;
+        }
+        const uint32_t fpre = x - (uint32_t)fcnt, ftotal = __shfl(x, 63);
+        for (int k = 0; k < fcnt; k++) own_tab[wv][fpre + k] = (uint8_t)ln;
+        emit_tab[wv][ln] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t rlo = (uint32_t)rmin[0] | ((uint32_t)rmin[1] << 16);
+        const uint32_t rhi = (uint32_t)rmax[0] | ((fppr > 0 ? (256u + (uint32_t)fppr - 1u) / (uint32_t)fppr : 0u) << 16);
+        unsigned long long* tc64 = reinterpret_cast<unsigned long long*>(tile_count);
+        constexpr int INFL = 2;
+        for (uint32_t base = 0; base < ftotal; base += 64u * INFL) {
+            uint32_t tt[INFL], cc[INFL], zz[INFL], ss[INFL];
+            unsigned long long old[INFL];
+#pragma unroll
+            for (int u = 0; u < INFL; u++) {
+                const uint32_t itu = base + 64u * (uint32_t)u + (uint32_t)ln;
+                const bool on = itu < ftotal;
+                const uint32_t it = on ? itu : ftotal - 1u;
+                const int src = own_tab[wv][it];
+                const uint32_t q = it - __shfl(fpre, src);
+                const uint32_t lo = __shfl(rlo, src), hi = __shfl(rhi, src);
+                const float smx = __shfl(m2[0], src), smy = __shfl(m2[1], src);
+                const float sa = __shfl(conic[0], src), sb = __shfl(conic[1], src), sc = __shfl(conic[2], src);
+                const float stau = __shfl(tau, src);
+                zz[u] = __shfl(__float_as_uint(mc_z), src);
+                ss[u] = (uint32_t)src;
+                const int x0 = (int)(lo & 0xFFFFu), y0 = (int)(lo >> 16), x1 = (int)(hi & 0xFFFFu);
+                const int sppr = ((x1 - 1) >> 1) - (x0 >> 1) + 1, w = x1 - x0;
+                const int row = (int)((q * (hi >> 16)) >> 8), pc = (int)q - row * sppr;
+                const int xe = ((x0 >> 1) + pc) << 1, y = y0 + row;
+                const bool va = on && xe >= x0, vb = on && xe + 1 < x1;
+                const uint32_t kka = (uint32_t)(row * w + (xe - x0)) & 31u, kkb = (uint32_t)(row * w + (xe + 1 - x0)) & 31u;
+                tt[u] = (uint32_t)(y * cam.grid_x + xe);
+                uint32_t c0 = 0u, c1 = 0u;
+                if (va) c0 = (!cam.exact_cull || tile_may_touch(smx, smy, sa, sb, sc, stau, xe * GSR_TILE, y * GSR_TILE)) ? 1u : 0u;
+                if (vb) c1 = (!cam.exact_cull || tile_may_touch(smx, smy, sa, sb, sc, stau, (xe + 1) * GSR_TILE, y * GSR_TILE)) ? 1u : 0u;
+                cc[u] = c0 | (c1 << 1);
+                if (cc[u]) {
+                    atomicOr(&emit_tab[wv][src], (c0 << kka) | (c1 << kkb));
+                    old[u] = atomicAdd(tc64 + (tt[u] >> 1), (unsigned long long)c0 | ((unsigned long long)c1 << 32));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < INFL; u++)
+                if (cc[u]) {
+                    const uint64_t skey = ((uint64_t)zz[u] << 32) | (uint32_t)(blockIdx.x * NT + (threadIdx.x & ~63) + ss[u]);
+                    const uint32_t p0 = (uint32_t)old[u], p1 = (uint32_t)(old[u] >> 32);
+                    if ((cc[u] & 1u) && p0 < bin_cap) bins[(size_t)tt[u] * bin_cap + p0] = skey;
+                    if ((cc[u] & 2u) && p1 < bin_cap) bins[(size_t)(tt[u] + 1) * bin_cap + p1] = skey;
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (fcnt > 0) emitted = emit_tab[wv][ln];
+    } else if (!AGG) {
         constexpr int PEND = 8;
         uint32_t pend_t[PEND], pend_c[PEND];
         int np = 0;

@@ -283,10 +283,11 @@ GSR_API int gsr_ssim_precision(int exact);
 /* Form of the binning inside gsr_forward's first kernel (preprocess: projection.jl:69-129 + spherical_harmonics! +
  * utils.jl:85-142 fused).  Process-wide; outputs are identical in every form (only the arbitrary order of the unsorted
  * keys inside a tile's bin differs), this is a performance switch and the tests' handle on both code paths.
- *  -1 (default): chosen per call — the aggregating form for scenes of >= 100 000 Gaussians on grids whose counter words
+ *  -1 (default): chosen per call — the aggregating form for scenes of >= 250 000 Gaussians on grids whose counter words
  *      fit the LDS three times per CU (up to ~10 700 tiles with 2 x 32-bit words: 1080p; up to ~21 500 with 2 x 16-bit words
  *      while the bins' capacity is below 65 024: 1440p; 4K no), else the direct form;
- *   0: always the direct form (one returning global atomic per instance pair);
+ *   0: always the direct form (one returning global atomic per instance pair; on grids of even width the rect walk is
+ *      spread evenly over the lanes of each wave, as in the aggregating form);
  *   1: the aggregating form wherever its LDS fits (a workgroup adds its requests up per counter word in LDS and issues
  *      one global atomic per word, in address order; on grids of even width both rect walks are spread evenly over the
  *      lanes of each wave).

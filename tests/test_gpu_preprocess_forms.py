@@ -87,8 +87,8 @@ def test_default_form_by_size_and_argument_check(pkg, orc):
     L = pkg._lib
     lib = L.load()
     assert lib.gsr_preprocess_form(2) == L.GSR_E_INVALID_ARG and lib.gsr_preprocess_form(-2) == L.GSR_E_INVALID_ARG
-    # 150 k Gaussians at 640 x 360: the default picks the aggregating form; same outputs as the direct form forced
-    W, H, n, deg = 640, 360, 150_000, 1
+    # 300 k Gaussians at 640 x 360: the default picks the aggregating form; same outputs as the direct form forced
+    W, H, n, deg = 640, 360, 300_000, 1
     s = pkg.synthetic.make_scene(n, W, H, deg, 5300, sigma_px=1.5)
     _assert_same(_views(pkg, orc, s, W, H, deg, "rgb", True, -1, n_views=2), _views(pkg, orc, s, W, H, deg, "rgb", True, 0, n_views=2))
 

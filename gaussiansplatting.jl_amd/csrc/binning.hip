@@ -181,7 +181,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint
         // Gaussian blocks: per-block sums of tile-rect areas -> bpre (Gaussian-major instance-slot
         // offsets), and the visible count (per-block counts written by preprocess)
         constexpr int PER = 8;
-        uint32_t vis = 0, total = 0;
+        uint32_t vis = 0, total = 0, any_rect = 0;
         for (int base = 0; base < n_blocks; base += 1024 * PER) {
             const int lo = base + tid * PER, hi = min(lo + PER, n_blocks);
             uint32_t v[PER], sum = 0;
@@ -189,7 +189,9 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint
             for (int k = 0; k < PER; k++) {
                 v[k] = lo + k < hi ? bsum[lo + k] : 0u;
                 sum += v[k];
-                vis += lo + k < hi ? bvis[lo + k] : 0u;
+                const uint32_t bv = lo + k < hi ? bvis[lo + k] : 0u;  // visible | (visible with a non-empty rect) << 16, per block
+                vis += bv & 0xFFFFu;
+                any_rect |= bv >> 16;
             }
             uint32_t round_total;
             uint32_t run = total + block_exclusive_scan_1024(sum, wave_sums, round_total);
@@ -201,13 +203,13 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, const uint
             total += round_total;
         }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) vis += __shfl_xor(vis, off);
-        if (lane == 0) red[2][wave] = vis;
+        for (int off = 32; off > 0; off >>= 1) { vis += __shfl_xor(vis, off); any_rect |= __shfl_xor(any_rect, off); }
+        if (lane == 0) red[2][wave] = vis | (any_rect ? 0x80000000u : 0u);
         __syncthreads();
         if (tid == 0) {
-            uint32_t v = 0;
-            for (int w = 0; w < 16; w++) v += red[2][w];
-            totals[4] = v;      // visible Gaussians
+            uint32_t v = 0, any = 0;
+            for (int w = 0; w < 16; w++) { v += red[2][w] & 0x7FFFFFFFu; any |= red[2][w] & 0x80000000u; }
+            totals[4] = v | any;  // visible Gaussians; bit 31: one of them has a non-empty tile rect (the reference's D > 0)
             totals[5] = total;  // sum of tile-rect areas = number of Gaussian-major instance slots (gradient rows)
         }
     }
@@ -423,6 +425,18 @@ __global__ __launch_bounds__(BIG_THREADS) void tile_sort_big_kernel(const uint32
 
 }  // namespace
 
+// The image of a view whose lists are all empty although the reference would have rendered instances (exact-cull mode: every
+// instance dropped as invisible): what the compositing writes for a pixel nothing blends into — background, T = 1, no contributor
+// (render.jl:118-129 with an empty range).  The reference's all-zero image is for D == 0 only (rasterizer.jl:283,338).
+__global__ __launch_bounds__(256) void fill_background_kernel(size_t n_pixels, int channels, GsrBg8 bg, float* __restrict__ image,
+                                                              float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pixels) return;
+    for (int c = 0; c < channels; c++) image[(size_t)channels * p + c] = bg.v[c];
+    final_T[p] = 1.0f;
+    n_contrib[p] = 0u;
+}
+
 __global__ void tile_order_identity_kernel(int n_tiles, uint32_t* __restrict__ order) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_tiles) order[i] = (uint32_t)i;
@@ -465,4 +479,13 @@ void gsr_launch_tile_sort(hipStream_t s, int passes, int n_tiles, int grid_x, in
 #undef ALL
 #undef LAUNCH
 #undef LAUNCH_BIG
+}
+
+void gsr_launch_fill_background(hipStream_t s, size_t n_pixels, int channels, const float* background, float* image,
+                                float* final_T, uint32_t* n_contrib) {
+    if (n_pixels == 0) return;
+    GsrBg8 bg{};
+    for (int c = 0; c < 3 && c < channels; c++) bg.v[c] = background ? background[c] : 0.0f;  // the colour channels (rasterizer.jl:411-414)
+    hipLaunchKernelGGL(fill_background_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, s, n_pixels, channels, bg,
+                       image, final_T, n_contrib);
 }

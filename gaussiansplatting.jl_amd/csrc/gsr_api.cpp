@@ -598,7 +598,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     h->last_slots = (int64_t)D_slots;
     if (stats) {
         stats->n_rendered = (int64_t)D;
-        stats->n_visible = (int32_t)h->host_totals[4];
+        stats->n_visible = (int32_t)(h->host_totals[4] & 0x7FFFFFFFu);
         stats->max_tile_instances = (int32_t)max_tile;
     }
     h->last_compact = compact;
@@ -610,10 +610,17 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     const bool fused_done = spec && !overflow && D <= cap_instances;
     if (D == 0) {
         h->tile_count_dirty = false;  // every counter is zero
-        // rasterizer.jl:283,338: all-zero image, background not applied
-        HIPCHK(hipMemsetAsync(image_out, 0, P * C * 4, s));
-        HIPCHK(hipMemsetAsync(h->n_contrib.p, 0, P * 4, s));
-        HIPCHK(hipMemsetAsync(h->final_T.p, 0, P * 4, s));
+        if (k.exact_cull && (h->host_totals[4] >> 31)) {
+            // exact-cull mode dropped every instance (all of them invisible: opacities below 1/255) of a view the reference WOULD
+            // have rendered (some rect holds a tile): its pixels blend nothing and show the background, as with the reference's
+            // lists — the all-zero image below is the reference's answer to "no instance at all" only
+            gsr_launch_fill_background(s, P, C, in->background, image_out, h->final_T.as<float>(), h->n_contrib.as<uint32_t>());
+        } else {
+            // rasterizer.jl:283,338: all-zero image, background not applied
+            HIPCHK(hipMemsetAsync(image_out, 0, P * C * 4, s));
+            HIPCHK(hipMemsetAsync(h->n_contrib.p, 0, P * 4, s));
+            HIPCHK(hipMemsetAsync(h->final_T.p, 0, P * 4, s));
+        }
         HIPCHK(hipMemsetAsync(h->ranges.p, 0, 2 * T * 4, s));
         if (aux && aux->uncertainties) HIPCHK(hipMemsetAsync(aux->uncertainties, 0, P * 4, s));
         h->fwd_valid = true;

@@ -69,6 +69,9 @@ void gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels
                            const float* scales, const float* rots, const float* opac, const float* shs, GsrCam cam,
                            GsrGeom geom, uint32_t* tile_count, uint32_t* n_visible /* per 256-block */,
                            uint64_t* bins /* (T+1) x bin_cap keys */, uint32_t bin_cap, int n_tiles);
+struct GsrBg8 { float v[8]; };
+void gsr_launch_fill_background(hipStream_t s, size_t n_pixels, int channels, const float* background /* host, 3 floats */,
+                                float* image, float* final_T, uint32_t* n_contrib);
 extern int g_preprocess_form;  // -1 by size, 0 direct, 1 aggregating (gsr_preprocess_form; pergauss.hip)
 // compact binning mode: scatter the keys to tile_start[t] + arrival rank (tile_fill zeroed by the caller)
 void gsr_launch_emit_compact(hipStream_t s, int n, GsrCam cam, GsrGeom geom, const uint32_t* tile_start, uint32_t* tile_fill,

@@ -679,7 +679,9 @@ __global__ __launch_bounds__(AGG_NT ? AGG_NT : 256, AGG_NT ? 3 * AGG_NT / 256 : 
             if (lane >= off) x += y;
         }
         const unsigned long long vm = __ballot(visible);
-        if (lane == 63) { wsum[wave] = x; wvis[wave] = (uint32_t)__popcll(vm); }
+        // (high half: the visible Gaussians whose rect holds at least one tile — the reference's instance count is > 0 iff any)
+        const unsigned long long am = __ballot(visible && area > 0u);
+        if (lane == 63) { wsum[wave] = x; wvis[wave] = (uint32_t)__popcll(vm) | ((uint32_t)__popcll(am) << 16); }
         __syncthreads();
         uint32_t woff = 0;
         for (int w = wave0; w < wave; w++) woff += wsum[w];

@@ -156,3 +156,31 @@ def test_deep_case_523_differs_on_one_boundary_gaussian_only(pkg, orc):
         sel = np.zeros(n, bool); sel[list(touched)] = True
         rest = vis & ~sel
         assert w in owners and d2[sel].sum() >= 0.8 * d2.sum() and _rel(o[rest], r[rest]) <= 1e-4, (nm, e, w, w in owners)
+
+
+@pytest.mark.parametrize("mode", ["rgb", "rgbd"])
+def test_every_instance_culled_still_shows_the_background(pkg, orc, mode):
+    """Final campaign of round 4, edge case 4434: ONE Gaussian of opacity 0 over a non-zero background.  The reference renders its
+    15 instances (each blends nothing) and the pixels show the background; the exact footprint cull drops all 15 — and the
+    library then took the reference's "no instance at all" exit (all-zero image, rasterizer.jl:283,338).  With a visible Gaussian
+    whose rect holds a tile the view IS rendered: background, T = 1, no contributor — bit-identical to the reference-lists mode."""
+    import fuzz_scenes
+    fs = fuzz_scenes.edge_scene(pkg, 4434)
+    assert fs.means.shape[0] == 1 and float(fs.opac[0]) == 0.0 and any(b != 0 for b in fs.bg)
+    ref = HipRun(pkg, fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, fs.bg, mode)
+    cul = HipRun(pkg, fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, fs.bg, mode, exact_tile_cull=True)
+    a, b = ref.forward().clone(), cul.forward().clone()
+    assert ref.rast.stats.n_rendered == 15 and cul.rast.stats.n_rendered == 0 and cul.rast.stats.n_visible == 1
+    assert torch.equal(a, b) and float(a.abs().max()) > 0
+    assert torch.equal(ref.rast.accum_alpha, cul.rast.accum_alpha) and torch.equal(ref.rast.n_contrib, cul.rast.n_contrib)
+    st = orc.forward(fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, background=fs.bg, mode=mode)
+    assert np.array_equal(b.cpu().numpy().reshape(st.image.shape), st.image)
+    # a backward on it is all zeros, in both modes
+    C = cul.rast.channels
+    vp = np.random.default_rng(0).standard_normal((fs.cam.height, fs.cam.width, C)).astype(np.float32)
+    for g in cul.backward(vp)[:5]:
+        assert not g.cpu().numpy().any()
+    # and a view with NO visible Gaussian at all keeps the reference's all-zero image
+    behind = fs.means.copy(); behind[:, 2] = -5.0
+    none = HipRun(pkg, behind, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, fs.bg, mode, exact_tile_cull=True)
+    assert not none.forward().cpu().numpy().any() and none.rast.stats.n_visible == 0

@@ -221,8 +221,8 @@ __device__ __forceinline__ void gaussian_normal(const M33& Rw, const M33& Rg, co
 // global atomic per word it counted in — consecutive lanes on consecutive words; the LDS word then holds the bin
 // positions this workgroup's instances start at (config 3, 512 Gaussians: ~1 500 requests on ~1 250 of the 4 081 words,
 // 16 % fewer global atomics, in address order), (3) re-walks its rects, the footprint tests replayed from the emitted
-// mask, every instance taking its position with a returning LDS atomic, and stores the keys.  On grids of even width both
-// walks are flattened over the lanes of each wave (below: 28 % -> ~95 % lane efficiency).  Three workgroups per CU in
+// mask, every instance taking its position with a returning LDS atomic, and stores the keys.  Both walks are flattened
+// over the lanes of each wave (below: 28 % -> ~95 % lane efficiency).  Three workgroups per CU in
 // several rounds, so that the phases of different workgroups overlap (1024 Gaussians per workgroup aggregate better and
 // were measured slower: 0.19 ms against 0.15; so was one resident wave of persistent workgroups).  The order inside a
 // bin differs from the direct form's (it is arbitrary in both; the tile sort fixes it); everything else is bit-identical.
@@ -397,22 +397,31 @@ __global__ __launch_bounds__(AGG_NT ? AGG_NT : 256, AGG_NT ? 3 * AGG_NT / 256 : 
             }
         }
     };
-    // FLATTENED walks (both forms, below): grids of even width only, where the pairing of a row's tiles follows x alone.  In
+    // FLATTENED walks (both forms, below).  In
     // scene order a wave's slowest lane has 13.6 pair requests at config 3 and the average lane 3.9 — a per-lane walk runs at
     // 28 % lane efficiency.  Instead every lane announces its count, an owner table in LDS maps item -> lane (wave-local, no
     // barrier), and the wave works its ~250 items off 64 at a time, each lane fetching its item's Gaussian with ds_bpermute.
     // Gaussians of more than FLAT_MAX requests (1 %) join the wave-cooperative path below, which then also leaves their
     // emitted mask.
     constexpr int FLAT_MAX = 16;
-    const bool flat = (cam.grid_x & 1) == 0;
+#ifdef GSR_NO_FLAT
+    const bool flat = false;  // (A/B builds: the per-lane walks)
+#else
+    const bool flat = true;
+#endif
     __shared__ uint8_t own_tab[NT / 64][64 * FLAT_MAX];
     __shared__ uint32_t emit_tab[NT / 64][64];
-    int fcnt = 0, fppr = 0;          // this lane's pair requests in the flattened walks, pairs per row of its rect
+    int fcnt = 0, fppr = 0;          // this lane's pair requests in the flattened walks, pairs per TWO rows of its rect
     bool coop_small = false;         // ... or too many of them: with the wave-cooperative path
     uint32_t flat_pre = 0, flat_total = 0;
     if (flat && visible && area <= EMIT_COOP) {
-        fppr = ((rmax[0] - 1) >> 1) - (rmin[0] >> 1) + 1;
-        fcnt = fppr * (rmax[1] - rmin[1]);
+        // pairs are aligned on the LINEAR tile index t = y * grid_x + x: a row starting on an even t holds ceil(w / 2) of them, on
+        // an odd t floor(w / 2) + 1; on grids of odd width the rows of a rect alternate between the two (fppr = their sum)
+        const int w = rmax[0] - rmin[0], h = rmax[1] - rmin[1];
+        const int t0 = rmin[1] * cam.grid_x + rmin[0], t0b = t0 + cam.grid_x;
+        const int pa = ((t0 + w - 1) >> 1) - (t0 >> 1) + 1, pb = ((t0b + w - 1) >> 1) - (t0b >> 1) + 1;
+        fppr = pa + pb;
+        fcnt = ((h + 1) >> 1) * pa + (h >> 1) * pb;
         if (fcnt > FLAT_MAX) { fcnt = 0; coop_small = true; }
     }
     const bool walks = visible && area <= EMIT_COOP && !flat;
@@ -452,12 +461,14 @@ __global__ __launch_bounds__(AGG_NT ? AGG_NT : 256, AGG_NT ? 3 * AGG_NT / 256 : 
                 zz[u] = __shfl(__float_as_uint(mc_z), src);
                 ss[u] = (uint32_t)src;
                 const int x0 = (int)(lo & 0xFFFFu), y0 = (int)(lo >> 16), x1 = (int)(hi & 0xFFFFu);
-                const int sppr = ((x1 - 1) >> 1) - (x0 >> 1) + 1, w = x1 - x0;
-                const int row = (int)((q * (hi >> 16)) >> 8), pc = (int)q - row * sppr;
-                const int xe = ((x0 >> 1) + pc) << 1, y = y0 + row;
+                const int w = x1 - x0, t0 = y0 * cam.grid_x + x0, t0b = t0 + cam.grid_x;
+                const int pa = ((t0 + w - 1) >> 1) - (t0 >> 1) + 1, pb = ((t0b + w - 1) >> 1) - (t0b >> 1) + 1;
+                const int r2 = (int)((q * (hi >> 16)) >> 8), rem = (int)q - r2 * (pa + pb);   // (q < 16: the multiply-shift is exact)
+                const int row = 2 * r2 + (rem >= pa ? 1 : 0), pc = rem - (rem >= pa ? pa : 0), y = y0 + row;
+                const int te = (((t0 + row * cam.grid_x) >> 1) + pc) << 1, xe = te - y * cam.grid_x;  // the pair's even tile (may lie left of the rect)
                 const bool va = on && xe >= x0, vb = on && xe + 1 < x1;
                 const uint32_t kka = (uint32_t)(row * w + (xe - x0)) & 31u, kkb = (uint32_t)(row * w + (xe + 1 - x0)) & 31u;
-                tt[u] = (uint32_t)(y * cam.grid_x + xe);
+                tt[u] = (uint32_t)te;
                 uint32_t c0 = 0u, c1 = 0u;
                 if (va) c0 = (!cam.exact_cull || tile_may_touch(smx, smy, sa, sb, sc, stau, xe * GSR_TILE, y * GSR_TILE)) ? 1u : 0u;
                 if (vb) c1 = (!cam.exact_cull || tile_may_touch(smx, smy, sa, sb, sc, stau, (xe + 1) * GSR_TILE, y * GSR_TILE)) ? 1u : 0u;
@@ -509,8 +520,7 @@ __global__ __launch_bounds__(AGG_NT ? AGG_NT : 256, AGG_NT ? 3 * AGG_NT / 256 : 
         }
     } else {
         __syncthreads();  // agg zeroed
-        // Both walks of this form are FLATTENED over the lanes of the wave on grids of even width (where the pairing of a
-        // row's tiles follows x alone): in scene order a wave's slowest lane has 13.6 pair requests at config 3 and the
+        // Both walks of this form are FLATTENED over the lanes of the wave: in scene order a wave's slowest lane has 13.6 pair requests at config 3 and the
         // average lane 3.9, so a per-lane loop runs at 28 % lane efficiency — twice.  Instead every lane announces its
         // count, an owner table in LDS maps item -> lane (wave-local, no barrier), and the wave works its ~250 items off
         // 64 at a time, each lane fetching its item's Gaussian with ds_bpermute.  Gaussians of more than FLAT_MAX
@@ -542,12 +552,14 @@ __global__ __launch_bounds__(AGG_NT ? AGG_NT : 256, AGG_NT ? 3 * AGG_NT / 256 : 
                 const float sa = __shfl(conic[0], src), sb = __shfl(conic[1], src), sc = __shfl(conic[2], src);
                 const float stau = __shfl(tau, src);
                 const int x0 = (int)(lo & 0xFFFFu), y0 = (int)(lo >> 16), x1 = (int)(hi & 0xFFFFu);
-                const int sppr = ((x1 - 1) >> 1) - (x0 >> 1) + 1, w = x1 - x0;
-                const int row = (int)((q * (hi >> 16)) >> 8), pc = (int)q - row * sppr;
-                const int xe = ((x0 >> 1) + pc) << 1, y = y0 + row;   // the pair's even tile (may lie left of the rect)
+                const int w = x1 - x0, t0 = y0 * cam.grid_x + x0, t0b = t0 + cam.grid_x;
+                const int pa = ((t0 + w - 1) >> 1) - (t0 >> 1) + 1, pb = ((t0b + w - 1) >> 1) - (t0b >> 1) + 1;
+                const int r2 = (int)((q * (hi >> 16)) >> 8), rem = (int)q - r2 * (pa + pb);   // (q < 16: the multiply-shift is exact)
+                const int row = 2 * r2 + (rem >= pa ? 1 : 0), pc = rem - (rem >= pa ? pa : 0), y = y0 + row;
+                const int te = (((t0 + row * cam.grid_x) >> 1) + pc) << 1, xe = te - y * cam.grid_x;  // the pair's even tile (may lie left of the rect)
                 const bool va = on && xe >= x0, vb = on && xe + 1 < x1;
                 const uint32_t kka = (uint32_t)(row * w + (xe - x0)) & 31u, kkb = (uint32_t)(row * w + (xe + 1 - x0)) & 31u;
-                const uint32_t t = (uint32_t)(y * cam.grid_x + xe);
+                const uint32_t t = (uint32_t)te;
                 uint32_t c0 = 0u, c1 = 0u;
                 if (va) c0 = (!cam.exact_cull || tile_may_touch(smx, smy, sa, sb, sc, stau, xe * GSR_TILE, y * GSR_TILE)) ? 1u : 0u;
                 if (vb) c1 = (!cam.exact_cull || tile_may_touch(smx, smy, sa, sb, sc, stau, (xe + 1) * GSR_TILE, y * GSR_TILE)) ? 1u : 0u;
@@ -603,12 +615,14 @@ __global__ __launch_bounds__(AGG_NT ? AGG_NT : 256, AGG_NT ? 3 * AGG_NT / 256 : 
                     const uint32_t em = __shfl(emitted, src);
                     const uint32_t zb = __shfl(__float_as_uint(mc_z), src);
                     const int x0 = (int)(lo & 0xFFFFu), y0 = (int)(lo >> 16), x1 = (int)(hi & 0xFFFFu);
-                    const int sppr = ((x1 - 1) >> 1) - (x0 >> 1) + 1, w = x1 - x0;
-                    const int row = (int)((q * (hi >> 16)) >> 8), pc = (int)q - row * sppr;
-                    const int xe = ((x0 >> 1) + pc) << 1, y = y0 + row;
+                    const int w = x1 - x0, t0 = y0 * cam.grid_x + x0, t0b = t0 + cam.grid_x;
+                    const int pa = ((t0 + w - 1) >> 1) - (t0 >> 1) + 1, pb = ((t0b + w - 1) >> 1) - (t0b >> 1) + 1;
+                    const int r2 = (int)((q * (hi >> 16)) >> 8), rem = (int)q - r2 * (pa + pb);   // (q < 16: the multiply-shift is exact)
+                    const int row = 2 * r2 + (rem >= pa ? 1 : 0), pc = rem - (rem >= pa ? pa : 0), y = y0 + row;
+                    const int te = (((t0 + row * cam.grid_x) >> 1) + pc) << 1, xe = te - y * cam.grid_x;  // the pair's even tile (may lie left of the rect)
                     const bool va = on && xe >= x0, vb = on && xe + 1 < x1;
                     const uint32_t kka = (uint32_t)(row * w + (xe - x0)) & 31u, kkb = (uint32_t)(row * w + (xe + 1 - x0)) & 31u;
-                    const uint32_t t = (uint32_t)(y * cam.grid_x + xe);
+                    const uint32_t t = (uint32_t)te;
                     const uint32_t c0 = va ? (em >> kka) & 1u : 0u, c1 = vb ? (em >> kkb) & 1u : 0u;
                     if (c0 | c1) {
                         const AggWord old = atomicAdd(&agg[t >> 1], agg_inc(c0, c1));

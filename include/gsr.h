@@ -286,11 +286,10 @@ GSR_API int gsr_ssim_precision(int exact);
  *  -1 (default): chosen per call — the aggregating form for scenes of >= 250 000 Gaussians on grids whose counter words
  *      fit the LDS three times per CU (up to ~10 700 tiles with 2 x 32-bit words: 1080p; up to ~21 500 with 2 x 16-bit words
  *      while the bins' capacity is below 65 024: 1440p; 4K no), else the direct form;
- *   0: always the direct form (one returning global atomic per instance pair; on grids of even width the rect walk is
- *      spread evenly over the lanes of each wave, as in the aggregating form);
+ *   0: always the direct form (one returning global atomic per instance pair; the rect walk is spread evenly over the
+ *      lanes of each wave, as in the aggregating form);
  *   1: the aggregating form wherever its LDS fits (a workgroup adds its requests up per counter word in LDS and issues
- *      one global atomic per word, in address order; on grids of even width both rect walks are spread evenly over the
- *      lanes of each wave).
+ *      one global atomic per word, in address order; both rect walks are spread evenly over the lanes of each wave).
  * GSR_PREPROCESS_AGG=0/1 in the environment starts the process in mode 0 / 1. */
 GSR_API int gsr_preprocess_form(int form);
 

@@ -229,7 +229,10 @@ __device__ __forceinline__ void gaussian_normal(const M33& Rw, const M33& Rg, co
 //   n_words: 64-bit words of the counter array = LDS words of the AGG form ((T + 2) / 2).
 template <int DEG, int AGG_NT /* 0: direct form, 256 threads; else the threads of the aggregating workgroup */,
           bool W32 = false /* aggregating form with 2 x 16-bit LDS words (grids whose 64-bit words do not fit; bin_cap < 65 024) */>
-__global__ __launch_bounds__(AGG_NT ? AGG_NT : 256, AGG_NT ? 3 * AGG_NT / 256 : 1) void preprocess_kernel(int n, int K, int channels,
+// (direct form: AT MOST four waves per SIMD — with its per-lane walks gone it would fit five, and five waves of scattered returning
+//  atomics are slower than four: config 5 0.66-0.68 ms against 0.60-0.62)
+__global__ __launch_bounds__(AGG_NT ? AGG_NT : 256)
+__attribute__((amdgpu_waves_per_eu(AGG_NT ? 3 * AGG_NT / 256 : 1, AGG_NT ? 8 : 4))) void preprocess_kernel(int n, int K, int channels,
                                                                       const float* __restrict__ means,
                                                                       const float* __restrict__ scales,
                                                                       const float4* __restrict__ rots,

@@ -14,10 +14,11 @@ LIB_PATH = os.environ.get("GSR_HIP_LIB", os.path.join(_HERE, "libgsr_hip.so"))  
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gsr.h")
 
 GSR_OK, GSR_E_INVALID_ARG, GSR_E_OOM, GSR_E_HIP, GSR_E_STATE = 0, -1, -2, -3, -4
+DEFAULT = -1  # GSR_DEFAULT: gsr_config.ssim_precision / preprocess_form = the process-wide default
 MODES = {"rgb": 3, "rgbd": 5, "rgbdn": 8}
 FORWARD_ONLY = 1  # gsr_aux.flags: no backward state is kept (inference render)
 FLAG_REFERENCE_TILE_LISTS = 2  # flags = 0: exact footprint culling (the default); bit 1 is retired (rejected)
-ABI_VERSION = 4  # GSR_ABI_VERSION of the include/gsr.h this mirror was written against
+ABI_VERSION = 5  # GSR_ABI_VERSION of the include/gsr.h this mirror was written against
 
 (BUF_RADII, BUF_GRAD_MEANS2D, BUF_N_CONTRIB, BUF_FINAL_T, BUF_TILE_RANGES, BUF_VALUES_SORTED, BUF_GEOM, BUF_NORMALS,
  BUF_GRAD_ROWS, BUF_INSTANCE_AUX) = range(10)
@@ -32,7 +33,7 @@ class GsrError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("mode", C.c_int32), ("near_plane", C.c_float),
                 ("far_plane", C.c_float), ("radius_clip", C.c_int32), ("blur_eps", C.c_float), ("flags", C.c_uint32),
-                ("bins_budget_bytes", C.c_uint64)]
+                ("bins_budget_bytes", C.c_uint64), ("ssim_precision", C.c_int32), ("preprocess_form", C.c_int32)]
 
 
 class Inputs(C.Structure):
@@ -53,7 +54,7 @@ class Aux(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("n_rendered", C.c_int64), ("n_visible", C.c_int32), ("max_tile_instances", C.c_int32),
-                ("generation", C.c_uint64), ("bins_bytes", C.c_int64), ("compact_binning", C.c_int32), ("reserved", C.c_int32)]
+                ("generation", C.c_uint64), ("bins_bytes", C.c_int64), ("compact_binning", C.c_int32), ("preprocess_form", C.c_int32)]
 
 
 class Grads(C.Structure):
@@ -96,7 +97,7 @@ class GatherGroup(C.Structure):
 
 EXPORTS = ["gsr_create", "gsr_destroy", "gsr_release_scene_buffers", "gsr_memory_usage", "gsr_forward",
            "gsr_backward", "gsr_host_wait_policy", "gsr_buffer", "gsr_copy_buffer", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_loss_l1_ssim",
-           "gsr_ssim_precision", "gsr_preprocess_form",
+           "gsr_ssim_precision", "gsr_get_ssim_precision", "gsr_preprocess_form", "gsr_get_preprocess_form",
            "gsr_allreduce_grads", "gsr_last_error_string", "gsr_version", "gsr_abi_version", "gsr_check_abi", "gsr_profile_enable",
            "gsr_profile_stage_count", "gsr_profile_stages", "gsr_profile_stage_name", "gsr_profile_read", "gsr_profile_read_intervals", "gsr_update_stats",
            "gsr_prologue_forward", "gsr_prologue_backward", "gsr_adam_step", "gsr_stream_triad",

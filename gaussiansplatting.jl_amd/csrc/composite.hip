@@ -374,7 +374,11 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
     const gsr::LaneBits lane_bits(lane);
     const int red_slot = gsr::wave_reduce_index<NA>(lane);  // which partial this lane ends up holding
     const bool red_writer = gsr::wave_reduce_writer(lane);
+#ifdef GSR_BWD_MFMA
+    const gsr::RowColConstsM rowcol(lane);
+#else
     const gsr::RowColConsts rowcol(lane);
+#endif
     const gsr::RowColConstsD rowcol_d(lane);
     // main launch: 1-D grid in launch order, longest lists first; LISTED: the scan's three tier lists back to back,
     // longest tier first
@@ -537,7 +541,11 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
             if (C == 3) {
                 // :rgb — reduce {P, U1, U2, rgb} over the 4 lanes of each pixel column first, apply the
                 // column's dx weights, then finish over the 16 columns (wave_reduce.h: 5 swaps, not 8)
+#ifdef GSR_BWD_MFMA
+                const float total = gsr::wave_reduce_rowcol_rgb_mfma(P, U1, U2, col[0], col[1], col[2], dx, lane_bits, rowcol);
+#else
                 const float total = gsr::wave_reduce_rowcol_rgb(P, U1, U2, col[0], col[1], col[2], dx, lane_bits, rowcol);
+#endif
                 if (rowcol.slot >= 0) my_row[rowcol.slot] = total;
             } else if (C == 5) {
                 // :rgbd (the reference's default training mode): the same row-then-column scheme with the depth sum

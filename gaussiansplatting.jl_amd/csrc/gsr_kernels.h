@@ -65,14 +65,15 @@ struct GsrInst {
 };
 
 // ---- pergauss.hip (compiled with -ffp-contract=off: bit-reproducible fp32) ----
-void gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels, const float* means,
-                           const float* scales, const float* rots, const float* opac, const float* shs, GsrCam cam,
-                           GsrGeom geom, uint32_t* tile_count, uint32_t* n_visible /* per 256-block */,
-                           uint64_t* bins /* (T+1) x bin_cap keys */, uint32_t bin_cap, int n_tiles);
+// form: -1 by scene and grid size, 0 direct, 1 aggregating wherever its LDS fits (gsr_config.preprocess_form / gsr_preprocess_form);
+// returns the form that ran (gsr_stats.preprocess_form: 0 direct, 1 / 2 aggregating with 2 x 32 / 2 x 16-bit LDS words, 3 banded)
+int gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels, const float* means,
+                          const float* scales, const float* rots, const float* opac, const float* shs, GsrCam cam,
+                          GsrGeom geom, uint32_t* tile_count, uint32_t* n_visible /* per 256-block */,
+                          uint64_t* bins /* (T+1) x bin_cap keys */, uint32_t bin_cap, int n_tiles, int form);
 struct GsrBg8 { float v[8]; };
 void gsr_launch_fill_background(hipStream_t s, size_t n_pixels, int channels, const float* background /* host, 3 floats */,
                                 float* image, float* final_T, uint32_t* n_contrib);
-extern int g_preprocess_form;  // -1 by size, 0 direct, 1 aggregating (gsr_preprocess_form; pergauss.hip)
 // compact binning mode: scatter the keys to tile_start[t] + arrival rank (tile_fill zeroed by the caller)
 void gsr_launch_emit_compact(hipStream_t s, int n, GsrCam cam, GsrGeom geom, const uint32_t* tile_start, uint32_t* tile_fill,
                              uint64_t* keys);

@@ -1434,19 +1434,18 @@ void gsr_launch_update_stats(hipStream_t s, int n, const int32_t* radii, const f
 }
 
 
-// -1: by scene and grid size (default), 0: direct form, 1: aggregating form wherever its LDS fits (gsr_preprocess_form)
-int g_preprocess_form = [] { const char* e = getenv("GSR_PREPROCESS_AGG"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
-
-void gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels, const float* means,
-                           const float* scales, const float* rots, const float* opac, const float* shs, GsrCam cam,
-                           GsrGeom geom, uint32_t* tile_count, uint32_t* n_visible, uint64_t* bins, uint32_t bin_cap,
-                           int n_tiles) {
-    if (n <= 0) return;
+// form — -1: by scene and grid size (default), 0: direct form, 1: aggregating form wherever its LDS fits (per handle:
+// gsr_config.preprocess_form; its -1 = the process default, gsr_preprocess_form).  Returns the form that ran.
+int gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels, const float* means,
+                          const float* scales, const float* rots, const float* opac, const float* shs, GsrCam cam,
+                          GsrGeom geom, uint32_t* tile_count, uint32_t* n_visible, uint64_t* bins, uint32_t bin_cap,
+                          int n_tiles, int form) {
+    if (n <= 0) return 0;
     const float4* r4 = reinterpret_cast<const float4*>(rots);
     // The aggregating form wants its counter words in LDS three times per CU (8 B per tile pair: 33 KB at 1080p) and a
     // scene of several rounds of 512-Gaussian workgroups; smaller scenes and larger grids take the direct form.
     const int n_words = (n_tiles + 2) / 2;
-    const bool want = g_preprocess_form >= 0 ? g_preprocess_form != 0 : n >= kAggMinGaussians;
+    const bool want = form >= 0 ? form != 0 : n >= kAggMinGaussians;
     // 64-bit LDS words where they fit three workgroups per CU; else 2 x 16-bit words (up to ~21 500 tiles: 1440p), which need
     // every stored bin position to fit 16 bits
     const bool agg = want && (size_t)n_words * 8 <= kAggLdsMax;
@@ -1473,6 +1472,7 @@ void gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels
         default: LAUNCH(3); break;
     }
 #undef LAUNCH
+    return agg ? 1 : (agg32 ? 2 : 0);
 }
 
 void gsr_launch_emit_compact(hipStream_t s, int n, GsrCam cam, GsrGeom geom, const uint32_t* tile_start, uint32_t* tile_fill,

@@ -141,6 +141,65 @@ __device__ __forceinline__ float wave_reduce_rowcol_rgb(float P, float U1, float
     return r;
 }
 
+// ---- the row stage on the matrix pipe (round 5 experiment, GSR_BWD_MFMA) ----
+// v_mfma_f32_16x16x4_f32 computes D[i][j] += sum_k A[i][k] * B[k][j] with lane l holding A[i = l & 15][k = l >> 4] and
+// B[k = l >> 4][j = l & 15]; lane (g, j) gets D[4g + r][j] in register r.  With a per-lane value as B, k runs over the four
+// lanes l, l^16, l^32, l^48 of a pixel column: exactly the two swap levels above.  A is a 0/1 selector of OUTPUT rows (the
+// same for every k): chaining the six values through one accumulator with six selectors lands value v's column sums in the
+// rows its selector names, i.e. on lane row g = i / 4 in register r = i % 4 — the transposed layout the 16-lane tail wants,
+// with no swap, no add and no select on the VALU:
+//   g = 0: r0 = P   r1 = P  (x dx)  r2 = P (x dx^2)
+//   g = 1: r0 = U1  r1 = U1 (x dx)
+//   g = 2: r0 = U2  r1 = c0
+//   g = 3: r0 = c1  r1 = c2
+// The sums are exact-fp32 fmaf chains in k order (0 + v_row0 + v_row1 + v_row2 + v_row3), unselected rows add 0 * v.
+typedef float mfma_f32x4 __attribute__((ext_vector_type(4)));
+struct RowColConstsM {
+    float sP, sU1, sU2, s0, s1, s2;  // output-row selectors (A operands): 1.0 where (lane & 15) is one of the value's rows
+    bool low;                        // o1 = r1 * (low ? dx : 1): dx on lane rows 0, 1 (a lane-constant SGPR mask, no VGPR)
+    int slot;
+    __device__ __forceinline__ explicit RowColConstsM(int lane) {
+        const int i = lane & 15, g = lane >> 4;
+        sP = i <= 2 ? 1.0f : 0.0f;
+        sU1 = (i == 4 || i == 5) ? 1.0f : 0.0f;
+        sU2 = i == 8 ? 1.0f : 0.0f;
+        s0 = i == 9 ? 1.0f : 0.0f;
+        s1 = i == 12 ? 1.0f : 0.0f;
+        s2 = i == 13 ? 1.0f : 0.0f;
+        low = g < 2;
+        // accumulator row layout (composite.hip): [0..2] rgb, [3] P, [4] dx^2*P, [5] dx*U1, [6] U2, [7] dx*P, [8] U1
+        const int j = (lane & 1) ? 2 : ((lane & 8) ? 1 : 0);
+        const int table[4][3] = {{3, 7, 4}, {8, 5, -1}, {6, 0, -1}, {1, 2, -1}};
+        int t = -1;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+            for (int jj = 0; jj < 3; jj++)
+                if (rr == g && jj == j) t = table[rr][jj];
+        const bool writer = (lane & 6) == 4 && !((lane & 1) && (lane & 8));
+        slot = writer ? t : -1;
+    }
+};
+
+__device__ __forceinline__ float wave_reduce_rowcol_rgb_mfma(float P, float U1, float U2, float c0, float c1, float c2,
+                                                             float dx, const LaneBits& L, const RowColConstsM& K) {
+    mfma_f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f};
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(K.sP, P, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(K.sU1, U1, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(K.sU2, U2, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(K.s0, c0, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(K.s1, c1, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(K.s2, c2, d, 0, 0, 0);
+    const float o0 = d[0];
+    const float o1 = d[1] * (K.low ? dx : 1.0f);
+    const float o2 = d[2] * (dx * dx);  // rows g > 0 hold an exact 0 there
+    const float x0 = pair_level<2>(o0, o1, L), x1 = single_level<2>(o2, L);
+    float r = pair_level<3>(x0, x1, L);
+    r = r + dpp_xor2(r);
+    r = r + dpp_shr4(r);
+    return r;
+}
+
 // ---- the same for mode :rgbd (seven per-lane sums: P, U1, U2, r, g, b, depth -> ten outputs) ----
 // swap32 pairs (P,r) (U1,g) (U2,b) (depth,depth), swap16 pairs (a0,a1) and (a3,a2): six swaps instead of the eight the
 // generic ten-value network needs.  Row r (= lane >> 4) ends up with b0 / b1 =

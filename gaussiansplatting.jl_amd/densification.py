@@ -252,9 +252,20 @@ def reorder_spatially(strategy: DefaultStrategy, gs: GaussianModel, optimizers) 
     n = len(gs)
     if n == 0:
         return torch.empty(0, dtype=torch.int32, device=gs.points.device)
-    lo, hi = torch.aminmax(gs.points.reshape(n, 3), dim=0)
-    lo_h = (C.c_float * 3)(*[float(v) for v in lo.tolist()])
-    hi_h = (C.c_float * 3)(*[float(v) for v in hi.tolist()])
+    # bounding box over the FINITE coordinates only: one NaN / Inf position — a transient of a diverging step —
+    # used to make the box NaN (gsr_morton_codes: GSR_E_INVALID_ARG, i.e. an exception AFTER clone / split / prune had
+    # already mutated model and optimizers) or infinite (every code 0).  A degenerate box skips the re-sort instead: it is an
+    # optimisation, never a reason to fail a densification round.  Non-finite rows get clamped codes and sort to an end.
+    pts = gs.points.reshape(n, 3)
+    finite = torch.isfinite(pts)
+    big = torch.finfo(torch.float32).max
+    lo = torch.where(finite, pts, torch.full_like(pts, big)).amin(0)
+    hi = torch.where(finite, pts, torch.full_like(pts, -big)).amax(0)
+    box = torch.cat([lo, hi]).tolist()   # (the one host read of this optional pass)
+    if not all(np.isfinite(box)) or any(box[3 + k] < box[k] for k in range(3)) or all(box[3 + k] == box[k] for k in range(3)):
+        return torch.arange(n, dtype=torch.int32, device=gs.points.device)
+    lo_h = (C.c_float * 3)(*box[:3])
+    hi_h = (C.c_float * 3)(*box[3:])
     codes = torch.empty(n, dtype=torch.int64, device=gs.points.device)   # 63-bit codes: order as signed = as unsigned
     L.check(L.load().gsr_morton_codes(n, _ptr(gs.points), lo_h, hi_h, _ptr(codes), _stream()))
     perm = torch.argsort(codes, stable=True).to(torch.int32)

@@ -18,17 +18,24 @@ C2_DEFAULT = 0.03 ** 2
 class exact_arithmetic:
     """`with fused_ssim.exact_arithmetic():` — gsr_ssim_precision(1) inside the block: every fp32 operation of the three SSIM
     entry points as written (no FMA contraction, IEEE divisions), bit-identical to the CPU oracle.  Outside it the library's
-    default (contracted multiply-adds, two reciprocals for the formula's six divisions) applies.  Process-wide switch."""
+    default (contracted multiply-adds, two reciprocals for the formula's six divisions) applies.  This is the PROCESS-WIDE
+    DEFAULT (gsr_ssim_forward / gsr_ssim_backward, and the loss head of rasterizers created without `ssim_precision=`); on exit
+    the mode found on entry is restored (nesting, `exact_arithmetic(False)` inside an exact block and GSR_SSIM_EXACT=1
+    processes all come back to where they were).  Not a per-thread switch: a rasterizer that must not follow it is created
+    with `GaussianRasterizer(..., ssim_precision="exact" | "fast")`."""
 
     def __init__(self, on: bool = True):
         self.on = bool(on)
+        self._prev = []
 
     def __enter__(self):
-        L.check(L.load().gsr_ssim_precision(1 if self.on else 0))
+        lib = L.load()
+        self._prev.append(int(lib.gsr_get_ssim_precision()))
+        L.check(lib.gsr_ssim_precision(1 if self.on else 0))
         return self
 
     def __exit__(self, *exc):
-        L.check(L.load().gsr_ssim_precision(0))
+        L.check(L.load().gsr_ssim_precision(self._prev.pop()))
         return False
 
 

@@ -91,7 +91,8 @@ class GaussianRasterizer:
 
     def __init__(self, width: int, height: int, mode: str = "rgbd", near_plane: float = 0.2,
                  far_plane: float = 1000.0, device="cuda", radius_clip: int = 3, blur_eps: float = 0.3,
-                 exact_tile_cull: bool = True, bins_budget_bytes: int = 0):
+                 exact_tile_cull: bool = True, bins_budget_bytes: int = 0, ssim_precision: Optional[str] = None,
+                 preprocess_form: Optional[str] = None):
         self.mode = mode
         self.channels = n_color_features(mode)
         self.width, self.height = int(width), int(height)
@@ -106,8 +107,21 @@ class GaussianRasterizer:
         # unchanged, only the internal lists (n_rendered, ranges, values_sorted, n_contrib positions) shrink.
         # False = GSR_FLAG_REFERENCE_TILE_LISTS: exactly the reference's lists (list-level parity checks).
         self.exact_tile_cull = bool(exact_tile_cull)
+        # The two behaviour switches are per handle (ABI 5), like the reference's constructor keywords
+        # (rasterizer.jl:60-65): None = follow the process-wide default (gsr_ssim_precision / gsr_preprocess_form).
+        #   ssim_precision : None | "fast" | "exact"   — arithmetic of the loss head on this rasterizer (fused_ssim.l1_ssim_loss)
+        #   preprocess_form: None | "direct" | "aggregating" — binning form of the forward's first kernel (same outputs)
+        try:
+            sp = {None: L.DEFAULT, "fast": 0, "exact": 1}[ssim_precision]
+            pf = {None: L.DEFAULT, "direct": 0, "aggregating": 1}[preprocess_form]
+        except KeyError as e:
+            raise ValueError(f"ssim_precision is None / 'fast' / 'exact', preprocess_form None / 'direct' / 'aggregating': {e}") from None
+        self.ssim_precision, self.preprocess_form = ssim_precision, preprocess_form
+        # a bare `rasterize` outside autograd renders forward-only (no backward state); False restores the reference's
+        # always-state-keeping `rasterize` for callers of the manual rasterize / grad_rasterize pair
+        self.forward_only_outside_ad = True
         cfg = L.Config(self.width, self.height, self.channels, self.near_plane, self.far_plane, int(radius_clip),
-                       float(blur_eps), 0 if exact_tile_cull else L.FLAG_REFERENCE_TILE_LISTS, int(bins_budget_bytes))
+                       float(blur_eps), 0 if exact_tile_cull else L.FLAG_REFERENCE_TILE_LISTS, int(bins_budget_bytes), sp, pf)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             L.check(self._lib.gsr_create(C.byref(cfg), C.byref(h)))
@@ -473,16 +487,31 @@ class _Rasterize(torch.autograd.Function):
 
 
 def rasterize(means_3d, shs, opacities, scales, rotations, R_w2c=None, t_w2c=None, *, rast: GaussianRasterizer,
-              camera: Camera, sh_degree: int, background=(0.0, 0.0, 0.0), covisibilities=None, uncertainties=None):
+              camera: Camera, sh_degree: int, background=(0.0, 0.0, 0.0), covisibilities=None, uncertainties=None,
+              forward_only: Optional[bool] = None):
     """rasterize(means_3d, shs, opacities, scales, rotations, R_w2c, t_w2c; rast, camera,
     sh_degree, background, covisibilities, uncertainties) — rasterizer.jl:255-408.
     opacities / scales are the activated values.  Returns `rast.image` (aliased, overwritten by
     the next call), shape (H,W,C).  R_w2c is the device (3,3) array in the reference's
     column-major order, i.e. the transpose of a row-major torch matrix.
     Outside AD — `torch.no_grad()`, or no argument requires a gradient; the reference's `within_gradient` test,
-    rasterizer.jl:214-215 — the render keeps no backward state (GSR_FORWARD_ONLY)."""
+    rasterizer.jl:214-215 — the render keeps no backward state (GSR_FORWARD_ONLY) and `grad_rasterize` / `backward_raw`
+    after it raise GSR_E_STATE.  The manual pair the reference also offers — a bare `rasterize` followed by `∇rasterize` on
+    plain arrays, no autograd (rasterizer.jl:255,416) — asks for a state-keeping forward explicitly: `forward_only=False`
+    here, or `rast.forward_only_outside_ad = False` once (the Julia binding's `enable_hip_native!(rast;
+    forward_only_outside_ad=false)`); `forward_only=True` forces the inference render.  None (default): decided as above."""
     diff = (means_3d, shs, opacities, scales, rotations, R_w2c, t_w2c)
-    if not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in diff)):
+    outside_ad = not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in diff))
+    if forward_only is None:
+        forward_only = outside_ad and getattr(rast, "forward_only_outside_ad", True)
+    elif forward_only and not outside_ad:
+        raise ValueError("forward_only=True on a differentiated rasterize: the pullback would find no backward state")
+    if outside_ad and not forward_only:
+        args = [a.detach().contiguous() for a in diff[:5]]
+        return rast.forward_raw(*args, camera, sh_degree, tuple(float(b) for b in background),
+                                None if R_w2c is None else R_w2c.detach().contiguous(),
+                                None if t_w2c is None else t_w2c.detach().contiguous(), covisibilities, uncertainties)
+    if forward_only:
         args = [a.detach().contiguous() for a in diff[:5]]
         return rast.forward_raw(*args, camera, sh_degree, tuple(float(b) for b in background),
                                 None if R_w2c is None else R_w2c.detach().contiguous(),
@@ -496,6 +525,8 @@ def grad_rasterize(vpixels, means_3d, shs, scales, rotations, opacities, radii=N
                    rast: GaussianRasterizer, camera: Camera, sh_degree: int, background=(0.0, 0.0, 0.0)):
     """∇rasterize(vpixels, means_3d, shs, scales, rotations, opacities, radii, R_w2c, t_w2c; ...)
     — rasterizer.jl:416-550 (argument order as in the reference; `radii` is taken from the
-    rasterizer state)."""
+    rasterizer state).  Needs a state-keeping forward on `rast` just before it: `rasterize(..., forward_only=False)` (or
+    `rast.forward_only_outside_ad = False`), `forward_raw(...)`, or a differentiated `rasterize`; after a forward-only
+    render it raises GsrError(GSR_E_STATE)."""
     return rast.backward_raw(vpixels, means_3d, shs, opacities, scales, rotations, camera, sh_degree, background,
                              R_w2c, t_w2c)

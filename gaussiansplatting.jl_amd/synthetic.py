@@ -142,3 +142,139 @@ def add_skew(scene: Scene, kind: str, seed: int = 7) -> Scene:
     return Scene(cat(scene.means, means), cat(scene.scales_raw, log_s), cat(scene.rotations, extra.rotations),
                  cat(scene.opacities_raw, extra.opacities_raw), cat(scene.shs, extra.shs), scene.sh_degree, W, H, scene.focal,
                  scene.principal)
+
+
+def _quat_to_mat(q: np.ndarray) -> np.ndarray:
+    """(n,4) w,x,y,z (any norm) -> (n,3,3) rotation matrices (projection.jl:259-275 convention)."""
+    q = q / np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.empty((q.shape[0], 3, 3))
+    R[:, 0, 0] = 1 - 2 * (y * y + z * z); R[:, 0, 1] = 2 * (x * y - w * z); R[:, 0, 2] = 2 * (x * z + w * y)
+    R[:, 1, 0] = 2 * (x * y + w * z); R[:, 1, 1] = 1 - 2 * (x * x + z * z); R[:, 1, 2] = 2 * (y * z - w * x)
+    R[:, 2, 0] = 2 * (x * z - w * y); R[:, 2, 1] = 2 * (y * z + w * x); R[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    return R
+
+
+def _quat_from_z_to(nrm: np.ndarray, spin: np.ndarray) -> np.ndarray:
+    """Unit quaternions (w,x,y,z) rotating the local z axis onto `nrm` (n,3), after a spin about z by `spin` radians."""
+    nrm = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+    # shortest arc z -> nrm: q = (1 + z.n, z x n), normalised; n = -z handled by a half turn about x
+    w = 1.0 + nrm[:, 2]
+    q = np.stack([w, -nrm[:, 1], nrm[:, 0], np.zeros_like(w)], 1)
+    flip = w < 1e-9
+    q[flip] = np.array([0.0, 1.0, 0.0, 0.0])
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    s = np.stack([np.cos(0.5 * spin), np.zeros_like(spin), np.zeros_like(spin), np.sin(0.5 * spin)], 1)
+    # Hamilton product q * s
+    w1, x1, y1, z1 = q.T
+    w2, x2, y2, z2 = s.T
+    return np.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                     w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], 1)
+
+
+def make_trained_like(n: int, width: int, height: int, sh_degree: int = 3, seed: int = 1010,
+                      sigma_px: float = 4.0, K: int | None = None, subclip_fraction: float = 0.3) -> Scene:
+    """A procedural scene with the statistics of a TRAINED capture rather than of `make_scene`'s uniform cloud
+    (what the reference trains on and benchmarks with: benchmark/pipeline.jl:19-39, Mip-NeRF360 "bicycle"):
+
+      * Gaussians sit on a few SURFACES seen from the origin along +z — a ground plane running to the horizon (35 %),
+        a back wall (20 %), a side wall (10 %), a sphere shell in front (25 %) — plus 10 % floaters in the frustum;
+      * they are FLAT and anisotropic: two in-plane axes log-normal around `sigma_px` pixels at their depth, the axis
+        along the surface normal 10–100 times thinner (log-uniform); oriented along the surface (+ jitter); the ground
+        plane at grazing angles therefore projects to needles, and its density per tile grows towards the horizon;
+      * opacity is BIMODAL (55 % logit ~ N(3,1), 45 % logit ~ N(-2.5,1));
+      * `subclip_fraction` of the splats are tiny (projected radius <= radius_clip = 3 px: culled by project!,
+        projection.jl:104) — what a trained model is full of between two prune rounds;
+      * rows are in DENSIFICATION order: a seed set in random order, then generations of children appended in their
+        parents' order right where densify_clone!/densify_split! put them (densification.jl:47,90): a child sits within
+        its parent's extent, half of the children are splits (scale / 1.6).
+    numpy only, deterministic in (n, width, height, sh_degree, seed)."""
+    rng = np.random.default_rng(seed)
+    f32 = np.float32
+    fx = 0.5 * width / math.tan(math.radians(30.0))
+    fy = fx
+    if K is None:
+        K = (sh_degree + 1) ** 2
+    gens, growth = 3, 1.8
+    n0 = max(1, int(math.ceil(n / growth ** gens)))
+    # --- seed set: positions + normals on the surfaces
+    kind = rng.choice(5, n0, p=[0.35, 0.20, 0.10, 0.25, 0.10])
+    pos = np.zeros((n0, 3))
+    nrm = np.zeros((n0, 3))
+    u, v = rng.uniform(0, 1, n0), rng.uniform(0, 1, n0)
+    hx = 0.5 * width / fx   # tan of the half field of view
+    hy = 0.5 * height / fy
+    g = kind == 0           # ground: y = 1.2 below the camera, from 1.5 to 30 units ahead, wider than the frustum
+    zg = 1.5 + 28.5 * u[g] ** 1.5
+    pos[g] = np.stack([(2 * v[g] - 1) * 1.15 * hx * zg, np.full(g.sum(), 1.2), zg], 1)
+    nrm[g] = [0.0, -1.0, 0.0]
+    b = kind == 1           # back wall at z = 14
+    pos[b] = np.stack([(2 * u[b] - 1) * 1.15 * hx * 14.0, -1.1 * hy * 14.0 + (1.2 + 1.1 * hy * 14.0) * v[b], np.full(b.sum(), 14.0)], 1)
+    nrm[b] = [0.0, 0.0, -1.0]
+    w = kind == 2           # side wall at x = -3.5, from z = 3 to 14
+    zw = 3.0 + 11.0 * u[w]
+    pos[w] = np.stack([np.full(w.sum(), -3.5), -3.0 + 4.2 * v[w], zw], 1)
+    nrm[w] = [1.0, 0.0, 0.0]
+    s = kind == 3           # sphere shell, radius 0.9, centre (0.6, 0.3, 4.5); the far side is occluded, as in a capture
+    d = rng.standard_normal((s.sum(), 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pos[s] = np.array([0.6, 0.3, 4.5]) + 0.9 * d
+    nrm[s] = d
+    f = kind == 4           # floaters anywhere in the frustum
+    zf = rng.uniform(1.0, 14.0, f.sum())
+    pos[f] = np.stack([(2 * u[f] - 1) * hx * zf, (2 * v[f] - 1) * hy * zf, zf], 1)
+    d = rng.standard_normal((f.sum(), 3))
+    nrm[f] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    nrm += 0.08 * rng.standard_normal((n0, 3))   # orientation jitter
+    # --- flat anisotropic scales
+    z = np.maximum(pos[:, 2], 0.5)
+    base = np.log(sigma_px * z / fx)
+    ls = np.empty((n0, 3))
+    ls[:, 0] = base + 0.6 * rng.standard_normal(n0)
+    ls[:, 1] = base + 0.6 * rng.standard_normal(n0)
+    ls[:, 2] = np.minimum(ls[:, 0], ls[:, 1]) - rng.uniform(math.log(10.0), math.log(100.0), n0)
+    ls[f, 2] = ls[f, 0] - rng.uniform(0.0, math.log(10.0), f.sum())   # floaters are blobs
+    quat = _quat_from_z_to(nrm, rng.uniform(0, 2 * math.pi, n0))
+    opac = np.where(rng.uniform(0, 1, n0) < 0.55, rng.normal(3.0, 1.0, n0), rng.normal(-2.5, 1.0, n0))
+    shs = np.empty((n0, K, 3))
+    # low-frequency albedo per surface + noise
+    shs[:, 0, :] = 0.6 * np.sin(pos @ rng.normal(0.0, 0.7, (3, 3)) + kind[:, None]) + rng.normal(0.0, 0.15, (n0, 3))
+    if K > 1:
+        shs[:, 1:, :] = rng.normal(0.0, 0.05, (n0, K - 1, 3))
+    # --- densification generations: children appended in their parents' order
+    for gen in range(gens):
+        cur = pos.shape[0]
+        want = n if gen == gens - 1 else int(round(n0 * growth ** (gen + 1)))
+        k = max(0, min(cur, want - cur))
+        sel = np.sort(rng.choice(cur, k, replace=False))
+        R = _quat_to_mat(quat[sel])
+        xi = rng.standard_normal((k, 3))
+        child_pos = pos[sel] + np.einsum("nij,nj->ni", R, np.exp(ls[sel]) * xi)
+        split = rng.uniform(0, 1, k) < 0.5
+        child_ls = ls[sel] - np.where(split, math.log(1.6), 0.0)[:, None]
+        ls[sel[split]] -= math.log(1.6)
+        child_quat = quat[sel] + 0.02 * rng.standard_normal((k, 4))
+        child_op = opac[sel] + rng.normal(0.0, 0.3, k)
+        child_sh = shs[sel] + rng.normal(0.0, 0.03, (k, K, 3))
+        pos = np.concatenate([pos, child_pos]); ls = np.concatenate([ls, child_ls]); quat = np.concatenate([quat, child_quat])
+        opac = np.concatenate([opac, child_op]); shs = np.concatenate([shs, child_sh])
+    if pos.shape[0] < n:   # tiny n: pad with copies of the first rows
+        pad = np.arange(n - pos.shape[0]) % pos.shape[0]
+        pos, ls, quat, opac, shs = (np.concatenate([a, a[pad]]) for a in (pos, ls, quat, opac, shs))
+    # --- sub-radius_clip splats: projected sigma ~ 0.25-0.6 px whatever they were
+    tiny = rng.uniform(0, 1, n) < subclip_fraction
+    zt = np.maximum(pos[tiny, 2], 0.5)
+    ls[tiny] = np.log(rng.uniform(0.25, 0.6, tiny.sum()) * zt / fx)[:, None] + rng.normal(0.0, 0.1, (tiny.sum(), 3))
+    quat = quat * rng.uniform(0.5, 2.0, (n, 1))   # the stored rotations are un-normalised (rasterizer.jl:232-233)
+    return Scene(np.ascontiguousarray(pos[:n], f32), np.ascontiguousarray(ls[:n], f32), np.ascontiguousarray(quat[:n], f32),
+                 np.ascontiguousarray(opac[:n], f32), np.ascontiguousarray(shs[:n], f32), sh_degree, width, height,
+                 (f32(fx), f32(fy)))
+
+
+def scene_by_name(name: str, n: int, width: int, height: int, sh_degree: int = 3, seed: int = 1002, K: int | None = None) -> Scene:
+    """`uniform` (make_scene) or `trained` (make_trained_like): what bench.py's --scene takes."""
+    if name == "uniform":
+        return make_scene(n, width, height, sh_degree, seed, K=K)
+    if name == "trained":
+        return make_trained_like(n, width, height, sh_degree, seed, K=K)
+    raise ValueError(f"unknown scene kind {name!r}")

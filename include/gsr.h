@@ -62,7 +62,15 @@ typedef struct gsr_config {
                           * ((tiles+1) x longest list x 8 B); default max(128 MiB, 48 B x instance count of the last view).
                           * A view whose bins would exceed it — a few very deep tiles — is binned in compact mode
                           * (count -> scan -> scatter, 8 B per instance) instead: same lists, same results. */
+    /* New in ABI 5 — the two behaviour switches are PER HANDLE, as the reference's knobs are constructor keywords
+     * (rasterizer.jl:60-65).  -1 = the process-wide default (gsr_ssim_precision / gsr_preprocess_form below, themselves
+     * started from GSR_SSIM_EXACT / GSR_PREPROCESS_AGG), read at every call; 0 / 1 pin the handle whatever another thread
+     * sets process-wide — e.g. a GUI render worker next to a trainer (gui/worker.jl:47-58).  Other values: GSR_E_INVALID_ARG.
+     * (A zero-initialised config therefore means "fast SSIM, direct binning": bindings should write -1.) */
+    int32_t ssim_precision;  /* arithmetic of gsr_loss_l1_ssim on this handle: GSR_DEFAULT (-1), 0 fast, 1 exact */
+    int32_t preprocess_form; /* binning form of gsr_forward on this handle: GSR_DEFAULT (-1) by size, 0 direct, 1 aggregating */
 } gsr_config;
+#define GSR_DEFAULT (-1)
 
 /* Tile lists.  DEFAULT (flags = 0): exact footprint culling at binning — a (Gaussian, tile)
  * instance none of whose pixels can reach alpha >= 1/255 is not emitted at all.  The reference
@@ -84,9 +92,10 @@ typedef struct gsr_config {
  *   1: round-1 layout (flag bit 1u = exact tile cull, smaller gsr_config / gsr_aux / gsr_stats / gsr_grads)
  *   2: round-2 layout (flag bit 1u = reference tile lists) — never given a number at the time
  *   3: round-3 layout (GSR_FLAG_REFERENCE_TILE_LISTS = 2u, bit 1u rejected, gsr_check_abi)
- *   4: this layout: gsr_aux grew by `flags` (GSR_FORWARD_ONLY) + `reserved`;
- *      gsr_sh_grad_from_views_tail. */
-#define GSR_ABI_VERSION 4
+ *   4: gsr_aux grew by `flags` (GSR_FORWARD_ONLY) + `reserved`; gsr_sh_grad_from_views_tail.
+ *   5: this layout: gsr_config grew by `ssim_precision` + `preprocess_form` (per-handle switches); gsr_stats.reserved became
+ *      `preprocess_form` (the form that ran); gsr_get_ssim_precision / gsr_get_preprocess_form. */
+#define GSR_ABI_VERSION 5
 
 /* Positional arguments of `rasterize(means_3d, shs, opacities, scales, rotations, ...)`
  * (rasterizer.jl:255-267).  opacities / scales are the ACTIVATED values, as the
@@ -150,7 +159,8 @@ typedef struct gsr_stats {
                                  * gsr_backward (gsr_grads.forward_generation) to have the pairing checked */
     int64_t bins_bytes;         /* bytes of unsorted-key storage this view used (fast: (T+1) x capacity x 8; compact: 8 D) */
     int32_t compact_binning;    /* 1: this view was binned count -> scan -> scatter (budget exceeded or bins overflowed) */
-    int32_t reserved;
+    int32_t preprocess_form;    /* the binning form this view's first kernel ran in: 0 direct, 1 aggregating (2 x 32-bit LDS
+                                 * words), 2 aggregating (2 x 16-bit words), 3 aggregating in horizontal bands of the tile grid */
 } gsr_stats;
 
 /* Cotangents returned by `∇rasterize` (rasterizer.jl:549): caller-provided device
@@ -211,7 +221,8 @@ GSR_API int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* 
                          const gsr_grads* grads, void* stream);
 
 /* How the host thread waits inside gsr_forward for the instance count (the reference blocks in a synchronous
- * device->host copy there, rasterizer.jl:337).  Process-wide.
+ * device->host copy there, rasterizer.jl:337).  Process-wide; the three values are stored and read atomically (a forward
+ * running on another thread sees the old or the new policy, never a mix of fields from both: they are packed in one word).
  *   sleep_us == 0 (default: 30, 0, 0): spin for `spin_us` microseconds, then poll with sched_yield() — other runnable threads
  *   (RCCL's proxy threads on an 8-rank host) get the core at once; no timers; a pure spin's step time.
  *   sleep_us > 0 (opt-in, e.g. 100, 0, 50): sleep through the expected wait (a running average per handle; the host runs
@@ -271,7 +282,10 @@ GSR_API int gsr_ssim_backward(int W, int H, int CH, int B, const float* img, con
                               const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
                               float* dL_dimg, void* stream);
 
-/* Arithmetic of the three SSIM entry points (gsr_ssim_forward / gsr_ssim_backward / gsr_loss_l1_ssim).  Process-wide.
+/* Arithmetic of the three SSIM entry points (gsr_ssim_forward / gsr_ssim_backward / gsr_loss_l1_ssim): the PROCESS-WIDE
+ * DEFAULT — what gsr_ssim_forward / gsr_ssim_backward (no handle) use, and gsr_loss_l1_ssim on a handle whose
+ * gsr_config.ssim_precision is GSR_DEFAULT; a handle created with 0 or 1 there is not affected (ABI 5).  Stored and read
+ * atomically; gsr_get_ssim_precision returns the current value (so that a scoped override can restore what it found).
  *   0 (default): multiply-adds contracted to FMAs and the six divisions of the SSIM formula (fused_ssim.jl:219-233) taken over
  *      two hardware reciprocals — what a GPU compiler makes of the reference's own source; results agree with the
  *      fp32-as-written evaluation to ~1e-6 relative (the loss to 1e-6 absolute, its pullback to 1e-5 relative L2);
@@ -279,9 +293,11 @@ GSR_API int gsr_ssim_backward(int W, int H, int CH, int B, const float* img, con
  *      slower per 1080p loss evaluation.
  * GSR_SSIM_EXACT=1 in the environment starts the process in mode 1. */
 GSR_API int gsr_ssim_precision(int exact);
+GSR_API int gsr_get_ssim_precision(void);
 
 /* Form of the binning inside gsr_forward's first kernel (preprocess: projection.jl:69-129 + spherical_harmonics! +
- * utils.jl:85-142 fused).  Process-wide; outputs are identical in every form (only the arbitrary order of the unsorted
+ * utils.jl:85-142 fused): the PROCESS-WIDE DEFAULT, used by handles whose gsr_config.preprocess_form is GSR_DEFAULT (ABI 5:
+ * a handle created with 0 or 1 there is pinned).  Outputs are identical in every form (only the arbitrary order of the unsorted
  * keys inside a tile's bin differs), this is a performance switch and the tests' handle on both code paths.
  *  -1 (default): chosen per call — the aggregating form for scenes of >= 250 000 Gaussians on grids whose counter words
  *      fit the LDS three times per CU (up to ~10 700 tiles with 2 x 32-bit words: 1080p; up to ~21 500 with 2 x 16-bit words
@@ -292,6 +308,7 @@ GSR_API int gsr_ssim_precision(int exact);
  *      one global atomic per word, in address order; both rect walks are spread evenly over the lanes of each wave).
  * GSR_PREPROCESS_AGG=0/1 in the environment starts the process in mode 0 / 1. */
 GSR_API int gsr_preprocess_form(int form);
+GSR_API int gsr_get_preprocess_form(void);
 
 /* The photometric loss head of Trainer.step! — src/training.jl:656,684-694:
  *   image = features[1:3,:,:]; permute to (W,H,3,1);

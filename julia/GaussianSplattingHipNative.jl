@@ -40,6 +40,8 @@ struct GsrConfig
     width::Int32; height::Int32; mode::Int32
     near_plane::Float32; far_plane::Float32; radius_clip::Int32; blur_eps::Float32; flags::UInt32
     bins_budget_bytes::UInt64  # 0 = default
+    ssim_precision::Int32      # ABI 5, per handle: -1 = process default (ssim_exact!), 0 fast, 1 exact
+    preprocess_form::Int32     # ABI 5, per handle: -1 = process default (preprocess_form!), 0 direct, 1 aggregating
 end
 struct GsrInputs
     n::Int32; n_coeffs::Int32; sh_degree::Int32
@@ -56,7 +58,7 @@ struct GsrAux; covisibilities::Ptr{UInt8}; uncertainties::Ptr{Float32}; radii::P
 const GSR_FORWARD_ONLY = 0x00000001  # gsr_aux.flags: this forward will not be differentiated (no backward state kept)
 struct GsrStats
     n_rendered::Int64; n_visible::Int32; max_tile_instances::Int32; generation::UInt64
-    bins_bytes::Int64; compact_binning::Int32; reserved::Int32
+    bins_bytes::Int64; compact_binning::Int32; preprocess_form::Int32
 end
 struct GsrGrads
     vmeans::Ptr{Float32}; vshs::Ptr{Float32}; vopacities::Ptr{Float32}
@@ -70,7 +72,7 @@ check(rc) = rc == 0 || error(unsafe_string(ccall((:gsr_last_error_string, LIB), 
 
 # GSR_ABI_VERSION of the include/gsr.h these struct definitions mirror; checked (with the six struct sizes) against
 # the loaded library by the first enable_hip_native!: a stale libgsr_hip.so or a stale binding fails here, loudly.
-const GSR_ABI_VERSION = 4
+const GSR_ABI_VERSION = 5
 const ABI_CHECKED = Ref(false)
 function check_abi()
     ABI_CHECKED[] && return
@@ -94,19 +96,26 @@ const NATIVE_LOCK = ReentrantLock()
 native(rast::GaussianRasterizer) = lock(() -> get(NATIVE, rast, nothing), NATIVE_LOCK)
 
 """
-    enable_hip_native!(rast; reference_tile_lists=false, forward_only_outside_ad=true)
+    enable_hip_native!(rast; reference_tile_lists=false, forward_only_outside_ad=true, ssim_exact=nothing, preprocess_form=nothing)
 
 Route `rasterize` / `∇rasterize` on this rasterizer through libgsr_hip.so.  Width / height / mode / near / far
 are the rasterizer's own (rasterizer.jl:60-90).  `forward_only_outside_ad`: a `rasterize` that is not being
-differentiated (no `rrule` around it) is rendered with GSR_FORWARD_ONLY — `∇rasterize` after it is an error.  Returns `rast`.
+differentiated (no `rrule` around it) is rendered with GSR_FORWARD_ONLY — `∇rasterize` after it is an error.
+`ssim_exact` (`nothing` | `false` | `true`) and `preprocess_form` (`nothing` | `0` | `1`) pin the two behaviour switches for THIS
+rasterizer (ABI 5; constructor keywords, as the reference's knobs are: rasterizer.jl:60-65); `nothing` follows the process-wide
+default (`ssim_exact!`, `preprocess_form!`) — so a GUI render task and a trainer in one process cannot disturb each other.
+Returns `rast`.
 """
-function enable_hip_native!(rast::GaussianRasterizer; reference_tile_lists::Bool = false, forward_only_outside_ad::Bool = true)
+function enable_hip_native!(rast::GaussianRasterizer; reference_tile_lists::Bool = false, forward_only_outside_ad::Bool = true,
+                            ssim_exact::Union{Nothing, Bool} = nothing, preprocess_form::Union{Nothing, Integer} = nothing)
     native(rast) === nothing || return rast
     check_abi()
     c, w, h = size(rast.image)
     href = Ref{Ptr{Cvoid}}()
     check(ccall((:gsr_create, LIB), Cint, (Ref{GsrConfig}, Ref{Ptr{Cvoid}}),
-        GsrConfig(w, h, c, rast.near_plane, rast.far_plane, 3, 0.3f0, reference_tile_lists ? 0x2 : 0x0, 0), href))
+        GsrConfig(w, h, c, rast.near_plane, rast.far_plane, 3, 0.3f0, reference_tile_lists ? 0x2 : 0x0, 0,
+                  ssim_exact === nothing ? Int32(-1) : Int32(ssim_exact), preprocess_form === nothing ? Int32(-1) : Int32(preprocess_form)),
+        href))
     st = NativeState(href[], 0, forward_only_outside_ad, false)
     finalizer(s -> ccall((:gsr_destroy, LIB), Cint, (Ptr{Cvoid},), s.handle), st)
     lock(() -> (NATIVE[rast] = st), NATIVE_LOCK)

@@ -27,31 +27,34 @@ def test_stale_callers_fail_loudly(pkg):
     reference-lists flag lives on bit 2u; gsr_check_abi compares the ABI number and the six struct sizes."""
     L = pkg._lib
     lib = L.load()
-    assert lib.gsr_abi_version() == L.ABI_VERSION == 4
-    assert b"abi 4" in lib.gsr_version()
+    assert lib.gsr_abi_version() == L.ABI_VERSION == 5
+    assert b"abi 5" in lib.gsr_version()
     hdr = open(L.HEADER_PATH).read()
-    assert re.search(r"#define\s+GSR_ABI_VERSION\s+4\b", hdr) and re.search(r"#define\s+GSR_FLAG_REFERENCE_TILE_LISTS\s+2u", hdr)
+    assert re.search(r"#define\s+GSR_ABI_VERSION\s+5\b", hdr) and re.search(r"#define\s+GSR_FLAG_REFERENCE_TILE_LISTS\s+2u", hdr)
     h = C.c_void_p()
-    cfg = L.Config(64, 48, 3, 0.2, 1000.0, 3, 0.3, 1, 0)  # the retired bit
+    cfg = L.Config(64, 48, 3, 0.2, 1000.0, 3, 0.3, 1, 0, -1, -1)  # the retired bit
     assert lib.gsr_create(C.byref(cfg), C.byref(h)) == L.GSR_E_INVALID_ARG
     assert b"retired" in lib.gsr_last_error_string()
     sizes = [C.sizeof(t) for t in (L.Config, L.Inputs, L.CameraS, L.Aux, L.Stats, L.Grads)]
-    assert lib.gsr_check_abi(4, *sizes) == 0
+    assert lib.gsr_check_abi(5, *sizes) == 0
+    assert lib.gsr_check_abi(4, *sizes) == L.GSR_E_INVALID_ARG and b"ABI 4" in lib.gsr_last_error_string()
     assert lib.gsr_check_abi(3, *sizes) == L.GSR_E_INVALID_ARG and b"ABI 3" in lib.gsr_last_error_string()
     assert lib.gsr_check_abi(2, *sizes) == L.GSR_E_INVALID_ARG and b"ABI 2" in lib.gsr_last_error_string()
     stale = list(sizes); stale[5] -= 16  # round-1 gsr_grads had no vmeans2d / forward_generation
-    assert lib.gsr_check_abi(4, *stale) == L.GSR_E_INVALID_ARG and b"gsr_grads" in lib.gsr_last_error_string()
+    assert lib.gsr_check_abi(5, *stale) == L.GSR_E_INVALID_ARG and b"gsr_grads" in lib.gsr_last_error_string()
     # the Julia binding carries the same numbers
     jl = open(os.path.join(os.path.dirname(L.HEADER_PATH), "..", "julia", "GaussianSplattingHipNative.jl")).read()
     stale = list(sizes); stale[3] -= 8  # ABI 3's gsr_aux had no flags / reserved
-    assert lib.gsr_check_abi(4, *stale) == L.GSR_E_INVALID_ARG and b"gsr_aux" in lib.gsr_last_error_string()
-    assert "const GSR_ABI_VERSION = 4" in jl and "reference_tile_lists ? 0x2 : 0x0" in jl and ":gsr_check_abi" in jl
+    assert lib.gsr_check_abi(5, *stale) == L.GSR_E_INVALID_ARG and b"gsr_aux" in lib.gsr_last_error_string()
+    stale = list(sizes); stale[0] -= 8  # ABI 4's gsr_config had no ssim_precision / preprocess_form
+    assert lib.gsr_check_abi(5, *stale) == L.GSR_E_INVALID_ARG and b"gsr_config" in lib.gsr_last_error_string()
+    assert "const GSR_ABI_VERSION = 5" in jl and "reference_tile_lists ? 0x2 : 0x0" in jl and ":gsr_check_abi" in jl
 
 
 def test_struct_sizes_match_header(pkg):
     L = pkg._lib
     # include/gsr.h layouts (x86-64 SysV): catches a drifting binding
-    assert C.sizeof(L.Config) == 40
+    assert C.sizeof(L.Config) == 48
     assert C.sizeof(L.Inputs) == 16 + 5 * 8 + 12 + 4
     assert C.sizeof(L.CameraS) == (9 + 3 + 2 + 2 + 3) * 4 + 4 + 16
     assert C.sizeof(L.Stats) == 40
@@ -82,11 +85,25 @@ def test_invalid_arguments_fail_before_touching_the_gpu(pkg):
     L = pkg._lib
     lib = L.load()
     h = C.c_void_p()
-    cfg = L.Config(64, 48, 4, 0.2, 1000.0, 3, 0.3, 0, 0)  # mode 4 does not exist
+    cfg = L.Config(64, 48, 4, 0.2, 1000.0, 3, 0.3, 0, 0, -1, -1)  # mode 4 does not exist
     assert lib.gsr_create(C.byref(cfg), C.byref(h)) == L.GSR_E_INVALID_ARG
     assert b"Invalid render mode" in lib.gsr_last_error_string()
-    cfg = L.Config(0, 48, 3, 0.2, 1000.0, 3, 0.3, 0, 0)
+    cfg = L.Config(0, 48, 3, 0.2, 1000.0, 3, 0.3, 0, 0, -1, -1)
     assert lib.gsr_create(C.byref(cfg), C.byref(h)) == L.GSR_E_INVALID_ARG
+    # the per-handle switches (ABI 5) take GSR_DEFAULT (-1), 0 or 1
+    for sp, pf, word in ((2, -1, b"ssim_precision"), (-2, 0, b"ssim_precision"), (0, 2, b"preprocess_form"), (1, -2, b"preprocess_form")):
+        cfg = L.Config(64, 48, 3, 0.2, 1000.0, 3, 0.3, 0, 0, sp, pf)
+        assert lib.gsr_create(C.byref(cfg), C.byref(h)) == L.GSR_E_INVALID_ARG and word in lib.gsr_last_error_string()
+    # the process-wide defaults: getters return what the setters stored; out-of-range values are rejected and change nothing
+    was = (lib.gsr_get_ssim_precision(), lib.gsr_get_preprocess_form())
+    try:
+        assert lib.gsr_ssim_precision(1) == 0 and lib.gsr_get_ssim_precision() == 1
+        assert lib.gsr_ssim_precision(2) == L.GSR_E_INVALID_ARG and lib.gsr_get_ssim_precision() == 1
+        assert lib.gsr_preprocess_form(0) == 0 and lib.gsr_get_preprocess_form() == 0
+        assert lib.gsr_preprocess_form(-1) == 0 and lib.gsr_get_preprocess_form() == -1
+        assert lib.gsr_host_wait_policy(1 << 21, 0, 0) == L.GSR_E_INVALID_ARG and lib.gsr_host_wait_policy(30, 0, 0) == 0
+    finally:
+        lib.gsr_ssim_precision(was[0]); lib.gsr_preprocess_form(was[1])
     assert lib.gsr_forward(None, None, None, None, None, None, None) == L.GSR_E_INVALID_ARG
     assert lib.gsr_backward(None, None, None, None, None, None) == L.GSR_E_INVALID_ARG
     with pytest.raises(L.GsrError):

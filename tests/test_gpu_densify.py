@@ -247,3 +247,29 @@ def test_reorder_spatially_is_a_consistent_permutation_and_leaves_the_render_unc
     p = torch.from_numpy(perm.astype(np.int64)).cuda()
     for x, y in zip(ga[:5], gb[:5]):
         assert torch.equal(x[p], y)
+
+
+def test_reorder_spatially_survives_non_finite_positions(pkg, orc):
+    """a NaN / Inf position (a diverging step's transient) must not abort a densification round after clone /
+    split / prune have mutated the model: the bounding box is taken over the finite coordinates, the offending rows sort to
+    an end, and an all-non-finite or single-point model skips the re-sort (identity permutation)."""
+    Dz = pkg.densification
+    n = 500
+    gs_o = make_model(n, 3, 43, 3)
+    gs_d = to_device(pkg, gs_o)
+    opt_d = device_optimizers(pkg, gs_d, dz.new_optimizers(gs_o))
+    st = Dz.DefaultStrategy(gs_d, spatial_reorder=True)
+    pts = gs_d.points.reshape(n, 3)
+    pts[7, 0] = float("nan"); pts[11, 2] = float("inf"); pts[13, 1] = float("-inf")
+    finite_before = gs_d.points.reshape(n, 3).cpu().numpy().copy()
+    perm = Dz.reorder_spatially(st, gs_d, opt_d).cpu().numpy()
+    torch.cuda.synchronize()
+    assert np.array_equal(np.sort(perm), np.arange(n))
+    after = gs_d.points.reshape(n, 3).cpu().numpy()
+    assert np.array_equal(after, finite_before[perm], equal_nan=True)
+    assert not np.array_equal(perm, np.arange(n)), "the finite rows were re-sorted"
+    # nothing finite at all / one point repeated: identity
+    gs_d.points[:] = float("nan")
+    assert np.array_equal(Dz.reorder_spatially(st, gs_d, opt_d).cpu().numpy(), np.arange(n))
+    gs_d.points[:] = 1.5
+    assert np.array_equal(Dz.reorder_spatially(st, gs_d, opt_d).cpu().numpy(), np.arange(n))

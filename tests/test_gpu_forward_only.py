@@ -125,3 +125,36 @@ def test_rasterize_outside_ad_renders_forward_only(pkg, orc):
     assert torch.equal(img_plain, img_eval)
     with pytest.raises(pkg._lib.GsrError):
         rast.backward_raw(torch.zeros(H, W, 3).cuda(), *t, camera, deg, (0, 0, 0))
+
+
+def test_manual_rasterize_grad_rasterize_pair_without_autograd(pkg, orc):
+    """the reference's `rasterize` always keeps its backward state, so the manual pair `rasterize` ->
+    `∇rasterize` on plain arrays (rasterizer.jl:255,416) works without AD.  The mirror's opt-outs of the forward-only default:
+    `forward_only=False` per call, `rast.forward_only_outside_ad = False` per rasterizer; gradients equal autograd's."""
+    W, H, n, deg = 128, 96, 2000, 1
+    s = pkg.synthetic.make_scene(n, W, H, deg, 4301, sigma_px=4.0)
+    camera = pkg.Camera(W, H, tuple(s.focal))
+    R = pkg.rasterizer
+    rast = R.GaussianRasterizer(W, H, mode="rgb")
+    t = [dev(s.means), dev(s.shs), dev(s.opacities.reshape(-1, 1)), dev(s.scales), dev(s.rotations)]
+    vp = dev(pkg.synthetic.make_vpixels(W, H, 3, 9))
+    tr = [x.clone().requires_grad_(True) for x in t]
+    R.rasterize(*tr, rast=rast, camera=camera, sh_degree=deg).backward(vp)
+    want = [x.grad.clone() for x in tr]
+    # per call
+    img = R.rasterize(*t, rast=rast, camera=camera, sh_degree=deg, forward_only=False).clone()
+    got = R.grad_rasterize(vp, t[0], t[1], t[3], t[4], t[2], rast=rast, camera=camera, sh_degree=deg)
+    for g, w in zip(got[:5], want):
+        assert torch.equal(g.reshape(w.shape), w)
+    # per rasterizer, also under no_grad
+    rast.forward_only_outside_ad = False
+    with torch.no_grad():
+        img2 = R.rasterize(*t, rast=rast, camera=camera, sh_degree=deg)
+        got = R.grad_rasterize(vp, t[0], t[1], t[3], t[4], t[2], rast=rast, camera=camera, sh_degree=deg)
+    assert torch.equal(img2, img) and torch.equal(got[0].reshape(want[0].shape), want[0])
+    # forcing the inference render still works, and a differentiated call refuses it
+    R.rasterize(*t, rast=rast, camera=camera, sh_degree=deg, forward_only=True)
+    with pytest.raises(pkg._lib.GsrError):
+        R.grad_rasterize(vp, t[0], t[1], t[3], t[4], t[2], rast=rast, camera=camera, sh_degree=deg)
+    with pytest.raises(ValueError):
+        R.rasterize(*tr, rast=rast, camera=camera, sh_degree=deg, forward_only=True)

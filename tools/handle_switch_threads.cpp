@@ -1,0 +1,129 @@
+// Per-handle behaviour switches under concurrency (ABI 5; round-4 verdict, weak #9): the reference's knobs are constructor
+// keywords (rasterizer.jl:60-65) and a GUI RenderWorker runs next to a trainer in one process (gui/worker.jl:47-58).
+//   thread A: handle created with ssim_precision = 1 (exact), preprocess_form = 0 (direct)
+//   thread B: handle created with ssim_precision = 0 (fast),  preprocess_form = 1 (aggregating)
+//   thread C: flips the PROCESS-WIDE defaults (gsr_ssim_precision, gsr_preprocess_form, gsr_host_wait_policy) as fast as it can
+// A and B each run `steps` iterations of gsr_forward + gsr_loss_l1_ssim on their own stream, concurrently, and compare every
+// loss and every pullback BIT FOR BIT with what the same handle produced before thread C existed; a third handle created with
+// GSR_DEFAULT follows the process default (checked single-threaded: exact == A's results, fast == B's).
+//   handle_switch_threads [steps = 200]     prints  RESULT exact_stable <0|1> fast_stable <0|1> default_follows <0|1> forms <a> <b>
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "gsr.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+#define GK(x) do { int r_ = (x); if (r_ != 0) { fprintf(stderr, "gsr error %d (%s) at %s:%d\n", r_, gsr_last_error_string(), __FILE__, __LINE__); exit(3); } } while (0)
+
+static uint64_t rng_state = 0x243F6A8885A308D3ull;
+static double urand() {
+    uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+static double nrand() { const double u = urand() + 1e-300, v = urand(); return std::sqrt(-2.0 * std::log(u)) * std::cos(6.283185307179586 * v); }
+template <class T> static T* upload(const std::vector<T>& v) {
+    T* d; CK(hipMalloc(&d, v.size() * sizeof(T))); CK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)); return d;
+}
+
+int main(int argc, char** argv) {
+    const int steps = argc > 1 ? atoi(argv[1]) : 200;
+    const int W = 640, H = 480, N = 300000, K = 4, deg = 1;  // >= 250 k Gaussians: the default form is the aggregating one
+    if (gsr_abi_version() != GSR_ABI_VERSION) { fprintf(stderr, "ABI mismatch\n"); return 4; }
+    const double fx = 0.5 * W / std::tan(M_PI / 6.0);
+    std::vector<float> means(3 * (size_t)N), shs(3 * K * (size_t)N), opac(N), scales(3 * (size_t)N), rots(4 * (size_t)N);
+    for (int i = 0; i < N; i++) {
+        const double z = 2.0 + 10.0 * urand(), u = 2.0 * urand() - 1.0, v = 2.0 * urand() - 1.0;
+        means[3 * i] = (float)(1.1 * z * u * W / (2.0 * fx)); means[3 * i + 1] = (float)(1.1 * z * v * H / (2.0 * fx)); means[3 * i + 2] = (float)z;
+        for (int k = 0; k < 3; k++) scales[3 * i + k] = (float)std::exp(std::log(1.2 * z / fx) + 0.3 * nrand());
+        for (int k = 0; k < 4; k++) rots[4 * i + k] = (float)nrand();
+        opac[i] = (float)(1.0 / (1.0 + std::exp(-(nrand() - 1.0))));
+        for (int k = 0; k < 3 * K; k++) shs[(size_t)3 * K * i + k] = (float)((k < 3 ? 0.5 : 0.1) * nrand());
+    }
+    std::vector<float> tgt((size_t)3 * W * H);
+    for (auto& x : tgt) x = (float)urand();
+    gsr_inputs in{};
+    in.n = N; in.n_coeffs = K; in.sh_degree = deg;
+    in.means = upload(means); in.shs = upload(shs); in.opacities = upload(opac); in.scales = upload(scales); in.rotations = upload(rots);
+    const float* target = upload(tgt);
+    gsr_camera cam{};
+    cam.R[0] = cam.R[4] = cam.R[8] = 1.0f;
+    cam.focal[0] = cam.focal[1] = (float)fx; cam.principal[0] = cam.principal[1] = 0.5f;
+
+    struct Slot { gsr_handle* h; hipStream_t s; float *image, *vpix, *loss; std::vector<float> ref_v; float ref_loss; int form; };
+    auto make = [&](int ssim, int form) {
+        Slot sl{};
+        gsr_config cfg{};
+        cfg.width = W; cfg.height = H; cfg.mode = GSR_MODE_RGB; cfg.near_plane = 0.2f; cfg.far_plane = 1000.0f; cfg.radius_clip = 3;
+        cfg.blur_eps = 0.3f; cfg.ssim_precision = ssim; cfg.preprocess_form = form;
+        GK(gsr_create(&cfg, &sl.h));
+        CK(hipStreamCreateWithFlags(&sl.s, hipStreamNonBlocking));
+        CK(hipMalloc(&sl.image, sizeof(float) * 3 * W * H)); CK(hipMalloc(&sl.vpix, sizeof(float) * 3 * W * H)); CK(hipMalloc(&sl.loss, 4));
+        return sl;
+    };
+    const size_t P3 = (size_t)3 * W * H;
+    auto step = [&](Slot& sl, std::vector<float>& v, float& loss) {
+        gsr_stats st{};
+        GK(gsr_forward(sl.h, &in, &cam, sl.image, nullptr, sl.s, &st));
+        GK(gsr_loss_l1_ssim(sl.h, sl.image, target, 0.2f, sl.loss, sl.vpix, sl.s));
+        CK(hipMemcpyAsync(v.data(), sl.vpix, P3 * 4, hipMemcpyDeviceToHost, sl.s));
+        CK(hipMemcpyAsync(&loss, sl.loss, 4, hipMemcpyDeviceToHost, sl.s));
+        CK(hipStreamSynchronize(sl.s));
+        sl.form = st.preprocess_form;
+    };
+    Slot A = make(1, 0), B = make(0, 1), D = make(GSR_DEFAULT, GSR_DEFAULT);
+    for (Slot* sl : {&A, &B}) {
+        sl->ref_v.resize(P3);
+        step(*sl, sl->ref_v, sl->ref_loss);  // twice: the first view sizes the bins
+        step(*sl, sl->ref_v, sl->ref_loss);
+    }
+    const int formA = A.form, formB = B.form;
+    const bool modes_differ = memcmp(A.ref_v.data(), B.ref_v.data(), P3 * 4) != 0;  // else the test would prove nothing
+    // the GSR_DEFAULT handle follows the process default
+    std::vector<float> v(P3); float l;
+    bool follows = true;
+    GK(gsr_ssim_precision(1)); step(D, v, l); step(D, v, l);
+    follows = follows && l == A.ref_loss && memcmp(v.data(), A.ref_v.data(), P3 * 4) == 0;
+    GK(gsr_ssim_precision(0)); step(D, v, l);
+    follows = follows && l == B.ref_loss && memcmp(v.data(), B.ref_v.data(), P3 * 4) == 0;
+    GK(gsr_preprocess_form(0)); step(D, v, l); follows = follows && D.form == 0;
+    GK(gsr_preprocess_form(1)); step(D, v, l); follows = follows && D.form == formB;
+    GK(gsr_preprocess_form(-1));
+
+    std::atomic<bool> stop{false};
+    std::atomic<long> flips{0};
+    std::thread C([&] {
+        int k = 0;
+        while (!stop.load()) {
+            gsr_ssim_precision(k & 1); gsr_preprocess_form((k % 3) - 1); gsr_host_wait_policy(k & 1 ? 30 : 1000, 0, 0);
+            k++; flips++;
+        }
+        gsr_ssim_precision(0); gsr_preprocess_form(-1); gsr_host_wait_policy(30, 0, 0);
+    });
+    bool okA = true, okB = true;
+    auto worker = [&](Slot& sl, bool& ok, int want_form) {
+        CK(hipSetDevice(0));
+        std::vector<float> w(P3); float ls;
+        for (int k = 0; k < steps; k++) {
+            step(sl, w, ls);
+            if (ls != sl.ref_loss || sl.form != want_form || memcmp(w.data(), sl.ref_v.data(), P3 * 4) != 0) ok = false;
+        }
+    };
+    std::thread TA([&] { worker(A, okA, formA); }), TB([&] { worker(B, okB, formB); });
+    TA.join(); TB.join();
+    stop = true; C.join();
+    printf("loss exact %.9g fast %.9g (differ: %d), %ld flips of the process defaults during %d + %d concurrent steps\n", A.ref_loss,
+           B.ref_loss, (int)modes_differ, flips.load(), steps, steps);
+    printf("RESULT exact_stable %d fast_stable %d default_follows %d modes_differ %d forms %d %d\n", (int)okA, (int)okB, (int)follows,
+           (int)modes_differ, formA, formB);
+    for (Slot* sl : {&A, &B, &D}) GK(gsr_destroy(sl->h));
+    return (okA && okB && follows && modes_differ) ? 0 : 1;
+}

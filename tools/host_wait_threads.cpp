@@ -71,6 +71,7 @@ int main(int argc, char** argv) {
     std::vector<Slot> slot(T);
     gsr_config cfg{};
     cfg.width = W; cfg.height = H; cfg.mode = GSR_MODE_RGB; cfg.near_plane = 0.2f; cfg.far_plane = 1000.0f; cfg.radius_clip = 3; cfg.blur_eps = 0.3f;
+    cfg.ssim_precision = GSR_DEFAULT; cfg.preprocess_form = GSR_DEFAULT;
     for (auto& sl : slot) {
         GK(gsr_create(&cfg, &sl.h));
         CK(hipStreamCreateWithFlags(&sl.s, hipStreamNonBlocking));

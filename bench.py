@@ -76,6 +76,30 @@ PREPROCESS_FORMS = {0: "direct", 1: "aggregating (2 x 32-bit LDS words)", 2: "ag
                     3: "aggregating, banded (2 x 16-bit LDS words per band)"}  # gsr_stats.preprocess_form
 
 
+# The kernel sources a PMC measurement belongs to (profiles/pmc_traffic.json: `kernel_sources`, written by
+# tools/pmc_parse.py): git blob hashes, computed from the file contents (the GPU box has no .git).  A measurement whose
+# hashes differ from the tree bench.py runs in is STALE — `traffic: null`, `pmc_stale: true` (round-4 verdict, weak #8).
+PMC_KERNEL_SOURCES = ("composite.hip", "pergauss.hip", "binning.hip", "wave_reduce.h", "tile_sort_device.h", "tile_mask.h")
+
+
+def git_blob_hash(path):
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def kernel_source_hashes(root=None):
+    d = os.path.join(root or ROOT, "gaussiansplatting.jl_amd", "csrc")
+    return {f: git_blob_hash(os.path.join(d, f)) for f in PMC_KERNEL_SOURCES}
+
+
+def pmc_stale_files(rec, root=None):
+    """Files whose blob hash differs from the one recorded with PMC record `rec` (all of them when it recorded none)."""
+    then = rec.get("kernel_sources") or {}
+    now = kernel_source_hashes(root)
+    return sorted(f for f in now if then.get(f) != now[f])
+
+
 def config_key(N, W, H, deg, mode, exact_cull, loss):
     """Key of a measured configuration in profiles/pmc_traffic.json (tools/pmc_workload.py writes the same)."""
     return f"N{N}_{W}x{H}_SH{deg}_{mode}_{'cull' if exact_cull else 'reflists'}_{'loss' if loss else 'noloss'}"
@@ -142,6 +166,11 @@ def parse_args(argv=None):
                          "could do at densification time) - reported, never the headline")
     ap.add_argument("--no-other-lists", action="store_true", help="skip the secondary timing of the other tile-list mode")
     ap.add_argument("--no-extra", action="store_true", help="skip `extra_configs` (configs 2 / 5, :rgbd, trainer step)")
+    ap.add_argument("--headline-form", default="default", choices=["default", "plain"],
+                    help="N > 1: which exchange form's rank group the line's top-level numbers (value, ms_per_step) are. "
+                         "'default' = the library default (factored+overlap) if its group completed, else the best completed "
+                         "form; 'plain' = the ONE all-reduce of the whole gradient arena that BASELINE.json's north_star names "
+                         "(if its group completed).  Every form is measured and reported under exchange.forms either way.")
     ap.add_argument("--no-scenes", action="store_true",
                     help="skip `extra_configs.scenes` (hot tile, dense 4K, the trained-like scenes)")
     ap.add_argument("--extra-steps", type=int, default=10, help="timed steps per `extra_configs` entry")
@@ -417,7 +446,8 @@ def merge_sections(args, sections, results):
     if not done:
         return None
     want = default_exchange_form()
-    head = want if want in done else max(done, key=lambda f: done[f].get("value", 0.0))
+    asked = "plain" if getattr(args, "headline_form", "default") == "plain" else want
+    head = asked if asked in done else max(done, key=lambda f: done[f].get("value", 0.0))
     line = dict(done[head])
     forms = {}
     for f in sections:
@@ -427,16 +457,23 @@ def merge_sections(args, sections, results):
         else:
             e = r.get("exchange", {})
             forms[f] = {"ms_per_step": r.get("ms_per_step"), "value": r.get("value"), "exchange_ms": e.get("ms"),
+                        "expected_ms": e.get("expected_ms"),
                         "bytes_per_gpu": e.get("bytes_per_gpu"), "xgmi_GBps": e.get("xgmi_GBps"), "overlap": e.get("overlap"),
                         "form_that_ran": e.get("form"), "wall_s": r.get("wall_s")}
     line.pop("wall_s", None)
     ex = dict(line.get("exchange", {}))
     ex["forms"] = forms
     ex["headline_form"] = head
+    ex["headline_form_requested"] = getattr(args, "headline_form", "default")
     ex["library_default_form"] = want
     ex["forms_note"] = ("every form ran in its OWN fresh rank group (new processes, new communicators, a wall-clock limit per "
-                        "group), the plain all-reduce first; the headline is the library default if its group completed, else the "
-                        "best completed form")
+                        "group), the plain all-reduce first; the headline is the library default (--headline-form default) or the "
+                        "plain all-reduce north_star names (--headline-form plain) if that group completed, else the best completed "
+                        "form; `expected_ms` = bytes_per_gpu / (7 x 153 GB/s): what the exchange would take at the xGMI peak")
+    if isinstance(line.get("config"), dict):
+        # the exchange form the top-level numbers belong to, in so many words (round-4 verdict, weak #10)
+        line["config"]["exchange_form"] = head
+        line["config"]["parallelism"] = f"[exchange form of this line: {head}] " + str(line["config"].get("parallelism", ""))
     line["exchange"] = ex
     return line
 
@@ -819,12 +856,16 @@ class Workload:
                if self.ply is None and not self.skew and self.order == "random" and self.scene_kind == "uniform" else None)
         if key is not None and self.forward_only:
             key = key.rsplit("_", 1)[0] + "_fwdonly"
-        traffic, valu, pmc_src = None, None, None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        traffic, valu, pmc_src, pmc_stale = None, None, None, None
+        tpath = os.environ.get("GSR_PMC_TRAFFIC_JSON") or os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if key is not None and os.path.exists(tpath) and self.tail is None:
             try:
                 rec = json.load(open(tpath)).get("configs", {}).get(key)
-                if rec is not None and int(rec.get("tile_instances", -1)) == Dn:
+                changed = pmc_stale_files(rec) if rec is not None else []
+                if rec is not None and changed:
+                    # measured on other kernel sources than the ones this run executes: not reported
+                    pmc_stale, pmc_src = changed, rec.get("source")
+                elif rec is not None and int(rec.get("tile_instances", -1)) == Dn:
                     traffic = rec.get("hbm_bytes", {}).get(dom)
                     insts = rec.get("sq", {}).get(dom, {}).get("SQ_INSTS_VALU")
                     pmc_src = rec.get("source")
@@ -837,6 +878,9 @@ class Workload:
         r = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "valu": valu, "pmc_source": pmc_src,
              "pmc_config_key": key}
+        if pmc_stale:
+            r["pmc_stale"] = True
+            r["pmc_stale_files"] = pmc_stale  # kernel sources changed since the counters were collected (tools/measure_pmc.sh)
         if triad_gbs:
             r["measured_triad_GBps"] = round(triad_gbs, 1)
             r["frac_of_measured_triad"] = round(achieved / triad_gbs, 5)
@@ -870,6 +914,7 @@ class Workload:
                "roofline": {"bound": "hbm", "frac": r["frac"], "achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "algorithmic_bytes": r["algorithmic_bytes"], "traffic": r["traffic"],
                             "valu_frac": (r["valu"] or {}).get("frac"), "pmc_config_key": r["pmc_config_key"],
+                            "pmc_stale": r.get("pmc_stale"),
                             "whole_step_algorithmic_GBps": r["whole_step_algorithmic_GBps"]},
                "stages_ms": r["stages_ms"]}
         if self.tail is not None and self.tail["n"]:
@@ -920,9 +965,12 @@ def exchange_timing(wl, steps, warmup):
     b = wl.exchange_bytes_per_gpu()
     gbps = round(b / (ex_ms * 1e-3) / 1e9, 2) if ex_ms > 0 else None
     form = wl.exchange_form
+    expected_ms = round(b / (XGMI_PEAK_GBS * 1e9) * 1e3, 4)  # the same bytes at 7 x 153 GB/s
     return {"form": ("factored (sequential: this backend cannot keep two communicators in flight)"
                      if wl.overlap and not wl.overlap_ran else form),
-            "requested_form": form, "ms": round(ex_ms, 4), "ms_per_step_with_event_pair": round(1e3 * dt, 4),
+            "requested_form": form, "ms": round(ex_ms, 4), "expected_ms": expected_ms,
+            "expected_ms_note": "bytes_per_gpu / (7 links x 153 GB/s): the exchange at the xGMI peak; ms / expected_ms = 1 / frac_of_xgmi_peak",
+            "ms_per_step_with_event_pair": round(1e3 * dt, 4),
             "bytes_per_gpu": b, "xgmi_GBps": gbps, "overlap": bool(wl.overlap and wl.overlap_ran),
             "xgmi_peak_GBps": XGMI_PEAK_GBS, "frac_of_xgmi_peak": round((gbps or 0.0) / XGMI_PEAK_GBS, 4),
             "backend": torch.distributed.get_backend(),
@@ -1126,12 +1174,12 @@ def run_section(args, section):
     is_headline = is_headline_config(args)
 
     if wl.factored:
-        par = (f"view-parallel x{world}, all-reduce of {11 * N * 4 / 1e6:.0f} MB + all-gather of "
+        par = (f"exchange form {wl.exchange_form}: view-parallel x{world}, all-reduce of {11 * N * 4 / 1e6:.0f} MB + all-gather of "
                f"{world} x {3 * N * 4 / 1e6:.0f} MB colour cotangents (factored SH gradient"
                f"{'; the two collectives overlapped on two communicators' if wl.overlap and wl.overlap_ran else ''}); "
                f"GSR_DIST_FULL_ARENA=1 selects the plain all-reduce of the whole arena")
     else:
-        par = (f"view-parallel x{world}, 1 all-reduce of {wl.arena.numel() * 4 / 1e6:.0f} MB" if wl.dist_on else
+        par = (f"exchange form plain: view-parallel x{world}, 1 all-reduce of {wl.arena.numel() * 4 / 1e6:.0f} MB" if wl.dist_on else
                "single GPU, one view (no collective)")
     untimed = args.warmup + SETTLE_STEPS + SURVEY_STEPS + RESETTLE_STEPS
     out = {
@@ -1290,7 +1338,9 @@ def fake_section(args, section):
                "ranks_seen": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
                "master_port": os.environ.get("MASTER_PORT")}
         if section in DIST_SECTIONS:
-            out["exchange"] = {"form": section, "ms": ms / 3, "bytes_per_gpu": 1, "xgmi_GBps": 1.0, "overlap": section.endswith("overlap")}
+            out["exchange"] = {"form": section, "ms": ms / 3, "expected_ms": 0.1, "bytes_per_gpu": 1, "xgmi_GBps": 1.0,
+                               "overlap": section.endswith("overlap")}
+            out["config"] = {"parallelism": f"exchange form {section}: fake"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     return 0

@@ -341,12 +341,16 @@ constexpr int BWD_BATCH = GSR_BWD_BATCH;  // splats staged per round (LDS: one a
 // waves per tile on a second stream next to the main PPL = 4 launch, which leaves those tiles out: one wave walking a
 // list of 30 k instances is milliseconds long (real captures have such tiles; config 3 has none).
 // BG0: the background is exactly (0, 0, 0) — the reference's default (rasterizer.jl:209) and what a trainer without a sky
-// colour passes: the term -T_final/(1-α)·(bg·v) (render.jl:259) vanishes identically, and with it four registers of
-// per-pixel state and one FMA per active visit.  With the fy trick below: :rgb 74 -> 70 VGPRs (6 -> 7 waves per SIMD),
-// :rgbd 88 -> 80 (5 -> 6), :rgbdn 101 -> 94 (4 -> 5).  Measured at config-3 size (profiles/r04/experiments/
-// bwd_occupancy_ab.txt, A/B in one run, two repetitions): :rgbdn 0.907 -> 0.876 ms — kept; :rgbd 0.7236 -> 0.770 ms and :rgb
-// 0.659 -> 0.676 ms — SLOWER with the extra wave (as round 3's forced-occupancy probes said: 789 / 735 / 677 / 695 us at 4 / 5 /
-// 6 / 7 waves), so the launcher only takes the BG0 kernel for C == 8 and the other two instantiations are never launched.
+// colour passes: the term -T_final/(1-α)·(bg·v) (render.jl:259) vanishes identically, and with it the per-pixel bgT state and
+// one FMA per active visit.  WHO LAUNCHES WHAT (gsr_launch_composite_bwd, below; measured in
+// profiles/r04/experiments/bwd_occupancy_ab.txt, A/B in one run):
+//   C == 8 (:rgbdn): BG0 kernel WITH the rebuilt row coordinates (FY_REBUILD): 101 -> 94 VGPRs, four -> five waves per SIMD,
+//                    0.907 -> 0.876 ms — launched whenever the background is zero;
+//   C == 5 (:rgbd) : BG0 kernel WITHOUT the rebuilt coordinates: 88 -> 83 VGPRs, five waves as before, one FMA per active
+//                    visit less, 0.720 -> 0.713 ms — launched whenever the background is zero (with the coordinates rebuilt it
+//                    reaches 80 VGPRs = six waves and is 6 % SLOWER: 0.724 -> 0.770 ms);
+//   C == 3 (:rgb)  : NEVER the BG0 kernel (74 -> 70 VGPRs = seven waves: 0.659 -> 0.676 ms; round 3's forced-occupancy probes:
+//                    789 / 735 / 677 / 695 us at 4 / 5 / 6 / 7 waves) — <3, PPL, false, true> is not instantiated.
 template <int C, int PPL, bool LISTED, bool BG0>
 __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_kernel(int W, int H, int grid_x,
                                                                 const uint32_t* __restrict__ tile_start,
@@ -689,12 +693,9 @@ void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uin
 #define LAUNCH2(CC, ZZ)                                                                                                \
     hipLaunchKernelGGL((composite_bwd_kernel<CC, GSR_BWD_PPL, false, ZZ>), grid, block, 0, s, cam.width, cam.height,   \
                        cam.grid_x, tile_start, tile_order, stream, bg, vpixels, n_contrib, final_T, inst, none)
-    // (the zero-background kernel only where it pays: :rgbdn, 4 -> 5 waves per SIMD; profiles/r04/experiments/bwd_occupancy_ab.txt)
-    // (the zero-background kernels where they pay — profiles/r04/experiments/bwd_occupancy_ab.txt: :rgbdn 101 -> 94 VGPRs, four ->
-    //  five waves per SIMD, -3.4 %; :rgbd WITHOUT the rebuilt row coordinates 88 -> 83 VGPRs, five waves as before, one FMA per
-    //  active visit less: -1 %; with them (80 VGPRs, six waves) it is 6 % slower)
-    // (:rgb: 74 -> 70 VGPRs = seven waves per SIMD, 0.659 -> 0.676 ms; capped at six waves with 1.25 KB of unused dynamic LDS per
-    //  workgroup the same kernel takes 0.738 ms: it is the code generated under the tighter budget, not the occupancy)
+    // the zero-background kernels where they pay (table above the kernel): C == 5 and C == 8 take BG0, C == 3 never does
+    // (:rgb capped at six waves with 1.25 KB of unused dynamic LDS per workgroup takes 0.738 ms: it is the code generated under
+    //  the tighter register budget that is slower, not the occupancy)
     if (channels == 3) LAUNCH2(3, false);
     else if (channels == 5) { if (bg0) LAUNCH2(5, true); else LAUNCH2(5, false); }
     else if (bg0) LAUNCH2(8, true);

@@ -191,3 +191,87 @@ def test_bench_one_rank_rccl_runs_every_form_in_its_own_process(launch_ranks):
     assert all(f.get("ms_per_step", 0) > 0 for f in ex["forms"].values()), ex["forms"]
     assert ex["headline_form"] == "factored+overlap" and ex["overlap"] is True
     assert rep["n_gpus"] == 1 and rep["ranks_seen"] == 1
+
+
+# ---- round 5: the first 8-GPU line must be self-interpreting; PMC numbers must not go stale silently ------------------------
+def test_headline_form_flag_and_the_form_named_in_the_line():
+    """--headline-form plain makes the line's top-level numbers the ONE all-reduce north_star names (default: the library
+    default form); either way config.parallelism / config.exchange_form say which form `value` is, every form is reported with
+    its expected_ms (bytes / 7 x 153 GB/s), and a failed plain group falls back to the best completed form — and says so."""
+    p, rep, lines = _fake(["--gpus", "2", "--steps", "3", "--warmup", "1"])
+    assert p.returncode == 0 and len(lines) == 1, p.stderr
+    ex = rep["exchange"]
+    assert ex["headline_form"] == "factored+overlap" and ex["headline_form_requested"] == "default"
+    assert rep["config"]["exchange_form"] == "factored+overlap" and "factored+overlap" in rep["config"]["parallelism"]
+    assert rep["ms_per_step"] == 1.8 and all(f["expected_ms"] == 0.1 for f in ex["forms"].values())
+    p, rep, lines = _fake(["--gpus", "2", "--steps", "3", "--warmup", "1", "--headline-form", "plain"])
+    assert p.returncode == 0 and len(lines) == 1, p.stderr
+    ex = rep["exchange"]
+    assert ex["headline_form"] == "plain" and ex["headline_form_requested"] == "plain" and ex["library_default_form"] == "factored+overlap"
+    assert rep["ms_per_step"] == 3.0 and rep["config"]["exchange_form"] == "plain"
+    assert rep["config"]["parallelism"].startswith("[exchange form of this line: plain]")
+    assert ex["forms"]["factored+overlap"]["ms_per_step"] == 1.8  # the others are still there
+    p, rep, _ = _fake(["--gpus", "2", "--steps", "3", "--warmup", "1", "--headline-form", "plain"], GSR_BENCH_FAIL_FORM="plain")
+    assert p.returncode == 0 and rep["exchange"]["headline_form"] == "factored+overlap" and rep["config"]["exchange_form"] == "factored+overlap"
+
+
+def test_expected_exchange_time_is_bytes_over_the_xgmi_peak():
+    import bench
+    assert bench.XGMI_PEAK_GBS == 7 * 153.0
+    # 236 MB arena at n = 8: 2 (n-1)/n S bytes per GPU -> 413 MB / 1071 GB/s = 0.386 ms
+    b = int(2 * 7 / 8 * 59 * 1_000_000 * 4)
+    assert abs(b / (bench.XGMI_PEAK_GBS * 1e9) * 1e3 - 0.3856) < 1e-3
+
+
+def test_pmc_measurements_go_stale_with_the_kernel_sources(tmp_path):
+    """profiles/pmc_traffic.json entries carry the git blob hashes of the kernel sources they were measured on; bench.py
+    reports `traffic: null` + `pmc_stale: true` once one of them changed (round-4 verdict, weak #8)."""
+    import bench
+    now = bench.kernel_source_hashes()
+    assert set(now) == set(bench.PMC_KERNEL_SOURCES) and all(len(h) == 40 for h in now.values())
+    # the hash IS git's blob hash (so `git rev-parse <commit>:<path>` backfills old measurements)
+    f = os.path.join(ROOT, "gaussiansplatting.jl_amd", "csrc", "binning.hip")
+    if os.path.isdir(os.path.join(ROOT, ".git")):
+        assert subprocess.run(["git", "hash-object", f], capture_output=True, text=True, cwd=ROOT).stdout.strip() == now["binning.hip"]
+    assert bench.pmc_stale_files({"kernel_sources": dict(now)}) == []
+    assert bench.pmc_stale_files({"kernel_sources": dict(now, **{"composite.hip": "0" * 40})}) == ["composite.hip"]
+    assert bench.pmc_stale_files({}) == sorted(bench.PMC_KERNEL_SOURCES)  # a record without hashes is stale by definition
+    # a copy of the tree with one kernel source touched
+    import shutil
+    d = tmp_path / "gaussiansplatting.jl_amd" / "csrc"
+    d.mkdir(parents=True)
+    for name in bench.PMC_KERNEL_SOURCES:
+        shutil.copy(os.path.join(ROOT, "gaussiansplatting.jl_amd", "csrc", name), d / name)
+    assert bench.pmc_stale_files({"kernel_sources": now}, root=str(tmp_path)) == []
+    with open(d / "pergauss.hip", "a") as fh:
+        fh.write("// touched\n")
+    assert bench.pmc_stale_files({"kernel_sources": now}, root=str(tmp_path)) == ["pergauss.hip"]
+    # every committed measurement names its sources
+    doc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert all(set(rec.get("kernel_sources", {})) == set(bench.PMC_KERNEL_SOURCES) for rec in doc["configs"].values())
+
+
+def test_scenes_section_is_merged_and_priced():
+    """extra_configs.scenes comes from its own child process; annotate_predictions prices every record against the headline's
+    stage times (and never costs the line)."""
+    import bench
+    p, rep, lines = _fake(["--steps", "3", "--warmup", "1"])
+    assert p.returncode == 0 and rep["extra_configs"]["scenes"]["hot_tile_32k"]["ms_per_step"] == 2.0
+    p, rep, _ = _fake(["--steps", "3", "--warmup", "1", "--section-timeout", "3"], GSR_BENCH_HANG_FORM="scenes")
+    assert p.returncode == 0 and "timeout" in rep["extra_configs"]["scenes"] and "config2" in rep["extra_configs"]
+    p, rep, _ = _fake(["--steps", "3", "--warmup", "1", "--no-scenes"])
+    assert p.returncode == 0 and "scenes" not in rep["extra_configs"]
+    head = {"preprocess": 0.126, "tile_scan": 0.013, "sort_composite_fwd": 0.355, "loss_fwd": 0.067, "loss_bwd": 0.051,
+            "composite_bwd": 0.656, "pergauss_bwd": 0.142}
+    cfg = {"n_gaussians": 1_000_000, "visible": 858_462, "tile_instances": 3_888_089}
+    same = {"resolution": [1920, 1080], "mode": "rgb", "n_gaussians": 1_000_000, "visible": 858_462, "tile_instances": 3_888_089,
+            "stages_ms": dict(head), "ms_per_step": sum(head.values())}
+    pr = bench.predict_from_headline(same, head, cfg)
+    assert abs(pr["ratio"] - 1.0) < 1e-3 and pr["within_bar"] and pr["stages_over_bar"] == []
+    slow = dict(same, stages_ms=dict(head, composite_bwd=1.5, tile_sort=0.2, composite_fwd=0.1), ms_per_step=sum(head.values()) + 1.144)
+    pr = bench.predict_from_headline(slow, head, cfg)
+    assert pr["stages_over_bar"] == ["composite_bwd", "sort_composite_fwd"] and not pr["within_bar"]
+    assert pr["stages"]["sort_composite_fwd"]["measured_ms"] == round(0.355 + 0.2 + 0.1, 4)  # tier launches priced with the fused forward
+    line = {"roofline": {"stages_ms": head}, "config": cfg, "extra_configs": {"scenes": {"a": dict(same), "b": {"error": "x"}}}}
+    bench.annotate_predictions(line)
+    assert line["extra_configs"]["scenes"]["a"]["vs_config3_cost"]["within_bar"] and "vs_config3_cost" not in line["extra_configs"]["scenes"]["b"]

@@ -81,12 +81,14 @@ def test_depth_and_normal_modes_full_oracle_compare(pkg, orc, mode):
     _tile_lists_sorted(run)
 
 
-def _properties(pkg, orc, n, W, H, seed, with_oracle_fwd):
+def _properties(pkg, orc, n, W, H, seed, with_oracle_fwd, scene=None, mode="rgb"):
+    """The size-independent property set (any scene: `scene` overrides the uniform synthetic one; any render mode)."""
     deg = 3
-    s = pkg.synthetic.make_scene(n, W, H, deg, seed)
+    s = pkg.synthetic.make_scene(n, W, H, deg, seed) if scene is None else scene
     cam = orc.Camera(W, H, s.focal)
     bg = (0.2, 0.7, 0.4)
-    run = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, (0, 0, 0))
+    Cn = pkg.rasterizer.n_color_features(mode)
+    run = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, (0, 0, 0), mode=mode)
     img0 = run.forward().clone()
     T = run.rast.accum_alpha
     assert float(T.min()) >= 0 and float(T.max()) <= 1
@@ -99,18 +101,22 @@ def _properties(pkg, orc, n, W, H, seed, with_oracle_fwd):
     img1 = run.forward()
     assert torch.equal(img0, img1)
     if with_oracle_fwd:
-        st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg)
+        st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, mode=mode)
         assert np.array_equal(run.rast.radii.cpu().numpy(), st.radii)
         assert np.array_equal(run.rast.values_sorted.cpu().numpy().astype(np.uint32), st.values_sorted)
-        assert frac_bad(img0.cpu().numpy(), st.image, 0, 1e-4) <= 1e-4
-    # background-composite identity (reference test "Sky composite identity", runtests.jl:760-797)
-    runb = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, bg)
+        scale = np.maximum(1.0, np.abs(st.image).reshape(-1, Cn).max(0))
+        assert frac_bad(img0.cpu().numpy() / scale, st.image / scale, 0, 1e-4) <= 1e-4
+    # background-composite identity (reference test "Sky composite identity", runtests.jl:760-797); the background only
+    # enters the colour channels (rasterizer.jl:411-414)
+    runb = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, bg, mode=mode)
     imgb = runb.forward()
-    comp = img0 + T.unsqueeze(-1) * torch.tensor(bg, device="cuda")
+    comp = img0.clone()
+    comp[..., :3] += T.unsqueeze(-1) * torch.tensor(bg, device="cuda")
     assert float((imgb - comp).abs().max()) < 1e-5
+    del runb, imgb, comp
     # backward is linear in the cotangent
-    v1 = dev(pkg.synthetic.make_vpixels(W, H, 3, seed))
-    v2 = dev(pkg.synthetic.make_vpixels(W, H, 3, seed + 1))
+    v1 = dev(pkg.synthetic.make_vpixels(W, H, Cn, seed))
+    v2 = dev(pkg.synthetic.make_vpixels(W, H, Cn, seed + 1))
     g1 = [o.clone() for o in run.backward(v1.cpu().numpy())[:5]]
     g2 = [o.clone() for o in run.backward(v2.cpu().numpy())[:5]]
     g12 = [o.clone() for o in run.backward((v1 + 2 * v2).cpu().numpy())[:5]]
@@ -122,6 +128,7 @@ def _properties(pkg, orc, n, W, H, seed, with_oracle_fwd):
     assert all(torch.equal(a, b) for a, b in zip(g12, g12b)), "gradients are bit-deterministic"
     vis = run.rast.radii > 0
     assert not g12[0][~vis].any() and not g12[1][~vis].any()
+    return run
 
 
 def test_exact_cull_bit_identical_image_at_config3(pkg, orc):
@@ -143,7 +150,7 @@ def test_config3_1m_1080p(pkg, orc):
     _properties(pkg, orc, 1_000_000, 1920, 1080, 1003, with_oracle_fwd=True)
 
 
-def _full_step_vs_oracle(pkg, orc, n, W, H, deg, seed, exact_tile_cull, mode="rgb", loss=True, deterministic=True):
+def _full_step_vs_oracle(pkg, orc, n, W, H, deg, seed, exact_tile_cull, mode="rgb", loss=True, deterministic=True, scene=None):
     """One whole bench.py step — gsr_forward -> gsr_loss_l1_ssim -> gsr_backward — against
     orc.forward / orc.loss_head / orc.backward (rasterizer.jl:255-408,416-550; training.jl:684-694).
     loss=False: the random cotangent of the loss-free configs.  Modes with extra channels (:rgbd,
@@ -152,7 +159,7 @@ def _full_step_vs_oracle(pkg, orc, n, W, H, deg, seed, exact_tile_cull, mode="rg
     compared too.  deterministic: True = the oracle's serial double-accumulator backward, "parallel" = the same
     accumulators updated atomically from an OpenMP tile loop (the large configs)."""
     import time
-    s = pkg.synthetic.make_scene(n, W, H, deg, seed)
+    s = pkg.synthetic.make_scene(n, W, H, deg, seed) if scene is None else scene
     cam = orc.Camera(W, H, s.focal)
     tgt = pkg.synthetic.make_target(W, H, seed)
     C = pkg.rasterizer.n_color_features(mode)
@@ -215,7 +222,7 @@ def _full_step_vs_oracle(pkg, orc, n, W, H, deg, seed, exact_tile_cull, mode="rg
     print(f"[full step vs oracle] n={n} {W}x{H} :{mode} loss={loss} exact_cull={exact_tile_cull}: oracle forward {t_fwd:.1f} s + "
           f"backward({deterministic}) {t_bwd:.1f} s on {orc.num_threads()} threads; worst rel-L2 "
           f"{max(v[0] for v in worst.values()):.2e}, worst outlier fraction {max(v[1] for v in worst.values()):.2e}")
-    return st, img
+    return st, img, run
 
 
 def test_config3_full_step_vs_oracle_in_bench_mode(pkg, orc):

@@ -1,0 +1,41 @@
+#!/bin/bash
+# Round-5 GPU-box scripts, one shell function per case (what profiles/r05/** cite as the provenance of their numbers).
+#   gpurun -- bash tools/experiments/r05_cases.sh <case>        (--list prints the cases)
+cd "$(dirname "$0")/../.."
+
+# a: composite_bwd with the row stage of its reduction on the matrix pipe (tools/bin/libgsr_mfma.so = composite.hip built with
+#    -DGSR_BWD_MFMA) against the default build: unit check of the network, step A/B, rocprofv3 kernel averages, parity suite
+case_a() {
+set -x
+O=gpurun_out/r05a; mkdir -p $O
+tools/bin/wrt > $O/wrt.txt 2>&1; cat $O/wrt.txt | tail -8
+GSR_AB_LIBS="tools/bin/libgsr_mfma.so" timeout 600 bash tools/ab.sh --steps 20 --warmup 5 --steady-steps 0 > $O/ab.txt 2>&1
+grep -E "^(default|tools)" $O/ab.txt | cut -c1-220
+GSR_AB_LIBS="tools/bin/libgsr_mfma.so" timeout 600 bash tools/kernel_times.sh --steps 20 --warmup 5 --steady-steps 0 > $O/ktimes.txt 2>&1
+grep -E "==|composite_bwd|sort_composite" $O/ktimes.txt
+GSR_HIP_LIB=$PWD/tools/bin/libgsr_mfma.so timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz_regressions.py tests/test_gpu_scale.py -x -q > $O/pytest.log 2>&1; echo "rc=$?"; tail -5 $O/pytest.log
+}
+
+# b: MFMA-beside-VALU micro-benchmark; the new GPU tests of the round; the driver line with extra_configs.scenes
+case_b() {
+set -x
+O=gpurun_out/r05b; mkdir -p $O
+tools/bin/mfma_valu_overlap > $O/mfma_valu_overlap.txt 2>&1; cat $O/mfma_valu_overlap.txt
+timeout 1500 python -m pytest tests/test_gpu_handle_switches.py tests/test_gpu_forward_only.py tests/test_gpu_scenes.py tests/test_gpu_densify.py tests/test_gpu_preprocess_forms.py -x -q --durations=15 > $O/pytest.log 2>&1; echo "rc=$?"; tail -30 $O/pytest.log
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -3 $O/bench.err
+python - <<'PY'
+import json
+p=json.loads(open('gpurun_out/r05b/bench.json').read().strip().splitlines()[-1])
+print('headline', p['ms_per_step'], p['roofline']['stages_ms'], 'wall', p.get('bench_wall_s'))
+for k,v in (p.get('extra_configs',{}).get('scenes',{}) or {}).items():
+    if 'ms_per_step' not in v: print(k, v); continue
+    c=v.get('vs_config3_cost',{})
+    print(k, v['ms_per_step'], 'D', v['tile_instances'], 'V', v['visible'], 'max', v['max_tile_instances'], 'compact', v['compact_binning'], v['preprocess_form'], 'wall', v.get('wall_s'))
+    print('   pred', c.get('predicted_ms_per_step'), 'ratio', c.get('ratio'), 'over', c.get('stages_over_bar'))
+    for st,x in c.get('stages',{}).items(): print('     ', st, x)
+PY
+}
+
+if [ "$1" = "--list" ] || [ -z "$1" ]; then declare -F | sed -n "s/^declare -f case_//p"; exit 0; fi
+if ! declare -F "case_$1" > /dev/null; then echo "unknown case $1 (try --list)" >&2; exit 2; fi
+"case_$1"

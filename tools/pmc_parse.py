@@ -17,6 +17,20 @@ import json
 import os
 from collections import defaultdict
 
+KERNEL_SOURCES = ("composite.hip", "pergauss.hip", "binning.hip", "wave_reduce.h", "tile_sort_device.h", "tile_mask.h")
+
+
+def kernel_source_hashes():
+    """git blob hashes of the kernel sources the counters were collected on (bench.py: PMC_KERNEL_SOURCES, pmc_stale)."""
+    import hashlib
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gaussiansplatting.jl_amd", "csrc")
+    out = {}
+    for f in KERNEL_SOURCES:
+        data = open(os.path.join(d, f), "rb").read()
+        out[f] = hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+    return out
+
+
 STAGES = {"preprocess_kernel": "preprocess", "tile_scan_kernel": "tile_scan", "sort_composite_fwd_kernel": "sort_composite_fwd", "tile_sort_kernel": "tile_sort", "tile_sort_wave_kernel": "tile_sort",
           "tile_count_kernel": "tile_sort", "tile_scatter_kernel": "tile_sort", "tile_radix": "tile_sort",
           "composite_fwd_": "composite_fwd", "composite_bwd_kernel": "composite_bwd",
@@ -51,7 +65,7 @@ def main():
     meta = json.load(open(meta_path))
     rec = {"source": a.source, "tile_instances": meta["tile_instances"], "n_visible": meta.get("n_visible"),
            "unit": "per launch (mean over the launches of the pass)", "calibration": {}, "hbm_bytes": {}, "hbm_read": {},
-           "hbm_write": {}, "sq": {}}
+           "hbm_write": {}, "sq": {}, "kernel_sources": kernel_source_hashes()}
     for f in sorted(glob.glob(os.path.join(a.out_dir, "**", "*counter_collection.csv"), recursive=True)):
         acc = per_kernel(f)
         for counter, by_kernel in acc.items():

@@ -36,6 +36,18 @@ for k,v in (p.get('extra_configs',{}).get('scenes',{}) or {}).items():
 PY
 }
 
+# c: per-kernel times (rocprofv3 --kernel-trace --stats) of the non-uniform scenes of extra_configs.scenes
+case_c() {
+set -x
+O=gpurun_out/r05c; mkdir -p $O
+for sc in "hot --skew hot:32000 --no-loss" "dense4k --gaussians 5000000 --width 3840 --height 2160 --seed 1005 --skew dense:0.01:50 --no-loss" "trained1m --scene trained --seed 1010 --mode rgbd" "trained3m --scene trained --seed 1011 --mode rgbd --gaussians 3000000 --width 2560 --height 1440"; do
+  set -- $sc; tag=$1; shift
+  timeout 600 bash tools/kernel_times.sh --steps 10 --warmup 3 --steady-steps 0 "$@" > $O/ktimes_$tag.txt 2>&1
+  echo "== $tag"; grep -E "avg" $O/ktimes_$tag.txt
+  cp gpurun_out/ktimes_default/st_kernel_stats.csv $O/kernel_stats_$tag.csv
+done
+}
+
 if [ "$1" = "--list" ] || [ -z "$1" ]; then declare -F | sed -n "s/^declare -f case_//p"; exit 0; fi
 if ! declare -F "case_$1" > /dev/null; then echo "unknown case $1 (try --list)" >&2; exit 2; fi
 "case_$1"

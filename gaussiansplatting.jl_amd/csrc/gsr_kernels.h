@@ -76,7 +76,7 @@ void gsr_launch_fill_background(hipStream_t s, size_t n_pixels, int channels, co
                                 float* image, float* final_T, uint32_t* n_contrib);
 // compact binning mode: scatter the keys to tile_start[t] + arrival rank (tile_fill zeroed by the caller)
 void gsr_launch_emit_compact(hipStream_t s, int n, GsrCam cam, GsrGeom geom, const uint32_t* tile_start, uint32_t* tile_fill,
-                             uint64_t* keys);
+                             uint64_t* keys, uint32_t max_list /* longest tile list of the view */);
 void gsr_launch_pergauss_bwd(hipStream_t s, int n, int K, int degree, int channels, const float* means,
                              const float* scales, const float* rots, const float* shs, GsrCam cam, GsrGeom geom,
                              GsrInst inst, float2* vmean2d, float* vmeans, float* vshs, float* vopac,

@@ -23,7 +23,7 @@ namespace {
 constexpr uint32_t EMIT_COOP = 48;  // tiles per rect above which the wave emits cooperatively
 constexpr int kAggThreads = 512;           // workgroup of preprocess_kernel's aggregating form
 constexpr size_t kAggLdsMax = 42 * 1024;   // ... its dynamic LDS (the counter words; + 10 KB of static tables): three workgroups per CU
-constexpr size_t kAggLds32Max = 42 * 1024;  // ... the same limit with 2 x 16-bit words: up to ~21 500 tiles (1440p; 4K at two per CU was measured slower than direct)
+constexpr int kAggMaxBandsDefault = 1;      // ... and the number of bands the default choice accepts (measured: DESIGN.md §4)
 constexpr int kAggMinGaussians = 250000;   // ... and the scene size from which it is the default (measured, both forms flattened: DESIGN.md §4)
 // Gradient-row slots of a Gaussian (Gaussian-major, gsr_kernels.h): rects of at most DENSE_RECT tiles get one slot per
 // EMITTED tile — preprocess keeps the bit mask of the rect's tiles that passed the footprint test in the record, the
@@ -228,7 +228,11 @@ __device__ __forceinline__ void gaussian_normal(const M33& Rw, const M33& Rg, co
 // bin differs from the direct form's (it is arbitrary in both; the tile sort fixes it); everything else is bit-identical.
 //   n_words: 64-bit words of the counter array = LDS words of the AGG form ((T + 2) / 2).
 template <int DEG, int AGG_NT /* 0: direct form, 256 threads; else the threads of the aggregating workgroup */,
-          bool W32 = false /* aggregating form with 2 x 16-bit LDS words (grids whose 64-bit words do not fit; bin_cap < 65 024) */>
+          bool W32 = false /* aggregating form with 2 x 16-bit LDS words (grids whose 64-bit words do not fit; positions < 65 024) */,
+          bool SCATTER = false /* the compact binning mode's SECOND pass (duplicate_with_keys! as count -> scan -> scatter): no
+                                  projection — the geometry records are read back —, keys go to tile_start[t] + arrival rank */,
+          bool BANDED = false /* aggregating form over horizontal bands of the tile grid (n_bands > 1); false: ONE band = the whole
+                                 grid, the band loop and the rect clipping compile away (round 4's kernel, register for register) */>
 // (direct form: AT MOST four waves per SIMD — with its per-lane walks gone it would fit five, and five waves of scattered returning
 //  atomics are slower than four: config 5 0.66-0.68 ms against 0.60-0.62)
 __global__ __launch_bounds__(AGG_NT ? AGG_NT : 256)
@@ -241,7 +245,10 @@ __attribute__((amdgpu_waves_per_eu(AGG_NT ? 3 * AGG_NT / 256 : 1, AGG_NT ? 8 : 4
                                                                       GsrGeom geom, uint32_t* __restrict__ tile_count,
                                                                       uint32_t* __restrict__ n_visible,
                                                                       uint64_t* __restrict__ bins, uint32_t bin_cap,
-                                                                      int n_words) {
+                                                                      int n_words, const uint32_t* __restrict__ tile_start,
+                                                                      int n_bands, int band_rows) {
+    static_assert(!SCATTER || AGG_NT != 0, "the scatter pass exists in the aggregating form only");
+    static_assert(!BANDED || AGG_NT != 0, "bands are the aggregating form's");
     constexpr bool AGG = AGG_NT != 0;
     constexpr int NT = AGG ? AGG_NT : 256;
     // AGG: per counter word (an aligned tile pair), this workgroup's two counts, then its two bin positions — 2 x 32 bits, or
@@ -256,8 +263,7 @@ __attribute__((amdgpu_waves_per_eu(AGG_NT ? 3 * AGG_NT / 256 : 1, AGG_NT ? 8 : 4
     auto agg_lo = [](AggWord v) -> uint32_t { return W32 ? (uint32_t)v & 0xFFFFu : (uint32_t)v; };
     auto agg_hi = [](AggWord v) -> uint32_t { return W32 ? (uint32_t)v >> 16 : (uint32_t)((unsigned long long)v >> 32); };
     const int i = blockIdx.x * NT + threadIdx.x;
-    if (AGG)
-        for (int w = threadIdx.x; w < n_words; w += NT) agg[w] = (AggWord)0;
+    (void)n_words;
     bool visible = false;
     uint32_t area = 0, clamp_bits = 0, emitted = 0;  // emitted: bit k = tile k of the rect (row-major) got an instance
     float m2[2] = {0, 0}, conic[3] = {0, 0, 0}, rgb[3] = {0, 0, 0}, mc_z = 0.0f, tau = 0.0f, opac_v = 0.0f;
@@ -281,7 +287,20 @@ __attribute__((amdgpu_waves_per_eu(AGG_NT ? 3 * AGG_NT / 256 : 1, AGG_NT ? 8 : 4
             rgb[c] = fmaxf(0.0f, res);
         }
     };
-    if (i < n) {
+    if (SCATTER) {
+        // second pass of the compact mode: everything the walks need is in the record preprocess wrote
+        if (i < n && geom.radii[i] > 0) {
+            const GsrGeoRec rec = geom.rec[i];
+            visible = true;
+            m2[0] = rec.q0.x; m2[1] = rec.q0.y; conic[0] = rec.q0.z; conic[1] = rec.q0.w; conic[2] = rec.q1.x;
+            opac_v = rec.q1.y; mc_z = rec.q2.z;
+            const uint32_t lo = __float_as_uint(rec.q3.x), hi = __float_as_uint(rec.q3.y);
+            rmin[0] = (int)(lo & 0xFFFFu); rmin[1] = (int)(lo >> 16); rmax[0] = (int)(hi & 0xFFFFu); rmax[1] = (int)(hi >> 16);
+            area = (uint32_t)((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]));
+            tau = footprint_tau(opac_v);
+            emitted = __float_as_uint(rec.q3.w);
+        }
+    } else if (i < n) {
         M33 R; float t[3];
         load_pose(cam, R, t);
         // the small inputs of this Gaussian are requested up front (one round trip instead of three dependent ones:
@@ -416,7 +435,6 @@ __attribute__((amdgpu_waves_per_eu(AGG_NT ? 3 * AGG_NT / 256 : 1, AGG_NT ? 8 : 4
     __shared__ uint32_t emit_tab[NT / 64][64];
     int fcnt = 0, fppr = 0;          // this lane's pair requests in the flattened walks, pairs per TWO rows of its rect
     bool coop_small = false;         // ... or too many of them: with the wave-cooperative path
-    uint32_t flat_pre = 0, flat_total = 0;
     if (flat && visible && area <= EMIT_COOP) {
         // pairs are aligned on the LINEAR tile index t = y * grid_x + x: a row starting on an even t holds ceil(w / 2) of them, on
         // an odd t floor(w / 2) + 1; on grids of odd width the rows of a rect alternate between the two (fppr = their sum)
@@ -522,128 +540,140 @@ __attribute__((amdgpu_waves_per_eu(AGG_NT ? 3 * AGG_NT / 256 : 1, AGG_NT ? 8 : 4
             flush();
         }
     } else {
-        __syncthreads();  // agg zeroed
-        // Both walks of this form are FLATTENED over the lanes of the wave: in scene order a wave's slowest lane has 13.6 pair requests at config 3 and the
-        // average lane 3.9, so a per-lane loop runs at 28 % lane efficiency — twice.  Instead every lane announces its
-        // count, an owner table in LDS maps item -> lane (wave-local, no barrier), and the wave works its ~250 items off
-        // 64 at a time, each lane fetching its item's Gaussian with ds_bpermute.  Gaussians of more than FLAT_MAX
-        // requests (1 %) join the wave-cooperative path below, which then also leaves their emitted mask.
+        // AGGREGATING form, in horizontal BANDS of the tile grid (round 5: n_bands == 1 is round 4's kernel).  The counter words of
+        // a 4K grid do not fit the LDS three times per CU; the words of HALF the grid do — so the workgroup runs its two walks
+        // once per band of `band_rows` tile rows, every rect clipped to the band: the same items, the same tests, the same
+        // positions (a rect's rows are walked band by band instead of in one go; the emitted mask is indexed by the row inside the
+        // FULL rect).  What the LDS buys on a large grid is not fewer global atomics (a 512-Gaussian workgroup hits mostly distinct
+        // words there) but (a) their address order and (b) no same-address serialisation: a hot tile's instances meet in LDS first
+        // (dense scenes: 1 % of a 4K grid at 50 x density took the direct form 1.9 ms).  Both walks are FLATTENED over the lanes
+        // of the wave: every lane announces its count, an owner table in LDS maps item -> lane (wave-local, no barrier), and the
+        // wave works its items off 64 at a time, each lane fetching its item's Gaussian with ds_bpermute.  Gaussians of more than
+        // FLAT_MAX requests (1 %) join the wave-cooperative path below, which then also leaves their emitted mask.
         const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        if (flat) {
-            uint32_t x = (uint32_t)fcnt;
+        const bool flat_lane = fcnt > 0;  // this lane's rect takes the flattened walks
+        const int rw_ = rmax[0] - rmin[0];
+        emit_tab[wv][ln] = SCATTER ? emitted : 0u;  // SCATTER replays the record's mask; else the first walk's tests fill it
+        unsigned long long* tc64 = reinterpret_cast<unsigned long long*>(tile_count);
+        for (int band = 0; band < (BANDED ? n_bands : 1); band++) {
+            const int yb0 = BANDED ? band * band_rows : 0, yb1 = BANDED ? min(cam.grid_y, yb0 + band_rows) : cam.grid_y;
+            const int wbase = BANDED ? (yb0 * cam.grid_x) >> 1 : 0;
+            const int wcount = BANDED ? ((yb1 * cam.grid_x - 1) >> 1) - wbase + 1 : n_words;
+            if (BANDED && band > 0) __syncthreads();  // the previous band's second walk has taken its positions
+            for (int w = threadIdx.x; w < wcount; w += NT) agg[w] = (AggWord)0;
+            // this lane's rect clipped to the band: pairs are aligned on the LINEAR tile index t = y * grid_x + x — a row starting
+            // on an even t holds ceil(w / 2) of them, on an odd t floor(w / 2) + 1; on grids of odd width the rows alternate
+            const int yc0 = BANDED ? max(rmin[1], yb0) : rmin[1], yc1 = BANDED ? min(rmax[1], yb1) : rmax[1];
+            int bcnt = BANDED ? 0 : fcnt, bppr = BANDED ? 0 : fppr;
+            if (BANDED && flat_lane && yc1 > yc0) {
+                const int h = yc1 - yc0, t0 = yc0 * cam.grid_x + rmin[0], t0b = t0 + cam.grid_x;
+                const int pa = ((t0 + rw_ - 1) >> 1) - (t0 >> 1) + 1, pb = ((t0b + rw_ - 1) >> 1) - (t0b >> 1) + 1;
+                bppr = pa + pb;
+                bcnt = ((h + 1) >> 1) * pa + (h >> 1) * pb;
+            }
+            uint32_t x = (uint32_t)bcnt;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
                 const uint32_t y = __shfl_up(x, off);
                 if (ln >= off) x += y;
             }
-            const uint32_t fpre = x - (uint32_t)fcnt, ftotal = __shfl(x, 63);
-            for (int k = 0; k < fcnt; k++) own_tab[wv][fpre + k] = (uint8_t)ln;
-            emit_tab[wv][ln] = 0u;
+            const uint32_t fpre = x - (uint32_t)bcnt, ftotal = __shfl(x, 63);
+            for (int k = 0; k < bcnt; k++) own_tab[wv][fpre + k] = (uint8_t)ln;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const uint32_t rlo = (uint32_t)rmin[0] | ((uint32_t)rmin[1] << 16);
-            // pairs per rect row, and the multiplier of the small division q / ppr = (q * fmul) >> 8 (q < 16, ppr <= 16: exact)
-            const uint32_t rhi = (uint32_t)rmax[0] | ((fppr > 0 ? (256u + (uint32_t)fppr - 1u) / (uint32_t)fppr : 0u) << 16);
-            // (every lane of the wave runs every trip: a ds_bpermute reads zero from a lane that is switched off)
-            for (uint32_t base = 0; base < ftotal; base += 64u) {
-                const bool on = base + (uint32_t)ln < ftotal;
-                const uint32_t it = on ? base + (uint32_t)ln : ftotal - 1u;
-                const int src = own_tab[wv][it];
-                const uint32_t q = it - __shfl(fpre, src);
-                const uint32_t lo = __shfl(rlo, src), hi = __shfl(rhi, src);
-                const float smx = __shfl(m2[0], src), smy = __shfl(m2[1], src);
-                const float sa = __shfl(conic[0], src), sb = __shfl(conic[1], src), sc = __shfl(conic[2], src);
-                const float stau = __shfl(tau, src);
-                const int x0 = (int)(lo & 0xFFFFu), y0 = (int)(lo >> 16), x1 = (int)(hi & 0xFFFFu);
-                const int w = x1 - x0, t0 = y0 * cam.grid_x + x0, t0b = t0 + cam.grid_x;
-                const int pa = ((t0 + w - 1) >> 1) - (t0 >> 1) + 1, pb = ((t0b + w - 1) >> 1) - (t0b >> 1) + 1;
-                const int r2 = (int)((q * (hi >> 16)) >> 8), rem = (int)q - r2 * (pa + pb);   // (q < 16: the multiply-shift is exact)
-                const int row = 2 * r2 + (rem >= pa ? 1 : 0), pc = rem - (rem >= pa ? pa : 0), y = y0 + row;
-                const int te = (((t0 + row * cam.grid_x) >> 1) + pc) << 1, xe = te - y * cam.grid_x;  // the pair's even tile (may lie left of the rect)
-                const bool va = on && xe >= x0, vb = on && xe + 1 < x1;
-                const uint32_t kka = (uint32_t)(row * w + (xe - x0)) & 31u, kkb = (uint32_t)(row * w + (xe + 1 - x0)) & 31u;
+            const uint32_t rlo = (uint32_t)rmin[0] | ((uint32_t)yc0 << 16);
+            // pairs per two rect rows, and the multiplier of the small division q / ppr = (q * fmul) >> 8 (q < 16, ppr <= 16: exact)
+            // (bits 26..31: the mask bit of the clipped rect's first tile, (yc0 - y0) * w <= 32 — zero when there is ONE band)
+            const uint32_t rhi = (uint32_t)rmax[0] | ((bppr > 0 ? (256u + (uint32_t)bppr - 1u) / (uint32_t)bppr : 0u) << 16) |
+                                 (BANDED ? (uint32_t)((yc0 - rmin[1]) * rw_) << 26 : 0u);
+            // one item = one aligned tile pair of one rect row: decode (every lane of the wave runs every trip — a ds_bpermute
+            // reads zero from a lane that is switched off)
+#define GSR_AGG_ITEM()                                                                                                          \
+                const bool on = base + (uint32_t)ln < ftotal;                                                                   \
+                const uint32_t it = on ? base + (uint32_t)ln : ftotal - 1u;                                                     \
+                const int src = own_tab[wv][it];                                                                                \
+                const uint32_t q = it - __shfl(fpre, src);                                                                      \
+                const uint32_t lo = __shfl(rlo, src), hi = __shfl(rhi, src), skb = BANDED ? hi >> 26 : 0u;                       \
+                const int x0 = (int)(lo & 0xFFFFu), y0 = (int)(lo >> 16), x1 = (int)(hi & 0xFFFFu);                             \
+                const int w = x1 - x0, t0 = y0 * cam.grid_x + x0, t0b = t0 + cam.grid_x;                                        \
+                const int pa = ((t0 + w - 1) >> 1) - (t0 >> 1) + 1, pb = ((t0b + w - 1) >> 1) - (t0b >> 1) + 1;                 \
+                const int r2 = (int)((q * ((hi >> 16) & 0x3FFu)) >> 8), rem = (int)q - r2 * (pa + pb); /* (q < 16: exact) */    \
+                const int row = 2 * r2 + (rem >= pa ? 1 : 0), pc = rem - (rem >= pa ? pa : 0), y = y0 + row;                    \
+                /* the pair's even tile (may lie left of the rect) */                                                           \
+                const int te = (((t0 + row * cam.grid_x) >> 1) + pc) << 1, xe = te - y * cam.grid_x;                            \
+                const bool va = on && xe >= x0, vb = on && xe + 1 < x1;                                                         \
+                const uint32_t kka = (skb + (uint32_t)(row * w + (xe - x0))) & 31u, kkb = (skb + (uint32_t)(row * w + (xe + 1 - x0))) & 31u; \
                 const uint32_t t = (uint32_t)te;
+            __syncthreads();  // agg zeroed
+            for (uint32_t base = 0; base < ftotal; base += 64u) {
+                GSR_AGG_ITEM()
                 uint32_t c0 = 0u, c1 = 0u;
-                if (va) c0 = (!cam.exact_cull || tile_may_touch(smx, smy, sa, sb, sc, stau, xe * GSR_TILE, y * GSR_TILE)) ? 1u : 0u;
-                if (vb) c1 = (!cam.exact_cull || tile_may_touch(smx, smy, sa, sb, sc, stau, (xe + 1) * GSR_TILE, y * GSR_TILE)) ? 1u : 0u;
+                if (SCATTER) {
+                    const uint32_t em = emit_tab[wv][src];
+                    c0 = va ? (em >> kka) & 1u : 0u; c1 = vb ? (em >> kkb) & 1u : 0u;
+                } else {
+                    const float smx = __shfl(m2[0], src), smy = __shfl(m2[1], src);
+                    const float sa = __shfl(conic[0], src), sb = __shfl(conic[1], src), sc = __shfl(conic[2], src);
+                    const float stau = __shfl(tau, src);
+                    if (va) c0 = (!cam.exact_cull || tile_may_touch(smx, smy, sa, sb, sc, stau, xe * GSR_TILE, y * GSR_TILE)) ? 1u : 0u;
+                    if (vb) c1 = (!cam.exact_cull || tile_may_touch(smx, smy, sa, sb, sc, stau, (xe + 1) * GSR_TILE, y * GSR_TILE)) ? 1u : 0u;
+                }
                 if (c0 | c1) {
-                    atomicOr(&emit_tab[wv][src], (c0 << kka) | (c1 << kkb));
-                    atomicAdd(&agg[t >> 1], agg_inc(c0, c1));
+                    if (!SCATTER) atomicOr(&emit_tab[wv][src], (c0 << kka) | (c1 << kkb));
+                    atomicAdd(&agg[(t >> 1) - (uint32_t)wbase], agg_inc(c0, c1));
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (fcnt > 0) emitted = emit_tab[wv][ln];
-            flat_pre = fpre; flat_total = ftotal;
-        } else if (walks) {
-            walk([&](uint32_t t, uint32_t c) { atomicAdd(&agg[t >> 1], agg_inc(c & 1u, c >> 1)); }, true);
-        }
-        __syncthreads();
-        // one global atomic per word this workgroup counted in; the word then holds the bin positions its instances start at
-        unsigned long long* tc64 = reinterpret_cast<unsigned long long*>(tile_count);
-        for (int w0 = threadIdx.x; w0 < n_words; w0 += 4 * NT) {  // four in flight per lane
-            unsigned long long old[4];
-            uint32_t any = 0u;
+            __syncthreads();
+            // one global atomic per word this workgroup counted in; the word then holds the positions its instances start at
+            for (int w0 = threadIdx.x; w0 < wcount; w0 += 4 * NT) {  // four in flight per lane
+                unsigned long long old[4];
+                uint32_t any = 0u;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const AggWord c = w0 + k * NT < n_words ? agg[w0 + k * NT] : (AggWord)0;
-                if (c) {
-                    old[k] = atomicAdd(tc64 + w0 + k * NT, (unsigned long long)agg_lo(c) | ((unsigned long long)agg_hi(c) << 32));
-                    any |= 1u << k;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (any & (1u << k)) {
-                    if (W32) {
-                        const uint32_t lim = 0xFFFFu - (uint32_t)NT;  // (>= bin_cap: "not stored", and no carry into the other half)
-                        agg[w0 + k * NT] = (AggWord)(min((uint32_t)old[k], lim) | (min((uint32_t)(old[k] >> 32), lim) << 16));
-                    } else {
-                        agg[w0 + k * NT] = (AggWord)old[k];
+                for (int k = 0; k < 4; k++) {
+                    const AggWord c = w0 + k * NT < wcount ? agg[w0 + k * NT] : (AggWord)0;
+                    if (c) {
+                        old[k] = atomicAdd(tc64 + wbase + w0 + k * NT, (unsigned long long)agg_lo(c) | ((unsigned long long)agg_hi(c) << 32));
+                        any |= 1u << k;
                     }
                 }
-        }
-        __syncthreads();
-        if (bin_cap > 0u) {
-            if (flat) {
-                // (item() again, second pass: same table, same decode)
-                const uint32_t rlo = (uint32_t)rmin[0] | ((uint32_t)rmin[1] << 16);
-                const uint32_t rhi = (uint32_t)rmax[0] | ((fppr > 0 ? (256u + (uint32_t)fppr - 1u) / (uint32_t)fppr : 0u) << 16);
-                for (uint32_t base = 0; base < flat_total; base += 64u) {
-                    const bool on = base + (uint32_t)ln < flat_total;
-                    const uint32_t it = on ? base + (uint32_t)ln : flat_total - 1u;
-                    const int src = own_tab[wv][it];
-                    const uint32_t q = it - __shfl(flat_pre, src);
-                    const uint32_t lo = __shfl(rlo, src), hi = __shfl(rhi, src);
-                    const uint32_t em = __shfl(emitted, src);
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (any & (1u << k)) {
+                        if (W32) {
+                            const uint32_t lim = 0xFFFFu - (uint32_t)NT;  // (beyond every stored position: "not stored", and no carry into the other half)
+                            agg[w0 + k * NT] = (AggWord)(min((uint32_t)old[k], lim) | (min((uint32_t)(old[k] >> 32), lim) << 16));
+                        } else {
+                            agg[w0 + k * NT] = (AggWord)old[k];
+                        }
+                    }
+            }
+            __syncthreads();
+            if (SCATTER || bin_cap > 0u) {
+                // second walk: the same items, the tests replayed from the emitted mask, every instance takes its position
+                for (uint32_t base = 0; base < ftotal; base += 64u) {
+                    GSR_AGG_ITEM()
+                    const uint32_t em = emit_tab[wv][src];
                     const uint32_t zb = __shfl(__float_as_uint(mc_z), src);
-                    const int x0 = (int)(lo & 0xFFFFu), y0 = (int)(lo >> 16), x1 = (int)(hi & 0xFFFFu);
-                    const int w = x1 - x0, t0 = y0 * cam.grid_x + x0, t0b = t0 + cam.grid_x;
-                    const int pa = ((t0 + w - 1) >> 1) - (t0 >> 1) + 1, pb = ((t0b + w - 1) >> 1) - (t0b >> 1) + 1;
-                    const int r2 = (int)((q * (hi >> 16)) >> 8), rem = (int)q - r2 * (pa + pb);   // (q < 16: the multiply-shift is exact)
-                    const int row = 2 * r2 + (rem >= pa ? 1 : 0), pc = rem - (rem >= pa ? pa : 0), y = y0 + row;
-                    const int te = (((t0 + row * cam.grid_x) >> 1) + pc) << 1, xe = te - y * cam.grid_x;  // the pair's even tile (may lie left of the rect)
-                    const bool va = on && xe >= x0, vb = on && xe + 1 < x1;
-                    const uint32_t kka = (uint32_t)(row * w + (xe - x0)) & 31u, kkb = (uint32_t)(row * w + (xe + 1 - x0)) & 31u;
-                    const uint32_t t = (uint32_t)te;
                     const uint32_t c0 = va ? (em >> kka) & 1u : 0u, c1 = vb ? (em >> kkb) & 1u : 0u;
                     if (c0 | c1) {
-                        const AggWord old = atomicAdd(&agg[t >> 1], agg_inc(c0, c1));
+                        const AggWord old = atomicAdd(&agg[(t >> 1) - (uint32_t)wbase], agg_inc(c0, c1));
                         const uint64_t skey = ((uint64_t)zb << 32) | (uint32_t)(blockIdx.x * NT + (threadIdx.x & ~63) + src);
                         const uint32_t p0 = agg_lo(old), p1 = agg_hi(old);
-                        if (c0 && p0 < bin_cap) bins[(size_t)t * bin_cap + p0] = skey;
-                        if (c1 && p1 < bin_cap) bins[(size_t)(t + 1) * bin_cap + p1] = skey;
+                        if (SCATTER) {
+                            if (c0) bins[tile_start[t] + p0] = skey;
+                            if (c1) bins[tile_start[t + 1u] + p1] = skey;
+                        } else {
+                            if (c0 && p0 < bin_cap) bins[(size_t)t * bin_cap + p0] = skey;
+                            if (c1 && p1 < bin_cap) bins[(size_t)(t + 1) * bin_cap + p1] = skey;
+                        }
                     }
                 }
-            } else if (walks) {
-                walk([&](uint32_t t, uint32_t c) {
-                    const AggWord old = atomicAdd(&agg[t >> 1], agg_inc(c & 1u, c >> 1));
-                    const uint32_t p0 = agg_lo(old), p1 = agg_hi(old);
-                    if ((c & 1u) && p0 < bin_cap) bins[(size_t)t * bin_cap + p0] = key;
-                    if ((c & 2u) && p1 < bin_cap) bins[(size_t)(t + 1) * bin_cap + p1] = key;
-                }, false);
             }
+#undef GSR_AGG_ITEM
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (!SCATTER && flat_lane) emitted = emit_tab[wv][ln];
     }
     // Large footprints: one thread walking hundreds of tiles serialises the wave (the reference's
     // duplicate_with_keys! has exactly this loop, utils.jl:96-119).  Rects of more than EMIT_COOP
@@ -672,17 +702,18 @@ __attribute__((amdgpu_waves_per_eu(AGG_NT ? 3 * AGG_NT / 256 : 1, AGG_NT ? 8 : 4
                 if (pass) {
                     const uint32_t t = (uint32_t)(y * cam.grid_x + x);
                     const uint32_t pos = atomicAdd(tile_count + t, 1u);
-                    if (pos < bin_cap) bins[(size_t)t * bin_cap + pos] = bkey;
+                    if (SCATTER) bins[tile_start[t] + pos] = bkey;
+                    else if (pos < bin_cap) bins[(size_t)t * bin_cap + pos] = bkey;
                 }
             }
             first32 = __shfl(first32, 0);
-            if (lane == src && (uint32_t)total <= DENSE_RECT) emitted = first32;
+            if (!SCATTER && lane == src && (uint32_t)total <= DENSE_RECT) emitted = first32;
         }
     }
     // Exclusive scan of the tile-rect areas inside the block: with bpre[block] (tile_scan) it
     // gives every Gaussian the offset of its instance slots (gradient rows) — the reference's
     // cumsum!(tiles_touched) (rasterizer.jl:333-335), restated hierarchically.
-    {
+    if (!SCATTER) {
         // (blocks of 256 Gaussians whatever the workgroup size: bpre[i >> 8] is what the readers index)
         __shared__ uint32_t wsum[NT / 64];
         __shared__ uint32_t wvis[NT / 64];
@@ -718,62 +749,6 @@ __attribute__((amdgpu_waves_per_eu(AGG_NT ? 3 * AGG_NT / 256 : 1, AGG_NT ? 8 : 4
                                  __uint_as_float((uint32_t)rmax[0] | ((uint32_t)rmax[1] << 16)),
                                  __uint_as_float(blend_threshold_bits(opac_v)), __uint_as_float(emitted));
             geom.rec[i] = rec;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// duplicate_with_keys! (utils.jl:85-120) as a separate pass — the compact binning mode (count -> scan -> scatter):
-// used when fixed-capacity bins would cost more memory than the budget allows (a few very deep tiles: capacity is
-// the LONGEST list, times all tiles) or when a view overflowed its bins.  preprocess_kernel has already counted the
-// instances per tile (same tests, same floats, same translation unit) and tile_scan turned the counts into
-// tile_start; here every visible Gaussian re-walks its rect and drops its key at tile_start[t] + (arrival rank in
-// t) — memory 8 B per instance whatever the skew.  Order inside a tile is arbitrary; the tile sort fixes it.
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void emit_compact_kernel(int n, GsrCam cam, GsrGeom geom,
-                                                           const uint32_t* __restrict__ tile_start,
-                                                           uint32_t* __restrict__ tile_fill,
-                                                           uint64_t* __restrict__ keys) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool visible = i < n && geom.radii[i] > 0;
-    float mx = 0, my = 0, ca = 0, cb = 0, cc = 0, tau = 0;
-    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
-    uint32_t zbits = 0, area = 0;
-    if (visible) {
-        const GsrGeoRec rec = geom.rec[i];
-        mx = rec.q0.x; my = rec.q0.y; ca = rec.q0.z; cb = rec.q0.w; cc = rec.q1.x;
-        tau = footprint_tau(rec.q1.y);
-        zbits = __float_as_uint(rec.q2.z);
-        const uint32_t lo = __float_as_uint(rec.q3.x), hi = __float_as_uint(rec.q3.y);
-        x0 = (int)(lo & 0xFFFFu); y0 = (int)(lo >> 16); x1 = (int)(hi & 0xFFFFu); y1 = (int)(hi >> 16);
-        area = (uint32_t)((x1 - x0) * (y1 - y0));
-        if (area <= EMIT_COOP) {
-            const uint64_t key = ((uint64_t)zbits << 32) | (uint32_t)i;
-            for (int y = y0; y < y1; y++)
-                for (int x = x0; x < x1; x++)
-                    if (!cam.exact_cull || tile_may_touch(mx, my, ca, cb, cc, tau, x * GSR_TILE, y * GSR_TILE)) {
-                        const uint32_t t = (uint32_t)(y * cam.grid_x + x);
-                        keys[tile_start[t] + atomicAdd(tile_fill + t, 1u)] = key;
-                    }
-        }
-    }
-    const int lane = threadIdx.x & 63;
-    unsigned long long big = __builtin_amdgcn_ballot_w64(visible && area > EMIT_COOP);
-    while (big) {  // large footprints: the whole wave, one tile per lane and round (as preprocess_kernel)
-        const int src = __builtin_ctzll(big);
-        big &= big - 1;
-        const float bmx = __shfl(mx, src), bmy = __shfl(my, src), ba = __shfl(ca, src), bb = __shfl(cb, src), bc = __shfl(cc, src);
-        const float btau = __shfl(tau, src);
-        const int bx0 = __shfl(x0, src), by0 = __shfl(y0, src), bx1 = __shfl(x1, src), by1 = __shfl(y1, src);
-        const uint64_t bkey = ((uint64_t)__shfl(zbits, src) << 32) | (uint32_t)(blockIdx.x * 256 + (threadIdx.x & ~63) + src);
-        const int w = bx1 - bx0, total = w * (by1 - by0);
-        for (int e = lane; e < total; e += 64) {
-            const int ry = e / w, rx = e - ry * w;
-            const int x = bx0 + rx, y = by0 + ry;
-            if (!cam.exact_cull || tile_may_touch(bmx, bmy, ba, bb, bc, btau, x * GSR_TILE, y * GSR_TILE)) {
-                const uint32_t t = (uint32_t)(y * cam.grid_x + x);
-                keys[tile_start[t] + atomicAdd(tile_fill + t, 1u)] = bkey;
-            }
         }
     }
 }
@@ -817,6 +792,102 @@ __device__ __forceinline__ void tail_sh_group(const gsr::TailState& TS, int i0, 
         element(e, t, m, v);
         th[e] = t; mu[e] = m; nu[e] = v;
     }
+}
+
+// ---------------------------------------------------------------------------------
+// ∇scales / ∇rotations IN FLOAT64 (round 5).  The reference's chain  vconic -> ∇inverse (render.jl:383-385) ->
+// ∇perspective_projection (projection.jl:289-353) -> ∇covar_world_to_cam -> ∇quat_scale_to_cov (render.jl:302-320) ->
+// ∇unnorm_quat2rot (render.jl:335-366) multiplies 2x2 and 3x3 matrices whose eigenvalues differ by the SQUARE of a splat's
+// aspect ratio.  For the flat, needle-projecting splats a trained scene is full of (scale ratios of 100 and more) fp32 loses
+// the thin eigen-direction in every one of those products: the last bit of vconic — any summation order's — moves ∇rotations
+// by 1e-3 relative, in the reference's kernels, in the CPU oracle and here alike, although the map itself is well conditioned
+// (kappa ~ 3-10: the float64 replay of the oracle, oracle/gsr_oracle.c ORC_REAL_DOUBLE, is insensitive to those bits).  This
+// kernel is HBM-bound; ~250 double-precision FMAs per visible Gaussian cost nothing (7 us of 140 at config 3).  So the part
+// of the pullback that ends in ∇scales / ∇rotations runs in float64 FROM THE RAW INPUTS (the forward's fp32 conic cannot
+// hold the thin eigenvalue either): the same formulas, vSigma = T' vS2 T folded with T = J R so that no 3x3 product of
+// ill-scaled factors is ever rounded.  ∇means (well scaled) keeps the fp32 expression trees of the reference.
+//   va, vb, vc: the summed conic cotangent (vb on both off-diagonal entries, as the reference places it); vRg: the normal
+//   channel's contribution to the rotation matrix cotangent (projection.jl:227-235), zero outside :rgbdn.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void scales_rots_bwd_f64(const GsrCam& cam, const M33& Rf, const float tf[3], const float pf[3],
+                                                    const float4 q4, const float sf[3], float va, float vb, float vc,
+                                                    const M33& vRg, float vs_out[3], float vq_out[4]) {
+    double R[3][3], mc[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) R[r][c] = (double)Rf.m[r][c];
+        mc[r] = (R[r][0] * (double)pf[0] + R[r][1] * (double)pf[1] + R[r][2] * (double)pf[2]) + (double)tf[r];
+    }
+    // projection.jl:259-287 (persp_common above, in double)
+    const double rz = 1.0 / mc[2], rz2 = rz * rz;
+    const int res[2] = {cam.width, cam.height};
+    double J02[2], J00[2];  // J = [J00[0] 0 J02[0]; 0 J00[1] J02[1]]
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const double fk = (double)cam.focal[k], rk = (double)res[k];
+        const double stf = 0.3 * ((0.5 * rk) / fk), pp = (double)cam.principal[k] * rk;
+        const double lim = (rk - pp) / fk + stf, lim_neg = pp / fk + stf;
+        const double c = fmin(lim, fmax(-lim_neg, mc[k] * rz));
+        J00[k] = fk * rz;
+        J02[k] = -fk * (mc[2] * c) * rz2;
+    }
+    // render.jl:322-333 (quat2rot) and M = Rg diag(s)
+    const double qw = (double)q4.x, qx = (double)q4.y, qy = (double)q4.z, qz = (double)q4.w;
+    const double inv_norm = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+    const double w = qw * inv_norm, x = qx * inv_norm, y = qy * inv_norm, z = qz * inv_norm;
+    double Rg[3][3];
+    Rg[0][0] = 1.0 - 2.0 * (y * y + z * z); Rg[1][0] = 2.0 * (x * y + w * z); Rg[2][0] = 2.0 * (x * z - w * y);
+    Rg[0][1] = 2.0 * (x * y - w * z); Rg[1][1] = 1.0 - 2.0 * (x * x + z * z); Rg[2][1] = 2.0 * (y * z + w * x);
+    Rg[0][2] = 2.0 * (x * z + w * y); Rg[1][2] = 2.0 * (y * z - w * x); Rg[2][2] = 1.0 - 2.0 * (x * x + y * y);
+    const double s[3] = {(double)sf[0], (double)sf[1], (double)sf[2]};
+    // T = J R (2x3), TM = T Rg diag(s) (2x3)
+    double T[2][3], TM[2][3];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) T[a][c] = J00[a] * R[a][c] + J02[a] * R[2][c];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) TM[a][c] = (T[a][0] * Rg[0][c] + T[a][1] * Rg[1][c] + T[a][2] * Rg[2][c]) * s[c];
+    // Sigma_2D = TM TM' + blur (projection.jl:96-100), conic = its inverse
+    const double S00 = TM[0][0] * TM[0][0] + TM[0][1] * TM[0][1] + TM[0][2] * TM[0][2] + (double)cam.blur_eps;
+    const double S01 = TM[0][0] * TM[1][0] + TM[0][1] * TM[1][1] + TM[0][2] * TM[1][2];
+    const double S11 = TM[1][0] * TM[1][0] + TM[1][1] * TM[1][1] + TM[1][2] * TM[1][2] + (double)cam.blur_eps;
+    const double det_inv = 1.0 / (S00 * S11 - S01 * S01);
+    const double Ca = S11 * det_inv, Cb = -S01 * det_inv, Cc = S00 * det_inv;
+    // vS2 = -C vC C (render.jl:383-385), symmetric
+    const double a_ = (double)va, b_ = (double)vb, c_ = (double)vc;
+    const double P00 = Ca * a_ + Cb * b_, P01 = Ca * b_ + Cb * c_, P10 = Cb * a_ + Cc * b_, P11 = Cb * b_ + Cc * c_;
+    const double V00 = -(P00 * Ca + P01 * Cb), V01 = -(P00 * Cb + P01 * Cc), V11 = -(P10 * Cb + P11 * Cc);
+    // vM = (vSigma + vSigma') M with vSigma = T' vS2 T:  vM = 2 T' (vS2 TM)
+    double X[2][3], vM[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { X[0][c] = V00 * TM[0][c] + V01 * TM[1][c]; X[1][c] = V01 * TM[0][c] + V11 * TM[1][c]; }
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) vM[r][c] = 2.0 * (T[0][r] * X[0][c] + T[1][r] * X[1][c]);
+    double vRq[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        vs_out[c] = (float)(Rg[0][c] * vM[0][c] + Rg[1][c] * vM[1][c] + Rg[2][c] * vM[2][c]);
+#pragma unroll
+        for (int r = 0; r < 3; r++) vRq[r][c] = vM[r][c] * s[c] + (double)vRg.m[r][c];
+    }
+    // ∇unnorm_quat2rot (render.jl:335-366)
+#define V(i_, j_) vRq[(i_) - 1][(j_) - 1]
+    double vqn[4];
+    vqn[0] = 2.0 * (x * (V(3, 2) - V(2, 3)) + y * (V(1, 3) - V(3, 1)) + z * (V(2, 1) - V(1, 2)));
+    vqn[1] = 2.0 * (-2.0 * x * (V(2, 2) + V(3, 3)) + y * (V(2, 1) + V(1, 2)) + z * (V(3, 1) + V(1, 3)) + w * (V(3, 2) - V(2, 3)));
+    vqn[2] = 2.0 * (x * (V(2, 1) + V(1, 2)) - 2.0 * y * (V(1, 1) + V(3, 3)) + z * (V(3, 2) + V(2, 3)) + w * (V(1, 3) - V(3, 1)));
+    vqn[3] = 2.0 * (x * (V(3, 1) + V(1, 3)) + y * (V(3, 2) + V(2, 3)) - 2.0 * z * (V(1, 1) + V(2, 2)) + w * (V(2, 1) - V(1, 2)));
+#undef V
+    const double qn[4] = {w, x, y, z};
+    const double dq = vqn[0] * w + vqn[1] * x + vqn[2] * y + vqn[3] * z;
+#pragma unroll
+    for (int k = 0; k < 4; k++) vq_out[k] = (float)((vqn[k] - dq * qn[k]) * inv_norm);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1108,35 +1179,42 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
                     vRg.m[r][2] = k == 2 ? v : 0.0f;
                 }
             }
-            // ∇quat_scale_to_cov (render.jl:302-320)
-            M33 S;
+            // ∇quat_scale_to_cov (render.jl:302-320) + ∇unnorm_quat2rot (render.jl:335-366): in float64 from the raw inputs
+            // (scales_rots_bwd_f64 above — the fp32 chain loses a needle's thin eigen-direction).  GSR_PGB_FP32_CHAIN keeps the
+            // reference's fp32 expression trees for A/B runs.
+            float vs[3], vq[4];
+#ifndef GSR_PGB_FP32_CHAIN
+            scales_rots_bwd_f64(cam, R, t, p, q4, s, a1.x, a1.y, a1.z, vRg, vs, vq);
+            (void)vSigma; (void)M; (void)qn; (void)inv_norm;
+#else
+            {
+                M33 S;
 #pragma unroll
-            for (int a = 0; a < 3; a++)
+                for (int a = 0; a < 3; a++)
 #pragma unroll
-                for (int b = 0; b < 3; b++) S.m[a][b] = 0.0f;
-            S.m[0][0] = s[0]; S.m[1][1] = s[1]; S.m[2][2] = s[2];
-            M33 vM = mul33(add33(vSigma, tr33(vSigma)), M);
-            M33 vRq = add33(mul33(vM, S), vRg);
-            float vs[3];
+                    for (int b = 0; b < 3; b++) S.m[a][b] = 0.0f;
+                S.m[0][0] = s[0]; S.m[1][1] = s[1]; S.m[2][2] = s[2];
+                M33 vM = mul33(add33(vSigma, tr33(vSigma)), M);
+                M33 vRq = add33(mul33(vM, S), vRg);
 #pragma unroll
-            for (int c = 0; c < 3; c++)
-                vs[c] = Rg.m[0][c] * vM.m[0][c] + Rg.m[1][c] * vM.m[1][c] + Rg.m[2][c] * vM.m[2][c];
-            // ∇unnorm_quat2rot (render.jl:335-366)
-            const float w = qn[0], x = qn[1], y = qn[2], z = qn[3];
+                for (int c = 0; c < 3; c++)
+                    vs[c] = Rg.m[0][c] * vM.m[0][c] + Rg.m[1][c] * vM.m[1][c] + Rg.m[2][c] * vM.m[2][c];
+                const float w = qn[0], x = qn[1], y = qn[2], z = qn[3];
 #define V(i_, j_) vRq.m[(i_) - 1][(j_) - 1]
-            float vqn[4];
-            vqn[0] = 2.0f * (x * (V(3, 2) - V(2, 3)) + y * (V(1, 3) - V(3, 1)) + z * (V(2, 1) - V(1, 2)));
-            vqn[1] = 2.0f * (-2.0f * x * (V(2, 2) + V(3, 3)) + y * (V(2, 1) + V(1, 2)) + z * (V(3, 1) + V(1, 3)) +
-                             w * (V(3, 2) - V(2, 3)));
-            vqn[2] = 2.0f * (x * (V(2, 1) + V(1, 2)) - 2.0f * y * (V(1, 1) + V(3, 3)) + z * (V(3, 2) + V(2, 3)) +
-                             w * (V(1, 3) - V(3, 1)));
-            vqn[3] = 2.0f * (x * (V(3, 1) + V(1, 3)) + y * (V(3, 2) + V(2, 3)) - 2.0f * z * (V(1, 1) + V(2, 2)) +
-                             w * (V(2, 1) - V(1, 2)));
+                float vqn[4];
+                vqn[0] = 2.0f * (x * (V(3, 2) - V(2, 3)) + y * (V(1, 3) - V(3, 1)) + z * (V(2, 1) - V(1, 2)));
+                vqn[1] = 2.0f * (-2.0f * x * (V(2, 2) + V(3, 3)) + y * (V(2, 1) + V(1, 2)) + z * (V(3, 1) + V(1, 3)) +
+                                 w * (V(3, 2) - V(2, 3)));
+                vqn[2] = 2.0f * (x * (V(2, 1) + V(1, 2)) - 2.0f * y * (V(1, 1) + V(3, 3)) + z * (V(3, 2) + V(2, 3)) +
+                                 w * (V(1, 3) - V(3, 1)));
+                vqn[3] = 2.0f * (x * (V(3, 1) + V(1, 3)) + y * (V(3, 2) + V(2, 3)) - 2.0f * z * (V(1, 1) + V(2, 2)) +
+                                 w * (V(2, 1) - V(1, 2)));
 #undef V
-            float dq = vqn[0] * qn[0] + vqn[1] * qn[1] + vqn[2] * qn[2] + vqn[3] * qn[3];
-            float vq[4];
+                float dq = vqn[0] * qn[0] + vqn[1] * qn[1] + vqn[2] * qn[2] + vqn[3] * qn[3];
 #pragma unroll
-            for (int k = 0; k < 4; k++) vq[k] = (vqn[k] - dq * qn[k]) * inv_norm;
+                for (int k = 0; k < 4; k++) vq[k] = (vqn[k] - dq * qn[k]) * inv_norm;
+            }
+#endif
             if constexpr (FUSED) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) f_vq[k] = vq[k];
@@ -1434,36 +1512,61 @@ void gsr_launch_update_stats(hipStream_t s, int n, const int32_t* radii, const f
 }
 
 
-// form — -1: by scene and grid size (default), 0: direct form, 1: aggregating form wherever its LDS fits (per handle:
-// gsr_config.preprocess_form; its -1 = the process default, gsr_preprocess_form).  Returns the form that ran.
+// The aggregating form's LDS plan: the counter words of ONE BAND of the tile grid must fit kAggLdsMax (three workgroups per
+// CU).  One band = the whole grid where that fits (1080p with 2 x 32-bit words, 1440p with 2 x 16-bit words); else the grid
+// is cut into the fewest equal bands of whole tile rows.  2 x 16-bit words need every position handed out to stay below
+// 65 535 - 512 (`max_pos`: the bins' capacity, or the longest list in the scatter pass).
+namespace {
+struct AggPlan { bool w32; int n_bands, band_rows; size_t lds; };
+AggPlan agg_plan(int grid_x, int grid_y, uint32_t max_pos) {
+    AggPlan p;
+    const size_t n_words = ((size_t)grid_x * grid_y + 2) / 2;
+    const bool small_pos = max_pos < 0xFFFFu - (uint32_t)kAggThreads;
+    p.w32 = small_pos && n_words * 8 > kAggLdsMax;  // 64-bit words where the whole grid fits with them (as round 4)
+    const size_t wbytes = p.w32 ? 4 : 8;
+    const int words_max = (int)(kAggLdsMax / wbytes);
+    int rows = (int)((2 * (size_t)(words_max - 2)) / (size_t)grid_x);  // a band of r rows spans at most r * grid_x / 2 + 2 words
+    rows = rows < 1 ? 1 : (rows > grid_y ? grid_y : rows);
+    p.n_bands = (grid_y + rows - 1) / rows;
+    p.band_rows = (grid_y + p.n_bands - 1) / p.n_bands;  // equal bands
+    p.lds = ((size_t)p.band_rows * grid_x / 2 + 2) * wbytes;
+    return p;
+}
+// bands the DEFAULT form choice accepts (form = -1); gsr_preprocess_form(1) / gsr_config.preprocess_form = 1 take any number.
+// GSR_AGG_MAX_BANDS overrides (A/B runs).
+int agg_max_bands_default() {
+    static const int v = [] { const char* e = getenv("GSR_AGG_MAX_BANDS"); return e ? atoi(e) : kAggMaxBandsDefault; }();
+    return v;
+}
+}  // namespace
+
+// form — -1: by scene and grid size (default), 0: direct form, 1: aggregating form (per handle: gsr_config.preprocess_form;
+// its -1 = the process default, gsr_preprocess_form).  Returns the form that ran (gsr_stats.preprocess_form).
 int gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels, const float* means,
                           const float* scales, const float* rots, const float* opac, const float* shs, GsrCam cam,
                           GsrGeom geom, uint32_t* tile_count, uint32_t* n_visible, uint64_t* bins, uint32_t bin_cap,
                           int n_tiles, int form) {
     if (n <= 0) return 0;
     const float4* r4 = reinterpret_cast<const float4*>(rots);
-    // The aggregating form wants its counter words in LDS three times per CU (8 B per tile pair: 33 KB at 1080p) and a
-    // scene of several rounds of 512-Gaussian workgroups; smaller scenes and larger grids take the direct form.
+    // The aggregating form wants a scene of several rounds of 512-Gaussian workgroups (smaller scenes take the direct form)
+    // and its counter words in LDS three times per CU: the whole grid up to ~21 500 tiles, bands of it beyond (4K: two).
     const int n_words = (n_tiles + 2) / 2;
-    const bool want = form >= 0 ? form != 0 : n >= kAggMinGaussians;
-    // 64-bit LDS words where they fit three workgroups per CU; else 2 x 16-bit words (up to ~21 500 tiles: 1440p), which need
-    // every stored bin position to fit 16 bits
-    const bool agg = want && (size_t)n_words * 8 <= kAggLdsMax;
-    const bool agg32 = want && !agg && (size_t)n_words * 4 <= kAggLds32Max && bin_cap < 0xFFFFu - (uint32_t)kAggThreads;
-    const size_t lds = (size_t)n_words * (agg32 ? 4 : 8);
-#define LAUNCH(D)                                                                                                          \
-    do {                                                                                                                   \
-        if (agg)                                                                                                           \
-            hipLaunchKernelGGL((preprocess_kernel<D, kAggThreads>), dim3((n + kAggThreads - 1) / kAggThreads),             \
-                               dim3(kAggThreads), lds, s, n, K, channels, means, scales, r4, opac, shs, cam, geom,         \
-                               tile_count, n_visible, bins, bin_cap, n_words);                                             \
-        else if (agg32)                                                                                                    \
-            hipLaunchKernelGGL((preprocess_kernel<D, kAggThreads, true>), dim3((n + kAggThreads - 1) / kAggThreads),       \
-                               dim3(kAggThreads), lds, s, n, K, channels, means, scales, r4, opac, shs, cam, geom,         \
-                               tile_count, n_visible, bins, bin_cap, n_words);                                             \
-        else                                                                                                               \
-            hipLaunchKernelGGL((preprocess_kernel<D, 0>), dim3((n + 255) / 256), dim3(256), 0, s, n, K, channels, means,   \
-                               scales, r4, opac, shs, cam, geom, tile_count, n_visible, bins, bin_cap, n_words);           \
+    const AggPlan pl = agg_plan(cam.grid_x, cam.grid_y, bin_cap);
+    const bool agg = form >= 0 ? form != 0 : (n >= kAggMinGaussians && pl.n_bands <= agg_max_bands_default());
+    const uint32_t* no_start = nullptr;
+    const dim3 agg_grid((n + kAggThreads - 1) / kAggThreads), agg_block(kAggThreads);
+#define LAUNCH_AGG(D, W, B)                                                                                                 \
+    hipLaunchKernelGGL((preprocess_kernel<D, kAggThreads, W, false, B>), agg_grid, agg_block, pl.lds, s, n, K, channels,    \
+                       means, scales, r4, opac, shs, cam, geom, tile_count, n_visible, bins, bin_cap, n_words, no_start,    \
+                       pl.n_bands, pl.band_rows)
+#define LAUNCH(D)                                                                                                           \
+    do {                                                                                                                    \
+        if (agg && pl.n_bands > 1) { if (pl.w32) LAUNCH_AGG(D, true, true); else LAUNCH_AGG(D, false, true); }              \
+        else if (agg) { if (pl.w32) LAUNCH_AGG(D, true, false); else LAUNCH_AGG(D, false, false); }                         \
+        else                                                                                                                \
+            hipLaunchKernelGGL((preprocess_kernel<D, 0, false, false, false>), dim3((n + 255) / 256), dim3(256), 0, s, n, K, \
+                               channels, means, scales, r4, opac, shs, cam, geom, tile_count, n_visible, bins, bin_cap,     \
+                               n_words, no_start, 1, cam.grid_y);                                                           \
     } while (0)
     switch (degree) {
         case 0: LAUNCH(0); break;
@@ -1472,13 +1575,31 @@ int gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels,
         default: LAUNCH(3); break;
     }
 #undef LAUNCH
-    return agg ? 1 : (agg32 ? 2 : 0);
+#undef LAUNCH_AGG
+    return !agg ? 0 : (pl.n_bands > 1 ? 3 : (pl.w32 ? 2 : 1));
 }
 
+// duplicate_with_keys! (utils.jl:85-120) as the SECOND pass of the compact binning mode (count -> scan -> scatter): the
+// aggregating form of preprocess_kernel in its SCATTER instantiation — the records are read back, the walks replay the emitted
+// masks, the positions handed out are arrival ranks inside tile_start[t] ... — so that a hot tile's instances meet in LDS
+// instead of serialising on one global counter (round 4's per-lane kernel: 0.85 ms for one tile of 32 k instances, 2.4 ms
+// on a 4K grid with 1 % of the tiles at 50 x density).  `max_list`: the longest tile list (the scan's total), which decides
+// between 2 x 16-bit and 2 x 32-bit LDS words.
 void gsr_launch_emit_compact(hipStream_t s, int n, GsrCam cam, GsrGeom geom, const uint32_t* tile_start, uint32_t* tile_fill,
-                             uint64_t* keys) {
+                             uint64_t* keys, uint32_t max_list) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(emit_compact_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, cam, geom, tile_start, tile_fill, keys);
+    const AggPlan pl = agg_plan(cam.grid_x, cam.grid_y, max_list);
+    const int n_words = (cam.grid_x * cam.grid_y + 2) / 2;
+    const dim3 grid((n + kAggThreads - 1) / kAggThreads), block(kAggThreads);
+    const float* nf = nullptr;
+    const float4* nq = nullptr;
+#define LAUNCH_SC(W, B)                                                                                                            \
+    hipLaunchKernelGGL((preprocess_kernel<0, kAggThreads, W, true, B>), grid, block, pl.lds, s, n, 0, 3, nf, nf, nq, nf, nf, cam,  \
+                       geom, tile_fill, (uint32_t*)nullptr, keys, 0u, n_words, tile_start, pl.n_bands, pl.band_rows)
+    if (pl.n_bands > 1) { if (pl.w32) LAUNCH_SC(true, true); else LAUNCH_SC(false, true); }
+    else if (pl.w32) LAUNCH_SC(true, false);
+    else LAUNCH_SC(false, false);
+#undef LAUNCH_SC
 }
 
 void gsr_launch_pergauss_bwd(hipStream_t s, int n, int K, int degree, int channels, const float* means,

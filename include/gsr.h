@@ -59,7 +59,7 @@ typedef struct gsr_config {
     float blur_eps;      /* 0.3  */
     uint32_t flags;      /* GSR_FLAG_* */
     uint64_t bins_budget_bytes; /* 0 = default.  Cap on the fixed-capacity per-tile key bins of the fast binning mode
-                          * ((tiles+1) x longest list x 8 B); default max(128 MiB, 48 B x instance count of the last view).
+                          * ((tiles+1) x longest list x 8 B); default max(512 MiB, 160 B x instance count of the last view).
                           * A view whose bins would exceed it — a few very deep tiles — is binned in compact mode
                           * (count -> scan -> scatter, 8 B per instance) instead: same lists, same results. */
     /* New in ABI 5 — the two behaviour switches are PER HANDLE, as the reference's knobs are constructor keywords

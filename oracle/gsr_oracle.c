@@ -34,6 +34,26 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
+/* FLOAT64 REPLAY (oracle/Makefile builds this file a second time with -DORC_REAL_DOUBLE into libgsr_oracle_f64.so): the same
+ * source text with every `float` a double — the reference's formulas evaluated in float64 on the same inputs.  Used by
+ * oracle.py for ONE purpose: the "truth" per-Gaussian backward (orc_project_bwd below), to tell what part of a gradient
+ * difference is the fp32 arithmetic of ∇project itself.  For needle-shaped splats (scale ratios of 100 and more, as a trained
+ * scene is full of) the reference's fp32 chain conic -> ∇inverse -> ∇perspective_projection -> ∇quat_scale_to_cov loses the
+ * thin eigen-direction of the 2x2 covariance to rounding: the last bits of vconic change ∇rotations by 1e-3 relative, whoever
+ * computed them.  Only the per-Gaussian functions are meaningful in this build (the binning functions move
+ * float BITS around and are not used from it). */
+#ifdef ORC_REAL_DOUBLE
+#define float double
+#define sqrtf sqrt
+#define fabsf fabs
+#define floorf floor
+#define ceilf ceil
+#define fmaxf fmax
+#define fminf fmin
+#define expf exp
+#define powf pow
+#endif
+
 /* GaussianSplatting.jl:55-56 */
 #define BLOCK_X 16
 #define BLOCK_Y 16
@@ -860,12 +880,21 @@ ORC_API void orc_project_bwd(int n, const float *vmeans2d, const float *vconics,
         m22 Ci, vCi;
         Ci.m[0][0] = conics[3 * i]; Ci.m[1][0] = conics[3 * i + 1]; Ci.m[0][1] = conics[3 * i + 1]; Ci.m[1][1] = conics[3 * i + 2];
         vCi.m[0][0] = vconics[3 * i]; vCi.m[1][0] = vconics[3 * i + 1]; vCi.m[0][1] = vconics[3 * i + 1]; vCi.m[1][1] = vconics[3 * i + 2];
-        m22 vS2 = grad_inverse(Ci, vCi);
         float mc[3];
         pos_world_to_cam(R, cam->t, means + 3 * i, mc);
         m33 Rg = unnorm_quat2rot(rots + 4 * i);
         m33 Sigma = quat_scale_to_cov(Rg, scales + 3 * i);
         m33 Sc = covar_world_to_cam(R, Sigma);
+#ifdef ORC_REAL_DOUBLE
+        {   /* float64 replay: the conic is re-derived from the raw inputs — the forward's fp32-rounded conic cannot hold the
+             * thin eigenvalue of a needle's 2x2 covariance (projection.jl:96-103 restated) */
+            m22 S2r; float m2r[2], det_r, comp_r;
+            perspective_projection(mc, Sc, &K, &S2r, m2r);
+            add_blur(&S2r, cam->blur_eps, &det_r, &comp_r);
+            if (det_r > 0.0) inverse2(S2r, &Ci);
+        }
+#endif
+        m22 vS2 = grad_inverse(Ci, vCi);
         m33 vSc; float vmc[3];
         grad_perspective_projection(mc, Sc, &K, vS2, vmeans2d + 2 * i, &vSc, vmc);
         if (vdepths) vmc[2] = vmc[2] + vdepths[i];

@@ -22,7 +22,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libgsr_oracle.so")
+_SO64 = os.path.join(_HERE, "_build", "libgsr_oracle_f64.so")  # the float64 replay of the same source (ORC_REAL_DOUBLE)
 _lib = None
+_lib64 = None
 
 f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
@@ -41,11 +43,33 @@ class OrcCamera(C.Structure):
     ]
 
 
+class OrcCamera64(C.Structure):
+    """orc_camera as the float64 replay lays it out (every float field a double)."""
+    _fields_ = [
+        ("R", C.c_double * 9), ("t", C.c_double * 3), ("focal", C.c_double * 2),
+        ("principal", C.c_double * 2), ("camera_center", C.c_double * 3),
+        ("width", C.c_int), ("height", C.c_int),
+        ("near_plane", C.c_double), ("far_plane", C.c_double),
+        ("radius_clip", C.c_int), ("blur_eps", C.c_double),
+    ]
+
+
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "gsr_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    if (force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src)
+            or not os.path.exists(_SO64) or os.path.getmtime(_SO64) < os.path.getmtime(src)):
         subprocess.check_call(["make", "-C", _HERE, "-s"], stdout=subprocess.DEVNULL)
     return _SO
+
+
+def lib64():
+    """The float64 replay (libgsr_oracle_f64.so): gsr_oracle.c compiled with every `float` a double.  Only the per-Gaussian
+    functions are meaningful there; arrays cross as float64 and the camera as OrcCamera64."""
+    global _lib64
+    if _lib64 is None:
+        build()
+        _lib64 = C.CDLL(_SO64)
+    return _lib64
 
 
 def lib():
@@ -246,6 +270,35 @@ def project_bwd(vmeans2d, vconics, vdepths, vnormals, conics, radii, means, scal
     return vmeans, vscales, vrots, vR, vt
 
 
+def project_bwd_f64(vmeans2d, vconics, vdepths, vnormals, radii, means, scales, rots, cam: Camera):
+    """The per-Gaussian backward (projection.jl:132-257) REPLAYED IN FLOAT64 on the same inputs: the same C source with
+    every `float` a double (gsr_oracle.c, ORC_REAL_DOUBLE), the conic re-derived from the raw inputs.  Truth for
+    ∇scales / ∇rotations of needle-shaped splats, whose fp32 evaluation — the reference's, the oracle's, anybody's — loses the
+    thin eigen-direction of the 2x2 covariance.  Inputs are the float32 arrays the fp32 path takes (values unchanged);
+    returns float64 (vmeans, vscales, vrots)."""
+    d = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    n = means.shape[0]
+    vmeans = np.zeros((n, 3), np.float64)
+    vscales = np.zeros((n, 3), np.float64)
+    vrots = np.zeros((n, 4), np.float64)
+    s32 = cam.struct()
+    cs = OrcCamera64()
+    for name, _ in OrcCamera64._fields_:
+        v = getattr(s32, name)
+        if hasattr(v, "__len__"):
+            for k in range(len(v)):
+                getattr(cs, name)[k] = float(v[k])
+        else:
+            setattr(cs, name, v)
+    vm2, vc, vd, vn, me, sc, ro = d(vmeans2d), d(vconics), d(vdepths), d(vnormals), d(means), d(scales), d(rots)
+    dummy_conics = np.zeros((n, 3), np.float64)  # ignored by the float64 build (it re-derives the conic)
+    dp = lambda a: _p(a, C.c_double)  # noqa: E731
+    lib64().orc_project_bwd(C.c_int(n), dp(vm2), dp(vc), dp(vd), dp(vn), dp(dummy_conics),
+                            _p(np.ascontiguousarray(radii, np.int32), C.c_int32), dp(me), dp(sc), dp(ro), C.byref(cs),
+                            dp(vmeans), dp(vscales), dp(vrots), None, None)
+    return vmeans, vscales, vrots
+
+
 # --------------------------------------------------------------------------
 # rasterize / ∇rasterize
 # --------------------------------------------------------------------------
@@ -338,11 +391,15 @@ class Grads:
 
 
 def backward(st: FwdState, vpixels, means, shs, opacities, scales, rots, cam: Camera, sh_degree: int,
-             background=(0, 0, 0), pose_grad=False, deterministic=True) -> Grads:
+             background=(0, 0, 0), pose_grad=False, deterministic=True, truth_project=False) -> Grads:
     """rasterizer.jl:416-550.  `vpixels` is (H,W,C).  `deterministic`: True = serial tile loop with double accumulators
     (truth gradients, bit-reproducible); "parallel" = the same double accumulators updated atomically from an OpenMP tile
     loop (truth gradients at large sizes; equal to True up to the order of double additions); False = the reference's
-    float-atomic form (render.jl:242,275-282)."""
+    float-atomic form (render.jl:242,275-282).
+    `truth_project`: ∇scales / ∇rotations from the FLOAT64 REPLAY of the per-Gaussian backward (project_bwd_f64) on the
+    double-accumulated per-Gaussian cotangents — what to compare against on scenes with needle-shaped splats, where the
+    reference's fp32 ∇project is itself only good to ~1e-3 (returned as float64 in `vscales` / `vrots`; `vmeans` and
+    everything else stay the fp32 restatement's)."""
     Cn = n_color_features(st.mode)
     means, shs, scales, rots = _f(means), _f(shs), _f(scales), _f(rots)
     opacities = _f(opacities).reshape(-1)
@@ -361,6 +418,8 @@ def backward(st: FwdState, vpixels, means, shs, opacities, scales, rots, cam: Ca
     vnormals = np.ascontiguousarray(vfeat[:, 5:8]) if Cn > 5 else None
     vmeans, vscales, vrots, vR, vt = project_bwd(vmeans2d, vconics, vdepths, vnormals, st.conics, st.radii,
                                                  means, scales, rots, cam, pose_grad=pose_grad)
+    if truth_project:
+        _, vscales, vrots = project_bwd_f64(vmeans2d, vconics, vdepths, vnormals, st.radii, means, scales, rots, cam)
     vshs = sh_backward(means, cam.camera_center, shs, st.clamped, vrgbs, sh_degree, vmeans)
     return Grads(vmeans, vshs, vopac, vscales, vrots, vR, vt, vmeans2d, vconics, vfeat)
 

@@ -119,6 +119,25 @@ def test_edge_failures_are_conditioning_or_boundary_pairs(pkg, orc, case):
     print(f"edge {case}", arbitrate(res, st, fs))
 
 
+# round 5 (round-4 verdict "weak #2"): the three hostile scenes of the last campaign in which HIP — not the oracle — was the side
+# far from float64 on ∇rotations (profiles/r04/fuzz_parity_last.txt: HIP-f64 2.1e-4 / 5.2e-4 / 2.7e-4 against oracle-f64
+# 1.3e-5 / 2.9e-4 / 3.9e-5).  Cause: the fp32 chain ∇inverse -> ... -> ∇unnorm_quat2rot loses a needle's thin
+# eigen-direction, so ANY fp32 evaluation turns the last bit of vconic into 1e-3 of ∇rotations; which side looks better is
+# luck.  pergauss_bwd now evaluates that chain in float64 from the raw inputs (scales_rots_bwd_f64): ∇scales and ∇rotations
+# must meet the suite's 1e-4 directly AGAINST FLOAT64, whatever the fp32 oracle does.
+@pytest.mark.parametrize("case", [5315, 5378, 5457])
+def test_needle_rotation_gradients_meet_the_tolerance_against_float64(pkg, orc, case):
+    fs = fuzz_scenes.edge_scene(pkg, case)
+    res, st = three_way(pkg, orc, fs)
+    vis = st.radii > 0
+    for nm in ("vscales", "vrots"):
+        o, h, t = res[nm]
+        e_h, e_o = _rel(h[vis], t[vis]), _rel(o[vis], t[vis])
+        print(f"edge {case} {nm}: HIP-f64 {e_h:.2e}, oracle-f64 {e_o:.2e}")
+        assert e_h <= 1e-4, (nm, e_h, e_o)
+    print(f"edge {case}", arbitrate(res, st, fs))
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_600_to_1_needles_hip_is_as_close_to_float64_as_the_oracle(pkg, orc, seed):
     """No 1e-4 criterion between two fp32 evaluations holds on 600 : 1 needles (round 3: 2.2e-4 / 3.2e-4 / 4.7e-4); what must
@@ -131,6 +150,12 @@ def test_600_to_1_needles_hip_is_as_close_to_float64_as_the_oracle(pkg, orc, see
     for nm in ("vmeans", "vscales", "vrots"):   # the needles alone, where the conditioning bites
         o, h, t = res[nm]
         assert _rel(h[m], t[m]) <= 4.0 * _rel(o[m], t[m]) + 1e-4, nm
+    # round 5: ∇scales / ∇rotations come out of a float64 chain — on the needles they now meet the suite's tolerance against
+    # float64 outright (round 3 measured 2.2e-4 .. 4.7e-4 for the fp32 chain, the oracle's fp32 chain 2e-4 .. 6e-2)
+    for nm in ("vscales", "vrots"):
+        o, h, t = res[nm]
+        print(f"needle {seed} {nm}: HIP-f64 {_rel(h[m], t[m]):.2e}, oracle-f64 {_rel(o[m], t[m]):.2e}")
+        assert _rel(h[m], t[m]) <= 1e-4, (nm, _rel(h[m], t[m]))
 
 
 def test_deep_case_523_differs_on_one_boundary_gaussian_only(pkg, orc):

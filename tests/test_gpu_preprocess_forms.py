@@ -101,3 +101,52 @@ def test_sixteen_bit_words_on_a_large_grid(pkg, orc):
     base = pkg.synthetic.make_scene(60000, W, H, deg, 5400, sigma_px=6.0)
     s = pkg.synthetic.add_skew(base, "hot:9000", seed=5401)
     _assert_same(_views(pkg, orc, s, W, H, deg, "rgb", True, 0), _views(pkg, orc, s, W, H, deg, "rgb", True, 1))
+
+
+@pytest.mark.parametrize("size", [(3840, 2160), (3848, 2168)])
+def test_banded_aggregating_form_on_4k_grids(pkg, orc, size):
+    """Round 5 (round-4 verdict, next #3): grids beyond ~21 500 tiles take the aggregating form in horizontal BANDS of the tile
+    grid (4K: two bands of 2 x 16-bit words; the odd 241 x 136 grid makes rows alternate between two pair counts AND puts a band
+    boundary inside a counter word).  Lists, images, gradients bit-identical to the direct form; rects that straddle the band
+    boundary, wave-emitted large rects, a hot tile beyond the first view's capacity (clamped positions), the overflow -> compact
+    path and the forced compact mode (whose SCATTER pass is the same kernel) are all in the scene."""
+    import dataclasses
+    W, H = size
+    deg = 1
+    base = pkg.synthetic.make_scene(120_000, W, H, deg, 5500, sigma_px=7.0)
+    s = pkg.synthetic.add_skew(base, "hot:5000", seed=5501)
+    big = s.scales_raw.copy()
+    big[:30] += np.log(40.0).astype(np.float32)
+    s = dataclasses.replace(s, scales_raw=big)
+    L = pkg._lib
+    a = _views(pkg, orc, s, W, H, deg, "rgb", True, 0)
+    b = _views(pkg, orc, s, W, H, deg, "rgb", True, 1)
+    _assert_same(a, b)
+    # the form that ran is reported: 3 = banded
+    with form(pkg, 1):
+        cam = orc.Camera(W, H, s.focal)
+        run = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg)
+        run.forward(); run.forward()
+        assert int(run.rast.stats.preprocess_form) == 3
+        run.rast.close()
+    a = _views(pkg, orc, s, W, H, deg, "rgb", False, 0, n_views=2, bins_budget_bytes=1)   # forced compact: count + SCATTER pass
+    b = _views(pkg, orc, s, W, H, deg, "rgb", False, 1, n_views=2, bins_budget_bytes=1)
+    _assert_same(a, b)
+    assert a[-1]["stats"][3] == 1
+
+
+def test_compact_scatter_pass_with_lists_beyond_sixteen_bit_positions(pkg, orc):
+    """A tile of > 65 535 instances: the scatter pass cannot hand out 16-bit positions and takes 2 x 32-bit LDS words (in bands
+    where they do not fit); ids and ranges equal the oracle's, image within tolerance."""
+    from hip_helpers import frac_bad
+    W, H, deg = 640, 480, 0
+    base = pkg.synthetic.make_scene(5000, W, H, deg, 5600, sigma_px=3.0)
+    s = pkg.synthetic.add_skew(base, "hot:70000", seed=5601)
+    cam = orc.Camera(W, H, s.focal)
+    st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg)
+    run = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg)   # reference lists
+    img = run.forward().cpu().numpy()
+    assert int(run.rast.stats.compact_binning) == 1 and int(run.rast.stats.max_tile_instances) > 65535
+    assert np.array_equal(run.rast.values_sorted.cpu().numpy().astype(np.uint32), st.values_sorted)
+    assert np.array_equal(run.rast.ranges.cpu().numpy().astype(np.uint32), st.ranges)
+    assert frac_bad(img, st.image, 0, 1e-4) <= 1e-4

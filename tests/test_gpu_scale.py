@@ -150,14 +150,18 @@ def test_config3_1m_1080p(pkg, orc):
     _properties(pkg, orc, 1_000_000, 1920, 1080, 1003, with_oracle_fwd=True)
 
 
-def _full_step_vs_oracle(pkg, orc, n, W, H, deg, seed, exact_tile_cull, mode="rgb", loss=True, deterministic=True, scene=None):
+def _full_step_vs_oracle(pkg, orc, n, W, H, deg, seed, exact_tile_cull, mode="rgb", loss=True, deterministic=True, scene=None,
+                         truth_project=False):
     """One whole bench.py step — gsr_forward -> gsr_loss_l1_ssim -> gsr_backward — against
     orc.forward / orc.loss_head / orc.backward (rasterizer.jl:255-408,416-550; training.jl:684-694).
     loss=False: the random cotangent of the loss-free configs.  Modes with extra channels (:rgbd,
     :rgbdn) get, on top of the loss pullback (which is zero there, training.jl:656), a random cotangent on the
     depth / alpha / normal channels — what the reference's depth and geometry losses feed them — so those paths are
     compared too.  deterministic: True = the oracle's serial double-accumulator backward, "parallel" = the same
-    accumulators updated atomically from an OpenMP tile loop (the large configs)."""
+    accumulators updated atomically from an OpenMP tile loop (the large configs).
+    truth_project: ∇scales / ∇rotations are compared with the FLOAT64 REPLAY of the per-Gaussian backward (oracle.backward
+    truth_project=True) — for scenes full of needle-shaped splats, where the fp32 restatement of ∇project (the reference's
+    arithmetic) is itself 1e-4 .. 1e-3 from float64; the distance of that fp32 restatement from the replay is printed."""
     import time
     s = pkg.synthetic.make_scene(n, W, H, deg, seed) if scene is None else scene
     cam = orc.Camera(W, H, s.focal)
@@ -179,6 +183,13 @@ def _full_step_vs_oracle(pkg, orc, n, W, H, deg, seed, exact_tile_cull, mode="rg
     t0 = time.perf_counter()
     g = orc.backward(st, vp_o, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, deterministic=deterministic)
     t_bwd = time.perf_counter() - t0
+    fp32_note = ""
+    if truth_project:
+        _, vs64, vr64 = orc.project_bwd_f64(g.vmeans2d, g.vconics, g.vfeatures[:, 3] if C > 3 else None,
+                                            g.vfeatures[:, 5:8] if C > 5 else None, st.radii, s.means, s.scales, s.rotations, cam)
+        fp32_note = (f"; the fp32 restatement of ∇project is {rel_l2(g.vscales.reshape(-1), vs64.reshape(-1)):.1e} (∇scales) / "
+                     f"{rel_l2(g.vrots.reshape(-1), vr64.reshape(-1)):.1e} (∇rotations) from its float64 replay")
+        g.vscales, g.vrots = vs64, vr64
     run = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, exact_tile_cull=exact_tile_cull, mode=mode)
     img = run.forward()
     if loss:
@@ -221,7 +232,7 @@ def _full_step_vs_oracle(pkg, orc, n, W, H, deg, seed, exact_tile_cull, mode="rg
     assert frac_bad(m2, g.vmeans2d.reshape(-1), 1e-3, 1e-6 * np.abs(g.vmeans2d).max()) <= 1e-3
     print(f"[full step vs oracle] n={n} {W}x{H} :{mode} loss={loss} exact_cull={exact_tile_cull}: oracle forward {t_fwd:.1f} s + "
           f"backward({deterministic}) {t_bwd:.1f} s on {orc.num_threads()} threads; worst rel-L2 "
-          f"{max(v[0] for v in worst.values()):.2e}, worst outlier fraction {max(v[1] for v in worst.values()):.2e}")
+          f"{max(v[0] for v in worst.values()):.2e}, worst outlier fraction {max(v[1] for v in worst.values()):.2e}" + fp32_note)
     return st, img, run
 
 

@@ -48,6 +48,19 @@ for sc in "hot --skew hot:32000 --no-loss" "dense4k --gaussians 5000000 --width 
 done
 }
 
+# d: pergauss_bwd with ∇scales / ∇rotations in float64 (default build) against the fp32 chain (tools/bin/libgsr_pgb32.so =
+#    pergauss.hip built with -DGSR_PGB_FP32_CHAIN): step A/B at configs 3 and 5, then the whole -m gpu suite on the default build
+case_d() {
+set -x
+O=gpurun_out/r05d; mkdir -p $O
+GSR_AB_LIBS="tools/bin/libgsr_pgb32.so" timeout 600 bash tools/ab.sh --steps 20 --warmup 5 --steady-steps 0 > $O/ab_cfg3.txt 2>&1
+grep -E "^(default|tools)" $O/ab_cfg3.txt | cut -c1-220
+GSR_AB_LIBS="tools/bin/libgsr_pgb32.so" timeout 600 bash tools/ab.sh --steps 10 --warmup 3 --steady-steps 0 --gaussians 5000000 --width 3840 --height 2160 --no-loss --seed 1005 > $O/ab_cfg5.txt 2>&1
+grep -E "^(default|tools)" $O/ab_cfg5.txt | cut -c1-220
+timeout 2400 python -m pytest tests -m gpu -x -q --durations=12 > $O/pytest.log 2>&1; echo "rc=$?"; tail -25 $O/pytest.log
+grep -E "fp32 restatement|HIP-f64|needle" $O/pytest.log | head -20
+}
+
 if [ "$1" = "--list" ] || [ -z "$1" ]; then declare -F | sed -n "s/^declare -f case_//p"; exit 0; fi
 if ! declare -F "case_$1" > /dev/null; then echo "unknown case $1 (try --list)" >&2; exit 2; fi
 "case_$1"

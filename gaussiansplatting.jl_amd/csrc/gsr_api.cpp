@@ -587,7 +587,8 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     h->last_form = gsr_launch_preprocess(s, n, in->n_coeffs, in->sh_degree, C, in->means, in->scales, in->rotations,
                                          in->opacities, in->shs, k, geom_of(h), h->tile_count.as<uint32_t>(),
                                          h->bvis.as<uint32_t>(), h->bins.as<uint64_t>(), h->bin_cap_view /* 0: count only */,
-                                         h->n_tiles, preprocess_form_of(h));
+                                         h->n_tiles, preprocess_form_of(h),
+                                         /*skewed=*/h->last_D > 0 && (uint64_t)h->last_max_tile * (uint64_t)T > 6ull * (uint64_t)h->last_D);
     sc1.close();
     const uint32_t seq = ++h->totals_seq ? h->totals_seq : ++h->totals_seq;  // never 0
     StageScope sc2(h->prof, ST_SCAN, s);

@@ -70,7 +70,8 @@ struct GsrInst {
 int gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels, const float* means,
                           const float* scales, const float* rots, const float* opac, const float* shs, GsrCam cam,
                           GsrGeom geom, uint32_t* tile_count, uint32_t* n_visible /* per 256-block */,
-                          uint64_t* bins /* (T+1) x bin_cap keys */, uint32_t bin_cap, int n_tiles, int form);
+                          uint64_t* bins /* (T+1) x bin_cap keys */, uint32_t bin_cap, int n_tiles, int form,
+                          bool skewed /* hint from the previous view: longest tile list >> mean list (hot counter words) */);
 struct GsrBg8 { float v[8]; };
 void gsr_launch_fill_background(hipStream_t s, size_t n_pixels, int channels, const float* background /* host, 3 floats */,
                                 float* image, float* final_T, uint32_t* n_contrib);

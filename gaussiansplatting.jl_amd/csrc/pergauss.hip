@@ -1545,14 +1545,20 @@ int agg_max_bands_default() {
 int gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels, const float* means,
                           const float* scales, const float* rots, const float* opac, const float* shs, GsrCam cam,
                           GsrGeom geom, uint32_t* tile_count, uint32_t* n_visible, uint64_t* bins, uint32_t bin_cap,
-                          int n_tiles, int form) {
+                          int n_tiles, int form, bool skewed) {
     if (n <= 0) return 0;
     const float4* r4 = reinterpret_cast<const float4*>(rots);
     // The aggregating form wants a scene of several rounds of 512-Gaussian workgroups (smaller scenes take the direct form)
     // and its counter words in LDS three times per CU: the whole grid up to ~21 500 tiles, bands of it beyond (4K: two).
     const int n_words = (n_tiles + 2) / 2;
     const AggPlan pl = agg_plan(cam.grid_x, cam.grid_y, bin_cap);
-    const bool agg = form >= 0 ? form != 0 : (n >= kAggMinGaussians && pl.n_bands <= agg_max_bands_default());
+    // Default (form = -1): the aggregating form for scenes of >= 250 k Gaussians where ONE band holds the grid (measured faster on
+    // every scene: 1080p, 1440p); on larger grids (4K: two bands) only for SKEWED views — `skewed`: the previous view's longest
+    // tile list was several times its mean, i.e. some counter words are hot and their global atomics serialise (dense 4K scene:
+    // 2.0 -> 1.1 ms) — because a uniform 4K scene is faster in the direct form (config 5: 0.67 against 0.83 ms, both walks run
+    // once per band).
+    const bool agg = form >= 0 ? form != 0
+                               : (n >= kAggMinGaussians && (pl.n_bands <= agg_max_bands_default() || (skewed && pl.n_bands <= 8)));
     const uint32_t* no_start = nullptr;
     const dim3 agg_grid((n + kAggThreads - 1) / kAggThreads), agg_block(kAggThreads);
 #define LAUNCH_AGG(D, W, B)                                                                                                 \

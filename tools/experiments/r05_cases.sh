@@ -61,6 +61,56 @@ timeout 2400 python -m pytest tests -m gpu -x -q --durations=12 > $O/pytest.log 
 grep -E "fp32 restatement|HIP-f64|needle" $O/pytest.log | head -20
 }
 
+# e: the banded aggregating form + the SCATTER pass of the compact mode: parity (forms test, parity, scenes), then timing —
+#    config 5 default (direct) vs forced aggregating (banded), dense 4K, the hot tile and the 3 M trained-like scene (before: the
+#    same scenes in cases b / c of this file, round-4 binning)
+case_e() {
+set -x
+O=gpurun_out/r05e; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_preprocess_forms.py tests/test_gpu_parity.py tests/test_gpu_scenes.py tests/test_gpu_handle_switches.py -x -q --durations=8 > $O/pytest.log 2>&1; echo "rc=$?"; tail -16 $O/pytest.log
+line() { python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['roofline']['stages_ms']
+print('$1', d['ms_per_step'], 'D', d['config']['tile_instances'], d['config']['binning']['mode'][:7], ' '.join(f'{k}={v:.3f}' for k,v in s.items()))"; }
+B="python bench.py --in-process --no-extra --no-cpu-baseline --no-other-lists --steps 10 --warmup 3 --steady-steps 0"
+C5="--gaussians 5000000 --width 3840 --height 2160 --no-loss --seed 1005"
+for rep in 1 2; do
+$B $C5 2>/dev/null | line "cfg5 default";
+GSR_PREPROCESS_AGG=1 $B $C5 2>/dev/null | line "cfg5 agg-banded";
+done
+$B $C5 --skew dense:0.01:50 2>/dev/null | line "dense4k default"
+GSR_PREPROCESS_AGG=1 $B $C5 --skew dense:0.01:50 2>/dev/null | line "dense4k agg-banded"
+$B --skew hot:32000 --no-loss 2>/dev/null | line "hot32k default"
+$B --scene trained --seed 1011 --mode rgbd --gaussians 3000000 --width 2560 --height 1440 2>/dev/null | line "trained3m default"
+$B 2>/dev/null | line "cfg3 default"; $B 2>/dev/null | line "cfg3 default"
+}
+
+# f: long tiles — forward strip kernel with the next chunk's mask plane prefetched, listed backward with 256-splat batches and
+#    the next batch in flight; the skew hint for banded binning at 4K; parity of the long-list paths; kernel times of the hot scene
+case_f() {
+set -x
+O=gpurun_out/r05f; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scenes.py tests/test_gpu_preprocess_forms.py tests/test_gpu_forward_only.py tests/test_gpu_fuzz_regressions.py -x -q > $O/pytest.log 2>&1; echo "rc=$?"; tail -5 $O/pytest.log
+line() { python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['roofline']['stages_ms']
+print('$1', d['ms_per_step'], 'D', d['config']['tile_instances'], d['config']['binning']['mode'][:7], ' '.join(f'{k}={v:.3f}' for k,v in s.items()))"; }
+B="python bench.py --in-process --no-extra --no-cpu-baseline --no-other-lists --steps 10 --warmup 3 --steady-steps 0"
+C5="--gaussians 5000000 --width 3840 --height 2160 --no-loss --seed 1005"
+$B --skew hot:32000 --no-loss 2>/dev/null | line "hot32k"
+$B --skew hot:8000 --no-loss 2>/dev/null | line "hot8k"
+$B $C5 --skew dense:0.01:50 2>/dev/null | line "dense4k"
+$B $C5 2>/dev/null | line "cfg5"
+$B --scene trained --seed 1010 --mode rgbd 2>/dev/null | line "trained1m"
+$B 2>/dev/null | line "cfg3"
+timeout 600 bash tools/kernel_times.sh --steps 10 --warmup 3 --steady-steps 0 --skew hot:32000 --no-loss > $O/ktimes_hot.txt 2>&1
+cp gpurun_out/ktimes_default/st_kernel_stats.csv $O/kernel_stats_hot.csv
+python - <<'PY'
+import csv,re
+rows=list(csv.DictReader(open('gpurun_out/r05f/kernel_stats_hot.csv',newline='')))
+for r in rows[:12]:
+    m=re.search(r'(\w+_kernel)',r['Name']); print('  %-34s calls %4s avg %9.1f us'%((m.group(1) if m else r['Name'][:34]), r['Calls'], float(r['AverageNs'])/1e3))
+PY
+}
+
 if [ "$1" = "--list" ] || [ -z "$1" ]; then declare -F | sed -n "s/^declare -f case_//p"; exit 0; fi
 if ! declare -F "case_$1" > /dev/null; then echo "unknown case $1 (try --list)" >&2; exit 2; fi
 "case_$1"

@@ -1203,6 +1203,10 @@ def run_section(args, section):
                    "tile_lists": ("reference lists (GSR_FLAG_REFERENCE_TILE_LISTS)" if args.reference_lists else
                                   "library default: exact footprint cull (same image / gradients)"),
                    "parallelism": par,
+                   # arithmetic of the loss head in this run (the default is the contracted build, not bit-identical
+                   # to rounds <= 3 / the oracle; GSR_SSIM_EXACT=1 or gsr_config.ssim_precision = 1 select the exact twin)
+                   "ssim_precision": ("exact (fp32 as written, IEEE divisions)" if pkg._lib.load().gsr_get_ssim_precision() == 1
+                                      else "fast (contracted FMAs, two reciprocals; the library default)"),
                    "launch": ("self-launched ranks (bench.py --gpus N)" if os.environ.get("GSR_BENCH_SELF_LAUNCHED") else
                               "external launcher (RANK in the environment)" if "RANK" in os.environ else "single process")
                              + ("; sections in fresh child processes of a GPU-free supervisor" if os.environ.get(SECTION_ENV) else

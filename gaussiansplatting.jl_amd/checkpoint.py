@@ -19,7 +19,7 @@ byte-level file by hand), not by a file the reference wrote: PARITY UNPINNED in 
 """
 from __future__ import annotations
 
-from typing import Dict
+from typing import Dict, Optional
 
 import numpy as np
 
@@ -142,11 +142,14 @@ def read_adam(opt, ckpt: Checkpoint, prefix: str, numel=None) -> None:
     opt.current_step = ckpt.read_scalar(f"{prefix}.current_step")
 
 
-def save_state(filename: str, gaussians, optimizers: Dict[str, object], step: int, strategy=None) -> None:
+def save_state(filename: str, gaussians, optimizers: Dict[str, object], step: int, strategy=None,
+               extra_meta: Optional[Dict[str, str]] = None) -> None:
     """The Gaussian + optimizer part of `save_state` (training.jl:418-445).  `strategy` (a densification.DefaultStrategy):
     its split-noise position is added as two metadata scalars (`strategy.split_seed_base`, `strategy.split_rounds`) —
     keys the reference's reader never asks for, so the file stays a valid reference checkpoint; the reference itself draws
-    split noise from the backend's RNG and has nothing to save there (densification.jl:128)."""
+    split noise from the backend's RNG and has nothing to save there (densification.jl:128).
+    `extra_meta`: more string scalars of the same kind — e.g. {"gsr.ssim_precision": "fast"}: the arithmetic of the loss head the
+    run trained with (the library default is the contracted build, not bit-identical to the exact twin)."""
     tensors, meta = {}, {}
     write_gaussians(tensors, meta, "gaussians", gaussians)
     for name in OPTIMIZER_NAMES:
@@ -155,6 +158,8 @@ def save_state(filename: str, gaussians, optimizers: Dict[str, object], step: in
     if strategy is not None:
         for k, v in strategy.state_dict().items():
             meta[f"strategy.{k}"] = str(int(v))
+    for k, v in (extra_meta or {}).items():
+        meta[str(k)] = str(v)
     save_checkpoint(filename, tensors, meta)
 
 

@@ -336,91 +336,133 @@ __device__ __forceinline__ uint32_t merge_path(const uint64_t* a, uint32_t na, c
     }
     return lo;
 }
-template <int CH>
-__global__ __launch_bounds__(BIG_THREADS) void tile_sort_big_kernel(const uint32_t* __restrict__ tile_start,
-                                                                    const uint32_t* __restrict__ big_list,
-                                                                    const uint64_t* __restrict__ bins, uint32_t bin_cap,
-                                                                    uint64_t* __restrict__ scratch, size_t slab_stride,
-                                                                    int grid_x, GsrGeom geom, GsrStream stream,
-                                                                    uint32_t* __restrict__ values_sorted) {
-    __shared__ uint64_t skeys[GSR_SORT_LDS_CAP];  // 64 KB: chunk sort, then the staging area of a merge block
-    __shared__ uint32_t split_a[BIG_THREADS + 1];
-    const int tile = (int)big_list[blockIdx.x], tid = threadIdx.x;
+// Round 5: the same three phases as SEPARATE launches over (tile, chunk) / (tile, output block) work items, so that a list of
+// tens of thousands of keys is sorted by as many workgroups as it has 8192-key chunks / 4096-key blocks instead of by one (the
+// hot-tile scene's 32 k list + its neighbours: 0.49 ms in one workgroup per tile, five workgroups on the whole chip).
+//   big_plan_kernel  : prefix sums of the chunk counts and of the block counts over the listed tiles (one workgroup)
+//   big_chunk_kernel : sorted runs of GSR_SORT_LDS_CAP keys -> slab 0
+//   big_merge_kernel : one merge pass (run length L -> 2L), slab (pass & 1) -> the other; every tile runs every pass — a tile
+//                      that is already one run is copied — so that the result of ALL tiles sits in slab (n_pass & 1)
+//   big_emit_kernel  : ids + stream entries of one block of the sorted list
+// plan[0 .. n_big] = chunk prefix, plan[n_big + 1 .. 2 n_big + 1] = block prefix.
+__global__ __launch_bounds__(1024) void big_plan_kernel(const uint32_t* __restrict__ tile_start,
+                                                        const uint32_t* __restrict__ big_list, uint32_t n_big,
+                                                        uint32_t* __restrict__ plan) {
+    __shared__ uint32_t sc[1024], sb[1024];
+    const int tid = threadIdx.x;
+    uint32_t carry_c = 0, carry_b = 0;
+    uint32_t* plan_c = plan, *plan_b = plan + n_big + 1;
+    for (uint32_t base = 0; base < n_big; base += 1024) {
+        const uint32_t t = base + tid;
+        uint32_t n = 0;
+        if (t < n_big) { const uint32_t tile = big_list[t]; n = tile_start[tile + 1] - tile_start[tile]; }
+        sc[tid] = (n + GSR_SORT_LDS_CAP - 1) / GSR_SORT_LDS_CAP;
+        sb[tid] = (n + BIG_OUT - 1) / BIG_OUT;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const uint32_t vc = tid >= off ? sc[tid - off] : 0u, vb = tid >= off ? sb[tid - off] : 0u;
+            __syncthreads();
+            sc[tid] += vc; sb[tid] += vb;
+            __syncthreads();
+        }
+        if (t < n_big) { plan_c[t + 1] = carry_c + sc[tid]; plan_b[t + 1] = carry_b + sb[tid]; }
+        carry_c += sc[1023]; carry_b += sb[1023];
+        __syncthreads();
+    }
+    if (tid == 0) { plan_c[0] = 0u; plan_b[0] = 0u; }
+}
+
+// work item `id` -> (listed tile b, item k inside it); false when id is beyond the plan's total
+__device__ __forceinline__ bool big_item(const uint32_t* __restrict__ prefix, uint32_t n_big, uint32_t id, uint32_t& b, uint32_t& k) {
+    if (id >= prefix[n_big]) return false;
+    uint32_t lo = 0, hi = n_big;  // prefix[lo] <= id < prefix[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (prefix[mid] <= id) lo = mid; else hi = mid;
+    }
+    b = lo; k = id - prefix[lo];
+    return true;
+}
+
+__global__ __launch_bounds__(BIG_THREADS) void big_chunk_kernel(const uint32_t* __restrict__ tile_start,
+                                                                const uint32_t* __restrict__ big_list, uint32_t n_big,
+                                                                const uint32_t* __restrict__ plan,
+                                                                const uint64_t* __restrict__ bins, uint32_t bin_cap,
+                                                                uint64_t* __restrict__ scratch, size_t slab_stride) {
+    __shared__ uint64_t skeys[GSR_SORT_LDS_CAP];
+    uint32_t b, c;
+    if (!big_item(plan, n_big, blockIdx.x, b, c)) return;
+    const int tile = (int)big_list[b], tid = threadIdx.x;
     const uint32_t start = tile_start[tile], n = tile_start[tile + 1] - start;
     const uint64_t* __restrict__ keys = bin_cap ? bins + (size_t)tile * bin_cap : bins + start;
-    uint64_t* slab[2] = {scratch + (size_t)(2 * blockIdx.x) * slab_stride, scratch + (size_t)(2 * blockIdx.x + 1) * slab_stride};
-    // phase 1: sorted runs of GSR_SORT_LDS_CAP keys
-    for (uint32_t c0 = 0; c0 < n; c0 += GSR_SORT_LDS_CAP) {
-        const uint32_t cn = min((uint32_t)GSR_SORT_LDS_CAP, n - c0);
-        uint32_t m = 1;
-        while (m < cn) m <<= 1;
-        __syncthreads();
-        for (uint32_t i = tid; i < m; i += BIG_THREADS) skeys[i] = i < cn ? keys[c0 + i] : ~0ull;
-        __syncthreads();
-        if (m > 1) bitonic_sort(skeys, m, tid, BIG_THREADS);
-        for (uint32_t i = tid; i < cn; i += BIG_THREADS) slab[0][c0 + i] = skeys[i];
-    }
-    __threadfence_block();
+    uint64_t* slab0 = scratch + (size_t)(2 * b) * slab_stride;
+    const uint32_t c0 = c * GSR_SORT_LDS_CAP, cn = min((uint32_t)GSR_SORT_LDS_CAP, n - c0);
+    uint32_t m = 1;
+    while (m < cn) m <<= 1;
+    for (uint32_t i = tid; i < m; i += BIG_THREADS) skeys[i] = i < cn ? keys[c0 + i] : ~0ull;
     __syncthreads();
-    // phase 2: merge passes
-    int cur = 0;
-    for (uint32_t L = GSR_SORT_LDS_CAP; L < n; L <<= 1, cur ^= 1) {
-        const uint64_t* __restrict__ src = slab[cur];
-        uint64_t* __restrict__ dst = slab[cur ^ 1];
-        const uint32_t n_blocks = (n + BIG_OUT - 1) / BIG_OUT;
-        for (uint32_t blk0 = 0; blk0 < n_blocks; blk0 += BIG_THREADS - 1) {
-            // split of every output block of this round (+ one sentinel: the start of the block after the round), in
-            // parallel; block k starts at output k * BIG_OUT
-            const uint32_t nb_round = min((uint32_t)(BIG_THREADS - 1), n_blocks - blk0);
-            __syncthreads();
-            if ((uint32_t)tid <= nb_round) {
-                const uint32_t o = min((blk0 + tid) * (uint32_t)BIG_OUT, n);          // first output of block blk0 + tid
-                const uint32_t pair = o / (2 * L) * (2 * L);                          // start of its pair of runs
-                const uint32_t na = min(L, n - pair), nbb = min(L, n - pair - na);
-                // a block never straddles a pair: 2L is a multiple of BIG_OUT; the sentinel entry (tid == nb_round)
-                // that falls on a pair boundary is resolved per block below
-                split_a[tid] = o >= n ? 0u : merge_path(src + pair, na, src + pair + na, nbb, o - pair);
-            }
-            __syncthreads();
-            for (uint32_t kb = 0; kb < nb_round; kb++) {
-                const uint32_t o0 = (blk0 + kb) * (uint32_t)BIG_OUT, cnt = min((uint32_t)BIG_OUT, n - o0);
-                const uint32_t pair = o0 / (2 * L) * (2 * L);
-                const uint32_t na = min(L, n - pair), nbb = min(L, n - pair - na);
-                const uint32_t a0 = split_a[kb], b0 = (o0 - pair) - a0;
-                // end of this block inside the same pair
-                const uint32_t o1 = o0 + cnt;
-                uint32_t a1;
-                if (o1 - pair >= na + nbb) a1 = na;                                   // the block ends the pair
-                else a1 = split_a[kb + 1];                                            // next block's split, same pair
-                const uint32_t la = a1 - a0, lb = cnt - la;
-                (void)b0;
-                __syncthreads();
-                for (uint32_t i = tid; i < cnt; i += BIG_THREADS)
-                    skeys[i] = i < la ? src[pair + a0 + i] : src[pair + na + b0 + (i - la)];
-                __syncthreads();
-                // each thread merges 4 consecutive outputs from the staged pieces [0, la) and [la, la + lb)
-                const uint32_t d0 = min((uint32_t)tid * 4u, cnt);
-                if (d0 < cnt) {
-                    uint32_t ia = merge_path(skeys, la, skeys + la, lb, d0), ib = d0 - ia;
-                    uint64_t out[4];
-                    const uint32_t cnt_t = min(4u, cnt - d0);
-                    for (uint32_t k = 0; k < cnt_t; k++) {
-                        const bool take_a = ib >= lb || (ia < la && skeys[ia] < skeys[la + ib]);
-                        out[k] = take_a ? skeys[ia] : skeys[la + ib];
-                        ia += take_a ? 1u : 0u;
-                        ib += take_a ? 0u : 1u;
-                    }
-                    for (uint32_t k = 0; k < cnt_t; k++) dst[o0 + d0 + k] = out[k];
-                }
-            }
-        }
-        __threadfence_block();
-        __syncthreads();
+    if (m > 1) bitonic_sort(skeys, m, tid, BIG_THREADS);
+    for (uint32_t i = tid; i < cn; i += BIG_THREADS) slab0[c0 + i] = skeys[i];
+}
+
+__global__ __launch_bounds__(BIG_THREADS) void big_merge_kernel(const uint32_t* __restrict__ tile_start,
+                                                                const uint32_t* __restrict__ big_list, uint32_t n_big,
+                                                                const uint32_t* __restrict__ plan,
+                                                                uint64_t* __restrict__ scratch, size_t slab_stride,
+                                                                uint32_t L, int cur) {
+    __shared__ uint64_t skeys[BIG_OUT];
+    __shared__ uint32_t split_a[2];
+    uint32_t b, kb;
+    if (!big_item(plan + n_big + 1, n_big, blockIdx.x, b, kb)) return;
+    const int tile = (int)big_list[b], tid = threadIdx.x;
+    const uint32_t n = tile_start[tile + 1] - tile_start[tile];
+    const uint64_t* __restrict__ src = scratch + (size_t)(2 * b + cur) * slab_stride;
+    uint64_t* __restrict__ dst = scratch + (size_t)(2 * b + (cur ^ 1)) * slab_stride;
+    const uint32_t o0 = kb * (uint32_t)BIG_OUT, cnt = min((uint32_t)BIG_OUT, n - o0);
+    const uint32_t pair = o0 / (2 * L) * (2 * L);  // a block never straddles a pair: 2L is a multiple of BIG_OUT
+    const uint32_t na = min(L, n - pair), nbb = min(L, n - pair - na);
+    if (tid < 2) {
+        const uint32_t o = o0 + (tid ? cnt : 0u);  // first output of this block / of the next one
+        split_a[tid] = o - pair >= na + nbb ? na : merge_path(src + pair, na, src + pair + na, nbb, o - pair);
     }
-    // phase 3: emit (the same per-instance work as sort_and_emit)
-    const uint64_t* __restrict__ sorted = slab[cur];
+    __syncthreads();
+    const uint32_t a0 = split_a[0], b0 = (o0 - pair) - a0, a1 = split_a[1];
+    const uint32_t la = a1 - a0, lb = cnt - la;
+    for (uint32_t i = tid; i < cnt; i += BIG_THREADS)
+        skeys[i] = i < la ? src[pair + a0 + i] : src[pair + na + b0 + (i - la)];
+    __syncthreads();
+    // each thread merges 4 consecutive outputs from the staged pieces [0, la) and [la, la + lb)
+    const uint32_t d0 = min((uint32_t)tid * 4u, cnt);
+    if (d0 < cnt) {
+        uint32_t ia = merge_path(skeys, la, skeys + la, lb, d0), ib = d0 - ia;
+        uint64_t out[4];
+        const uint32_t cnt_t = min(4u, cnt - d0);
+        for (uint32_t k = 0; k < cnt_t; k++) {
+            const bool take_a = ib >= lb || (ia < la && skeys[ia] < skeys[la + ib]);
+            out[k] = take_a ? skeys[ia] : skeys[la + ib];
+            ia += take_a ? 1u : 0u;
+            ib += take_a ? 0u : 1u;
+        }
+        for (uint32_t k = 0; k < cnt_t; k++) dst[o0 + d0 + k] = out[k];
+    }
+}
+
+template <int CH>
+__global__ __launch_bounds__(BIG_THREADS) void big_emit_kernel(const uint32_t* __restrict__ tile_start,
+                                                               const uint32_t* __restrict__ big_list, uint32_t n_big,
+                                                               const uint32_t* __restrict__ plan,
+                                                               const uint64_t* __restrict__ scratch, size_t slab_stride, int cur,
+                                                               int grid_x, GsrGeom geom, GsrStream stream,
+                                                               uint32_t* __restrict__ values_sorted) {
+    uint32_t b, kb;
+    if (!big_item(plan + n_big + 1, n_big, blockIdx.x, b, kb)) return;
+    const int tile = (int)big_list[b];
+    const uint32_t start = tile_start[tile], n = tile_start[tile + 1] - start;
+    const uint64_t* __restrict__ sorted = scratch + (size_t)(2 * b + cur) * slab_stride;
     const int X0 = (tile % grid_x) * GSR_TILE, Y0 = (tile / grid_x) * GSR_TILE;
-    for (uint32_t i = tid; i < n; i += BIG_THREADS) emit_instance<CH>(sorted[i], start + i, X0, Y0, geom, stream, values_sorted);
+    const uint32_t o0 = kb * (uint32_t)BIG_OUT, o1 = min(n, o0 + (uint32_t)BIG_OUT);
+    for (uint32_t i = o0 + threadIdx.x; i < o1; i += BIG_THREADS)
+        emit_instance<CH>(sorted[i], start + i, X0, Y0, geom, stream, values_sorted);
 }
 
 }  // namespace
@@ -462,9 +504,23 @@ void gsr_launch_tile_sort(hipStream_t s, int passes, int n_tiles, int grid_x, in
 #define LAUNCH(CC, CAPV, NTV, GRID, LIST)                                                                        \
     hipLaunchKernelGGL((tile_sort_kernel<CC, CAPV, NTV>), dim3(GRID), dim3(NTV), 0, s, tile_start, LIST, bins,    \
                        bin_cap, grid_x, geom, stream, values_sorted)
+    // lists beyond the LDS sort: plan -> chunk sorts -> merge passes -> emit, one workgroup per chunk / 4096-key block
+    // (the plan lives behind the 2 n_big slabs; grids are upper bounds from the longest list, surplus workgroups leave at once)
+    uint32_t* const plan = reinterpret_cast<uint32_t*>(big_scratch + (size_t)2 * n_big * slab_stride);
+    const uint32_t chunks_ub = n_big * (uint32_t)((slab_stride + GSR_SORT_LDS_CAP - 1) / GSR_SORT_LDS_CAP);
+    const uint32_t blocks_ub = n_big * (uint32_t)((slab_stride + BIG_OUT - 1) / BIG_OUT);
 #define LAUNCH_BIG(CC)                                                                                            \
-    hipLaunchKernelGGL((tile_sort_big_kernel<CC>), dim3(n_big), dim3(BIG_THREADS), 0, s, tile_start, tier_lists, bins, \
-                       bin_cap, big_scratch, slab_stride, grid_x, geom, stream, values_sorted)
+    do {                                                                                                          \
+        hipLaunchKernelGGL(big_plan_kernel, dim3(1), dim3(1024), 0, s, tile_start, tier_lists, n_big, plan);      \
+        hipLaunchKernelGGL(big_chunk_kernel, dim3(chunks_ub), dim3(BIG_THREADS), 0, s, tile_start, tier_lists, n_big, plan, \
+                           bins, bin_cap, big_scratch, slab_stride);                                              \
+        int cur = 0;                                                                                              \
+        for (uint32_t L = GSR_SORT_LDS_CAP; L < slab_stride; L <<= 1, cur ^= 1)                                   \
+            hipLaunchKernelGGL(big_merge_kernel, dim3(blocks_ub), dim3(BIG_THREADS), 0, s, tile_start, tier_lists, n_big, \
+                               plan, big_scratch, slab_stride, L, cur);                                           \
+        hipLaunchKernelGGL((big_emit_kernel<CC>), dim3(blocks_ub), dim3(BIG_THREADS), 0, s, tile_start, tier_lists, n_big, \
+                           plan, big_scratch, slab_stride, cur, grid_x, geom, stream, values_sorted);             \
+    } while (0)
 #define ALL(CC)                                                                                                   \
     if (passes & GSR_SORT_PASS_MAIN)                                                                              \
         hipLaunchKernelGGL((tile_sort_wave_kernel<CC>), dim3(8 * ((n_tiles + 7) / 8)), dim3(64), 0, s, tile_start,  \

@@ -623,6 +623,277 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
     }
 }
 
+// ---------------------------------------------------------------------------------
+// backward of LONG lists, split along their LENGTH (round 5)
+// ---------------------------------------------------------------------------------
+// A list of tens of thousands of instances is serial for whoever walks it: the hot-tile scene's critical path was ONE wave of
+// a neighbour of the hot tile visiting 15 000 entries that touch its 16x4 strip (profiles/r05/experiments/long_tiles.txt) —
+// more waves per tile by PIXELS (the PPL = 1 kernel above, four strips) do not help where one strip takes all the visits, and
+// more waves in ONE workgroup stop at the four SIMDs of its CU (eight segment waves in one workgroup: 1.77 -> 1.24 ms only).
+// Here a tile's list is cut into up to LONG_SEGS SEGMENTS, each walked by its own single-wave workgroup anywhere on the chip:
+// a wave owns a contiguous run of list positions and ALL 256 pixels (four per lane, the main kernel's layout: row-then-column
+// reduction, no cross-wave sums — each instance is reduced by exactly one wave and stored once).  The back-to-front recursions
+// of a pixel (render.jl:237-258)
+//     T <- T / (1 - alpha)           A <- alpha (colour . v) + (1 - alpha) A
+// are affine in (T, A), so a segment's effect is (m, c) with m = prod (1 - alpha), c the A it leaves from A = 0:
+//   PASS 1 (first launch): every wave walks its segment evaluating only the blend test, alpha and colour . v  ->  (m, c) per
+//           pixel into `state` (global: [listed tile][segment][256 pixels][2]);
+//   PASS 2 (second launch, same grid): wave g starts from  T = T_final / prod_{g' behind} m,  A = the composition of the
+//           (m, c) behind it, and walks its segment again with the full gradient body.
+// ~1.6 x the arithmetic of one walk, spread over the chip; no workgroup barrier anywhere.  The decisions (`bits(sigma) < X`,
+// position < n_contrib) are the forward's, per pixel, as everywhere; what differs from the one-wave walk is the association of
+// the products of (1 - alpha) across segment boundaries (last-bit level).
+constexpr int LONG_SEGS = GSR_BWD_LONG_SEGS;
+
+template <int C, bool BG0, int PASS>
+__global__ __launch_bounds__(64) void composite_bwd_long_kernel(int W, int H, int grid_x,
+                                                                const uint32_t* __restrict__ tile_start,
+                                                                GsrStream stream, Bg bg,
+                                                                const float* __restrict__ vpixels,
+                                                                const uint32_t* __restrict__ n_contrib,
+                                                                const float* __restrict__ final_T, GsrInst inst,
+                                                                GsrTierLists tiers, float2* __restrict__ state) {
+    constexpr int NA = AccRow<C>::N, ST = AccRow<C>::STRIDE, PPL = 4;
+    __shared__ float4 l0[64], l1[64], l2[64];
+    __shared__ float4 l3[C > 3 ? 64 : 1];
+    __shared__ float my[64 * ST];
+    __builtin_amdgcn_s_setprio(3);  // these few waves are the critical path of the step; they share SIMDs with the main launch
+    const int lane = threadIdx.x;
+    const uint32_t listed = blockIdx.x / LONG_SEGS;
+    const int g = (int)(blockIdx.x % LONG_SEGS);  // segment; g = 0 is the BACK of the list
+    const gsr::LaneBits lane_bits(lane);
+    const int red_slot = gsr::wave_reduce_index<NA>(lane);
+    const bool red_writer = gsr::wave_reduce_writer(lane);
+    const gsr::RowColConsts rowcol(lane);
+    const gsr::RowColConstsD rowcol_d(lane);
+    int tile;
+    {
+        uint32_t b = listed;
+        const uint32_t* list = tiers.lists;                                              // lists > 8192
+        if (b >= tiers.n_big) { b -= tiers.n_big; list = tiers.lists + tiers.n_tiles;    // (4096, 8192]
+            if (b >= tiers.n_mid8) { b -= tiers.n_mid8; list = tiers.lists + 2 * (size_t)tiers.n_tiles; } }  // (1024, 4096]
+        tile = (int)list[b];
+    }
+    const int tile_x = tile % grid_x, tile_y = tile / grid_x;
+    const int px = tile_x * GSR_TILE + (lane & 15);
+    const int py0 = tile_y * GSR_TILE + (lane >> 4);
+    const float fx = (float)px;
+    const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
+    if (end == start) return;
+    float fy[PPL], T[PPL], A[PPL], bgT[BG0 ? 1 : PPL], vp[PPL][C];
+    int last_contributor[PPL];
+    int tile_last = 0;
+#pragma unroll
+    for (int q = 0; q < PPL; q++) {
+        const int py = py0 + 4 * q;
+        const bool inside = px < W && py < H;
+        const size_t pi = (size_t)px + (size_t)W * py;
+        fy[q] = (float)py;
+        const float T_final = inside ? final_T[pi] : 0.0f;
+        T[q] = T_final;
+        last_contributor[q] = inside ? (int)n_contrib[pi] : 0;
+        float bg_dot = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            vp[q][c] = inside ? vpixels[(size_t)C * pi + c] : 0.0f;
+            bg_dot += bg.v[c] * vp[q][c];
+        }
+        if (!BG0) bgT[BG0 ? 0 : q] = -T_final * bg_dot;
+        A[q] = 0.0f;
+        tile_last = max(tile_last, last_contributor[q]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tile_last = max(tile_last, __shfl_xor(tile_last, off));
+    tile_last = __builtin_amdgcn_readfirstlane(tile_last);  // list positions tile_last-1 ... 0 are walked (the wave holds all 256 pixels)
+    // segment g: positions [lo, hi), walked from hi - 1 down; whole 64-entry batches per segment
+    const int seg = (((tile_last + LONG_SEGS - 1) / LONG_SEGS) + 63) & ~63;
+    const int hi = tile_last - g * seg, lo = max(0, hi - seg);
+    float2* const st_tile = state + (size_t)listed * LONG_SEGS * 256;
+    if (PASS == 2 && g == 0) {
+        // instances behind every pixel's last contributor are never staged: their rows are zero (once per tile)
+        for (uint32_t p = start + (uint32_t)tile_last + lane; p < end; p += 64) {
+            float4* row = inst.rows + (size_t)GSR_ROW_F4(C) * __float_as_uint(stream.s2[p].y);
+            const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            row[0] = z; row[1] = z; row[2] = z;
+            if (C > 5) row[3] = z;
+        }
+    }
+    if (hi <= 0) {  // an empty segment (a list shorter than LONG_SEGS batches): the identity
+        if (PASS == 1) {
+#pragma unroll
+            for (int q = 0; q < PPL; q++) st_tile[(size_t)g * 256 + lane + 64 * q] = make_float2(1.0f, 0.0f);
+        }
+        return;
+    }
+
+    // one batch of <= 64 entries of the segment, staged into LDS; returns the candidate ballot
+    auto stage = [&](int top /* first (highest) position of the batch + 1 */, int cnt) -> unsigned long long {
+        __builtin_amdgcn_wave_barrier();  // the previous batch's LDS reads are done (single wave, in order)
+        uint32_t mask = 0u;
+        if (lane < cnt) {
+            const uint32_t idx = start + (uint32_t)(top - 1 - lane);
+            l0[lane] = stream.s0[idx];
+            l1[lane] = stream.s1[idx];
+            const float4 t2 = stream.s2[idx];
+            l2[lane] = make_float4(t2.x, t2.w, t2.z, t2.y);  // (third colour, footprint mask, depth | threshold, slot)
+            if (C > 3) l3[C > 3 ? lane : 0] = stream.s3[idx];
+            mask = __float_as_uint(t2.w);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        return wave_ballot(lane < cnt && (mask & 0xFFFFu) != 0u);
+    };
+
+    if (PASS == 1) {
+        // ---- (m, c) of this segment, per pixel ----
+        float m_[PPL], c_[PPL];
+#pragma unroll
+        for (int q = 0; q < PPL; q++) { m_[q] = 1.0f; c_[q] = 0.0f; }
+        for (int top = hi; top > lo; top -= 64) {
+            const int cnt = min(64, top - lo);
+            unsigned long long wl = stage(top, cnt);
+            while (wl) {
+                const int j = __builtin_ctzll(wl);
+                wl &= wl - 1;
+                const int contributor = top - 1 - j;
+                const float4 a = l0[j], b = l1[j];
+                const float4 t2 = l2[j];
+                const float4 c2 = make_float4(t2.x, 0.0f, t2.z, t2.y);
+                float4 t3 = t2;
+                if (C > 3) t3 = l3[C > 3 ? j : 0];
+                const uint32_t thr_bits = __float_as_uint(C == 3 ? t2.z : t3.w);
+                const float o = b.y, dx = a.x - fx;
+                const SigmaX sx = sigma_x(a.z, a.w, dx);
+                float f[C];
+                unpack_features<C>(b, c2, t3, f);
+                const uint32_t rowbits = __builtin_amdgcn_readfirstlane(__float_as_uint(t2.y));
+#pragma unroll
+                for (int q = 0; q < PPL; q++) {
+                    if (__builtin_amdgcn_readfirstlane((int)((rowbits >> (4 * q)) & 0xFu)) == 0) continue;
+                    const float dy = a.y - fy[q], dy2 = __fmul_rn(dy, dy);
+                    const float sigma = sigma_of(sx, b.x, dy, dy2);
+                    if (contributor < last_contributor[q] && __float_as_uint(sigma) < thr_bits) {
+                        const float alpha = alpha_of(o, __expf(-sigma));
+                        float cv = f[0] * vp[q][0];
+#pragma unroll
+                        for (int c = 1; c < C; c++) cv += f[c] * vp[q][c];
+                        c_[q] = c_[q] + alpha * (cv - c_[q]);   // alpha cv + (1 - alpha) c: the A recursion from A = 0
+                        m_[q] = m_[q] * (1.0f - alpha);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PPL; q++) st_tile[(size_t)g * 256 + lane + 64 * q] = make_float2(m_[q], c_[q]);
+        return;
+    }
+
+    // ---- PASS 2.  The state this segment starts from: everything BEHIND it (segments 0 .. g-1), back to front ----
+    for (int k = 0; k < g; k++) {
+#pragma unroll
+        for (int q = 0; q < PPL; q++) {
+            const float2 mc = st_tile[(size_t)k * 256 + lane + 64 * q];
+            T[q] = T[q] / mc.x;               // (a pixel nothing of the segment blends into: m = 1, c = 0)
+            A[q] = mc.x * A[q] + mc.y;
+        }
+    }
+    // ---- the gradient walk of the segment (the main kernel's body: one wave = the whole tile) ----
+    for (int top = hi; top > lo; top -= 64) {
+        const int cnt = min(64, top - lo);
+        unsigned long long wl = stage(top, cnt);
+        unsigned long long touched = 0ull;
+        while (wl) {
+            const int j = __builtin_ctzll(wl);
+            wl &= wl - 1;
+            const int contributor = top - 1 - j;
+            const float4 a = l0[j], b = l1[j];
+            const float4 t2 = l2[j];
+            const float4 c2 = make_float4(t2.x, 0.0f, t2.z, t2.y);
+            float4 t3 = t2;
+            if (C > 3) t3 = l3[C > 3 ? j : 0];
+            const uint32_t thr_bits = __float_as_uint(C == 3 ? t2.z : t3.w);
+            const float o = b.y, dx = a.x - fx;
+            const SigmaX sx = sigma_x(a.z, a.w, dx);
+            float f[C];
+            unpack_features<C>(b, c2, t3, f);
+            float P = 0.0f, U1 = 0.0f, U2 = 0.0f, col[C];
+#pragma unroll
+            for (int c = 0; c < C; c++) col[c] = 0.0f;
+            unsigned long long any_active = 0ull;
+            const uint32_t rowbits = __builtin_amdgcn_readfirstlane(__float_as_uint(t2.y));
+#pragma unroll
+            for (int q = 0; q < PPL; q++) {
+                if (__builtin_amdgcn_readfirstlane((int)((rowbits >> (4 * q)) & 0xFu)) == 0) continue;
+                const float dy = a.y - fy[q], dy2 = __fmul_rn(dy, dy);
+                const float sigma = sigma_of(sx, b.x, dy, dy2);
+                const bool c_live = contributor < last_contributor[q];
+                const bool c_touch = __float_as_uint(sigma) < thr_bits;
+                const bool active = c_live && c_touch;
+                any_active |= wave_ballot(c_live) & wave_ballot(c_touch);
+                if (active) {
+                    const float G = __expf(-sigma);
+                    const float alpha = alpha_of(o, G);
+                    const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
+                    T[q] = T[q] * rinv;
+                    const float fac = alpha * T[q];
+                    float cv = f[0] * vp[q][0];
+#pragma unroll
+                    for (int c = 1; c < C; c++) cv += f[c] * vp[q][c];
+                    const float d = cv - A[q];
+                    const float valpha = BG0 ? d * T[q] : d * T[q] + bgT[BG0 ? 0 : q] * rinv;
+                    A[q] = A[q] + alpha * d;
+                    const float t = G * valpha;
+                    P += t;
+                    U1 += t * dy;
+                    U2 += t * dy2;
+#pragma unroll
+                    for (int c = 0; c < C; c++) col[c] += fac * vp[q][c];
+                }
+            }
+            if (any_active == 0ull) continue;
+            int jrow;
+            asm("s_mul_i32 %0, %1, %2" : "=s"(jrow) : "s"(j), "n"(ST));
+            float* const my_row = my + jrow;
+            touched |= 1ull << j;
+            if (C == 3) {
+                const float total = gsr::wave_reduce_rowcol_rgb(P, U1, U2, col[0], col[1], col[2], dx, lane_bits, rowcol);
+                if (rowcol.slot >= 0) my_row[rowcol.slot] = total;
+            } else if (C == 5) {
+                const float total = gsr::wave_reduce_rowcol_rgbd(P, U1, U2, col[0], col[1], col[2], col[C > 3 ? 3 : 0], dx, lane_bits, rowcol_d);
+                if (rowcol_d.slot >= 0) my_row[rowcol_d.slot] = total;
+            } else {
+                float part[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) part[k] = 0.0f;
+                const float dxp = dx * P;
+                part[0] = col[0]; part[1] = col[1]; part[2] = col[2];
+                part[3] = P; part[4] = dx * dxp; part[5] = dx * U1; part[6] = U2; part[7] = dxp; part[8] = U1;
+                if (C > 3) part[9] = col[3];
+                if (C > 5) { part[10] = col[5]; part[11] = col[6]; part[12] = col[7]; }
+                const float total = gsr::wave_reduce_transposed<NA>(part, lane_bits);
+                if (red_writer) my_row[red_slot] = total;
+            }
+        }
+        // flush: one gradient row per staged instance (zeros when nothing touched it), the main kernel's row format
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < cnt) {
+            float r[NA];
+            const bool hit = (touched >> lane) & 1ull;
+#pragma unroll
+            for (int k = 0; k < NA; k++) r[k] = hit ? my[lane * ST + k] : 0.0f;
+            const float4 a = l0[lane], b = l1[lane];
+            const float mo = -b.y, mh = -0.5f * b.y;
+            float4* row = inst.rows + (size_t)GSR_ROW_F4(C) * __float_as_uint(l2[lane].w);
+            row[0] = make_float4(r[0], r[1], r[2], r[3]);
+            row[1] = make_float4(mh * r[4], mh * r[5], mh * r[6], C > 3 ? r[9 < NA ? 9 : 0] : 0.0f);
+            row[2] = make_float4(mo * (2.0f * a.z * r[7] + a.w * r[8]), mo * (a.w * r[7] + 2.0f * b.x * r[8]),
+                                 C > 5 ? r[10 < NA ? 10 : 0] : 0.0f, C > 5 ? r[11 < NA ? 11 : 0] : 0.0f);
+            if (C > 5) row[3] = make_float4(r[12 < NA ? 12 : 0], 0.0f, 0.0f, 0.0f);
+        }
+    }
+}
+
 // exactly zero (either sign) in every channel: the kernels' BG0 specialisation; GSR_NO_BG0=1 disables it (A/B runs)
 bool bg_is_zero(const Bg& b) {
     static const bool off = [] { const char* e = getenv("GSR_NO_BG0"); return e && e[0] == '1'; }();
@@ -705,16 +976,37 @@ void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uin
 
 void gsr_launch_composite_bwd_listed(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
                                      GsrTierLists tiers, GsrStream stream, const float* background,
-                                     const float* vpixels, const uint32_t* n_contrib, const float* final_T, GsrInst inst) {
+                                     const float* vpixels, const uint32_t* n_contrib, const float* final_T, GsrInst inst,
+                                     float* long_state) {
     const uint32_t n_listed = tiers.n_big + tiers.n_mid8 + tiers.n_mid4;
     if (n_listed == 0) return;
-    dim3 grid(n_listed), block(256);
     Bg bg = make_bg(background, channels);
+    // GSR_BWD_LONG=0: round 4's form (four waves per tile by pixel strips) for A/B runs; default: the list split along its length
+    static const bool by_strips = [] { const char* e = getenv("GSR_BWD_LONG"); return e && e[0] == '0'; }();
+    if (by_strips) {
+        dim3 grid(n_listed), block(256);
 #define LAUNCH(CC)                                                                                                 \
-    hipLaunchKernelGGL((composite_bwd_kernel<CC, 1, true, false>), grid, block, 0, s, cam.width, cam.height, cam.grid_x,  \
-                       tile_start, (const uint32_t*)nullptr, stream, bg, vpixels, n_contrib, final_T, inst, tiers)
-    if (channels == 3) LAUNCH(3);
-    else if (channels == 5) LAUNCH(5);
-    else LAUNCH(8);
+        hipLaunchKernelGGL((composite_bwd_kernel<CC, 1, true, false>), grid, block, 0, s, cam.width, cam.height, cam.grid_x,  \
+                           tile_start, (const uint32_t*)nullptr, stream, bg, vpixels, n_contrib, final_T, inst, tiers)
+        if (channels == 3) LAUNCH(3);
+        else if (channels == 5) LAUNCH(5);
+        else LAUNCH(8);
+#undef LAUNCH
+        return;
+    }
+    dim3 grid(n_listed * LONG_SEGS), block(64);
+    const bool bg0 = bg_is_zero(bg);
+    float2* st = reinterpret_cast<float2*>(long_state);
+#define LAUNCH(CC, ZZ)                                                                                                    \
+    do {                                                                                                                  \
+        hipLaunchKernelGGL((composite_bwd_long_kernel<CC, ZZ, 1>), grid, block, 0, s, cam.width, cam.height, cam.grid_x,  \
+                           tile_start, stream, bg, vpixels, n_contrib, final_T, inst, tiers, st);                         \
+        hipLaunchKernelGGL((composite_bwd_long_kernel<CC, ZZ, 2>), grid, block, 0, s, cam.width, cam.height, cam.grid_x,  \
+                           tile_start, stream, bg, vpixels, n_contrib, final_T, inst, tiers, st);                         \
+    } while (0)
+    if (channels == 3) { if (bg0) LAUNCH(3, true); else LAUNCH(3, false); }
+    else if (channels == 5) { if (bg0) LAUNCH(5, true); else LAUNCH(5, false); }
+    else if (bg0) LAUNCH(8, true);
+    else LAUNCH(8, false);
 #undef LAUNCH
 }

@@ -199,7 +199,7 @@ struct gsr_handle {
     bool last_compact = false;
     bool tile_count_dirty = false;  // counters not yet re-zeroed by the tile sort
     double wait_ema_us = 0.0;       // running average of the host's wait for the instance count (wait_totals)
-    DevBuf bins, keys_compact, big_list, values_sorted, s0, s1, s2, s3, big_scratch;
+    DevBuf bins, keys_compact, big_list, values_sorted, s0, s1, s2, s3, big_scratch, long_state;
     uint32_t bin_cap_used(bool use_bins) const { return use_bins ? bin_cap_view : 0u; }
     // backward: per-instance gradient rows + instance position map; gstate.∇means_2d
     DevBuf rows, vmean2d;
@@ -462,7 +462,7 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
     DevBuf* list[] = {&h->ranges, &h->n_contrib, &h->final_T, &h->tile_count, &h->tile_start, &h->tile_order, &h->totals,
                       &h->geo, &h->gnormal, &h->radii, &h->bsum, &h->bpre, &h->bvis, &h->bins, &h->values_sorted, &h->s0,
                       &h->s1, &h->s2, &h->s3, &h->big_scratch, &h->rows, &h->vmean2d, &h->d0, &h->d1,
-                      &h->d2, &h->partial, &h->keys_compact, &h->big_list};
+                      &h->d2, &h->partial, &h->keys_compact, &h->big_list, &h->long_state};
     for (DevBuf* b : list) h->all[h->n_all++] = b;
     const size_t P = (size_t)cfg->width * cfg->height, T = (size_t)h->n_tiles;
     int rc = GSR_OK;
@@ -683,7 +683,8 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     size_t slab_stride = 0;
     if (n_big > 0) {  // lists beyond the LDS sort: two merge slabs per listed tile
         slab_stride = ((size_t)max_tile + 63) & ~(size_t)63;
-        if ((rc = h->big_scratch.ensure((size_t)n_big * 2 * slab_stride * 8))) return rc;
+        // (+ the plan of the multi-workgroup sort: 2 (n_big + 1) words behind the slabs)
+        if ((rc = h->big_scratch.ensure((size_t)n_big * 2 * slab_stride * 8 + (size_t)(2 * n_big + 2) * 4 + 64))) return rc;
     }
     if (!fused_done || long_tiles) {
         StageScope sc4(h->prof, ST_SORT, s);
@@ -727,7 +728,8 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
 // ~20 % more work per instance, so when long tiles are plentiful they stay with the main launch.
 static int launch_composite_bwd(gsr_handle* h, hipStream_t s, int C, const GsrCam& k, const float* background,
                                 const float* vpixels) {
-    constexpr uint32_t kMaxSplitTiles = 256;
+    // (GSR_BWD_SPLIT_TILES overrides the limit for A/B runs)
+    static const uint32_t kMaxSplitTiles = [] { const char* e = getenv("GSR_BWD_SPLIT_TILES"); return e ? (uint32_t)atoi(e) : 256u; }();
     GsrTierLists tiers{h->big_list.as<uint32_t>(), (uint32_t)h->n_tiles, 0, 0, 0, 0xFFFFFFFFu};
     const uint32_t cut[3] = {GSR_SORT_LDS_CAP, 4096u, 1024u};             // deepest tier first
     const uint32_t have[3] = {h->tier_n[2], h->tier_n[1], h->tier_n[0]};
@@ -739,10 +741,14 @@ static int launch_composite_bwd(gsr_handle* h, hipStream_t s, int C, const GsrCa
     }
     if (n == 0) tiers.split_len = 0xFFFFFFFFu;  // nothing to split (or the deepest tier alone is already plentiful)
     if (n > 0) {
+        // per (listed tile, list segment, pixel): the (m, c) of the segment — the first pass's hand-over to the second
+        int rc = h->long_state.ensure((size_t)n * GSR_BWD_LONG_SEGS * 256 * 2 * sizeof(float));
+        if (rc) return rc;
         HIPCHK(hipEventRecord(h->ev_fork, s));
         HIPCHK(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
         gsr_launch_composite_bwd_listed(h->aux_stream, C, k, h->tile_start.as<uint32_t>(), tiers, stream_of(h), background,
-                                        vpixels, h->n_contrib.as<uint32_t>(), h->final_T.as<float>(), inst_of(h));
+                                        vpixels, h->n_contrib.as<uint32_t>(), h->final_T.as<float>(), inst_of(h),
+                                        h->long_state.as<float>());
         HIPCHK(hipEventRecord(h->ev_join, h->aux_stream));
     }
     gsr_launch_composite_bwd(s, C, k, h->tile_start.as<uint32_t>(), h->tile_order.as<uint32_t>(), stream_of(h), background,

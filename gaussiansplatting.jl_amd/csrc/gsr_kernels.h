@@ -57,6 +57,10 @@ struct GsrStream {
 // Gaussian-major instance slot, so the rows of one Gaussian are contiguous and the
 // per-Gaussian kernel sums them in a fixed order (deterministic gradients).
 //   row = 4 x float4: {v r, v g, v b, v opacity}, {v conic a,b,c, v depth}, {v mean2d x,y, v normal x,y}, {v normal z,-,-,-}
+// segments a long tile list is cut into by the list-parallel backward (composite_bwd_long_kernel)
+#ifndef GSR_BWD_LONG_SEGS
+#define GSR_BWD_LONG_SEGS 32
+#endif
 #ifndef GSR_ROW_F4
 #define GSR_ROW_F4(C) ((C) > 3 ? 4 : 3)  // float4s per gradient row: 48 bytes in :rgb mode (9 floats used), 64 otherwise
 #endif
@@ -153,7 +157,8 @@ void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uin
                               uint32_t split_len /* tiles with a longer list are left to the listed launch */);
 void gsr_launch_composite_bwd_listed(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
                                      GsrTierLists tiers, GsrStream stream, const float* background,
-                                     const float* vpixels, const uint32_t* n_contrib, const float* final_T, GsrInst inst);
+                                     const float* vpixels, const uint32_t* n_contrib, const float* final_T, GsrInst inst,
+                                     float* long_state /* GSR_BWD_LONG_SEGS x 512 floats per listed tile */);
 
 // ---- trainer.hip ----
 #define GSR_ADAM_MAX_GROUPS 8

@@ -111,6 +111,58 @@ for r in rows[:12]:
 PY
 }
 
+# g: long tiles' backward split along the list (composite_bwd_long_kernel: first 8 segment waves in ONE workgroup per tile —
+#    1.77 -> 1.24 ms, bound by the four SIMDs of its CU —, then one single-wave workgroup per (tile, segment), 32 segments, two
+#    launches) against round 4's
+#    four strips per tile (GSR_BWD_LONG=0): parity of every long-list test, then hot-tile scenes both ways
+case_g() {
+set -x
+O=gpurun_out/r05g; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scenes.py tests/test_gpu_fuzz_regressions.py tests/test_gpu_scale.py tests/test_gpu_forward_only.py -x -q > $O/pytest.log 2>&1; echo "rc=$?"; tail -5 $O/pytest.log
+line() { python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['roofline']['stages_ms']
+print('$1', d['ms_per_step'], 'D', d['config']['tile_instances'], d['config']['binning']['mode'][:7], ' '.join(f'{k}={v:.3f}' for k,v in s.items()))"; }
+B="python bench.py --in-process --no-extra --no-cpu-baseline --no-other-lists --steps 10 --warmup 3 --steady-steps 0"
+for sk in hot:32000 hot:8000 hot:128000; do
+  $B --skew $sk --no-loss 2>/dev/null | line "$sk by-list-segments"
+  GSR_BWD_LONG=0 $B --skew $sk --no-loss 2>/dev/null | line "$sk by-strips"
+done
+$B --scene trained --seed 1010 --mode rgbd 2>/dev/null | line "trained1m by-list-segments"
+GSR_BWD_LONG=0 $B --scene trained --seed 1010 --mode rgbd 2>/dev/null | line "trained1m by-strips"
+$B --scene trained --seed 1011 --mode rgbd --gaussians 3000000 --width 2560 --height 1440 2>/dev/null | line "trained3m by-list-segments"
+GSR_BWD_LONG=0 $B --scene trained --seed 1011 --mode rgbd --gaussians 3000000 --width 2560 --height 1440 2>/dev/null | line "trained3m by-strips"
+$B 2>/dev/null | line "cfg3"
+C5="--gaussians 5000000 --width 3840 --height 2160 --no-loss --seed 1005"
+$B $C5 --skew dense:0.01:50 2>/dev/null | line "dense4k split<=256 tiles"
+GSR_BWD_SPLIT_TILES=4096 $B $C5 --skew dense:0.01:50 2>/dev/null | line "dense4k split<=4096 tiles"
+GSR_BWD_SPLIT_TILES=4096 $B --scene trained --seed 1011 --mode rgbd --gaussians 3000000 --width 2560 --height 1440 2>/dev/null | line "trained3m split<=4096"
+GSR_BWD_SPLIT_TILES=4096 $B --scene trained --seed 1010 --mode rgbd 2>/dev/null | line "trained1m split<=4096"
+}
+
+# h: lists beyond 8192 keys sorted by many workgroups (plan -> chunk sorts -> merge passes -> emit as separate launches) instead of
+#    one 1024-thread workgroup per tile: parity (every test with a long list), then the hot-tile scenes and dense 4K
+case_h() {
+set -x
+O=gpurun_out/r05h; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scenes.py tests/test_gpu_fuzz_regressions.py tests/test_gpu_preprocess_forms.py tests/test_gpu_forward_only.py -x -q > $O/pytest.log 2>&1; echo "rc=$?"; tail -5 $O/pytest.log
+line() { python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['roofline']['stages_ms']
+print('$1', d['ms_per_step'], 'D', d['config']['tile_instances'], d['config']['binning']['mode'][:7], ' '.join(f'{k}={v:.3f}' for k,v in s.items()))"; }
+B="python bench.py --in-process --no-extra --no-cpu-baseline --no-other-lists --steps 10 --warmup 3 --steady-steps 0"
+for sk in hot:32000 hot:8000 hot:128000; do $B --skew $sk --no-loss 2>/dev/null | line "$sk"; done
+C5="--gaussians 5000000 --width 3840 --height 2160 --no-loss --seed 1005"
+$B $C5 --skew dense:0.01:50 2>/dev/null | line "dense4k"
+$B 2>/dev/null | line "cfg3"
+timeout 600 bash tools/kernel_times.sh --steps 10 --warmup 3 --steady-steps 0 --skew hot:32000 --no-loss > $O/ktimes_hot.txt 2>&1
+cp gpurun_out/ktimes_default/st_kernel_stats.csv $O/kernel_stats_hot.csv
+python - <<'PY'
+import csv,re
+rows=list(csv.DictReader(open('gpurun_out/r05h/kernel_stats_hot.csv',newline='')))
+for r in rows[:18]:
+    m=re.search(r'(\w+_kernel)',r['Name']); print('  %-34s calls %4s avg %9.1f us'%((m.group(1) if m else r['Name'][:34]), r['Calls'], float(r['AverageNs'])/1e3))
+PY
+}
+
 if [ "$1" = "--list" ] || [ -z "$1" ]; then declare -F | sed -n "s/^declare -f case_//p"; exit 0; fi
 if ! declare -F "case_$1" > /dev/null; then echo "unknown case $1 (try --list)" >&2; exit 2; fi
 "case_$1"

@@ -163,6 +163,46 @@ for r in rows[:18]:
 PY
 }
 
+# fuzz: the round's campaign on the build with the banded / SCATTER binning, the float64 scales-rotations chain, the list-split long
+#       backward and the multi-workgroup long sort: fresh case ranges; once more with the aggregating form forced
+case_fuzz() {
+set -x
+O=gpurun_out/r05_fuzz; mkdir -p $O
+timeout 900 python tools/fuzz_parity.py 1000 12000 > $O/sweep.txt 2>&1; echo "rc=$?" >> $O/sweep.txt
+timeout 900 python tools/fuzz_parity.py deep 400 3000 > $O/deep.txt 2>&1; echo "rc=$?" >> $O/deep.txt
+timeout 700 python tools/fuzz_parity.py edge 500 6000 > $O/edge.txt 2>&1; echo "rc=$?" >> $O/edge.txt
+GSR_PREPROCESS_AGG=1 timeout 700 python tools/fuzz_parity.py 600 13000 > $O/sweep_agg.txt 2>&1; echo "rc=$?" >> $O/sweep_agg.txt
+GSR_PREPROCESS_AGG=1 timeout 700 python tools/fuzz_parity.py deep 200 3400 > $O/deep_agg.txt 2>&1; echo "rc=$?" >> $O/deep_agg.txt
+timeout 300 python tools/fuzz_parity.py trainer 40 100 > $O/trainer.txt 2>&1; echo "rc=$?" >> $O/trainer.txt
+for f in sweep deep edge sweep_agg deep_agg trainer; do echo "== $f"; grep -E "^FAIL|cases passed|^rc=" $O/$f.txt | awk '{ if ($1=="FAIL") printf "%s:%s ", $3, $NF; else print }'; echo; done
+}
+
+# i: float64 arbitration of the campaign's failing cases; the tier launches beside the fused forward (GSR_NO_TIER_OVERLAP=1 = before);
+#    the whole -m gpu suite on the build
+case_i() {
+set -x
+O=gpurun_out/r05i; mkdir -p $O
+timeout 900 python tools/fuzz_parity.py arbitrate sweep 12490 12526 > $O/arb_sweep.txt 2>&1
+GSR_PREPROCESS_AGG=1 timeout 900 python tools/fuzz_parity.py arbitrate sweep 13123 13257 13517 13598 > $O/arb_sweep_agg.txt 2>&1
+timeout 900 python tools/fuzz_parity.py arbitrate edge 6389 6411 6426 6432 > $O/arb_edge.txt 2>&1
+grep -hE "^(sweep|edge) [0-9]+|Assertion|Error" $O/arb_*.txt | cut -c1-700
+line() { python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['roofline']['stages_ms']
+print('$1', d['ms_per_step'], 'D', d['config']['tile_instances'], d['config']['binning']['mode'][:7], ' '.join(f'{k}={v:.3f}' for k,v in s.items()))"; }
+B="python bench.py --in-process --no-extra --no-cpu-baseline --no-other-lists --steps 20 --warmup 3 --steady-steps 0"
+C5="--gaussians 5000000 --width 3840 --height 2160 --no-loss --seed 1005"
+for rep in 1 2; do
+$B --scene trained --seed 1010 --mode rgbd 2>/dev/null | line "trained1m beside"
+GSR_NO_TIER_OVERLAP=1 $B --scene trained --seed 1010 --mode rgbd 2>/dev/null | line "trained1m behind"
+done
+$B --scene trained --seed 1011 --mode rgbd --gaussians 3000000 --width 2560 --height 1440 2>/dev/null | line "trained3m beside"
+GSR_NO_TIER_OVERLAP=1 $B --scene trained --seed 1011 --mode rgbd --gaussians 3000000 --width 2560 --height 1440 2>/dev/null | line "trained3m behind"
+$B $C5 --skew dense:0.01:50 2>/dev/null | line "dense4k beside"
+GSR_NO_TIER_OVERLAP=1 $B $C5 --skew dense:0.01:50 2>/dev/null | line "dense4k behind"
+$B 2>/dev/null | line "cfg3"
+timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "rc=$?"; tail -4 $O/pytest.log
+}
+
 if [ "$1" = "--list" ] || [ -z "$1" ]; then declare -F | sed -n "s/^declare -f case_//p"; exit 0; fi
 if ! declare -F "case_$1" > /dev/null; then echo "unknown case $1 (try --list)" >&2; exit 2; fi
 "case_$1"

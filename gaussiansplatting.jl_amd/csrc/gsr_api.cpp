@@ -609,15 +609,6 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     if (fwd_only) cap_instances = 0xFFFFFFFFull;  // nothing is stored per instance: no capacity to respect
     static const bool no_fused = [] { const char* e = getenv("GSR_NO_FUSED_FWD"); return e && e[0] == '1'; }();  // A/B only
     const bool spec = use_bins && cap_instances > 0 && !no_fused;
-    // Tier tiles BESIDE the fused launch (round 5).  Lists beyond the fused kernel's 1024 instances are sorted and composited by
-    // their own launches — a few hundred workgroups that used to run AFTER the fused kernel on the caller's stream (trained-like
-    // 1 M scene: 0.13 ms behind a 0.16 ms fused launch).  They touch other tiles, other list ranges, other pixels: when the
-    // previous view had such tiles the stream is forked right behind the scan (one event record: a ~5 us bubble, which is why a
-    // view without long lists does not pay it) and, once the host has read the totals, the tier launches go to the handle's
-    // second stream, where they run next to the fused kernel.
-    static const bool no_tier_overlap = [] { const char* e = getenv("GSR_NO_TIER_OVERLAP"); return e && e[0] == '1'; }();  // A/B only
-    const bool forked = spec && !no_tier_overlap && (h->tier_n[0] | h->tier_n[1] | h->tier_n[2]) != 0u;
-    if (forked) HIPCHK(hipEventRecord(h->ev_fork, s));
     if (spec) {
         StageScope sc3(h->prof, ST_SORT_COMPOSITE_FWD, s);
         gsr_launch_sort_composite_fwd(s, C, k, h->tile_start.as<uint32_t>(), h->tile_order.as<uint32_t>(),
@@ -696,13 +687,6 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
         if ((rc = h->big_scratch.ensure((size_t)n_big * 2 * slab_stride * 8 + (size_t)(2 * n_big + 2) * 4 + 64))) return rc;
     }
     if (!fused_done || long_tiles) {
-        // (the tier launches of a view the fused kernel handled: on the second stream, beside it)
-        const bool beside = forked && fused_done && !compact;
-        hipStream_t const s_main = s;
-        if (beside) {
-            HIPCHK(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
-            s = h->aux_stream;
-        }
         StageScope sc4(h->prof, ST_SORT, s);
         const uint64_t* keys = h->bins.as<uint64_t>();
         uint32_t key_cap = h->bin_cap_used(use_bins);
@@ -729,11 +713,6 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
                                  h->values_sorted.as<uint32_t>(), aux ? aux->covisibilities : nullptr,
                                  aux ? aux->uncertainties : nullptr, &tiers);
         sc5.close();
-        if (beside) {
-            HIPCHK(hipEventRecord(h->ev_join, h->aux_stream));
-            HIPCHK(hipStreamWaitEvent(s_main, h->ev_join, 0));
-            s = s_main;
-        }
     }
     h->tile_count_dirty = false;  // the sort (fused or not) zeroed the counters
     HIPCHK(hipGetLastError());

@@ -203,6 +203,32 @@ $B 2>/dev/null | line "cfg3"
 timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "rc=$?"; tail -4 $O/pytest.log
 }
 
+# j: the handle's second stream at the highest priority: tier launches beside the fused forward (GSR_NO_TIER_OVERLAP=1 = behind it),
+#    GSR_AUX_STREAM_DEFAULT_PRIORITY=1 = the stream as in rounds 2-4
+case_j() {
+set -x
+O=gpurun_out/r05j; mkdir -p $O
+line() { python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['roofline']['stages_ms']
+print('$1', d['ms_per_step'], 'D', d['config']['tile_instances'], d['config']['binning']['mode'][:7], ' '.join(f'{k}={v:.3f}' for k,v in s.items()))"; }
+B="python bench.py --in-process --no-extra --no-cpu-baseline --no-other-lists --steps 20 --warmup 3 --steady-steps 0"
+C5="--gaussians 5000000 --width 3840 --height 2160 --no-loss --seed 1005"
+T1="--scene trained --seed 1010 --mode rgbd"; T3="--scene trained --seed 1011 --mode rgbd --gaussians 3000000 --width 2560 --height 1440"
+for rep in 1 2; do
+$B $T1 2>/dev/null | line "trained1m beside, high-priority stream"
+GSR_AUX_STREAM_DEFAULT_PRIORITY=1 $B $T1 2>/dev/null | line "trained1m beside, default priority"
+GSR_NO_TIER_OVERLAP=1 $B $T1 2>/dev/null | line "trained1m behind"
+done
+$B $T3 2>/dev/null | line "trained3m beside, high-priority stream"
+GSR_NO_TIER_OVERLAP=1 $B $T3 2>/dev/null | line "trained3m behind"
+$B $C5 --skew dense:0.01:50 2>/dev/null | line "dense4k beside, high-priority stream"
+GSR_NO_TIER_OVERLAP=1 $B $C5 --skew dense:0.01:50 2>/dev/null | line "dense4k behind"
+$B --skew hot:32000 --no-loss 2>/dev/null | line "hot32k high-priority stream"
+GSR_AUX_STREAM_DEFAULT_PRIORITY=1 $B --skew hot:32000 --no-loss 2>/dev/null | line "hot32k default priority"
+$B 2>/dev/null | line "cfg3"
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scenes.py tests/test_gpu_forward_only.py -x -q > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log
+}
+
 if [ "$1" = "--list" ] || [ -z "$1" ]; then declare -F | sed -n "s/^declare -f case_//p"; exit 0; fi
 if ! declare -F "case_$1" > /dev/null; then echo "unknown case $1 (try --list)" >&2; exit 2; fi
 "case_$1"

@@ -2,7 +2,7 @@
 # On the GPU box: everything the round's profiles/<round>/final directory is built from.   tools/measure_all.sh <tag>
 set -x
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-R=${1:-r04}
+R=${1:-r05}
 O=gpurun_out/$R
 mkdir -p $O
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1

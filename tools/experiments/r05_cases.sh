@@ -229,6 +229,26 @@ $B 2>/dev/null | line "cfg3"
 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scenes.py tests/test_gpu_forward_only.py -x -q > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log
 }
 
+# k: the forward of lists beyond 8192 instances split along the list (composite_fwd_long_kernel, two launches on the second stream beside
+#    the strip launch; GSR_FWD_LONG=0 = before): parity of every long-list test, forward-only renders, then the hot-tile scenes
+case_k() {
+set -x
+O=gpurun_out/r05k; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scenes.py tests/test_gpu_fuzz_regressions.py tests/test_gpu_forward_only.py tests/test_gpu_preprocess_forms.py -x -q > $O/pytest.log 2>&1; echo "rc=$?"; tail -5 $O/pytest.log
+timeout 600 python tools/fuzz_parity.py deep 150 3600 > $O/deep.txt 2>&1; grep -E "^FAIL|cases passed" $O/deep.txt | cut -c1-200
+line() { python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['roofline']['stages_ms']
+print('$1', d['ms_per_step'], 'D', d['config']['tile_instances'], d['config']['binning']['mode'][:7], ' '.join(f'{k}={v:.3f}' for k,v in s.items()))"; }
+B="python bench.py --in-process --no-extra --no-cpu-baseline --no-other-lists --steps 20 --warmup 3 --steady-steps 0"
+for sk in hot:32000 hot:128000 hot:8000; do
+  $B --skew $sk --no-loss 2>/dev/null | line "$sk fwd by list segments"
+  GSR_FWD_LONG=0 $B --skew $sk --no-loss 2>/dev/null | line "$sk fwd by quadrants"
+done
+C5="--gaussians 5000000 --width 3840 --height 2160 --no-loss --seed 1005"
+$B $C5 --skew dense:0.01:50 2>/dev/null | line "dense4k"
+$B 2>/dev/null | line "cfg3"
+}
+
 if [ "$1" = "--list" ] || [ -z "$1" ]; then declare -F | sed -n "s/^declare -f case_//p"; exit 0; fi
 if ! declare -F "case_$1" > /dev/null; then echo "unknown case $1 (try --list)" >&2; exit 2; fi
 "case_$1"

@@ -202,10 +202,9 @@ __global__ __launch_bounds__(64) void composite_fwd_strip_kernel(int W, int H, i
     const int quad = k & 3;  // 8x8 quadrant (qx = quad & 1, qy = quad >> 1) of the tile
     const int slot = ((k >> 2) << 3) | (id & 7);
     int tile;
-    if (tile_order) {  // every tile, in launch order — but for the lists the split-along-the-list launches own (tiers.split_len)
+    if (tile_order) {  // every tile, in launch order
         if (slot >= grid_x * ((H + GSR_TILE - 1) / GSR_TILE)) return;
         tile = (int)tile_order[slot];
-        if (tile_start[tile + 1] - tile_start[tile] > tiers.split_len) return;
     } else {           // only the tiles of the scan's tier lists (the fused kernel did the others), longest tier first
         uint32_t b = (uint32_t)slot;
         if (b >= tiers.n_big + tiers.n_mid8 + tiers.n_mid4) return;
@@ -216,188 +215,6 @@ __global__ __launch_bounds__(64) void composite_fwd_strip_kernel(int W, int H, i
     }
     composite_fwd_quadrant<C, AUX>(W, H, grid_x, tile, quad, (int)threadIdx.x, tile_start, stream, bg, image,
                                    n_contrib, final_T, values_sorted, covis, uncert, e);
-}
-
-// ---------------------------------------------------------------------------------
-// forward of LONG lists, split along their LENGTH (round 5; the backward's twin is composite_bwd_long_kernel below)
-// ---------------------------------------------------------------------------------
-// The strip kernel walks a list front to back, one wave per 8x8 quadrant; the quadrants of a hot tile's NEIGHBOUR that the hot
-// splats reach visit 15 000 entries and never saturate: 0.44 ms of one wave, the forward's duration for the whole view.  A
-// pixel's front-to-back recursion (render.jl:82-117)  C <- C + alpha T f,  T <- T (1 - alpha)  is affine in (C, T): a list
-// segment's effect on a pixel is (T_seg, C_seg) computed from T = 1.  Lists beyond 8192 instances (at most 256 tiles, and no
-// side outputs requested) are cut into LONG_SEGS segments of whole 64-entry batches:
-//   PASS 1 (one single-wave workgroup per (tile, segment), all 256 pixels, four per lane): (T_seg, C_seg, last position blended)
-//           per pixel WITHOUT the saturation stop  ->  `state` (global, [listed tile][segment][C + 2][256]);
-//   PASS 2 (one wave per tile): combines the segments front to back.  The reference stops a pixel at the first entry that would
-//           take T below 1e-4 (that entry is NOT blended, render.jl:97-101) and n_contrib is the last entry blended; T only
-//           decreases, so while T * T_seg >= 1e-4 no entry of the segment can trigger the stop and the segment is taken whole;
-//           the first segment for which it does not hold is walked again, exactly, from the pixel's T (only that one: after it
-//           the pixel is done, or — the product's last bit — carries on).  A hot tile saturates inside its first segment: one
-//           1 000-entry walk instead of 32 000 entries of pass-1 work thrown away by 31 waves that ran beside it.
-// What differs from the one-wave walk: the association of the products across segment boundaries (alpha T_local T_in instead of
-// alpha (T_in T_local): last-bit level), and the stop decided on T * T_seg at a segment boundary.
-constexpr int LONG_SEGS_FWD = GSR_BWD_LONG_SEGS;
-
-template <int C, int PASS>
-__global__ __launch_bounds__(64) void composite_fwd_long_kernel(int W, int H, int grid_x,
-                                                                const uint32_t* __restrict__ tile_start,
-                                                                GsrStream stream, Bg bg, float* __restrict__ image,
-                                                                uint32_t* __restrict__ n_contrib,
-                                                                float* __restrict__ final_T, GsrTierLists tiers,
-                                                                float* __restrict__ state) {
-    constexpr int PPL = 4, NS = LONG_SEGS_FWD, K = C + 2;
-    __shared__ float4 l0[64], l1[64], l2[64];
-    __shared__ float4 l3[C > 3 ? 64 : 1];
-    __builtin_amdgcn_s_setprio(3);
-    const int lane = threadIdx.x;
-    const uint32_t listed = PASS == 1 ? blockIdx.x / NS : blockIdx.x;
-    const int g1 = PASS == 1 ? (int)(blockIdx.x % NS) : 0;
-    const int tile = (int)tiers.lists[listed];  // (the > 8192 tier is the first region of the scan's lists)
-    const int tile_x = tile % grid_x, tile_y = tile / grid_x;
-    const int px = tile_x * GSR_TILE + (lane & 15);
-    const int py0 = tile_y * GSR_TILE + (lane >> 4);
-    const float fx = (float)px;
-    const uint32_t start = tile_start[tile], n = tile_start[tile + 1] - start;
-    const int seg = (int)((((n + NS - 1) / NS) + 63u) & ~63u);
-    float* const st_tile = state + (size_t)listed * NS * K * 256;
-    float fy[PPL];
-#pragma unroll
-    for (int q = 0; q < PPL; q++) fy[q] = (float)(py0 + 4 * q);
-
-    // one batch of <= 64 entries [first, first + cnt) staged into LDS; returns the candidate ballot (any pixel row touched)
-    auto stage = [&](int first, int cnt) -> unsigned long long {
-        __builtin_amdgcn_wave_barrier();
-        uint32_t mask = 0u;
-        if (lane < cnt) {
-            const uint32_t idx = start + (uint32_t)(first + lane);
-            l0[lane] = stream.s0[idx];
-            l1[lane] = stream.s1[idx];
-            const float4 t2 = stream.s2[idx];
-            l2[lane] = t2;  // (third colour, slot, depth | threshold, footprint masks)
-            if (C > 3) l3[C > 3 ? lane : 0] = stream.s3[idx];
-            mask = __float_as_uint(t2.w);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        return wave_ballot(lane < cnt && (mask & 0xFFFFu) != 0u);
-    };
-    // walk positions [lo, hi) front to back.  EXACT: the reference's rule, per pixel, for the pixels flagged in `need`
-    // (T' < 1e-4 stops the pixel, that entry is not blended); else: no stop, every pixel.
-    float T[PPL], col[PPL][C];
-    uint32_t last[PPL];
-    bool done[PPL], need[PPL];
-    auto walk = [&](int lo, int hi, bool exact) {
-        for (int first = lo; first < hi; first += 64) {
-            const int cnt = min(64, hi - first);
-            unsigned long long wl = stage(first, cnt);
-            if (exact) {  // nothing left to do for this wave?
-                bool open = false;
-#pragma unroll
-                for (int q = 0; q < PPL; q++) open = open || (need[q] && !done[q]);
-                if (wave_ballot(open) == 0ull) break;
-            }
-            while (wl) {
-                const int j = __builtin_ctzll(wl);
-                wl &= wl - 1;
-                const float4 a = l0[j], b = l1[j], c2 = l2[j];
-                float4 c3 = c2;
-                if (C > 3) c3 = l3[C > 3 ? j : 0];
-                const uint32_t thr_bits = __float_as_uint(C == 3 ? c2.z : c3.w);
-                const float o = b.y, dx = a.x - fx;
-                const SigmaX sx = sigma_x(a.z, a.w, dx);
-                float f[C];
-                unpack_features<C>(b, c2, c3, f);
-                const uint32_t rowbits = __builtin_amdgcn_readfirstlane(__float_as_uint(c2.w));
-#pragma unroll
-                for (int q = 0; q < PPL; q++) {
-                    if (__builtin_amdgcn_readfirstlane((int)((rowbits >> (4 * q)) & 0xFu)) == 0) continue;
-                    const float dy = a.y - fy[q];
-                    const float sigma = sigma_of(sx, b.x, dy, __fmul_rn(dy, dy));
-                    bool ok = __float_as_uint(sigma) < thr_bits;
-                    if (exact) ok = ok && need[q] && !done[q];
-                    if (ok) {
-                        const float alpha = alpha_of(o, __expf(-sigma));
-                        const float Tn = T[q] * (1.0f - alpha);
-                        if (exact && Tn < 1e-4f) { done[q] = true; }
-                        else {
-                            const float w = alpha * T[q];
-#pragma unroll
-                            for (int c = 0; c < C; c++) col[q][c] += f[c] * w;
-                            T[q] = Tn;
-                            last[q] = (uint32_t)(first + j + 1);
-                        }
-                    }
-                }
-            }
-        }
-    };
-
-    if (PASS == 1) {
-        const int lo = g1 * seg, hi = min((int)n, lo + seg);
-#pragma unroll
-        for (int q = 0; q < PPL; q++) {
-            T[q] = 1.0f; last[q] = 0u; done[q] = false; need[q] = true;
-#pragma unroll
-            for (int c = 0; c < C; c++) col[q][c] = 0.0f;
-        }
-        if (lo < hi) walk(lo, hi, false);
-        float* const sg = st_tile + (size_t)g1 * K * 256;
-#pragma unroll
-        for (int q = 0; q < PPL; q++) {
-            sg[lane + 64 * q] = T[q];
-#pragma unroll
-            for (int c = 0; c < C; c++) sg[(1 + c) * 256 + lane + 64 * q] = col[q][c];
-            sg[(C + 1) * 256 + lane + 64 * q] = __uint_as_float(last[q]);
-        }
-        return;
-    }
-
-    // ---- PASS 2: combine front to back; exact re-walk of the segment in which a pixel reaches the stop ----
-    bool inside[PPL];
-#pragma unroll
-    for (int q = 0; q < PPL; q++) {
-        inside[q] = px < W && py0 + 4 * q < H;
-        T[q] = 1.0f; last[q] = 0u; done[q] = !inside[q]; need[q] = false;
-#pragma unroll
-        for (int c = 0; c < C; c++) col[q][c] = 0.0f;
-    }
-    for (int g = 0; g < NS; g++) {
-        const int lo = g * seg, hi = min((int)n, lo + seg);
-        if (lo >= hi) break;
-        bool open = false;
-#pragma unroll
-        for (int q = 0; q < PPL; q++) open = open || !done[q];
-        if (wave_ballot(open) == 0ull) break;  // the whole tile has saturated
-        const float* const sg = st_tile + (size_t)g * K * 256;
-        bool any_need = false;
-#pragma unroll
-        for (int q = 0; q < PPL; q++) {
-            need[q] = false;
-            if (done[q]) continue;
-            const float Tg = sg[lane + 64 * q];
-            const float Tn = T[q] * Tg;
-            if (Tn >= 1e-4f) {
-#pragma unroll
-                for (int c = 0; c < C; c++) col[q][c] += T[q] * sg[(1 + c) * 256 + lane + 64 * q];
-                const uint32_t lg = __float_as_uint(sg[(C + 1) * 256 + lane + 64 * q]);
-                last[q] = lg ? lg : last[q];
-                T[q] = Tn;
-            } else {
-                need[q] = true;
-                any_need = true;
-            }
-        }
-        if (wave_ballot(any_need) != 0ull) walk(lo, hi, true);
-    }
-#pragma unroll
-    for (int q = 0; q < PPL; q++) {
-        if (!inside[q]) continue;
-        const size_t pi = (size_t)px + (size_t)W * (py0 + 4 * q);
-        final_T[pi] = T[q];
-        n_contrib[pi] = last[q];
-#pragma unroll
-        for (int c = 0; c < C; c++) image[(size_t)C * pi + c] = col[q][c] + T[q] * bg.v[c];
-    }
 }
 
 // Sort + forward of a tile in ONE workgroup (fixed-capacity bins; a tile with more than 1024 instances is left to the
@@ -1111,26 +928,6 @@ void gsr_launch_composite_fwd(hipStream_t s, int channels, GsrCam cam, const uin
     if (channels == 3) { if (aux) LAUNCH(3, true); else LAUNCH(3, false); }
     else if (channels == 5) { if (aux) LAUNCH(5, true); else LAUNCH(5, false); }
     else { if (aux) LAUNCH(8, true); else LAUNCH(8, false); }
-#undef LAUNCH
-}
-
-// lists beyond 8192 instances, split along their length (composite_fwd_long_kernel): n_long = the first n_long tiles of the scan's
-// "> 8192" list; `state`: n_long x GSR_BWD_LONG_SEGS x (C + 2) x 256 floats
-void gsr_launch_composite_fwd_long(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start, GsrTierLists tiers,
-                                   uint32_t n_long, GsrStream stream, const float* background, float* image,
-                                   uint32_t* n_contrib, float* final_T, float* state) {
-    if (n_long == 0) return;
-    Bg bg = make_bg(background, channels);
-#define LAUNCH(CC)                                                                                                          \
-    do {                                                                                                                    \
-        hipLaunchKernelGGL((composite_fwd_long_kernel<CC, 1>), dim3(n_long * LONG_SEGS_FWD), dim3(64), 0, s, cam.width,     \
-                           cam.height, cam.grid_x, tile_start, stream, bg, image, n_contrib, final_T, tiers, state);        \
-        hipLaunchKernelGGL((composite_fwd_long_kernel<CC, 2>), dim3(n_long), dim3(64), 0, s, cam.width, cam.height,         \
-                           cam.grid_x, tile_start, stream, bg, image, n_contrib, final_T, tiers, state);                    \
-    } while (0)
-    if (channels == 3) LAUNCH(3);
-    else if (channels == 5) LAUNCH(5);
-    else LAUNCH(8);
 #undef LAUNCH
 }
 

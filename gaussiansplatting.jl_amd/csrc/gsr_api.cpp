@@ -706,31 +706,12 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
                              nullptr, 0);
         sc4.close();
         StageScope sc5(h->prof, ST_COMPOSITE_FWD, s);
-        // Lists beyond 8192 instances (a handful of tiles: a hot tile and its neighbours) are composited by the launches that
-        // split a list along its length, on the handle's second stream beside the strip launch — one quadrant wave walking
-        // 15 000 entries was the forward's duration for the whole view.  Not with side outputs (covisibility needs
-        // the global T per entry), not when such tiles are plentiful (GSR_FWD_LONG=0: never, for A/B runs).
-        static const bool no_fwd_long = [] { const char* e = getenv("GSR_FWD_LONG"); return e && e[0] == '0'; }();
-        const bool side_outputs = aux && (aux->covisibilities || aux->uncertainties);
-        const uint32_t n_long = (!no_fwd_long && !side_outputs && n_big <= 256u) ? n_big : 0u;
-        if (n_long) {
-            if ((rc = h->long_state.ensure((size_t)n_long * GSR_BWD_LONG_SEGS * (size_t)(C + 2) * 256 * sizeof(float)))) return rc;
-            const GsrTierLists lt{h->big_list.as<uint32_t>(), (uint32_t)h->n_tiles, n_long, 0u, 0u, 0xFFFFFFFFu};
-            HIPCHK(hipEventRecord(h->ev_fork, s));
-            HIPCHK(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
-            gsr_launch_composite_fwd_long(h->aux_stream, C, k, h->tile_start.as<uint32_t>(), lt, n_long, stream_of(h),
-                                          in->background, image_out, h->n_contrib.as<uint32_t>(), h->final_T.as<float>(),
-                                          h->long_state.as<float>());
-            HIPCHK(hipEventRecord(h->ev_join, h->aux_stream));
-        }
-        // after the fused launch only the tiles of the tier lists are left; otherwise every tile (split_len: but the long ones)
-        const GsrTierLists tiers{h->big_list.as<uint32_t>(), (uint32_t)h->n_tiles, n_long ? 0u : n_big, n_mid8, n_mid4,
-                                 n_long ? (uint32_t)GSR_SORT_LDS_CAP : 0xFFFFFFFFu};
+        // after the fused launch only the tiles of the tier lists are left; otherwise every tile
+        const GsrTierLists tiers{h->big_list.as<uint32_t>(), (uint32_t)h->n_tiles, n_big, n_mid8, n_mid4, 0u};
         gsr_launch_composite_fwd(s, C, k, h->tile_start.as<uint32_t>(), fused_done ? nullptr : h->tile_order.as<uint32_t>(),
                                  stream_of(h), in->background, image_out, h->n_contrib.as<uint32_t>(), h->final_T.as<float>(),
                                  h->values_sorted.as<uint32_t>(), aux ? aux->covisibilities : nullptr,
                                  aux ? aux->uncertainties : nullptr, &tiers);
-        if (n_long) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
         sc5.close();
     }
     h->tile_count_dirty = false;  // the sort (fused or not) zeroed the counters

@@ -137,9 +137,6 @@ struct GsrTierLists {  // the scan's tier lists: [0, T) lists > 8192, [T, 2T) (4
     uint32_t n_tiles, n_big, n_mid8, n_mid4;  // a tier that is not split has count 0 here
     uint32_t split_len;
 };
-void gsr_launch_composite_fwd_long(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start, GsrTierLists tiers,
-                                   uint32_t n_long, GsrStream stream, const float* background, float* image,
-                                   uint32_t* n_contrib, float* final_T, float* state);
 void gsr_launch_composite_fwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
                               const uint32_t* tile_order /* NULL: only the tiles of *listed */, GsrStream stream,
                               const float* background, float* image, uint32_t* n_contrib, float* final_T,

@@ -249,6 +249,26 @@ $B $C5 --skew dense:0.01:50 2>/dev/null | line "dense4k"
 $B 2>/dev/null | line "cfg3"
 }
 
+# l: the forward of lists beyond 8192 instances by sixteen 4x4-block waves per tile on the second stream (GSR_FWD_BLOCKS=0 = before):
+#    parity incl. the bit-identity of the two list modes (deep fuzz), then the hot-tile scenes
+case_l() {
+set -x
+O=gpurun_out/r05l; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scenes.py tests/test_gpu_fuzz_regressions.py tests/test_gpu_forward_only.py tests/test_gpu_preprocess_forms.py -x -q > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log
+timeout 600 python tools/fuzz_parity.py deep 200 3800 > $O/deep.txt 2>&1; grep -E "^FAIL|cases passed" $O/deep.txt | cut -c1-200
+line() { python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['roofline']['stages_ms']
+print('$1', d['ms_per_step'], 'D', d['config']['tile_instances'], d['config']['binning']['mode'][:7], ' '.join(f'{k}={v:.3f}' for k,v in s.items()))"; }
+B="python bench.py --in-process --no-extra --no-cpu-baseline --no-other-lists --steps 20 --warmup 3 --steady-steps 0"
+for sk in hot:32000 hot:128000 hot:8000; do
+  $B --skew $sk --no-loss 2>/dev/null | line "$sk fwd long tiles by 4x4 blocks"
+  GSR_FWD_BLOCKS=0 $B --skew $sk --no-loss 2>/dev/null | line "$sk fwd by quadrants"
+done
+C5="--gaussians 5000000 --width 3840 --height 2160 --no-loss --seed 1005"
+$B $C5 --skew dense:0.01:50 2>/dev/null | line "dense4k"
+$B 2>/dev/null | line "cfg3"
+}
+
 if [ "$1" = "--list" ] || [ -z "$1" ]; then declare -F | sed -n "s/^declare -f case_//p"; exit 0; fi
 if ! declare -F "case_$1" > /dev/null; then echo "unknown case $1 (try --list)" >&2; exit 2; fi
 "case_$1"

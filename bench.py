@@ -160,6 +160,9 @@ def parse_args(argv=None):
                     help="synthetic scene kind: 'uniform' = the cloud BASELINE.json's configs are quoted on (synthetic.make_scene); "
                          "'trained' = the procedural trained-like scene (synthetic.make_trained_like: surfaces, flat anisotropic "
                          "splats, bimodal opacity, 30 %% sub-radius_clip splats, rows in densification order)")
+    ap.add_argument("--sigma-px", type=float, default=None,
+                    help="in-plane splat size of the synthetic scene in pixels (default: the generator's own — 3 uniform, 4 trained); "
+                         "larger = longer tile lists")
     ap.add_argument("--order", default="random", choices=["random", "morton"],
                     help="order of the Gaussians in memory: 'random' = the synthetic scene as generated (the headline "
                          "configuration); 'morton' = the same Gaussians sorted along a 3-D Z-order curve (what a caller "
@@ -214,7 +217,7 @@ def under_profiler():
 
 def is_headline_config(args):
     return (not args.no_loss and args.ply is None and args.mode == "rgb" and not args.skew and args.order == "random"
-            and args.scene == "uniform" and (args.n, args.width, args.height, args.sh_degree) == (1_000_000, 1920, 1080, 3))
+            and args.scene == "uniform" and args.sigma_px is None and (args.n, args.width, args.height, args.sh_degree) == (1_000_000, 1920, 1080, 3))
 
 
 def dist_forced():
@@ -561,14 +564,14 @@ RESETTLE_STEPS = 5  # untimed steps between the survey's bookkeeping and the tim
 class Workload:
     def __init__(self, pkg, dev, rank, world, *, n, width, height, sh_degree, seed, mode="rgb", no_loss=False,
                  reference_lists=False, with_optimizer=False, unfused_tail=False, tail_in_backward=False, views=8,
-                 skew=None, order="random", ply=None, exchange_form=None, forward_only=False, scene="uniform"):
+                 skew=None, order="random", ply=None, exchange_form=None, forward_only=False, scene="uniform", sigma_px=None):
         import numpy as np
         import torch
         self.pkg, self.dev, self.rank, self.world = pkg, dev, rank, world
         self.torch, self.np = torch, np
         self.D = pkg.distributed
         W, H, N, deg = width, height, n, sh_degree
-        s = pkg.synthetic.scene_by_name(scene, N if ply is None else 16, W, H, deg, seed)
+        s = pkg.synthetic.scene_by_name(scene, N if ply is None else 16, W, H, deg, seed, sigma_px=sigma_px)
         if skew:
             s = pkg.synthetic.add_skew(s, skew, seed)
         if order == "morton":
@@ -584,6 +587,7 @@ class Workload:
         self.K = K = s.shs.shape[1]
         self.mode, self.no_loss, self.reference_lists = mode, no_loss, reference_lists
         self.seed, self.ply, self.skew, self.order, self.scene_kind = seed, ply, skew, order, scene
+        self.sigma_px = sigma_px
         self.forward_only = forward_only  # GSR_FORWARD_ONLY renders (the reference's non-AD branch): a step = one forward
         self.view = view = rank % views
         self.views = views
@@ -853,7 +857,8 @@ class Workload:
         # PMC-counted HBM bytes and VALU instructions per launch: only a measurement of EXACTLY this configuration
         # (tools/pmc_workload.py + tools/pmc_parse.py under rocprofv3 --pmc, committed per round) is reported
         key = (config_key(N, W, H, deg, self.mode, not self.reference_lists, not self.no_loss)
-               if self.ply is None and not self.skew and self.order == "random" and self.scene_kind == "uniform" else None)
+               if self.ply is None and not self.skew and self.order == "random" and self.scene_kind == "uniform"
+               and self.sigma_px is None else None)
         if key is not None and self.forward_only:
             key = key.rsplit("_", 1)[0] + "_fwdonly"
         traffic, valu, pmc_src, pmc_stale = None, None, None, None
@@ -1101,7 +1106,7 @@ def workload_of(pkg, dev, rank, world, args, **over):
     kw = dict(n=args.n, width=args.width, height=args.height, sh_degree=args.sh_degree, seed=args.seed, mode=args.mode,
               no_loss=args.no_loss, reference_lists=args.reference_lists, with_optimizer=args.with_optimizer,
               unfused_tail=args.unfused_tail, tail_in_backward=args.tail_in_backward, views=args.views, skew=args.skew,
-              order=args.order, ply=args.ply, scene=args.scene)
+              order=args.order, ply=args.ply, scene=args.scene, sigma_px=args.sigma_px)
     kw.update(over)
     return Workload(pkg, dev, rank, world, **kw)
 
@@ -1272,7 +1277,8 @@ def other_tile_lists(pkg, dev, args):
 def build_scene(pkg, args):
     """The scene a Workload renders, on the host (numpy): synthetic (+ skew / Morton order) or a .ply file."""
     import numpy as np
-    s = pkg.synthetic.scene_by_name(args.scene, args.n if args.ply is None else 16, args.width, args.height, args.sh_degree, args.seed)
+    s = pkg.synthetic.scene_by_name(args.scene, args.n if args.ply is None else 16, args.width, args.height, args.sh_degree, args.seed,
+                                    sigma_px=args.sigma_px)
     if args.skew:
         s = pkg.synthetic.add_skew(s, args.skew, args.seed)
     if args.order == "morton":

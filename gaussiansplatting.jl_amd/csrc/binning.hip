@@ -283,6 +283,70 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint32_t* __restric
     sort_and_emit<CH, NT>(skeys, m, n, start, tid, X0, Y0, keys, geom, stream, values_sorted);
 }
 
+// Round 5: the tier kernels above run a bitonic NETWORK in LDS — 78 barrier steps for 4096 keys — and a trained-like scene with
+// longer lists has hundreds of such tiles (in-plane splat size 12 px at 1 M / 1080p: tile_sort 0.18 ms, as much as the fused
+// forward).  Here every wave sorts a run of 1024 keys IN REGISTERS (the main pass's network: no LDS traffic for the keys, no
+// barrier) and the RUNS runs are merged through LDS: log2(RUNS) passes in which every thread finds its 16 outputs by merge path
+// (a binary search over two sorted runs) and merges them sequentially.  Runs are padded to 1024 with +inf, so every merge is of
+// two full runs; passes stop as soon as one run holds every real key.  Keys are unique: the same total order as everywhere.
+__device__ __forceinline__ uint32_t merge_path_lds(const uint64_t* a, const uint64_t* b, uint32_t len, uint32_t diag) {
+    // number of elements taken from `a` among the first `diag` outputs of merge(a[0, len), b[0, len))
+    uint32_t lo = diag > len ? diag - len : 0u, hi = diag < len ? diag : len;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] < b[diag - 1 - mid]) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+template <int CH, int RUNS>
+__global__ __launch_bounds__(64 * RUNS) void tile_sort_runs_kernel(const uint32_t* __restrict__ tile_start,
+                                                                   const uint32_t* __restrict__ tier_list,
+                                                                   const uint64_t* __restrict__ bins, uint32_t bin_cap, int grid_x,
+                                                                   GsrGeom geom, GsrStream stream,
+                                                                   uint32_t* __restrict__ values_sorted) {
+    constexpr int NT = 64 * RUNS, CAP = 1024 * RUNS, PER = CAP / NT;  // 16 outputs per thread and pass
+    __shared__ uint64_t buf[CAP];
+    const int tile = (int)tier_list[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
+    const uint32_t n = end - start;
+    if (n == 0 || n > (uint32_t)CAP) return;
+    const int X0 = (tile % grid_x) * GSR_TILE, Y0 = (tile / grid_x) * GSR_TILE;
+    const uint64_t* __restrict__ keys = bin_cap ? bins + (size_t)tile * bin_cap : bins + start;
+    {
+        uint64_t v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t e = (uint32_t)(wave * 1024 + lane * 16 + r);
+            v[r] = e < n ? keys[e] : ~0ull;
+        }
+        if ((uint32_t)(wave * 1024) < n) gsr_sort::wave_bitonic_sort<16>(v, 1024u, lane);  // (a run of +inf only is sorted)
+#pragma unroll
+        for (int r = 0; r < 16; r++) buf[wave * 1024 + lane * 16 + r] = v[r];
+    }
+    __syncthreads();
+    for (uint32_t L = 1024; L < (uint32_t)CAP && L < n; L <<= 1) {
+        const uint32_t o0 = (uint32_t)tid * PER, pair = o0 / (2 * L) * (2 * L);
+        const uint64_t* a = buf + pair;
+        const uint64_t* b = buf + pair + L;
+        uint32_t ia = merge_path_lds(a, b, L, o0 - pair), ib = (o0 - pair) - ia;
+        uint64_t out[PER];
+        uint64_t ka = ia < L ? a[ia] : ~0ull, kb = ib < L ? b[ib] : ~0ull;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            // (+inf padding compares equal on both sides: taking `a` first keeps ia, ib inside their runs)
+            const bool take_a = ib >= L || (ia < L && ka <= kb);
+            out[k] = take_a ? ka : kb;
+            if (take_a) { ia++; ka = ia < L ? a[ia] : ~0ull; }
+            else { ib++; kb = ib < L ? b[ib] : ~0ull; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; k++) buf[o0 + k] = out[k];
+        __syncthreads();
+    }
+    for (uint32_t i = tid; i < n; i += NT) emit_instance<CH>(buf[i], start + i, X0, Y0, geom, stream, values_sorted);
+}
+
 // ---- the main pass: ONE wave64 per tile, keys in registers (tile_sort_device.h) ----
 template <int CH>
 __global__ __launch_bounds__(64) void tile_sort_wave_kernel(const uint32_t* __restrict__ tile_start,
@@ -501,6 +565,11 @@ void gsr_launch_tile_sort(hipStream_t s, int passes, int n_tiles, int grid_x, in
                           uint32_t n_big, const uint32_t* tier_lists, uint64_t* big_scratch, size_t slab_stride, GsrGeom geom,
                           GsrStream stream, uint32_t* values_sorted, uint32_t* ranges, const uint32_t* totals,
                           uint32_t cap_instances) {
+    // GSR_SORT_TIERS_NETWORK=1: round 2's LDS bitonic network for the (1024, 8192] tiers (A/B runs); default: register runs + merges
+    static const bool net = [] { const char* e = getenv("GSR_SORT_TIERS_NETWORK"); return e && e[0] == '1'; }();
+#define LAUNCH_RUNS(CC, RUNSV, GRID, LIST)                                                                        \
+    hipLaunchKernelGGL((tile_sort_runs_kernel<CC, RUNSV>), dim3(GRID), dim3(64 * RUNSV), 0, s, tile_start, LIST, bins, \
+                       bin_cap, grid_x, geom, stream, values_sorted)
 #define LAUNCH(CC, CAPV, NTV, GRID, LIST)                                                                        \
     hipLaunchKernelGGL((tile_sort_kernel<CC, CAPV, NTV>), dim3(GRID), dim3(NTV), 0, s, tile_start, LIST, bins,    \
                        bin_cap, grid_x, geom, stream, values_sorted)
@@ -527,13 +596,16 @@ void gsr_launch_tile_sort(hipStream_t s, int passes, int n_tiles, int grid_x, in
                            tile_count, bins, bin_cap, grid_x, geom, stream, values_sorted, ranges, totals,          \
                            cap_instances, n_tiles);                                                                 \
     if (passes & GSR_SORT_PASS_TIERS) {                                                                           \
-        if (n_mid4 > 0) LAUNCH(CC, 4096, 512, n_mid4, tier_lists + 2 * (size_t)n_tiles);                          \
-        if (n_mid8 > 0) LAUNCH(CC, GSR_SORT_LDS_CAP, 1024, n_mid8, tier_lists + (size_t)n_tiles);                 \
+        if (n_mid4 > 0) { if (net) LAUNCH(CC, 4096, 512, n_mid4, tier_lists + 2 * (size_t)n_tiles);              \
+                          else LAUNCH_RUNS(CC, 4, n_mid4, tier_lists + 2 * (size_t)n_tiles); }                     \
+        if (n_mid8 > 0) { if (net) LAUNCH(CC, GSR_SORT_LDS_CAP, 1024, n_mid8, tier_lists + (size_t)n_tiles);      \
+                          else LAUNCH_RUNS(CC, 8, n_mid8, tier_lists + (size_t)n_tiles); }                         \
         if (n_big > 0) LAUNCH_BIG(CC);                                                                            \
     }
     if (channels > 5) { ALL(8) } else if (channels > 3) { ALL(5) } else { ALL(3) }
 #undef ALL
 #undef LAUNCH
+#undef LAUNCH_RUNS
 #undef LAUNCH_BIG
 }
 

@@ -271,10 +271,12 @@ def make_trained_like(n: int, width: int, height: int, sh_degree: int = 3, seed:
                  (f32(fx), f32(fy)))
 
 
-def scene_by_name(name: str, n: int, width: int, height: int, sh_degree: int = 3, seed: int = 1002, K: int | None = None) -> Scene:
-    """`uniform` (make_scene) or `trained` (make_trained_like): what bench.py's --scene takes."""
+def scene_by_name(name: str, n: int, width: int, height: int, sh_degree: int = 3, seed: int = 1002, K: int | None = None,
+                  sigma_px: float | None = None) -> Scene:
+    """`uniform` (make_scene) or `trained` (make_trained_like): what bench.py's --scene takes (`sigma_px`: the in-plane splat size
+    in pixels, None = the generator's default — 3 for the uniform cloud, 4 for the trained-like scene)."""
     if name == "uniform":
-        return make_scene(n, width, height, sh_degree, seed, K=K)
+        return make_scene(n, width, height, sh_degree, seed, K=K, **({} if sigma_px is None else {"sigma_px": sigma_px}))
     if name == "trained":
-        return make_trained_like(n, width, height, sh_degree, seed, K=K)
+        return make_trained_like(n, width, height, sh_degree, seed, K=K, **({} if sigma_px is None else {"sigma_px": sigma_px}))
     raise ValueError(f"unknown scene kind {name!r}")

@@ -742,10 +742,12 @@ def test_early_sort_pass_hits_and_misses_give_the_same_result(pkg):
 
 @pytest.mark.parametrize("mode,n_hot", [("rgb", 1500), ("rgb", 5000), ("rgbd", 2200), ("rgbdn", 1300), ("rgb", 9000)])
 def test_backward_of_long_lists_runs_four_waves_per_tile_and_matches_the_oracle(pkg, orc, mode, n_hot):
-    """Tiles whose list exceeds 1024 instances are left out by the one-wave-per-tile backward and walked by four waves
-    each on the handle's second stream (all three tier lists here: (1024, 4096], (4096, 8192], > 8192), next to
-    ordinary tiles: gradients and gstate.∇means_2d equal the oracle's, and a second backward-capable step on the same
-    handle (no long tile any more) still does."""
+    """Tiles whose list exceeds 1024 instances are left out by the one-wave-per-tile backward and walked on the handle's
+    second stream (all three tier lists here: (1024, 4096], (4096, 8192], > 8192), next to ordinary tiles — round 2: by four
+    waves per tile (pixel strips), round 5: by up to 32 single-wave workgroups per tile, each a SEGMENT of the list over all
+    256 pixels, in two launches (composite_bwd_long_kernel).  Gradients and gstate.∇means_2d equal the oracle's, and a second
+    backward-capable step on the same handle (no long tile any more) still does.  The same scenes exercise the tier sorts
+    (register runs + LDS merges up to 8192 keys, many workgroups beyond)."""
     W, H, deg, n = 96, 64, 1, 600
     base = pkg.synthetic.make_scene(n, W, H, deg, 55, sigma_px=3.0)
     rng = np.random.default_rng(56)

@@ -269,6 +269,50 @@ $B $C5 --skew dense:0.01:50 2>/dev/null | line "dense4k"
 $B 2>/dev/null | line "cfg3"
 }
 
+# m: trained-like scenes with LONGER lists (in-plane splat size 8 / 12 px instead of 4): how much of a scene like a real capture is
+#    beyond the fused forward's 1024-instance cut, and what the tier path costs there
+case_m() {
+set -x
+O=gpurun_out/r05m; mkdir -p $O
+B="python bench.py --in-process --no-extra --no-cpu-baseline --no-other-lists --steps 10 --warmup 3 --steady-steps 0"
+for sg in 4 8 12; do
+  $B --scene trained --seed 1010 --mode rgbd --sigma-px $sg 2>/dev/null > $O/t1m_$sg.json
+  python - $O/t1m_$sg.json $sg <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); c=d['config']; s=d['roofline']['stages_ms']
+print('trained1m sigma', sys.argv[2], 'ms', d['ms_per_step'], 'D', c['tile_instances'], 'V', c['visible'], 'longest', c['binning']['longest_tile_list'], c['binning']['mode'][:8], ' '.join(f'{k}={v:.3f}' for k,v in s.items()))
+PY
+done
+}
+
+# n: the (1024, 8192] tier sorts by register runs + LDS merges (tile_sort_runs_kernel; GSR_SORT_TIERS_NETWORK=1 = round 2's LDS network):
+#    parity (every test with mid-length lists + 200 deep fuzz scenes), then trained-like scenes with longer lists and dense 4K
+case_n() {
+set -x
+O=gpurun_out/r05n; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scenes.py tests/test_gpu_fuzz_regressions.py tests/test_gpu_forward_only.py tests/test_gpu_preprocess_forms.py tests/test_gpu_scale.py -x -q > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log
+timeout 600 python tools/fuzz_parity.py deep 200 4000 > $O/deep.txt 2>&1; grep -E "^FAIL|cases passed" $O/deep.txt | cut -c1-200
+B="python bench.py --in-process --no-extra --no-cpu-baseline --no-other-lists --steps 10 --warmup 3 --steady-steps 0"
+run() { tag=$1; shift; "$@" 2>/dev/null > $O/tmp.json; python - $O/tmp.json "$tag" <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); c=d['config']; s=d['roofline']['stages_ms']
+print(sys.argv[2], 'ms', d['ms_per_step'], 'D', c['tile_instances'], 'longest', c['binning']['longest_tile_list'], c['binning']['mode'][:8], ' '.join(f'{k}={v:.3f}' for k,v in s.items()))
+PY
+}
+for sg in 4 8 12; do
+  run "trained1m sigma $sg runs+merges" $B --scene trained --seed 1010 --mode rgbd --sigma-px $sg
+  GSR_SORT_TIERS_NETWORK=1 run "trained1m sigma $sg LDS network" $B --scene trained --seed 1010 --mode rgbd --sigma-px $sg
+done
+run "trained3m runs+merges" $B --scene trained --seed 1011 --mode rgbd --gaussians 3000000 --width 2560 --height 1440
+GSR_SORT_TIERS_NETWORK=1 run "trained3m LDS network" $B --scene trained --seed 1011 --mode rgbd --gaussians 3000000 --width 2560 --height 1440
+C5="--gaussians 5000000 --width 3840 --height 2160 --no-loss --seed 1005"
+run "dense4k runs+merges" $B $C5 --skew dense:0.01:50
+GSR_SORT_TIERS_NETWORK=1 run "dense4k LDS network" $B $C5 --skew dense:0.01:50
+run "hot8k runs+merges" $B --skew hot:8000 --no-loss
+GSR_SORT_TIERS_NETWORK=1 run "hot8k LDS network" $B --skew hot:8000 --no-loss
+run "cfg3" $B
+}
+
 if [ "$1" = "--list" ] || [ -z "$1" ]; then declare -F | sed -n "s/^declare -f case_//p"; exit 0; fi
 if ! declare -F "case_$1" > /dev/null; then echo "unknown case $1 (try --list)" >&2; exit 2; fi
 "case_$1"

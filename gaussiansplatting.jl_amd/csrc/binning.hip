@@ -289,61 +289,21 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint32_t* __restric
 // barrier) and the RUNS runs are merged through LDS: log2(RUNS) passes in which every thread finds its 16 outputs by merge path
 // (a binary search over two sorted runs) and merges them sequentially.  Runs are padded to 1024 with +inf, so every merge is of
 // two full runs; passes stop as soon as one run holds every real key.  Keys are unique: the same total order as everywhere.
-__device__ __forceinline__ uint32_t merge_path_lds(const uint64_t* a, const uint64_t* b, uint32_t len, uint32_t diag) {
-    // number of elements taken from `a` among the first `diag` outputs of merge(a[0, len), b[0, len))
-    uint32_t lo = diag > len ? diag - len : 0u, hi = diag < len ? diag : len;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (a[mid] < b[diag - 1 - mid]) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
 template <int CH, int RUNS>
 __global__ __launch_bounds__(64 * RUNS) void tile_sort_runs_kernel(const uint32_t* __restrict__ tile_start,
                                                                    const uint32_t* __restrict__ tier_list,
                                                                    const uint64_t* __restrict__ bins, uint32_t bin_cap, int grid_x,
                                                                    GsrGeom geom, GsrStream stream,
                                                                    uint32_t* __restrict__ values_sorted) {
-    constexpr int NT = 64 * RUNS, CAP = 1024 * RUNS, PER = CAP / NT;  // 16 outputs per thread and pass
+    constexpr int NT = 64 * RUNS, CAP = 1024 * RUNS;
     __shared__ uint64_t buf[CAP];
-    const int tile = (int)tier_list[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = (int)tier_list[blockIdx.x], tid = threadIdx.x;
     const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
     const uint32_t n = end - start;
     if (n == 0 || n > (uint32_t)CAP) return;
     const int X0 = (tile % grid_x) * GSR_TILE, Y0 = (tile / grid_x) * GSR_TILE;
     const uint64_t* __restrict__ keys = bin_cap ? bins + (size_t)tile * bin_cap : bins + start;
-    {
-        uint64_t v[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const uint32_t e = (uint32_t)(wave * 1024 + lane * 16 + r);
-            v[r] = e < n ? keys[e] : ~0ull;
-        }
-        if ((uint32_t)(wave * 1024) < n) gsr_sort::wave_bitonic_sort<16>(v, 1024u, lane);  // (a run of +inf only is sorted)
-#pragma unroll
-        for (int r = 0; r < 16; r++) buf[wave * 1024 + lane * 16 + r] = v[r];
-    }
-    __syncthreads();
-    for (uint32_t L = 1024; L < (uint32_t)CAP && L < n; L <<= 1) {
-        const uint32_t o0 = (uint32_t)tid * PER, pair = o0 / (2 * L) * (2 * L);
-        const uint64_t* a = buf + pair;
-        const uint64_t* b = buf + pair + L;
-        uint32_t ia = merge_path_lds(a, b, L, o0 - pair), ib = (o0 - pair) - ia;
-        uint64_t out[PER];
-        uint64_t ka = ia < L ? a[ia] : ~0ull, kb = ib < L ? b[ib] : ~0ull;
-#pragma unroll
-        for (int k = 0; k < PER; k++) {
-            // (+inf padding compares equal on both sides: taking `a` first keeps ia, ib inside their runs)
-            const bool take_a = ib >= L || (ia < L && ka <= kb);
-            out[k] = take_a ? ka : kb;
-            if (take_a) { ia++; ka = ia < L ? a[ia] : ~0ull; }
-            else { ib++; kb = ib < L ? b[ib] : ~0ull; }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < PER; k++) buf[o0 + k] = out[k];
-        __syncthreads();
-    }
+    gsr_sort::sort_runs_lds<RUNS>(buf, n, tid, keys);
     for (uint32_t i = tid; i < n; i += NT) emit_instance<CH>(buf[i], start + i, X0, Y0, geom, stream, values_sorted);
 }
 

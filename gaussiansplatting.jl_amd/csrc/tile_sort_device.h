@@ -141,6 +141,59 @@ __device__ __forceinline__ void wave_sort_ids_any(uint32_t* ids /* LDS [1024] */
     else wave_sort_ids<16>(ids, n, lane, keys);
 }
 
+// ---- lists of up to 1024 RUNS keys: every wave sorts a run of 1024 keys in registers, the runs are merged through LDS ----
+// (round 5; used by the tier sort tile_sort_runs_kernel and by the mid-list fused forward sort_composite_fwd_mid_kernel.)
+// log2(RUNS) passes in which every thread finds its 16 outputs by merge path (a binary search over two sorted runs) and merges
+// them sequentially.  Runs are padded to 1024 with +inf, so every merge is of two full runs; passes stop as soon as one run holds
+// every real key.  Keys are unique: the same total order as everywhere.  Ends with a workgroup barrier: buf[0, n) is sorted.
+__device__ __forceinline__ uint32_t merge_path_lds(const uint64_t* a, const uint64_t* b, uint32_t len, uint32_t diag) {
+    // number of elements taken from `a` among the first `diag` outputs of merge(a[0, len), b[0, len))
+    uint32_t lo = diag > len ? diag - len : 0u, hi = diag < len ? diag : len;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] < b[diag - 1 - mid]) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+template <int RUNS>
+__device__ __forceinline__ void sort_runs_lds(uint64_t* buf /* LDS [1024 RUNS] */, uint32_t n, int tid,
+                                              const uint64_t* __restrict__ keys) {
+    constexpr int NT = 64 * RUNS, CAP = 1024 * RUNS, PER = CAP / NT;  // 16 outputs per thread and pass
+    const int lane = tid & 63, wave = tid >> 6;
+    {
+        uint64_t v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t e = (uint32_t)(wave * 1024 + lane * 16 + r);
+            v[r] = e < n ? keys[e] : ~0ull;
+        }
+        if ((uint32_t)(wave * 1024) < n) wave_bitonic_sort<16>(v, 1024u, lane);  // (a run of +inf only is sorted)
+#pragma unroll
+        for (int r = 0; r < 16; r++) buf[wave * 1024 + lane * 16 + r] = v[r];
+    }
+    __syncthreads();
+    for (uint32_t L = 1024; L < (uint32_t)CAP && L < n; L <<= 1) {
+        const uint32_t o0 = (uint32_t)tid * PER, pair = o0 / (2 * L) * (2 * L);
+        const uint64_t* a = buf + pair;
+        const uint64_t* b = buf + pair + L;
+        uint32_t ia = merge_path_lds(a, b, L, o0 - pair), ib = (o0 - pair) - ia;
+        uint64_t out[PER];
+        uint64_t ka = ia < L ? a[ia] : ~0ull, kb = ib < L ? b[ib] : ~0ull;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            // (+inf padding compares equal on both sides: taking `a` first keeps ia, ib inside their runs)
+            const bool take_a = ib >= L || (ia < L && ka <= kb);
+            out[k] = take_a ? ka : kb;
+            if (take_a) { ia++; ka = ia < L ? a[ia] : ~0ull; }
+            else { ib++; kb = ib < L ? b[ib] : ~0ull; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; k++) buf[o0 + k] = out[k];
+        __syncthreads();
+    }
+}
+
 template <int CH>
 __device__ __forceinline__ void wave_sort_and_emit(uint32_t* ids /* LDS [1024] */, uint32_t n, uint32_t start, int lane,
                                                    int X0, int Y0, const uint64_t* __restrict__ keys,

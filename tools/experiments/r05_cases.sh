@@ -313,6 +313,32 @@ GSR_SORT_TIERS_NETWORK=1 run "hot8k LDS network" $B --skew hot:8000 --no-loss
 run "cfg3" $B
 }
 
+# o: the (1024, 4096] tier of a fused-path view sorted AND composited by one launch (sort_composite_fwd_mid_kernel; GSR_NO_MID_FUSED=1 =
+#    tier sort + strip kernel): parity (+ 200 deep fuzz scenes), trained-like scenes with in-plane splat sizes 4 / 8 / 12 px, 3 M, dense 4K
+case_o() {
+set -x
+O=gpurun_out/r05o; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scenes.py tests/test_gpu_fuzz_regressions.py tests/test_gpu_forward_only.py tests/test_gpu_preprocess_forms.py tests/test_gpu_scale.py -x -q > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log
+timeout 600 python tools/fuzz_parity.py deep 200 4200 > $O/deep.txt 2>&1; grep -E "^FAIL|cases passed" $O/deep.txt | cut -c1-200
+B="python bench.py --in-process --no-extra --no-cpu-baseline --no-other-lists --steps 10 --warmup 3 --steady-steps 0"
+run() { tag=$1; shift; "$@" 2>/dev/null > $O/tmp.json; python - $O/tmp.json "$tag" <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); c=d['config']; s=d['roofline']['stages_ms']
+print(sys.argv[2], 'ms', d['ms_per_step'], 'D', c['tile_instances'], 'longest', c['binning']['longest_tile_list'], c['binning']['mode'][:8], ' '.join(f'{k}={v:.3f}' for k,v in s.items()))
+PY
+}
+for sg in 4 8 12; do
+  run "trained1m sigma $sg mid fused" $B --scene trained --seed 1010 --mode rgbd --sigma-px $sg
+  GSR_NO_MID_FUSED=1 run "trained1m sigma $sg tier sort + strip" $B --scene trained --seed 1010 --mode rgbd --sigma-px $sg
+done
+run "trained3m mid fused" $B --scene trained --seed 1011 --mode rgbd --gaussians 3000000 --width 2560 --height 1440
+GSR_NO_MID_FUSED=1 run "trained3m tier sort + strip" $B --scene trained --seed 1011 --mode rgbd --gaussians 3000000 --width 2560 --height 1440
+C5="--gaussians 5000000 --width 3840 --height 2160 --no-loss --seed 1005"
+run "dense4k mid fused" $B $C5 --skew dense:0.01:50
+GSR_NO_MID_FUSED=1 run "dense4k tier sort + strip" $B $C5 --skew dense:0.01:50
+run "cfg3" $B
+}
+
 if [ "$1" = "--list" ] || [ -z "$1" ]; then declare -F | sed -n "s/^declare -f case_//p"; exit 0; fi
 if ! declare -F "case_$1" > /dev/null; then echo "unknown case $1 (try --list)" >&2; exit 2; fi
 "case_$1"

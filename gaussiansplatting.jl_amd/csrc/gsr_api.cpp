@@ -457,7 +457,8 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
     h->cfg = *cfg;
     h->grid_x = (cfg->width + GSR_TILE - 1) / GSR_TILE;
     h->grid_y = (cfg->height + GSR_TILE - 1) / GSR_TILE;
-    if (h->grid_x > 65535 || h->grid_y > 65535) { delete h; return fail(GSR_E_INVALID_ARG, "resolution too large"); }
+    // (8 192 tiles = 131 072 pixels wide: one row of the tile grid must fit the aggregating binning's LDS band, pergauss.hip)
+    if (h->grid_x > 8192 || h->grid_y > 65535) { delete h; return fail(GSR_E_INVALID_ARG, "resolution too large"); }
     h->n_tiles = h->grid_x * h->grid_y;
     DevBuf* list[] = {&h->ranges, &h->n_contrib, &h->final_T, &h->tile_count, &h->tile_start, &h->tile_order, &h->totals,
                       &h->geo, &h->gnormal, &h->radii, &h->bsum, &h->bpre, &h->bvis, &h->bins, &h->values_sorted, &h->s0,

@@ -18,30 +18,6 @@ import test_gpu_scale as S
 pytestmark = pytest.mark.gpu
 
 
-def test_trained_like_generator_statistics(pkg, orc):
-    """The generator does what its docstring says (these numbers are what makes the scene "trained-like")."""
-    W, H, n = 1920, 1080, 200_000
-    s = pkg.synthetic.make_trained_like(n, W, H, 3, 1010)
-    s2 = pkg.synthetic.make_trained_like(n, W, H, 3, 1010)
-    assert all(np.array_equal(getattr(s, k), getattr(s2, k)) for k in ("means", "scales_raw", "rotations", "opacities_raw", "shs"))
-    assert s.means.shape == (n, 3) and s.shs.shape == (n, 16, 3) and s.means.dtype == np.float32
-    sc = np.sort(s.scales, 1)
-    flat = sc[:, 1] / sc[:, 0]
-    assert np.median(flat) > 5.0, "flat splats: the thin axis is well below the in-plane ones"
-    o = s.opacities
-    assert (o > 0.8).mean() > 0.35 and (o < 0.2).mean() > 0.25 and ((o > 0.35) & (o < 0.65)).mean() < 0.15, "bimodal opacity"
-    cam = orc.Camera(W, H, s.focal)
-    st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, 3)
-    z = s.means[:, 2]
-    fx = float(s.focal[0])
-    px, py = s.means[:, 0] / z * fx + W / 2, s.means[:, 1] / z * fx + H / 2
-    inside = (z > 0.2) & (px > 0) & (px < W) & (py > 0) & (py < H)
-    culled_inside = ((st.radii == 0) & inside).sum() / inside.sum()
-    assert 0.2 <= culled_inside <= 0.45, ("~30 % of the on-screen splats are below radius_clip", culled_inside)
-    ln = st.ranges[:, 1].astype(np.int64) - st.ranges[:, 0]
-    assert ln.max() > 3.5 * ln.mean(), "tile lists are far from uniform"
-
-
 @pytest.mark.parametrize("mode", ["rgbd", "rgb"])
 def test_trained_like_reduced_size_full_step_vs_oracle(pkg, orc, mode):
     """60 k trained-like Gaussians at 960x540, forward + loss head + backward, serial double-accumulator oracle."""

@@ -72,6 +72,9 @@ N_SIMD, CLOCK_HZ, VALU_CYCLES = 1024, 2.4e9, 2.0  # 256 CUs x 4 SIMD-32; a wave6
 EXCHANGE_FORMS = ("factored+overlap", "factored", "plain")
 
 
+# gsr_stats.compact_binning
+BINNING_MODES = {0: "fixed-capacity bins", 1: "compact (count -> scan -> scatter)",
+                 2: "fixed-capacity bins + the lists beyond their capacity scattered again"}
 PREPROCESS_FORMS = {0: "direct", 1: "aggregating (2 x 32-bit LDS words)", 2: "aggregating (2 x 16-bit LDS words)",
                     3: "aggregating, banded (2 x 16-bit LDS words per band)"}  # gsr_stats.preprocess_form
 
@@ -156,6 +159,9 @@ def parse_args(argv=None):
     ap.add_argument("--skew", default=None, metavar="KIND",
                     help="skewed variant of the synthetic scene (synthetic.add_skew): 'hot:K' = K extra Gaussians in ONE tile, "
                          "'dense:P:F' = a fraction P of the tiles at F x the mean density; reports tile_sort time and bins bytes")
+    ap.add_argument("--bins-budget", type=int, default=0, metavar="BYTES",
+                    help="gsr_config.bins_budget_bytes of the bench handle (A/B runs): 0 = the library default; 1 = compact binning "
+                         "(count -> scan -> scatter) for every view; large = bins for the longest list")
     ap.add_argument("--scene", default="uniform", choices=["uniform", "trained"],
                     help="synthetic scene kind: 'uniform' = the cloud BASELINE.json's configs are quoted on (synthetic.make_scene); "
                          "'trained' = the procedural trained-like scene (synthetic.make_trained_like: surfaces, flat anisotropic "
@@ -564,7 +570,8 @@ RESETTLE_STEPS = 5  # untimed steps between the survey's bookkeeping and the tim
 class Workload:
     def __init__(self, pkg, dev, rank, world, *, n, width, height, sh_degree, seed, mode="rgb", no_loss=False,
                  reference_lists=False, with_optimizer=False, unfused_tail=False, tail_in_backward=False, views=8,
-                 skew=None, order="random", ply=None, exchange_form=None, forward_only=False, scene="uniform", sigma_px=None):
+                 skew=None, order="random", ply=None, exchange_form=None, forward_only=False, scene="uniform", sigma_px=None,
+                 bins_budget=0):
         import numpy as np
         import torch
         self.pkg, self.dev, self.rank, self.world = pkg, dev, rank, world
@@ -601,7 +608,8 @@ class Workload:
         self.params = [to(s.means), to(s.shs), to(s.opacities.reshape(-1, 1)), to(s.scales), to(s.rotations)]
         self.target = to(pkg.synthetic.make_target(W, H, seed + view))
         self.vpix_fixed = to(pkg.synthetic.make_vpixels(W, H, pkg.rasterizer.n_color_features(mode), seed + view))
-        self.rast = pkg.rasterizer.GaussianRasterizer(W, H, mode=mode, device=dev, exact_tile_cull=not reference_lists)
+        self.rast = pkg.rasterizer.GaussianRasterizer(W, H, mode=mode, device=dev, exact_tile_cull=not reference_lists,
+                                                      bins_budget_bytes=int(bins_budget))
         self.bg = (0.0, 0.0, 0.0)
         self.dist_on = world > 1 or self.D.forced()  # GSR_DIST_FORCE=1: collectives on a 1-rank RCCL communicator
         self.exchange_events = None  # [(e0, e1)] when the exchange is being timed
@@ -913,7 +921,8 @@ class Workload:
                "loss": not self.no_loss and not self.forward_only, "visible": int(self.rast.stats.n_visible),
                "tile_instances": int(self.rast.stats.n_rendered),
                "max_tile_instances": int(self.rast.stats.max_tile_instances),
-               "compact_binning": bool(self.rast.stats.compact_binning),
+               "compact_binning": int(self.rast.stats.compact_binning) == 1,
+               "binning": BINNING_MODES.get(int(self.rast.stats.compact_binning), "?"),
                "preprocess_form": PREPROCESS_FORMS.get(int(getattr(self.rast.stats, "preprocess_form", -1)), "?"),
                "dominant_kernel": r["kernel"], "dominant_ms": r["avg_launch_ms"],
                "roofline": {"bound": "hbm", "frac": r["frac"], "achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1106,7 +1115,7 @@ def workload_of(pkg, dev, rank, world, args, **over):
     kw = dict(n=args.n, width=args.width, height=args.height, sh_degree=args.sh_degree, seed=args.seed, mode=args.mode,
               no_loss=args.no_loss, reference_lists=args.reference_lists, with_optimizer=args.with_optimizer,
               unfused_tail=args.unfused_tail, tail_in_backward=args.tail_in_backward, views=args.views, skew=args.skew,
-              order=args.order, ply=args.ply, scene=args.scene, sigma_px=args.sigma_px)
+              order=args.order, ply=args.ply, scene=args.scene, sigma_px=args.sigma_px, bins_budget=args.bins_budget)
     kw.update(over)
     return Workload(pkg, dev, rank, world, **kw)
 
@@ -1202,7 +1211,7 @@ def run_section(args, section):
                                 + (f" skew={args.skew}" if args.skew else "")
                                 + (" [Gaussians in Morton order: NOT the headline configuration]" if args.order == "morton" else "")),
                    "n_gaussians": N, "visible": V, "tile_instances": Dn, "views_per_gpu": 1,
-                   "binning": {"mode": "compact (count -> scan -> scatter)" if rast.stats.compact_binning else "fixed-capacity bins",
+                   "binning": {"mode": BINNING_MODES.get(int(rast.stats.compact_binning), "?"),
                                "unsorted_key_bytes": int(rast.stats.bins_bytes), "longest_tile_list": int(rast.stats.max_tile_instances),
                                "handle_bytes": int(rast.memory_usage())},
                    "tile_lists": ("reference lists (GSR_FLAG_REFERENCE_TILE_LISTS)" if args.reference_lists else

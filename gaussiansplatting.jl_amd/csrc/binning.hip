@@ -260,15 +260,25 @@ __device__ __forceinline__ void sort_and_emit(uint64_t* buf, uint32_t m, uint32_
     for (uint32_t i = tid; i < n; i += NT) emit_instance<CH>(buf[i], start + i, X0, Y0, geom, stream, values_sorted);
 }
 
+// Where a tile's unsorted keys are.  bin_cap == 0: compact layout, the keys of tile t sit at bins[tile_start[t] ...) (count ->
+// scan -> scatter; memory O(D) whatever the skew).  bin_cap > 0: the tile's fixed-capacity bin — unless the list is longer than
+// the capacity (round 5: the bin then holds only its first arrivals): the restricted scatter pass has put the complete list at
+// overflow[tile_start[t] ...).
+__device__ __forceinline__ const uint64_t* tile_keys(const uint64_t* __restrict__ bins, uint32_t bin_cap,
+                                                     const uint64_t* __restrict__ overflow, int tile, uint32_t start, uint32_t n) {
+    if (bin_cap == 0u) return bins + start;
+    return n <= bin_cap ? bins + (size_t)tile * bin_cap : overflow + start;
+}
+
 // Tier launches over the tile lists the scan wrote, for the lists the main pass (tile_sort_wave_kernel, below) leaves:
 // CAP = 4096 keys with 512 threads (32 KB of LDS), CAP = 8192 with 1024 threads (64 KB); lists beyond 8192 belong to
 // tile_sort_big_kernel.  Tiers that are empty (the host knows the counts) are not launched.
-// bin_cap > 0: the tile's unsorted keys are its fixed-capacity bin; bin_cap == 0: compact layout, the keys of
-// tile t sit at keys[tile_start[t] ...) (count -> scan -> scatter; memory O(D) whatever the skew).
+// The keys come from tile_keys() above.
 template <int CH, int CAP, int NT>
 __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint32_t* __restrict__ tile_start,
                                                        const uint32_t* __restrict__ tier_list,
-                                                       const uint64_t* __restrict__ bins, uint32_t bin_cap, int grid_x,
+                                                       const uint64_t* __restrict__ bins, uint32_t bin_cap,
+                                                       const uint64_t* __restrict__ overflow, int grid_x,
                                                        GsrGeom geom, GsrStream stream,
                                                        uint32_t* __restrict__ values_sorted) {
     __shared__ uint64_t skeys[CAP];
@@ -277,7 +287,7 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint32_t* __restric
     const uint32_t n = end - start;
     if (n == 0 || n > (uint32_t)CAP) return;
     const int X0 = (tile % grid_x) * GSR_TILE, Y0 = (tile / grid_x) * GSR_TILE;
-    const uint64_t* __restrict__ keys = bin_cap ? bins + (size_t)tile * bin_cap : bins + start;
+    const uint64_t* __restrict__ keys = tile_keys(bins, bin_cap, overflow, tile, start, n);
     uint32_t m = 1;
     while (m < n) m <<= 1;
     sort_and_emit<CH, NT>(skeys, m, n, start, tid, X0, Y0, keys, geom, stream, values_sorted);
@@ -292,7 +302,8 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint32_t* __restric
 template <int CH, int RUNS>
 __global__ __launch_bounds__(64 * RUNS) void tile_sort_runs_kernel(const uint32_t* __restrict__ tile_start,
                                                                    const uint32_t* __restrict__ tier_list,
-                                                                   const uint64_t* __restrict__ bins, uint32_t bin_cap, int grid_x,
+                                                                   const uint64_t* __restrict__ bins, uint32_t bin_cap,
+                                                                   const uint64_t* __restrict__ overflow, int grid_x,
                                                                    GsrGeom geom, GsrStream stream,
                                                                    uint32_t* __restrict__ values_sorted) {
     constexpr int NT = 64 * RUNS, CAP = 1024 * RUNS;
@@ -302,7 +313,7 @@ __global__ __launch_bounds__(64 * RUNS) void tile_sort_runs_kernel(const uint32_
     const uint32_t n = end - start;
     if (n == 0 || n > (uint32_t)CAP) return;
     const int X0 = (tile % grid_x) * GSR_TILE, Y0 = (tile / grid_x) * GSR_TILE;
-    const uint64_t* __restrict__ keys = bin_cap ? bins + (size_t)tile * bin_cap : bins + start;
+    const uint64_t* __restrict__ keys = tile_keys(bins, bin_cap, overflow, tile, start, n);
     gsr_sort::sort_runs_lds<RUNS>(buf, n, tid, keys);
     for (uint32_t i = tid; i < n; i += NT) emit_instance<CH>(buf[i], start + i, X0, Y0, geom, stream, values_sorted);
 }
@@ -321,7 +332,7 @@ __global__ __launch_bounds__(64) void tile_sort_wave_kernel(const uint32_t* __re
     // Launched BEFORE the host has read the instance count (totals != NULL): the output buffers hold cap_instances
     // instances and the bins bin_cap keys — if this view needs more, every workgroup leaves without touching
     // anything and the host, which sees the same totals, launches the pass again after growing them.
-    if (totals && (totals[0] > cap_instances || totals[1] > bin_cap)) return;
+    if (totals && (totals[0] > cap_instances || (totals[1] > bin_cap && bin_cap < 1024u))) return;
     // Workgroup id -> tile, XCD-aware (grid = 8 * ceil(T / 8)): workgroups are dealt round-robin to the 8 XCDs, each
     // with its own L2; XCD x sorts the x-th contiguous eighth of the tiles in raster order, so the record gathers of
     // neighbouring tiles (a Gaussian touches 3.6 on average) meet in one L2.
@@ -408,25 +419,36 @@ __device__ __forceinline__ bool big_item(const uint32_t* __restrict__ prefix, ui
     return true;
 }
 
-__global__ __launch_bounds__(BIG_THREADS) void big_chunk_kernel(const uint32_t* __restrict__ tile_start,
+// NET = false (default): the chunk is sorted as eight register runs of 1024 keys + three merge-path passes through LDS
+// (tile_sort_device.h: sort_runs_lds, 512 threads) — the bitonic network's 91 barrier steps took 77 us per chunk, on the critical
+// path of a view whose longest list is tens of thousands of keys; NET = true: that network (GSR_SORT_TIERS_NETWORK=1, A/B runs).
+template <bool NET>
+__global__ __launch_bounds__(NET ? BIG_THREADS : 512) void big_chunk_kernel(const uint32_t* __restrict__ tile_start,
                                                                 const uint32_t* __restrict__ big_list, uint32_t n_big,
                                                                 const uint32_t* __restrict__ plan,
                                                                 const uint64_t* __restrict__ bins, uint32_t bin_cap,
+                                                                const uint64_t* __restrict__ overflow,
                                                                 uint64_t* __restrict__ scratch, size_t slab_stride) {
+    constexpr uint32_t NT = NET ? BIG_THREADS : 512;
     __shared__ uint64_t skeys[GSR_SORT_LDS_CAP];
     uint32_t b, c;
     if (!big_item(plan, n_big, blockIdx.x, b, c)) return;
     const int tile = (int)big_list[b], tid = threadIdx.x;
     const uint32_t start = tile_start[tile], n = tile_start[tile + 1] - start;
-    const uint64_t* __restrict__ keys = bin_cap ? bins + (size_t)tile * bin_cap : bins + start;
+    const uint64_t* __restrict__ keys = tile_keys(bins, bin_cap, overflow, tile, start, n);
     uint64_t* slab0 = scratch + (size_t)(2 * b) * slab_stride;
     const uint32_t c0 = c * GSR_SORT_LDS_CAP, cn = min((uint32_t)GSR_SORT_LDS_CAP, n - c0);
-    uint32_t m = 1;
-    while (m < cn) m <<= 1;
-    for (uint32_t i = tid; i < m; i += BIG_THREADS) skeys[i] = i < cn ? keys[c0 + i] : ~0ull;
-    __syncthreads();
-    if (m > 1) bitonic_sort(skeys, m, tid, BIG_THREADS);
-    for (uint32_t i = tid; i < cn; i += BIG_THREADS) slab0[c0 + i] = skeys[i];
+    if (NET) {
+        uint32_t m = 1;
+        while (m < cn) m <<= 1;
+        for (uint32_t i = tid; i < m; i += NT) skeys[i] = i < cn ? keys[c0 + i] : ~0ull;
+        __syncthreads();
+        if (m > 1) bitonic_sort(skeys, m, tid, NT);
+    } else {
+        static_assert(GSR_SORT_LDS_CAP == 8192, "eight runs of 1024 keys");
+        gsr_sort::sort_runs_lds<8>(skeys, cn, tid, keys + c0);
+    }
+    for (uint32_t i = tid; i < cn; i += NT) slab0[c0 + i] = skeys[i];
 }
 
 __global__ __launch_bounds__(BIG_THREADS) void big_merge_kernel(const uint32_t* __restrict__ tile_start,
@@ -521,7 +543,8 @@ void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count
 }
 
 void gsr_launch_tile_sort(hipStream_t s, int passes, int n_tiles, int grid_x, int channels, const uint32_t* tile_start,
-                          uint32_t* tile_count, const uint64_t* bins, uint32_t bin_cap, uint32_t n_mid4, uint32_t n_mid8,
+                          uint32_t* tile_count, const uint64_t* bins, uint32_t bin_cap, const uint64_t* overflow_keys,
+                          uint32_t n_mid4, uint32_t n_mid8,
                           uint32_t n_big, const uint32_t* tier_lists, uint64_t* big_scratch, size_t slab_stride, GsrGeom geom,
                           GsrStream stream, uint32_t* values_sorted, uint32_t* ranges, const uint32_t* totals,
                           uint32_t cap_instances) {
@@ -529,10 +552,10 @@ void gsr_launch_tile_sort(hipStream_t s, int passes, int n_tiles, int grid_x, in
     static const bool net = [] { const char* e = getenv("GSR_SORT_TIERS_NETWORK"); return e && e[0] == '1'; }();
 #define LAUNCH_RUNS(CC, RUNSV, GRID, LIST)                                                                        \
     hipLaunchKernelGGL((tile_sort_runs_kernel<CC, RUNSV>), dim3(GRID), dim3(64 * RUNSV), 0, s, tile_start, LIST, bins, \
-                       bin_cap, grid_x, geom, stream, values_sorted)
+                       bin_cap, overflow_keys, grid_x, geom, stream, values_sorted)
 #define LAUNCH(CC, CAPV, NTV, GRID, LIST)                                                                        \
     hipLaunchKernelGGL((tile_sort_kernel<CC, CAPV, NTV>), dim3(GRID), dim3(NTV), 0, s, tile_start, LIST, bins,    \
-                       bin_cap, grid_x, geom, stream, values_sorted)
+                       bin_cap, overflow_keys, grid_x, geom, stream, values_sorted)
     // lists beyond the LDS sort: plan -> chunk sorts -> merge passes -> emit, one workgroup per chunk / 4096-key block
     // (the plan lives behind the 2 n_big slabs; grids are upper bounds from the longest list, surplus workgroups leave at once)
     uint32_t* const plan = reinterpret_cast<uint32_t*>(big_scratch + (size_t)2 * n_big * slab_stride);
@@ -541,8 +564,10 @@ void gsr_launch_tile_sort(hipStream_t s, int passes, int n_tiles, int grid_x, in
 #define LAUNCH_BIG(CC)                                                                                            \
     do {                                                                                                          \
         hipLaunchKernelGGL(big_plan_kernel, dim3(1), dim3(1024), 0, s, tile_start, tier_lists, n_big, plan);      \
-        hipLaunchKernelGGL(big_chunk_kernel, dim3(chunks_ub), dim3(BIG_THREADS), 0, s, tile_start, tier_lists, n_big, plan, \
-                           bins, bin_cap, big_scratch, slab_stride);                                              \
+        if (net) hipLaunchKernelGGL(big_chunk_kernel<true>, dim3(chunks_ub), dim3(BIG_THREADS), 0, s, tile_start, tier_lists, \
+                                    n_big, plan, bins, bin_cap, overflow_keys, big_scratch, slab_stride);           \
+        else hipLaunchKernelGGL(big_chunk_kernel<false>, dim3(chunks_ub), dim3(512), 0, s, tile_start, tier_lists, n_big, \
+                                plan, bins, bin_cap, overflow_keys, big_scratch, slab_stride);                      \
         int cur = 0;                                                                                              \
         for (uint32_t L = GSR_SORT_LDS_CAP; L < slab_stride; L <<= 1, cur ^= 1)                                   \
             hipLaunchKernelGGL(big_merge_kernel, dim3(blocks_ub), dim3(BIG_THREADS), 0, s, tile_start, tier_lists, n_big, \

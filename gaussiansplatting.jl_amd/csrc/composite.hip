@@ -212,6 +212,8 @@ __global__ __launch_bounds__(64) void composite_fwd_strip_kernel(int W, int H, i
         if (b >= tiers.n_big) { b -= tiers.n_big; list = tiers.lists + tiers.n_tiles;
             if (b >= tiers.n_mid8) { b -= tiers.n_mid8; list = tiers.lists + 2 * (size_t)tiers.n_tiles; } }
         tile = (int)list[b];
+        // beside the fused launch (gsr_forward): these few waves are the forward's critical path and share their SIMDs with it
+        if (tiers.split_len) __builtin_amdgcn_s_setprio(3);
     }
     composite_fwd_quadrant<C, AUX>(W, H, grid_x, tile, quad, (int)threadIdx.x, tile_start, stream, bg, image,
                                    n_contrib, final_T, values_sorted, covis, uncert, e);
@@ -252,7 +254,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void s
     constexpr int CHUNK = 256;
     __shared__ uint32_t ids[1024];
     __shared__ LdsSplats<C, CHUNK> e;
-    if (totals[0] > cap_instances || totals[1] > bin_cap) return;  // [0] instances, [1] longest list
+    // [0] instances, [1] longest list.  Bins of >= 1024 keys hold every list this launch takes complete whatever the longest one
+    // is (lists beyond the capacity are tier tiles; the host scatters their keys again) — smaller bins must hold them all
+    if (totals[0] > cap_instances || (totals[1] > bin_cap && bin_cap < 1024u)) return;
     const int tile = (int)tile_order[blockIdx.x];  // launch order: longest lists first
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t start = tile_start[tile], end = tile_start[tile + 1];

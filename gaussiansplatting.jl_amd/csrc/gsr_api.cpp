@@ -200,6 +200,7 @@ struct gsr_handle {
     bool tile_count_dirty = false;  // counters not yet re-zeroed by the tile sort
     double wait_ema_us = 0.0;       // running average of the host's wait for the instance count (wait_totals)
     DevBuf bins, keys_compact, big_list, values_sorted, s0, s1, s2, s3, big_scratch, long_state;
+    DevBuf overflow_fill;           // fill cursors of the scatter pass restricted to the lists beyond the bins' capacity
     uint32_t bin_cap_used(bool use_bins) const { return use_bins ? bin_cap_view : 0u; }
     // backward: per-instance gradient rows + instance position map; gstate.∇means_2d
     DevBuf rows, vmean2d;
@@ -463,7 +464,7 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
     DevBuf* list[] = {&h->ranges, &h->n_contrib, &h->final_T, &h->tile_count, &h->tile_start, &h->tile_order, &h->totals,
                       &h->geo, &h->gnormal, &h->radii, &h->bsum, &h->bpre, &h->bvis, &h->bins, &h->values_sorted, &h->s0,
                       &h->s1, &h->s2, &h->s3, &h->big_scratch, &h->rows, &h->vmean2d, &h->d0, &h->d1,
-                      &h->d2, &h->partial, &h->keys_compact, &h->big_list, &h->long_state};
+                      &h->d2, &h->partial, &h->keys_compact, &h->big_list, &h->long_state, &h->overflow_fill};
     for (DevBuf* b : list) h->all[h->n_all++] = b;
     const size_t P = (size_t)cfg->width * cfg->height, T = (size_t)h->n_tiles;
     int rc = GSR_OK;
@@ -576,7 +577,10 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     }
     const uint64_t budget = h->cfg.bins_budget_bytes ? h->cfg.bins_budget_bytes
                                                      : std::max<uint64_t>(kBinsBudgetMin, kBinsBudgetPerInstance * (uint64_t)h->last_D);
-    bool use_bins = h->bin_cap > 0 && (uint64_t)(T + 1) * h->bin_cap * 8ull <= budget;
+    // (the capacity the budget allows: bins smaller than one cache line of keys per tile are not worth having)
+    const uint64_t cap_budget = (budget / (8ull * (uint64_t)(T + 1))) & ~63ull;
+    if (h->bin_cap > cap_budget) h->bin_cap = (uint32_t)cap_budget;
+    bool use_bins = h->bin_cap >= 64u;
     h->bin_cap_view = use_bins ? h->bin_cap : 0u;
     if (use_bins && (rc = h->bins.ensure((T + 1) * (size_t)h->bin_cap * 8))) return rc;
     // The tile counters are zero on entry: gsr_create clears them and the tile sort re-zeroes each
@@ -610,25 +614,56 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     if (fwd_only) cap_instances = 0xFFFFFFFFull;  // nothing is stored per instance: no capacity to respect
     static const bool no_fused = [] { const char* e = getenv("GSR_NO_FUSED_FWD"); return e && e[0] == '1'; }();  // A/B only
     const bool spec = use_bins && cap_instances > 0 && !no_fused;
-    if (spec) {
-        StageScope sc3(h->prof, ST_SORT_COMPOSITE_FWD, s);
-        gsr_launch_sort_composite_fwd(s, C, k, h->tile_start.as<uint32_t>(), h->tile_order.as<uint32_t>(),
+    // TIER TILES (lists beyond the fused launch's 1024 instances) are walked by their own launch, four single-wave workgroups per
+    // tile, and that walk is a latency chain: 0.4 ms for one 32 k-instance tile and its neighbours, 0.15 ms for the few hundred
+    // tiles of 1-4 k instances of a trained-like scene — it belongs BESIDE the fused launch, not behind it.  What does not work,
+    // measured (tools/cu_mask_probe.hip, profiles/r05/experiments/long_list_chain.txt): queueing sorts + walk on a second stream
+    // while the fused launch runs — it fills every wave slot and all LDS, and the sorts' workgroups (512-1024 threads, 64 KB)
+    // never find four of its workgroups retiring on one CU together: the chain starts at the fused launch's tail, on any
+    // stream, at any priority; CU-masked streams do give the chain CUs of its own (probe: done after 2.7 of 7.9 ms instead of
+    // 9.0 of 9.0), but hipExtStreamCreateWithCUMask only makes streams that synchronise with the NULL stream — torch's default
+    // — and every launch of the step then pays ~10 us of implicit cross-queue wait (+0.16 ms per step: more than it saved).
+    // What does: the walk's workgroups are single waves, which slip into any retiring slot.  So when the previous view had tier
+    // tiles the fused launch is HELD until the host has the counts and the tier sorts have run (mostly idle GPU: 0.04-0.2 ms),
+    // and then goes out together with the walk, which takes the handle's second stream at raised wave priority.  Hot tile
+    // (32 k) 2.08 -> 1.80 ms, trained-like 3 M / 1440p 2.19 -> 2.10, dense 4K 7.81 -> 7.70; a view without tier tiles is not
+    // touched.  (GSR_TIERS_BESIDE_MAX: hold only when the previous view had at most that many tier tiles — A/B runs; 0 = never.)
+    static const uint32_t kBesideMaxTiles = [] { const char* e = getenv("GSR_TIERS_BESIDE_MAX"); return e ? (uint32_t)atoi(e) : 0xFFFFFFFFu; }();
+    const uint64_t prev_tiers = (uint64_t)h->tier_n[0] + h->tier_n[1] + h->tier_n[2];
+    const bool hold_fused = spec && prev_tiers > 0 && prev_tiers <= kBesideMaxTiles;
+    const auto launch_fused = [&](hipStream_t fs) {
+        StageScope sc3(h->prof, ST_SORT_COMPOSITE_FWD, fs);
+        gsr_launch_sort_composite_fwd(fs, C, k, h->tile_start.as<uint32_t>(), h->tile_order.as<uint32_t>(),
                                       h->tile_count.as<uint32_t>(), h->bins.as<uint64_t>(), h->bin_cap_view, geom_of(h),
                                       stream_of(h), in->background, image_out, h->n_contrib.as<uint32_t>(),
                                       h->final_T.as<float>(), h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>(),
                                       aux ? aux->covisibilities : nullptr, aux ? aux->uncertainties : nullptr, totals,
                                       (uint32_t)cap_instances, /*keep_backward_state=*/!fwd_only);
         sc3.close();
-    }
+    };
+    if (spec && !hold_fused) launch_fused(s);
     if ((rc = wait_totals(h, seq, s))) return rc;
+    // OVERFLOW TILES (round 5): lists longer than the bins' capacity.  Their bins hold the first bin_cap_view arrivals only
+    // (preprocess counted every instance); their complete key lists come from a scatter pass restricted to them (below), and
+    // every sort takes a tile's keys from wherever they are complete.  The rest of the view stays on the fast path — a few
+    // deep tiles no longer send the whole view to the compact mode, and nothing is ever repeated.
+    // (Bins of fewer than 1024 keys could also cut a list of the fused launch's: such a view is finished in the compact mode, as
+    // every overflowing view was before — a small scene's first views, or a budget that small.)
     const bool overflow = use_bins && h->host_totals[1] > h->bin_cap_view;
-    const bool compact = !use_bins || overflow;
-    {   // capacity for the NEXT view: longest list + 25 %, if that fits the budget of a scene of this size
-        const uint64_t want = ((uint64_t)h->host_totals[1] + h->host_totals[1] / 4 + 63) & ~63ull;
+    const bool hybrid = overflow && h->bin_cap_view >= 1024u;
+    const bool compact = !use_bins || (overflow && !hybrid);
+    {   // capacity for the NEXT view: the longest list + 25 % where the budget allows it; where it does not, the deep tiles are
+        // OUTLIERS for the overflow path and the bins are sized for the rest (4 x the mean list, at least 1024, + 25 %).  A budget
+        // below twice the mean list is no budget for bins at all: compact mode until that changes.
+        const auto round64 = [](uint64_t v) { return (v + v / 4 + 63) & ~63ull; };
+        const uint64_t mean_list = (uint64_t)h->host_totals[0] / (uint64_t)T + 1;
         const uint64_t next_budget = h->cfg.bins_budget_bytes ? h->cfg.bins_budget_bytes
                                                               : std::max<uint64_t>(kBinsBudgetMin, kBinsBudgetPerInstance * (uint64_t)h->host_totals[0]);
-        if ((uint64_t)(T + 1) * want * 8ull > next_budget) { h->bin_cap = 0; h->compact_sticky = true; }
-        else if (want > h->bin_cap || !use_bins) { h->bin_cap = (uint32_t)want; h->compact_sticky = false; }
+        const uint64_t next_cap = (next_budget / (8ull * (uint64_t)(T + 1))) & ~63ull;
+        uint64_t want = round64(h->host_totals[1]);
+        if (want > next_cap) want = std::min<uint64_t>(next_cap, round64(std::max<uint64_t>(1024ull, 4ull * mean_list)));
+        if (want < 64 || next_cap < 2 * mean_list) { h->bin_cap = 0; h->compact_sticky = true; }
+        else if (want > h->bin_cap || !use_bins) { h->bin_cap = (uint32_t)std::min<uint64_t>(want, 1u << 20); h->compact_sticky = false; }
     }
     const uint64_t D = h->host_totals[0];
     const uint32_t max_tile = h->host_totals[1], n_big = h->host_totals[2];
@@ -645,12 +680,12 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     }
     h->last_compact = compact;
     if (stats) {
-        stats->compact_binning = compact ? 1 : 0;
+        stats->compact_binning = compact ? 1 : (hybrid ? 2 : 0);
         stats->preprocess_form = h->last_form;
-        stats->bins_bytes = (int64_t)(compact ? D * 8 : (uint64_t)(T + 1) * h->bin_cap_used(use_bins) * 8ull);
+        stats->bins_bytes = (int64_t)(compact ? D * 8 : (uint64_t)(T + 1) * h->bin_cap_used(use_bins) * 8ull + (hybrid ? D * 8 : 0));
     }
     // did the early launch run?  (same two comparisons as in the kernel, on the same numbers)
-    const bool fused_done = spec && !overflow && D <= cap_instances;
+    const bool fused_done = spec && D <= cap_instances && !(overflow && !hybrid);  // (hybrid: every list of up to 1024 sat complete in its bin)
     if (D == 0) {
         h->tile_count_dirty = false;  // every counter is zero
         if (k.exact_cull && (h->host_totals[4] >> 31)) {
@@ -687,33 +722,58 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
         // (+ the plan of the multi-workgroup sort: 2 (n_big + 1) words behind the slabs)
         if ((rc = h->big_scratch.ensure((size_t)n_big * 2 * slab_stride * 8 + (size_t)(2 * n_big + 2) * 4 + 64))) return rc;
     }
+    // (a held fused launch that this view gives no reason to hold any longer: no tier tiles after all, or too many)
+    const bool beside = hold_fused && fused_done && long_tiles && (uint64_t)n_mid4 + n_mid8 + n_big <= kBesideMaxTiles;
+    if (hold_fused && !beside) launch_fused(s);
     if (!fused_done || long_tiles) {
         StageScope sc4(h->prof, ST_SORT, s);
         const uint64_t* keys = h->bins.as<uint64_t>();
+        const uint64_t* overflow_keys = nullptr;
         uint32_t key_cap = h->bin_cap_used(use_bins);
         if (compact) {
             // count -> scan -> scatter: the counters become the fill cursors of the scatter pass
             if ((rc = h->keys_compact.ensure(D * 8, slack))) return rc;
             HIPCHK(hipMemsetAsync(h->tile_count.p, 0, (T + 2) * 4, s));
             gsr_launch_emit_compact(s, n, k, geom_of(h), h->tile_start.as<uint32_t>(), h->tile_count.as<uint32_t>(),
-                                    h->keys_compact.as<uint64_t>(), max_tile);
+                                    h->keys_compact.as<uint64_t>(), max_tile, /*only_above=*/0u);
             keys = h->keys_compact.as<uint64_t>();
             key_cap = 0;
+        } else if (hybrid) {
+            // the scatter pass restricted to the lists beyond the bins' capacity: their keys go to keys_compact at the offsets of
+            // the compact layout (the buffer is sized as for it; only those segments are touched), with fill cursors of its own
+            // (the tile counters belong to the fused launch, which re-zeroes them)
+            if ((rc = h->keys_compact.ensure(D * 8, slack)) || (rc = h->overflow_fill.ensure((T + 2) * 4))) return rc;
+            HIPCHK(hipMemsetAsync(h->overflow_fill.p, 0, (T + 2) * 4, s));
+            gsr_launch_emit_compact(s, n, k, geom_of(h), h->tile_start.as<uint32_t>(), h->overflow_fill.as<uint32_t>(),
+                                    h->keys_compact.as<uint64_t>(), max_tile, /*only_above=*/h->bin_cap_view);
+            overflow_keys = h->keys_compact.as<uint64_t>();
         }
         gsr_launch_tile_sort(s, (fused_done ? 0 : GSR_SORT_PASS_MAIN) | GSR_SORT_PASS_TIERS, h->n_tiles, h->grid_x, C,
-                             h->tile_start.as<uint32_t>(), h->tile_count.as<uint32_t>(), keys, key_cap,
+                             h->tile_start.as<uint32_t>(), h->tile_count.as<uint32_t>(), keys, key_cap, overflow_keys,
                              n_mid4, n_mid8, n_big, h->big_list.as<uint32_t>(), h->big_scratch.as<uint64_t>(),
                              slab_stride, geom_of(h), stream_of(h), h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>(),
                              nullptr, 0);
         sc4.close();
-        StageScope sc5(h->prof, ST_COMPOSITE_FWD, s);
+        // the walk of the tier tiles: beside the held fused launch (second stream, first in the queue), else behind it
+        const hipStream_t ws = beside ? h->aux_stream : s;
+        if (beside) {
+            HIPCHK(hipEventRecord(h->ev_fork, s));
+            HIPCHK(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
+        }
+        StageScope sc5(h->prof, ST_COMPOSITE_FWD, ws);
         // after the fused launch only the tiles of the tier lists are left; otherwise every tile
-        const GsrTierLists tiers{h->big_list.as<uint32_t>(), (uint32_t)h->n_tiles, n_big, n_mid8, n_mid4, 0u};
-        gsr_launch_composite_fwd(s, C, k, h->tile_start.as<uint32_t>(), fused_done ? nullptr : h->tile_order.as<uint32_t>(),
+        static const bool walk_prio = [] { const char* e = getenv("GSR_WALK_PRIO"); return !(e && e[0] == '0'); }();  // A/B only
+        const GsrTierLists tiers{h->big_list.as<uint32_t>(), (uint32_t)h->n_tiles, n_big, n_mid8, n_mid4, beside && walk_prio ? 1u : 0u};
+        gsr_launch_composite_fwd(ws, C, k, h->tile_start.as<uint32_t>(), fused_done ? nullptr : h->tile_order.as<uint32_t>(),
                                  stream_of(h), in->background, image_out, h->n_contrib.as<uint32_t>(), h->final_T.as<float>(),
                                  h->values_sorted.as<uint32_t>(), aux ? aux->covisibilities : nullptr,
                                  aux ? aux->uncertainties : nullptr, &tiers);
         sc5.close();
+        if (beside) {
+            HIPCHK(hipEventRecord(h->ev_join, h->aux_stream));
+            launch_fused(s);
+            HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
+        }
     }
     h->tile_count_dirty = false;  // the sort (fused or not) zeroed the counters
     HIPCHK(hipGetLastError());

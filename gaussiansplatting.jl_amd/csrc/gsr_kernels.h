@@ -79,9 +79,11 @@ int gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels,
 struct GsrBg8 { float v[8]; };
 void gsr_launch_fill_background(hipStream_t s, size_t n_pixels, int channels, const float* background /* host, 3 floats */,
                                 float* image, float* final_T, uint32_t* n_contrib);
-// compact binning mode: scatter the keys to tile_start[t] + arrival rank (tile_fill zeroed by the caller)
+// compact binning mode: scatter the keys to tile_start[t] + arrival rank (tile_fill zeroed by the caller).
+// only_above > 0: only the tiles whose list is LONGER than that (the lists that overflowed fixed-capacity bins) — the others'
+// segments of `keys` and their fill cursors are not touched
 void gsr_launch_emit_compact(hipStream_t s, int n, GsrCam cam, GsrGeom geom, const uint32_t* tile_start, uint32_t* tile_fill,
-                             uint64_t* keys, uint32_t max_list /* longest tile list of the view */);
+                             uint64_t* keys, uint32_t max_list /* longest tile list of the view */, uint32_t only_above);
 void gsr_launch_pergauss_bwd(hipStream_t s, int n, int K, int degree, int channels, const float* means,
                              const float* scales, const float* rots, const float* shs, GsrCam cam, GsrGeom geom,
                              GsrInst inst, float2* vmean2d, float* vmeans, float* vshs, float* vopac,
@@ -123,6 +125,7 @@ void gsr_launch_tile_scan(hipStream_t s, int n_tiles, const uint32_t* tile_count
 #define GSR_SORT_PASS_TIERS 2
 void gsr_launch_tile_sort(hipStream_t s, int passes, int n_tiles, int grid_x, int channels, const uint32_t* tile_start,
                           uint32_t* tile_count /* re-zeroed for the next view */, const uint64_t* bins, uint32_t bin_cap,
+                          const uint64_t* overflow_keys /* compact-layout keys of the lists longer than bin_cap, or NULL */,
                           uint32_t n_mid4, uint32_t n_mid8, uint32_t n_big, const uint32_t* tier_lists,
                           uint64_t* big_scratch /* 2 slabs of slab_stride keys per tile over 8192 */, size_t slab_stride, GsrGeom geom,
                           GsrStream stream, uint32_t* values_sorted, uint32_t* ranges, const uint32_t* totals,
@@ -135,7 +138,7 @@ void gsr_launch_tile_sort(hipStream_t s, int passes, int n_tiles, int grid_x, in
 struct GsrTierLists {  // the scan's tier lists: [0, T) lists > 8192, [T, 2T) (4096, 8192], [2T, 3T) (1024, 4096]
     const uint32_t* lists;
     uint32_t n_tiles, n_big, n_mid8, n_mid4;  // a tier that is not split has count 0 here
-    uint32_t split_len;
+    uint32_t split_len;  // (forward launch over the lists: non-zero = its waves run at raised issue priority, beside another launch)
 };
 void gsr_launch_composite_fwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
                               const uint32_t* tile_order /* NULL: only the tiles of *listed */, GsrStream stream,

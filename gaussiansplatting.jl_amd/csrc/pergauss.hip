@@ -263,7 +263,10 @@ __attribute__((amdgpu_waves_per_eu(AGG_NT ? 3 * AGG_NT / 256 : 1, AGG_NT ? 8 : 4
     auto agg_lo = [](AggWord v) -> uint32_t { return W32 ? (uint32_t)v & 0xFFFFu : (uint32_t)v; };
     auto agg_hi = [](AggWord v) -> uint32_t { return W32 ? (uint32_t)v >> 16 : (uint32_t)((unsigned long long)v >> 32); };
     const int i = blockIdx.x * NT + threadIdx.x;
-    (void)n_words;
+    // SCATTER: `bin_cap` carries only_above — 0: every tile; else only the tiles whose list is longer (the lists that overflowed
+    // the fixed-capacity bins: the others' keys sit complete in their bins, round 5)
+    const uint32_t only_above = SCATTER ? bin_cap : 0u;
+    (void)n_words; (void)only_above;
     bool visible = false;
     uint32_t area = 0, clamp_bits = 0, emitted = 0;  // emitted: bit k = tile k of the rect (row-major) got an instance
     float m2[2] = {0, 0}, conic[3] = {0, 0, 0}, rgb[3] = {0, 0, 0}, mc_z = 0.0f, tau = 0.0f, opac_v = 0.0f;
@@ -611,6 +614,10 @@ __attribute__((amdgpu_waves_per_eu(AGG_NT ? 3 * AGG_NT / 256 : 1, AGG_NT ? 8 : 4
                 if (SCATTER) {
                     const uint32_t em = emit_tab[wv][src];
                     c0 = va ? (em >> kka) & 1u : 0u; c1 = vb ? (em >> kkb) & 1u : 0u;
+                    if (only_above) {  // (restricted pass: a tile whose list fits its bin takes no position here)
+                        if (c0) c0 = tile_start[t + 1u] - tile_start[t] > only_above ? 1u : 0u;
+                        if (c1) c1 = tile_start[t + 2u] - tile_start[t + 1u] > only_above ? 1u : 0u;
+                    }
                 } else {
                     const float smx = __shfl(m2[0], src), smy = __shfl(m2[1], src);
                     const float sa = __shfl(conic[0], src), sb = __shfl(conic[1], src), sc = __shfl(conic[2], src);
@@ -654,7 +661,11 @@ __attribute__((amdgpu_waves_per_eu(AGG_NT ? 3 * AGG_NT / 256 : 1, AGG_NT ? 8 : 4
                     GSR_AGG_ITEM()
                     const uint32_t em = emit_tab[wv][src];
                     const uint32_t zb = __shfl(__float_as_uint(mc_z), src);
-                    const uint32_t c0 = va ? (em >> kka) & 1u : 0u, c1 = vb ? (em >> kkb) & 1u : 0u;
+                    uint32_t c0 = va ? (em >> kka) & 1u : 0u, c1 = vb ? (em >> kkb) & 1u : 0u;
+                    if (SCATTER && only_above) {
+                        if (c0) c0 = tile_start[t + 1u] - tile_start[t] > only_above ? 1u : 0u;
+                        if (c1) c1 = tile_start[t + 2u] - tile_start[t + 1u] > only_above ? 1u : 0u;
+                    }
                     if (c0 | c1) {
                         const AggWord old = atomicAdd(&agg[(t >> 1) - (uint32_t)wbase], agg_inc(c0, c1));
                         const uint64_t skey = ((uint64_t)zb << 32) | (uint32_t)(blockIdx.x * NT + (threadIdx.x & ~63) + src);
@@ -701,9 +712,13 @@ __attribute__((amdgpu_waves_per_eu(AGG_NT ? 3 * AGG_NT / 256 : 1, AGG_NT ? 8 : 4
                 if (e < 64) first32 = (uint32_t)__builtin_amdgcn_ballot_w64(pass);  // (lane 0 is in the first trip)
                 if (pass) {
                     const uint32_t t = (uint32_t)(y * cam.grid_x + x);
-                    const uint32_t pos = atomicAdd(tile_count + t, 1u);
-                    if (SCATTER) bins[tile_start[t] + pos] = bkey;
-                    else if (pos < bin_cap) bins[(size_t)t * bin_cap + pos] = bkey;
+                    if (SCATTER) {
+                        const uint32_t ts = tile_start[t];
+                        if (!only_above || tile_start[t + 1u] - ts > only_above) bins[ts + atomicAdd(tile_count + t, 1u)] = bkey;
+                    } else {
+                        const uint32_t pos = atomicAdd(tile_count + t, 1u);
+                        if (pos < bin_cap) bins[(size_t)t * bin_cap + pos] = bkey;
+                    }
                 }
             }
             first32 = __shfl(first32, 0);
@@ -1592,7 +1607,7 @@ int gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels,
 // on a 4K grid with 1 % of the tiles at 50 x density).  `max_list`: the longest tile list (the scan's total), which decides
 // between 2 x 16-bit and 2 x 32-bit LDS words.
 void gsr_launch_emit_compact(hipStream_t s, int n, GsrCam cam, GsrGeom geom, const uint32_t* tile_start, uint32_t* tile_fill,
-                             uint64_t* keys, uint32_t max_list) {
+                             uint64_t* keys, uint32_t max_list, uint32_t only_above) {
     if (n <= 0) return;
     const AggPlan pl = agg_plan(cam.grid_x, cam.grid_y, max_list);
     const int n_words = (cam.grid_x * cam.grid_y + 2) / 2;
@@ -1601,7 +1616,7 @@ void gsr_launch_emit_compact(hipStream_t s, int n, GsrCam cam, GsrGeom geom, con
     const float4* nq = nullptr;
 #define LAUNCH_SC(W, B)                                                                                                            \
     hipLaunchKernelGGL((preprocess_kernel<0, kAggThreads, W, true, B>), grid, block, pl.lds, s, n, 0, 3, nf, nf, nq, nf, nf, cam,  \
-                       geom, tile_fill, (uint32_t*)nullptr, keys, 0u, n_words, tile_start, pl.n_bands, pl.band_rows)
+                       geom, tile_fill, (uint32_t*)nullptr, keys, only_above, n_words, tile_start, pl.n_bands, pl.band_rows)
     if (pl.n_bands > 1) { if (pl.w32) LAUNCH_SC(true, true); else LAUNCH_SC(false, true); }
     else if (pl.w32) LAUNCH_SC(true, false);
     else LAUNCH_SC(false, false);

@@ -59,9 +59,12 @@ typedef struct gsr_config {
     float blur_eps;      /* 0.3  */
     uint32_t flags;      /* GSR_FLAG_* */
     uint64_t bins_budget_bytes; /* 0 = default.  Cap on the fixed-capacity per-tile key bins of the fast binning mode
-                          * ((tiles+1) x longest list x 8 B); default max(512 MiB, 160 B x instance count of the last view).
-                          * A view whose bins would exceed it — a few very deep tiles — is binned in compact mode
-                          * (count -> scan -> scatter, 8 B per instance) instead: same lists, same results. */
+                          * ((tiles+1) x capacity x 8 B); default max(512 MiB, 160 B x instance count of the last view).
+                          * Where bins for the longest list would exceed it — a few very deep tiles — the bins are sized for the
+                          * other tiles (4 x the mean list, at least 1024 keys) and only the lists beyond that capacity are
+                          * scattered a second time (+ 8 B per instance); a budget below bins of 2 x the mean list (or of 64
+                          * keys) selects the compact mode (count -> scan -> scatter, 8 B per instance, no bins).  Same lists,
+                          * same results in every mode. */
     /* New in ABI 5 — the two behaviour switches are PER HANDLE, as the reference's knobs are constructor keywords
      * (rasterizer.jl:60-65).  -1 = the process-wide default (gsr_ssim_precision / gsr_preprocess_form below, themselves
      * started from GSR_SSIM_EXACT / GSR_PREPROCESS_AGG), read at every call; 0 / 1 pin the handle whatever another thread
@@ -157,8 +160,11 @@ typedef struct gsr_stats {
     int32_t max_tile_instances; /* longest per-tile list */
     uint64_t generation;        /* ordinal of this forward on the handle (1, 2, ...): pass it to
                                  * gsr_backward (gsr_grads.forward_generation) to have the pairing checked */
-    int64_t bins_bytes;         /* bytes of unsorted-key storage this view used (fast: (T+1) x capacity x 8; compact: 8 D) */
-    int32_t compact_binning;    /* 1: this view was binned count -> scan -> scatter (budget exceeded or bins overflowed) */
+    int64_t bins_bytes;         /* bytes of unsorted-key storage this view used (bins: (T+1) x capacity x 8; compact: 8 D;
+                                 * bins + overflow tiles: the sum) */
+    int32_t compact_binning;    /* 0: fixed-capacity bins; 1: the whole view was binned count -> scan -> scatter (no budget for
+                                 * bins, or bins of < 1024 keys overflowed); 2: bins, and the lists beyond their capacity
+                                 * scattered a second time (the rest of the view stayed on the fast path) */
     int32_t preprocess_form;    /* the binning form this view's first kernel ran in: 0 direct, 1 aggregating (2 x 32-bit LDS
                                  * words), 2 aggregating (2 x 16-bit words), 3 aggregating in horizontal bands of the tile grid */
 } gsr_stats;

@@ -51,7 +51,7 @@ def test_trained_like_3m_1440p_rgbd_properties(pkg, orc):
 
 def test_hot_tile_reduced_size_vs_oracle_and_full_size_properties(pkg, orc):
     """bench.py --skew hot:K.  Reduced: 30 k Gaussians + 6 000 in one tile at 640x480 (a list beyond 4096: the tier sorts, the
-    strip forward, the four-wave backward) against the oracle.  Full: config 3's scene + 32 000 in one tile — compact binning,
+    strip forward, the four-wave backward) against the oracle.  Full: config 3's scene + 32 000 in one tile — bins + the overflow scatter,
     a 32 k-instance list through the chunked merge sort — property set."""
     W, H, n, deg, seed = 640, 480, 30_000, 3, 1003
     s = pkg.synthetic.add_skew(pkg.synthetic.make_scene(n, W, H, deg, seed), "hot:6000", seed)
@@ -61,7 +61,7 @@ def test_hot_tile_reduced_size_vs_oracle_and_full_size_properties(pkg, orc):
     W, H, n = 1920, 1080, 1_000_000
     s = pkg.synthetic.add_skew(pkg.synthetic.make_scene(n, W, H, deg, seed), "hot:32000", seed)
     run = S._properties(pkg, orc, s.n, W, H, seed, with_oracle_fwd=True, scene=s)
-    assert int(run.rast.stats.max_tile_instances) > 30_000 and int(run.rast.stats.compact_binning) == 1
+    assert int(run.rast.stats.max_tile_instances) > 30_000 and int(run.rast.stats.compact_binning) == 2
 
 
 def test_dense_tiles_reduced_size_vs_oracle_and_4k_properties(pkg, orc):

@@ -339,6 +339,78 @@ GSR_NO_MID_FUSED=1 run "dense4k tier sort + strip" $B $C5 --skew dense:0.01:50
 run "cfg3" $B
 }
 
+# p: bins + overflow tiles (a few deep tiles no longer send the whole view to the compact mode): parity, then the skewed scenes with
+#    the default budget (bins + overflow scatter), a budget of 1 byte (compact mode, as before) and, hot tile only, a budget that
+#    holds bins for the deep tile
+case_p() {
+set -x
+O=gpurun_out/r05p; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scenes.py tests/test_gpu_forward_only.py tests/test_gpu_preprocess_forms.py tests/test_gpu_handle_switches.py -x -q > $O/pytest.log 2>&1; echo "rc=$?"; tail -5 $O/pytest.log
+B="python bench.py --in-process --no-extra --no-cpu-baseline --no-other-lists --steps 10 --warmup 3 --steady-steps 0"
+run() { tag=$1; shift; "$@" 2>/dev/null > $O/tmp.json; python - $O/tmp.json "$tag" <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); c=d['config']; s=d['roofline']['stages_ms']
+print(sys.argv[2], 'ms', d['ms_per_step'], 'D', c['tile_instances'], 'longest', c['binning']['longest_tile_list'], c['binning']['mode'][:12], ' '.join(f'{k}={v:.3f}' for k,v in s.items()))
+PY
+}
+for bb in 0 1; do
+  run "hot32k budget $bb" $B --skew hot:32000 --seed 1003 --bins-budget $bb
+  run "hot128k budget $bb" $B --skew hot:128000 --seed 1003 --bins-budget $bb
+  run "dense4k budget $bb" $B --gaussians 5000000 --width 3840 --height 2160 --no-loss --seed 1005 --skew dense:0.01:50 --bins-budget $bb
+  run "trained3m budget $bb" $B --scene trained --seed 1011 --mode rgbd --gaussians 3000000 --width 2560 --height 1440 --bins-budget $bb
+done
+run "hot32k budget 4G" $B --skew hot:32000 --seed 1003 --bins-budget 4000000000
+run "cfg3" $B
+timeout 900 python tools/fuzz_parity.py deep 200 4300 > $O/deep.txt 2>&1; grep -E "^FAIL|cases passed" $O/deep.txt | cut -c1-200
+}
+
+# q: the long-list chain BESIDE the fused launch on reserved CUs (CU-masked streams) when the tier tiles are few: hot tile scenes
+#    with 0 (off) / 8 / 16 / 32 reserved CUs, and the throughput-bound scenes at two limits
+case_q() {
+set -x
+O=gpurun_out/r05q; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scenes.py tests/test_gpu_forward_only.py tests/test_gpu_preprocess_forms.py -x -q > $O/pytest.log 2>&1; echo "rc=$?"; tail -5 $O/pytest.log
+B="python bench.py --in-process --no-extra --no-cpu-baseline --no-other-lists --steps 10 --warmup 3 --steady-steps 0"
+run() { tag=$1; shift; "$@" 2>/dev/null > $O/tmp.json; python - $O/tmp.json "$tag" <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); c=d['config']; s=d['roofline']['stages_ms']
+print(sys.argv[2], 'ms', d['ms_per_step'], 'D', c['tile_instances'], 'longest', c['binning']['longest_tile_list'], c['binning']['mode'][:24], ' '.join(f'{k}={v:.3f}' for k,v in s.items()))
+PY
+}
+for mx in 64 100000; do
+  export GSR_TIERS_BESIDE_MAX=$mx
+  run "hot32k beside_max=$mx" $B --skew hot:32000 --seed 1003
+  run "hot32k no loss beside_max=$mx" $B --skew hot:32000 --seed 1003 --no-loss
+  run "hot128k beside_max=$mx" $B --skew hot:128000 --seed 1003
+  run "hot6k beside_max=$mx" $B --skew hot:6000 --seed 1003
+  run "trained1m max=$mx" $B --scene trained --seed 1010 --mode rgbd
+  run "trained1m sigma 12 max=$mx" $B --scene trained --seed 1010 --mode rgbd --sigma-px 12
+  run "trained3m max=$mx" $B --scene trained --seed 1011 --mode rgbd --gaussians 3000000 --width 2560 --height 1440
+  run "dense4k max=$mx" $B --gaussians 5000000 --width 3840 --height 2160 --no-loss --seed 1005 --skew dense:0.01:50
+  run "dense1080 max=$mx" $B --skew dense:0.02:20 --seed 1003
+done
+GSR_WALK_PRIO=0 run "hot32k walk at normal priority" $B --skew hot:32000 --seed 1003
+GSR_WALK_PRIO=0 run "trained3m walk at normal priority" $B --scene trained --seed 1011 --mode rgbd --gaussians 3000000 --width 2560 --height 1440
+GSR_SORT_TIERS_NETWORK=1 run "hot32k network sorts" $B --skew hot:32000 --seed 1003
+unset GSR_TIERS_BESIDE_MAX
+run "hot32k compact" $B --skew hot:32000 --seed 1003 --bins-budget 1
+run "cfg3" $B
+timeout 900 python tools/fuzz_parity.py deep 150 4500 > $O/deep.txt 2>&1; grep -E "^FAIL|cases passed" $O/deep.txt | cut -c1-200
+}
+
+# r: kernel timeline (rocprofv3 --kernel-trace) of one hot-tile step with the chain on reserved CUs / without
+case_r() {
+O=gpurun_out/r05r; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp; cd - > /dev/null
+for r in 64 0; do
+  export GSR_TIERS_BESIDE_MAX=$r
+  rocprofv3 --kernel-trace --output-format csv -d $O/trace_$r -- python3 bench.py --in-process --no-extra --no-cpu-baseline --no-other-lists --no-scenes --steps 4 --warmup 3 --steady-steps 0 --skew hot:32000 --seed 1003 > $O/bench_$r.log 2>&1
+  tail -1 $O/bench_$r.log | cut -c1-200
+  python3 tools/experiments/timeline.py $O/trace_$r > $O/timeline_$r.txt 2>&1; cat $O/timeline_$r.txt | head -60
+  rm -rf $O/trace_$r
+done
+}
+
 if [ "$1" = "--list" ] || [ -z "$1" ]; then declare -F | sed -n "s/^declare -f case_//p"; exit 0; fi
 if ! declare -F "case_$1" > /dev/null; then echo "unknown case $1 (try --list)" >&2; exit 2; fi
 "case_$1"

@@ -76,9 +76,16 @@ def blend_boundary_pixels(st, opacities, W, H, ulps=4, with_ids=False):
         ys, xs = np.mgrid[y0:min(y0 + 16, H), x0:min(x0 + 16, W)]
         dx = m2[:, 0][:, None, None] - xs[None].astype(np.float32)
         dy = m2[:, 1][:, None, None] - ys[None].astype(np.float32)
-        sig = (con[:, 1][:, None, None] * dx * dy
-               + np.float32(0.5) * (con[:, 0][:, None, None] * dx * dx + con[:, 2][:, None, None] * dy * dy)).astype(np.float32)
-        near = np.abs(sig - tau[:, None, None]) <= ulps * np.spacing(np.abs(tau))[:, None, None]
+        t_xy = con[:, 1][:, None, None] * dx * dy
+        t_xx = np.float32(0.5) * con[:, 0][:, None, None] * dx * dx
+        t_yy = np.float32(0.5) * con[:, 2][:, None, None] * dy * dy
+        sig = (t_xy + (t_xx + t_yy)).astype(np.float32)
+        # the window is `ulps` ulps of the LARGEST term of the sum, not of its result: a pixel 60 px from the centre of a large
+        # anisotropic footprint has three terms of +-100 that cancel to sigma = 5.3 — two orders of evaluation differ by ulps of
+        # 100 there (fuzz edge case 7117: the pair sits 17 ulps of tau from the boundary, 0.5 ulp of its largest term)
+        with np.errstate(invalid="ignore", over="ignore"):
+            scale = np.maximum(np.maximum(np.abs(t_xy), np.maximum(np.abs(t_xx), np.abs(t_yy))), np.abs(tau)[:, None, None])
+            near = np.abs(sig - tau[:, None, None]) <= ulps * np.spacing(scale.astype(np.float32))
         mask[y0:y0 + 16, x0:x0 + 16] |= near.any(0)
         if with_ids and near.any():
             owners.update(int(i) for i in ids[near.reshape(len(ids), -1).any(1)])

@@ -60,28 +60,36 @@ def _compare_forward(st, run, img, opacities=None):
     im = img.cpu().numpy()
     assert im.shape == st.image.shape
     T = run.rast.accum_alpha.cpu().numpy()
+    nc = run.rast.n_contrib.cpu().numpy().astype(np.uint32)
+    # (the last contributor moves by one where the saturation test T' < 1e-4 is decided by the last bits of T:
+    #  one such pixel is already more than 1e-3 of a 25 x 32 image)
+    sat = (nc != st.n_contrib).reshape(im.shape[:2])
+    assert sat.sum() <= max(1, 1e-3 * nc.size)
     if opacities is not None and im.shape[0] * im.shape[1] < 20000:
         # (one pixel of a small image is already more than the 1e-4 outlier fraction: pixels with a pair ON the blend-test
-        #  boundary, where the decision is the last bit of an exp, do not count — hip_helpers.blend_boundary_pixels)
-        keep = ~blend_boundary_pixels(st, opacities, im.shape[1], im.shape[0])
+        #  boundary, where the decision is the last bit of an exp, do not count — hip_helpers.blend_boundary_pixels — and
+        #  neither does the at most one pixel whose walk stopped one entry apart, fuzz sweep case 14113)
+        edge = blend_boundary_pixels(st, opacities, im.shape[1], im.shape[0])
+        keep = ~(edge | sat)
         # a handful of pixels, not a tenth of the image (round-3 verdict / ADVICE: the measured worst case of 9 000 fuzzed
         # scenes was 17 of 1 634 pixels = 1.04 %, under 50 763 splats per pixel)
         assert (~keep).sum() <= max(4, 0.02 * keep.size), ((~keep).sum(), keep.size)
         assert frac_bad(im[keep], st.image[keep], 0.0, 1e-4) <= 1e-4
         assert frac_bad(T[keep], st.accum_alpha[keep], 0.0, 1e-4) <= 1e-4
-        if (~keep).any():
+        fmax = float(max(1.0, np.abs(st.image).max()))
+        if edge.any():
             # ... and what is excluded may only differ by ONE flipped pair: its blend weight is alpha·T <= 1/255 (+ the
             # renormalisation of what lies behind it), times the largest feature value
-            fmax = float(max(1.0, np.abs(st.image).max()))
-            assert np.abs(im[~keep] - st.image[~keep]).max() <= 2.0 / 255.0 * fmax
-            assert np.abs(T[~keep] - st.accum_alpha[~keep]).max() <= 2.0 / 255.0
+            assert np.abs(im[edge] - st.image[edge]).max() <= 2.0 / 255.0 * fmax
+            assert np.abs(T[edge] - st.accum_alpha[edge]).max() <= 2.0 / 255.0
+        if (sat & ~edge).any():
+            # ... or by the ONE entry blended on one side only: at most the transmittance the other side stopped at
+            left = float((1.0 - np.minimum(T, st.accum_alpha.reshape(T.shape))[sat & ~edge]).max())
+            assert np.abs(im[sat & ~edge] - st.image[sat & ~edge]).max() <= 2.0 * (left + 1e-4) * fmax
+            assert np.abs(T[sat & ~edge] - st.accum_alpha.reshape(T.shape)[sat & ~edge]).max() <= 2.0 * (left + 1e-4)
     else:
         assert frac_bad(im, st.image, 0.0, 1e-4) <= 1e-4, np.abs(im - st.image).max()
         assert frac_bad(T, st.accum_alpha, 0.0, 1e-4) <= 1e-4
-    nc = run.rast.n_contrib.cpu().numpy().astype(np.uint32)
-    # (the last contributor moves by one where the saturation test T' < 1e-4 is decided by the last bits of T:
-    #  one such pixel is already more than 1e-3 of a 25 x 32 image)
-    assert (nc != st.n_contrib).sum() <= max(1, 1e-3 * nc.size)
 
 
 def _compare_backward(g, out, vis):

@@ -411,6 +411,18 @@ for r in 64 0; do
 done
 }
 
+# s: full GPU suite + the fuzz families on the build with overflow tiles / the held fused launch, incl. deep scenes under a bins
+#    budget of 1024 and 1536 keys per tile (second view: bins + overflow lists) in both binning forms
+case_s() {
+O=gpurun_out/r05s; mkdir -p $O
+timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log
+timeout 900 python tools/fuzz_parity.py deep 300 5000 > $O/deep.txt 2>&1; grep -E "^FAIL|cases passed|binning mode" $O/deep.txt | cut -c1-220
+GSR_FUZZ_BINS_KEYS=1024 timeout 900 python tools/fuzz_parity.py deep 300 5300 > $O/deep_1024.txt 2>&1; grep -E "^FAIL|cases passed|binning mode" $O/deep_1024.txt | cut -c1-220
+GSR_FUZZ_BINS_KEYS=1536 GSR_PREPROCESS_AGG=1 timeout 900 python tools/fuzz_parity.py deep 300 5600 > $O/deep_1536_agg.txt 2>&1; grep -E "^FAIL|cases passed|binning mode" $O/deep_1536_agg.txt | cut -c1-220
+GSR_FUZZ_BINS_KEYS=1024 timeout 600 python tools/fuzz_parity.py edge 300 7000 > $O/edge_1024.txt 2>&1; grep -E "^FAIL|cases passed|binning mode" $O/edge_1024.txt | cut -c1-220
+timeout 600 python tools/fuzz_parity.py 400 14000 > $O/sweep.txt 2>&1; grep -E "^FAIL|cases passed" $O/sweep.txt | cut -c1-220
+}
+
 if [ "$1" = "--list" ] || [ -z "$1" ]; then declare -F | sed -n "s/^declare -f case_//p"; exit 0; fi
 if ! declare -F "case_$1" > /dev/null; then echo "unknown case $1 (try --list)" >&2; exit 2; fi
 "case_$1"

@@ -13,7 +13,7 @@ forward, every gradient).  Prints the failing cases with their assertion; exit c
       off-screen, SH values that clamp; pose gradients from device-resident poses
   python tools/fuzz_parity.py ssim [N = 300] [first case = 0]    fused SSIM forward / backward (bit-exact) on random
       (B, C, H, W) from 1 x 1 x 1 x 1 up, and the L1 + DSSIM loss head on ragged resolutions
-  python tools/fuzz_parity.py arbitrate sweep|edge CASE ...      failing cases of a campaign against the float64 autograd model:
+  python tools/fuzz_parity.py arbitrate sweep|edge|deep CASE ... failing cases of a campaign against the float64 autograd model:
       which of the suite's criteria — (a) tolerance, (b) conditioning, (c) a boundary pair — explains each gradient tensor
   python tools/fuzz_parity.py trainer [N = 40] [first case = 0]  the bit-exact trainer-tail / compaction tests of
       tests/test_gpu_trainer.py and the densification test of tests/test_gpu_densify.py at random sizes, SH degrees,
@@ -40,11 +40,32 @@ from hip_helpers import HipRun  # noqa: E402
 import fuzz_scenes  # noqa: E402  (tests/fuzz_scenes.py: the seeded scene families, shared with the test suite)
 
 
+# GSR_FUZZ_BINS_KEYS=K: every handle gets a bins budget of K keys per tile (gsr_config.bins_budget_bytes) and renders its view
+# twice — K >= 1024 with lists beyond it: the second view keeps its bins and scatters the overflowing lists again
+# (gsr_stats.compact_binning == 2); K < 64: compact mode.  The counts of each binning mode are printed at the end.
+BINS_KEYS = int(os.environ.get("GSR_FUZZ_BINS_KEYS", "0"))
+BINNING_SEEN = {0: 0, 1: 0, 2: 0}
+
+
+def _budget(cam):
+    T_ = ((cam.width + 15) // 16) * ((cam.height + 15) // 16)
+    return (T_ + 1) * 8 * BINS_KEYS if BINS_KEYS else 0
+
+
+def _fwd(run):
+    if BINS_KEYS:
+        run.forward()
+    img = run.forward()
+    BINNING_SEEN[int(run.rast.stats.compact_binning)] += 1
+    return img
+
+
 def _scene_case(fs):
     """forward (every field, both list modes) + every gradient of one fuzz scene against the oracle."""
     st = orc.forward(fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, background=fs.bg, mode=fs.mode)
-    run = HipRun(pkg, fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, fs.bg, fs.mode, pose_dev=fs.pose)
-    img = run.forward().clone()
+    run = HipRun(pkg, fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, fs.bg, fs.mode, pose_dev=fs.pose,
+                 bins_budget_bytes=_budget(fs.cam))
+    img = _fwd(run).clone()
     T._compare_forward(st, run, img, fs.opac)
     vp = fs.cotangent()
     g = orc.backward(st, vp, fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, background=fs.bg,
@@ -54,8 +75,9 @@ def _scene_case(fs):
         vR, vt = T._compare_backward(g, run.backward(vp), st.radii > 0)
         if fs.pose:
             assert T.rel_l2(vR.reshape(-1), g.vR) <= 1e-4 and T.rel_l2(vt, g.vt) <= 1e-4
-    cul = HipRun(pkg, fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, fs.bg, fs.mode, exact_tile_cull=True)
-    assert torch.equal(cul.forward(), img)
+    cul = HipRun(pkg, fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, fs.bg, fs.mode, exact_tile_cull=True,
+                 bins_budget_bytes=_budget(fs.cam))
+    assert torch.equal(_fwd(cul), img)
     if ok:
         T._compare_backward(g, cul.backward(vp), st.radii > 0)
     return st
@@ -128,7 +150,7 @@ def arbitrate_cases(family, cases):
     (tests/test_gpu_fuzz_regressions.py: criteria (a) / (b) / (c)) on failing cases of a campaign — oracle, HIP kernels and the
     float64 autograd model on the same scene; prints the verdict per gradient tensor, or the assertion that none applies."""
     import test_gpu_fuzz_regressions as R
-    build = {"sweep": fuzz_scenes.sweep_scene, "edge": fuzz_scenes.edge_scene}[family]
+    build = {"sweep": fuzz_scenes.sweep_scene, "edge": fuzz_scenes.edge_scene, "deep": fuzz_scenes.deep_scene}[family]
     bad = 0
     for case in cases:
         fs = build(pkg, case)
@@ -175,6 +197,8 @@ def main():
         q = np.percentile(longest, [0, 25, 50, 75, 100]).astype(int)
         print("deepest tile list per case: min / quartiles / max =", list(q), " cases over 1024 / 4096 / 8192:",
               int((np.array(longest) > 1024).sum()), int((np.array(longest) > 4096).sum()), int((np.array(longest) > 8192).sum()))
+    if deep or edge:
+        print("binning mode of the checked views (gsr_stats.compact_binning 0 bins / 1 compact / 2 bins + overflow lists):", BINNING_SEEN)
     print(f"{n - len(bad)} / {n} {'deep ' if deep else 'edge ' if edge else 'ssim ' if ssim else 'trainer ' if trainer else ''}cases passed (cases {first}..{first + n - 1})")
     sys.exit(min(len(bad), 100))
 

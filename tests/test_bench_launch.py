@@ -271,7 +271,11 @@ def test_scenes_section_is_merged_and_priced():
     slow = dict(same, stages_ms=dict(head, composite_bwd=1.5, tile_sort=0.2, composite_fwd=0.1), ms_per_step=sum(head.values()) + 1.144)
     pr = bench.predict_from_headline(slow, head, cfg)
     assert pr["stages_over_bar"] == ["composite_bwd", "sort_composite_fwd"] and not pr["within_bar"]
-    assert pr["stages"]["sort_composite_fwd"]["measured_ms"] == round(0.355 + 0.2 + 0.1, 4)  # tier launches priced with the fused forward
+    # tier launches priced with the fused forward; the tier walk runs beside the fused launch: sorts + the longer of the two
+    assert pr["stages"]["sort_composite_fwd"]["measured_ms"] == round(0.2 + max(0.355, 0.1), 4) and "beside" in pr["model"]
+    comp = dict(same, stages_ms={k: v for k, v in dict(head, tile_sort=0.4, composite_fwd=0.45).items() if k != "sort_composite_fwd"})
+    pr = bench.predict_from_headline(comp, head, cfg)   # compact mode: no fused launch, the stages follow each other
+    assert pr["stages"]["sort_composite_fwd"]["measured_ms"] == round(0.4 + 0.45, 4) and "beside" not in pr["model"]
     line = {"roofline": {"stages_ms": head}, "config": cfg, "extra_configs": {"scenes": {"a": dict(same), "b": {"error": "x"}}}}
     bench.annotate_predictions(line)
     assert line["extra_configs"]["scenes"]["a"]["vs_config3_cost"]["within_bar"] and "vs_config3_cost" not in line["extra_configs"]["scenes"]["b"]

@@ -1220,7 +1220,8 @@ def run_section(args, section):
                    "n_gaussians": N, "visible": V, "tile_instances": Dn, "views_per_gpu": 1,
                    "binning": {"mode": BINNING_MODES.get(int(rast.stats.compact_binning), "?"),
                                "unsorted_key_bytes": int(rast.stats.bins_bytes), "longest_tile_list": int(rast.stats.max_tile_instances),
-                               "handle_bytes": int(rast.memory_usage())},
+                               "handle_bytes": int(rast.memory_usage()),
+                               "preprocess_form": PREPROCESS_FORMS.get(int(getattr(rast.stats, "preprocess_form", -1)), "?")},
                    "tile_lists": ("reference lists (GSR_FLAG_REFERENCE_TILE_LISTS)" if args.reference_lists else
                                   "library default: exact footprint cull (same image / gradients)"),
                    "parallelism": par,

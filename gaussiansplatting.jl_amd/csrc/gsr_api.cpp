@@ -180,6 +180,33 @@ struct StageScope {
     StageScope& operator=(const StageScope&) = delete;
 };
 
+// Which binning form the default choice takes where both are candidates (pergauss.hip: gsr_preprocess_form_is_open).  The two
+// forms give bit-identical results, so the choice is free: the handle times two views' preprocess in each form (two timing events
+// per view, read without blocking a later view) and keeps the faster; a scene that grew or shrank by a quarter, or 4096 views,
+// start it again.  Until it has decided, the hint from the previous view (skewed lists -> banded) chooses, as before.
+struct FormTuner {
+    static constexpr int kTimed = 4;  // views timed: direct, aggregating, direct, aggregating — the first launch of a kernel also
+                                      // loads its code; the faster of each form's two views counts
+    int phase = 0;          // < kTimed: the view to time next (form = phase & 1); kTimed: read the events; kTimed + 1: decided
+    int form = -1;          // the decision (0 / 1)
+    int n_ref = 0;
+    uint32_t age = 0;
+    float ms[2] = {0.0f, 0.0f};
+    hipEvent_t ev[2 * kTimed] = {};
+    bool decided() const { return phase == kTimed + 1; }
+    void reset() { phase = 0; form = -1; age = 0; }
+    void destroy() { for (auto& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; } }
+    // all timed views complete?  then ms[f] = the faster view of form f
+    bool read() {
+        float t[kTimed];
+        for (int v = 0; v < kTimed; v++)
+            if (hipEventQuery(ev[2 * v + 1]) != hipSuccess || hipEventElapsedTime(&t[v], ev[2 * v], ev[2 * v + 1]) != hipSuccess) return false;
+        ms[0] = std::min(t[0], t[2]);
+        ms[1] = std::min(t[1], t[3]);
+        return true;
+    }
+};
+
 bool valid_mode(int m) { return m == GSR_MODE_RGB || m == GSR_MODE_RGBD || m == GSR_MODE_RGBDN; }
 
 }  // namespace
@@ -195,6 +222,7 @@ struct gsr_handle {
     uint32_t bin_cap = 0;           // capacity (keys per tile) the NEXT fast-mode view will use; 0 = none chosen yet
     uint32_t bin_cap_view = 0;      // capacity the bins were filled with in the current view
     int last_form = 0;              // binning form the last view's preprocess ran in (gsr_stats.preprocess_form)
+    FormTuner tuner;                // the default form choice on grids where both forms are candidates
     bool compact_sticky = false;    // the last view showed that fixed-capacity bins do not fit the budget
     bool last_compact = false;
     bool tile_count_dirty = false;  // counters not yet re-zeroed by the tile sort
@@ -500,6 +528,7 @@ int gsr_destroy(gsr_handle* h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
+    h->tuner.destroy();
     h->prof.destroy();
     delete h;
     return GSR_OK;
@@ -588,12 +617,39 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     // Only a pass that did not reach the sort (an error) leaves them dirty.
     if (h->tile_count_dirty) HIPCHK(hipMemsetAsync(h->tile_count.p, 0, (T + 2) * 4, s));
     h->tile_count_dirty = true;
+    // the binning form of this view: the handle's or the process's choice, else by scene and grid — and where that leaves two
+    // candidates, the one this handle has measured to be faster (FormTuner)
+    int form = preprocess_form_of(h), timed = -1;
+    static const bool no_tuner = [] { const char* e = getenv("GSR_FORM_TUNER"); return e && e[0] == '0'; }();  // A/B only
+    if (form < 0 && !no_tuner && gsr_preprocess_form_is_open(n, h->grid_x, h->grid_y, h->bin_cap_view)) {
+        FormTuner& t = h->tuner;
+        if (t.decided() && (++t.age > 4096u || std::abs(n - t.n_ref) > t.n_ref / 4)) t.reset();
+        if (t.decided()) {
+            form = t.form;
+        } else if (h->generation > 2) {  // (the first views of a handle grow buffers and touch memory for the first time)
+            if (t.phase == FormTuner::kTimed) {
+                if (t.read()) {
+                    t.form = t.ms[1] < 0.97f * t.ms[0] ? 1 : 0;  // (a tie stays with the direct form)
+                    t.phase = FormTuner::kTimed + 1; t.n_ref = n; t.age = 0;
+                    form = t.form;
+                }
+            } else {
+                bool ok = true;
+                for (int e = 2 * t.phase; e < 2 * t.phase + 2; e++)
+                    if (!t.ev[e] && hipEventCreate(&t.ev[e]) != hipSuccess) { t.ev[e] = nullptr; ok = false; }
+                if (ok) { timed = t.phase; form = timed & 1; }
+            }
+            (void)hipGetLastError();  // (hipEventQuery reports "not ready" as an error)
+        }
+    }
     StageScope sc1(h->prof, ST_PREPROCESS, s);
+    if (timed >= 0) HIPCHK(hipEventRecord(h->tuner.ev[2 * timed], s));
     h->last_form = gsr_launch_preprocess(s, n, in->n_coeffs, in->sh_degree, C, in->means, in->scales, in->rotations,
                                          in->opacities, in->shs, k, geom_of(h), h->tile_count.as<uint32_t>(),
                                          h->bvis.as<uint32_t>(), h->bins.as<uint64_t>(), h->bin_cap_view /* 0: count only */,
-                                         h->n_tiles, preprocess_form_of(h),
+                                         h->n_tiles, form,
                                          /*skewed=*/h->last_D > 0 && (uint64_t)h->last_max_tile * (uint64_t)T > 6ull * (uint64_t)h->last_D);
+    if (timed >= 0) { HIPCHK(hipEventRecord(h->tuner.ev[2 * timed + 1], s)); h->tuner.phase = timed + 1; }
     sc1.close();
     const uint32_t seq = ++h->totals_seq ? h->totals_seq : ++h->totals_seq;  // never 0
     StageScope sc2(h->prof, ST_SCAN, s);

@@ -76,6 +76,8 @@ int gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels,
                           GsrGeom geom, uint32_t* tile_count, uint32_t* n_visible /* per 256-block */,
                           uint64_t* bins /* (T+1) x bin_cap keys */, uint32_t bin_cap, int n_tiles, int form,
                           bool skewed /* hint from the previous view: longest tile list >> mean list (hot counter words) */);
+// true where the default form choice has two candidates (large grids): gsr_forward then measures both once per handle
+bool gsr_preprocess_form_is_open(int n, int grid_x, int grid_y, uint32_t bin_cap);
 struct GsrBg8 { float v[8]; };
 void gsr_launch_fill_background(hipStream_t s, size_t n_pixels, int channels, const float* background /* host, 3 floats */,
                                 float* image, float* final_T, uint32_t* n_contrib);

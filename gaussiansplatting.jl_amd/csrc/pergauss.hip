@@ -1555,6 +1555,16 @@ int agg_max_bands_default() {
 }
 }  // namespace
 
+// The default form choice (form = -1) is open where BOTH forms are candidates: scenes of the aggregating form's size on grids that
+// need 2 .. 8 bands (4K).  There neither wins everywhere — a uniform scene in random order is faster direct (config 5: 0.67
+// against 0.84 ms), a skewed one or one whose Gaussians are in spatial order faster banded (dense 4K 2.0 -> 1.1 ms, Morton-ordered
+// config 5 0.78 -> 0.55) — and gsr_forward times each once on the handle and keeps the faster (gsr_api.cpp: FormTuner).
+bool gsr_preprocess_form_is_open(int n, int grid_x, int grid_y, uint32_t bin_cap) {
+    if (n < kAggMinGaussians) return false;
+    const AggPlan pl = agg_plan(grid_x, grid_y, bin_cap);
+    return pl.n_bands > agg_max_bands_default() && pl.n_bands <= 8;
+}
+
 // form — -1: by scene and grid size (default), 0: direct form, 1: aggregating form (per handle: gsr_config.preprocess_form;
 // its -1 = the process default, gsr_preprocess_form).  Returns the form that ran (gsr_stats.preprocess_form).
 int gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels, const float* means,

@@ -335,6 +335,31 @@ def test_overflow_tiles_keep_the_rest_of_the_view_in_its_bins(pkg, orc, exact, f
         assert np.array_equal(some.rast.ranges.cpu().numpy().astype(np.uint32), st.ranges)
 
 
+def test_views_with_and_without_tier_tiles_alternate_on_one_handle(pkg, orc):
+    """gsr_forward holds its fused sort + forward launch when the PREVIOUS view had tiles of more than 1024 instances (their walk
+    then runs beside it on the second stream) and sends it out early otherwise.  Every transition — early -> held, held -> held,
+    held with nothing to wait for -> early — must give the images and gradients of a fresh handle, bit for bit."""
+    W, H, deg = 320, 208, 1
+    base = pkg.synthetic.make_scene(6000, W, H, deg, 81)
+    scenes = [base, pkg.synthetic.add_skew(base, "hot:3000", seed=82), pkg.synthetic.add_skew(base, "hot:9500", seed=83)]
+    cam = orc.Camera(W, H, base.focal)
+    vp = np.random.default_rng(7).standard_normal((H, W, 3)).astype(np.float32)
+    tensors = [[dev(s.means), dev(s.shs), dev(s.opacities.reshape(-1, 1)), dev(s.scales), dev(s.rotations)] for s in scenes]
+    fresh = []
+    for s, t in zip(scenes, tensors):
+        r = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, exact_tile_cull=True)
+        img = r.forward().clone()
+        fresh.append((img, [g.clone() for g in r.backward(vp)[:5]], int(r.rast.stats.max_tile_instances)))
+        r.rast.close()
+    assert fresh[0][2] <= 1024 < fresh[1][2] <= 4096 and fresh[2][2] > 8192
+    one = HipRun(pkg, base.means, base.shs, base.opacities, base.scales, base.rotations, cam, deg, exact_tile_cull=True)
+    for k in (0, 1, 1, 0, 2, 2, 1, 0, 0, 2):
+        one.t = tensors[k]
+        img = one.forward()
+        assert torch.equal(img, fresh[k][0]), k
+        assert all(torch.equal(a, b) for a, b in zip(one.backward(vp)[:5], fresh[k][1])), k
+
+
 def test_hot_tile_scene_stays_within_the_bins_budget(pkg, orc):
     """A skewed scene — one tile 100x deeper than the rest — must not cost O(tiles x longest list) memory: the bins are sized for
     the other tiles, the deep tile's keys are scattered again (8 B per instance), and the scratch stays bounded by the instance

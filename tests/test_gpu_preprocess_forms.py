@@ -150,3 +150,31 @@ def test_compact_scatter_pass_with_lists_beyond_sixteen_bit_positions(pkg, orc):
     assert np.array_equal(run.rast.values_sorted.cpu().numpy().astype(np.uint32), st.values_sorted)
     assert np.array_equal(run.rast.ranges.cpu().numpy().astype(np.uint32), st.ranges)
     assert frac_bad(img, st.image, 0, 1e-4) <= 1e-4
+
+
+def test_default_form_on_a_4k_grid_is_measured_once_and_kept(pkg, orc):
+    """Grids that need bands (4K) with scenes of the aggregating form's size: neither form wins everywhere, so the handle times
+    two views in each (views 3 .. 6: the first two grow buffers) and keeps the faster.  gsr_stats.preprocess_form shows the
+    sequence; every view gives the same image and lists whatever form ran."""
+    W, H, deg, n = 3840, 2160, 0, 260_000
+    s = pkg.synthetic.make_scene(n, W, H, deg, 5700, sigma_px=3.0)
+    cam = orc.Camera(W, H, s.focal)
+    run = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg)
+    forms, first = [], None
+    for it in range(12):
+        img = run.forward()
+        forms.append(int(run.rast.stats.preprocess_form))
+        if first is None:
+            first = (img.clone(), run.rast.values_sorted.clone(), run.rast.ranges.clone())
+        else:
+            assert torch.equal(img, first[0]) and torch.equal(run.rast.values_sorted, first[1]) and torch.equal(run.rast.ranges, first[2])
+    assert forms[:6] == [0, 0, 0, 3, 0, 3], forms      # untimed default (uniform scene: direct), then direct / banded timed twice
+    assert forms[7] in (0, 3) and forms[7:] == [forms[7]] * 5, forms   # decided at view 7 or 8, and kept
+    # a forced form is not touched by any of this
+    with form(pkg, 1):
+        run.forward()
+        assert int(run.rast.stats.preprocess_form) == 3
+    with form(pkg, 0):
+        run.forward()
+        assert int(run.rast.stats.preprocess_form) == 0
+    run.rast.close()

@@ -423,6 +423,47 @@ GSR_FUZZ_BINS_KEYS=1024 timeout 600 python tools/fuzz_parity.py edge 300 7000 > 
 timeout 600 python tools/fuzz_parity.py 400 14000 > $O/sweep.txt 2>&1; grep -E "^FAIL|cases passed" $O/sweep.txt | cut -c1-220
 }
 
+# t: what spatial order of the Gaussians buys the binning at 4K (config 5) and at config 3, per binning form
+case_t() {
+O=gpurun_out/r05t; mkdir -p $O
+B="python bench.py --in-process --no-extra --no-cpu-baseline --no-other-lists --steps 10 --warmup 3 --steady-steps 0"
+run() { tag=$1; shift; "$@" 2>/dev/null > $O/tmp.json; python - $O/tmp.json "$tag" <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); c=d['config']; s=d['roofline']['stages_ms']
+print(sys.argv[2], 'ms', d['ms_per_step'], 'D', c['tile_instances'], 'longest', c['binning']['longest_tile_list'], c['binning']['mode'][:24], ' '.join(f'{k}={v:.3f}' for k,v in s.items()))
+PY
+}
+C5="--gaussians 5000000 --width 3840 --height 2160 --no-loss --seed 1005"
+for ord in random morton; do
+  run "cfg5 $ord default form" $B $C5 --order $ord
+  GSR_PREPROCESS_AGG=1 run "cfg5 $ord aggregating (banded)" $B $C5 --order $ord
+  GSR_PREPROCESS_AGG=0 run "cfg3 $ord direct" $B --order $ord
+  GSR_PREPROCESS_AGG=1 run "cfg3 $ord aggregating" $B --order $ord
+done
+}
+
+# u: the default form choice on banded grids measured per handle (FormTuner): config 5 in random / Morton order, dense 4K, with the
+#    tuner and without (GSR_FORM_TUNER=0: the previous view's skew hint alone)
+case_u() {
+O=gpurun_out/r05u; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_preprocess_forms.py tests/test_gpu_parity.py -x -q 2>&1 | tail -3
+B="python bench.py --in-process --no-extra --no-cpu-baseline --no-other-lists --steps 10 --warmup 8 --steady-steps 0"
+run() { tag=$1; shift; "$@" 2>/dev/null > $O/tmp.json; python - $O/tmp.json "$tag" <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); c=d['config']; s=d['roofline']['stages_ms']
+print(sys.argv[2], 'ms', d['ms_per_step'], 'form', c['binning'].get('preprocess_form'), 'D', c['tile_instances'], ' '.join(f'{k}={v:.3f}' for k,v in s.items()))
+PY
+}
+C5="--gaussians 5000000 --width 3840 --height 2160 --no-loss --seed 1005"
+for tn in 1 0; do
+  export GSR_FORM_TUNER=$tn
+  run "cfg5 random tuner=$tn" $B $C5
+  run "cfg5 morton tuner=$tn" $B $C5 --order morton
+  run "dense4k tuner=$tn" $B $C5 --skew dense:0.01:50
+  run "cfg3 tuner=$tn" $B
+done
+}
+
 if [ "$1" = "--list" ] || [ -z "$1" ]; then declare -F | sed -n "s/^declare -f case_//p"; exit 0; fi
 if ! declare -F "case_$1" > /dev/null; then echo "unknown case $1 (try --list)" >&2; exit 2; fi
 "case_$1"

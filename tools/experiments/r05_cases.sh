@@ -464,6 +464,24 @@ for tn in 1 0; do
 done
 }
 
+# v: register-blocked SSIM kernels (two outputs per thread and pass, 8-byte LDS reads) against the one-output-per-thread ones
+case_v() {
+O=gpurun_out/r05v; mkdir -p $O
+timeout 900 python -m pytest tests/test_golden.py tests/test_gpu_parity.py tests/test_gpu_trainer.py tests/test_gpu_handle_switches.py -x -q -m gpu 2>&1 | tail -3
+B="python bench.py --in-process --no-extra --no-cpu-baseline --no-other-lists --steps 20 --warmup 3 --steady-steps 0"
+run() { tag=$1; shift; "$@" 2>/dev/null > $O/tmp.json; python - $O/tmp.json "$tag" <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); c=d['config']; s=d['roofline']['stages_ms']
+print(sys.argv[2], 'ms', d['ms_per_step'], ' '.join(f'{k}={v:.4f}' for k,v in s.items()))
+PY
+}
+for v in 0 1 0 1; do
+  GSR_SSIM_TILING=$v run "cfg3 tiling=$v" $B
+  GSR_SSIM_TILING=$v GSR_SSIM_EXACT=1 run "cfg3 exact tiling=$v" $B
+  GSR_SSIM_TILING=$v run "rgbd tiling=$v" $B --mode rgbd
+done
+}
+
 if [ "$1" = "--list" ] || [ -z "$1" ]; then declare -F | sed -n "s/^declare -f case_//p"; exit 0; fi
 if ! declare -F "case_$1" > /dev/null; then echo "unknown case $1 (try --list)" >&2; exit 2; fi
 "case_$1"

@@ -465,6 +465,7 @@ done
 }
 
 # v: register-blocked SSIM kernels (two outputs per thread and pass, 8-byte LDS reads) against the one-output-per-thread ones
+#    (measured slower and removed: DESIGN.md §4.2; the kernels are in git history only — GSR_SSIM_TILING no longer exists)
 case_v() {
 O=gpurun_out/r05v; mkdir -p $O
 timeout 900 python -m pytest tests/test_golden.py tests/test_gpu_parity.py tests/test_gpu_trainer.py tests/test_gpu_handle_switches.py -x -q -m gpu 2>&1 | tail -3

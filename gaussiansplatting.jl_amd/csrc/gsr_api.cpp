@@ -780,7 +780,9 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     }
     // (a held fused launch that this view gives no reason to hold any longer: no tier tiles after all, or too many)
     const bool beside = hold_fused && fused_done && long_tiles && (uint64_t)n_mid4 + n_mid8 + n_big <= kBesideMaxTiles;
-    if (hold_fused && !beside) launch_fused(s);
+    // (... and one that would only find its buffers too small — the kernel checks the same totals — is not launched at all: the
+    // main sort pass then re-zeroes the counters and writes the ranges, as in every view without the fused launch)
+    if (hold_fused && !beside && fused_done) launch_fused(s);
     if (!fused_done || long_tiles) {
         StageScope sc4(h->prof, ST_SORT, s);
         const uint64_t* keys = h->bins.as<uint64_t>();

@@ -353,7 +353,8 @@ def test_views_with_and_without_tier_tiles_alternate_on_one_handle(pkg, orc):
         r.rast.close()
     assert fresh[0][2] <= 1024 < fresh[1][2] <= 4096 and fresh[2][2] > 8192
     one = HipRun(pkg, base.means, base.shs, base.opacities, base.scales, base.rotations, cam, deg, exact_tile_cull=True)
-    for k in (0, 1, 1, 0, 2, 2, 1, 0, 0, 2):
+    # (1 -> 2 at its first occurrence: a held launch whose buffers turn out too small — it is not sent, the unfused path runs)
+    for k in (0, 1, 1, 2, 0, 2, 2, 1, 0, 0, 2):
         one.t = tensors[k]
         img = one.forward()
         assert torch.equal(img, fresh[k][0]), k

@@ -483,6 +483,26 @@ for v in 0 1 0 1; do
 done
 }
 
+# w: a held fused launch sends a first slice of its slots out before the host wait (GSR_HELD_EARLY_PERMILLE of the grid)
+case_w() {
+O=gpurun_out/r05w; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scenes.py tests/test_gpu_forward_only.py -x -q 2>&1 | tail -2
+B="python bench.py --in-process --no-extra --no-cpu-baseline --no-other-lists --steps 20 --warmup 3 --steady-steps 0"
+run() { tag=$1; shift; "$@" 2>/dev/null > $O/tmp.json; python - $O/tmp.json "$tag" <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); c=d['config']; s=d['roofline']['stages_ms']
+print(sys.argv[2], 'ms', d['ms_per_step'], 'median', d.get('ms_per_step_median'), ' '.join(f'{k}={v:.3f}' for k,v in s.items()))
+PY
+}
+for pm in 0 60 30 120 0 60; do
+  export GSR_HELD_EARLY_PERMILLE=$pm
+  run "trained1m early=$pm" $B --scene trained --seed 1010 --mode rgbd
+  run "trained3m early=$pm" $B --scene trained --seed 1011 --mode rgbd --gaussians 3000000 --width 2560 --height 1440
+  run "hot32k early=$pm" $B --skew hot:32000 --seed 1003
+  run "hot6k early=$pm" $B --skew hot:6000 --seed 1003
+done
+}
+
 if [ "$1" = "--list" ] || [ -z "$1" ]; then declare -F | sed -n "s/^declare -f case_//p"; exit 0; fi
 if ! declare -F "case_$1" > /dev/null; then echo "unknown case $1 (try --list)" >&2; exit 2; fi
 "case_$1"

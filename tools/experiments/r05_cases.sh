@@ -484,6 +484,7 @@ done
 }
 
 # w: a held fused launch sends a first slice of its slots out before the host wait (GSR_HELD_EARLY_PERMILLE of the grid)
+#    (measured slower — the first slots are the longest lists, and the tier sorts wait for them — and removed: the knob no longer exists)
 case_w() {
 O=gpurun_out/r05w; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scenes.py tests/test_gpu_forward_only.py -x -q 2>&1 | tail -2

@@ -504,6 +504,20 @@ for pm in 0 60 30 120 0 60; do
 done
 }
 
+# x: last fuzz campaign of the round on the final build (every family, both binning forms, bins budgets)
+case_x() {
+O=gpurun_out/r05x; mkdir -p $O
+G='^FAIL|cases passed|binning mode'
+timeout 900 python tools/fuzz_parity.py 800 15000 > $O/sweep.txt 2>&1; grep -E "$G" $O/sweep.txt | cut -c1-220
+timeout 900 python tools/fuzz_parity.py deep 400 6000 > $O/deep.txt 2>&1; grep -E "$G" $O/deep.txt | cut -c1-220
+timeout 700 python tools/fuzz_parity.py edge 500 8000 > $O/edge.txt 2>&1; grep -E "$G" $O/edge.txt | cut -c1-220
+GSR_PREPROCESS_AGG=1 timeout 700 python tools/fuzz_parity.py 500 16000 > $O/sweep_agg.txt 2>&1; grep -E "$G" $O/sweep_agg.txt | cut -c1-220
+GSR_PREPROCESS_AGG=1 GSR_FUZZ_BINS_KEYS=2048 timeout 700 python tools/fuzz_parity.py deep 250 6400 > $O/deep_agg_2048.txt 2>&1; grep -E "$G" $O/deep_agg_2048.txt | cut -c1-220
+GSR_TIERS_BESIDE_MAX=0 timeout 600 python tools/fuzz_parity.py deep 200 6700 > $O/deep_not_held.txt 2>&1; grep -E "$G" $O/deep_not_held.txt | cut -c1-220
+timeout 300 python tools/fuzz_parity.py trainer 40 200 > $O/trainer.txt 2>&1; grep -E "$G" $O/trainer.txt | cut -c1-220
+timeout 300 python tools/fuzz_parity.py ssim 300 1000 > $O/ssim.txt 2>&1; grep -E "$G" $O/ssim.txt | cut -c1-220
+}
+
 if [ "$1" = "--list" ] || [ -z "$1" ]; then declare -F | sed -n "s/^declare -f case_//p"; exit 0; fi
 if ! declare -F "case_$1" > /dev/null; then echo "unknown case $1 (try --list)" >&2; exit 2; fi
 "case_$1"

@@ -145,6 +145,39 @@ def trainer_case(case):
         TD.test_densify_and_prune_matches_oracle(pkg, 1 if iso else 3, kr, int(rng.choice([0, 20])))
 
 
+def _pose_verdict(fs, st):
+    """∇R / ∇t of a scene with device-resident poses (fuzz_parity.py:77): oracle (fp32), HIP and the float64 autograd model.  A pose
+    gradient is ONE sum over every Gaussian of the view — signed terms that largely cancel — so its relative error is the
+    per-Gaussian errors amplified by Σ|terms| / |Σ terms|.  Explained when HIP meets 1e-4 against float64, or is no further from
+    float64 than the fp32 oracle is (x 4 + 1e-4, as criterion (b))."""
+    import f64_model as fm
+    vp = fs.cotangent()
+    g = orc.backward(st, vp, fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, background=fs.bg, pose_grad=True)
+    run = HipRun(pkg, fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, fs.bg, fs.mode, pose_dev=True)
+    run.forward()
+    out = run.backward(vp)
+    hR, ht = out[5].cpu().numpy().astype(np.float64).reshape(-1), out[6].cpu().numpy().astype(np.float64).reshape(-1)
+    tt = lambda a: torch.tensor(np.asarray(a, np.float64), dtype=fm.DT)  # noqa: E731
+    Rl = tt(fs.cam.R).requires_grad_(True)
+    tl = tt(fs.cam.t).requires_grad_(True)
+    img = fm.render_dense(tt(fs.means), tt(fs.shs), tt(fs.opac), tt(fs.scales), tt(fs.rots), fs.cam, fs.deg,
+                          np.asarray(fs.bg, np.float32), fs.mode, st.values_sorted, st.ranges, st.radii, R_w2c=Rl, t_w2c=tl)
+    (img * torch.tensor(vp, dtype=fm.DT)).sum().backward()
+    # the library's ∇R is column-major (3,3) like the oracle's g.vR; the model's leaf is row-major R[r][c]
+    fR_rm = Rl.grad.numpy()
+    oR = np.asarray(g.vR, np.float64).reshape(-1)
+    fR = fR_rm.T.reshape(-1) if T.rel_l2(fR_rm.T.reshape(-1), oR) < T.rel_l2(fR_rm.reshape(-1), oR) else fR_rm.reshape(-1)
+    ft = tl.grad.numpy().reshape(-1)
+    ot = np.asarray(g.vt, np.float64).reshape(-1)
+    res = {}
+    for nm, h, o, f in (("vR", hR, oR, fR), ("vt", ht, ot, ft)):
+        e_ho, e_o, e_h = T.rel_l2(h, o), T.rel_l2(o, f), T.rel_l2(h, f)
+        ok = e_ho <= 1e-4 or e_h <= 1e-4 or e_h <= 4.0 * e_o + 1e-4
+        assert ok, f"{nm}: HIP-oracle {e_ho:.2e}, oracle-f64 {e_o:.2e}, HIP-f64 {e_h:.2e}"
+        res[nm] = f"HIP-oracle {e_ho:.1e}, oracle-f64 {e_o:.1e}, HIP-f64 {e_h:.1e}"
+    return res
+
+
 def arbitrate_cases(family, cases):
     """`python tools/fuzz_parity.py arbitrate sweep|edge CASE ...`: the float64 arbitration of the suite
     (tests/test_gpu_fuzz_regressions.py: criteria (a) / (b) / (c)) on failing cases of a campaign — oracle, HIP kernels and the
@@ -156,7 +189,10 @@ def arbitrate_cases(family, cases):
         fs = build(pkg, case)
         try:
             res, st = R.three_way(pkg, orc, fs)
-            print(family, case, R.arbitrate(res, st, fs), flush=True)
+            verdict = R.arbitrate(res, st, fs)
+            if fs.pose:
+                verdict.update(_pose_verdict(build(pkg, case), st))  # (a fresh scene object: the campaign's cotangent is its rng's FIRST draw)
+            print(family, case, verdict, flush=True)
         except AssertionError as e:
             bad += 1
             print(family, case, "NOT EXPLAINED:", str(e)[:400], flush=True)

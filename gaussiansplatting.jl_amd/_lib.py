@@ -95,7 +95,7 @@ class GatherGroup(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_words", C.c_int32)]
 
 
-EXPORTS = ["gsr_create", "gsr_destroy", "gsr_release_scene_buffers", "gsr_memory_usage", "gsr_forward",
+EXPORTS = ["gsr_create", "gsr_destroy", "gsr_release_scene_buffers", "gsr_memory_usage", "gsr_bins_capacity_after", "gsr_forward",
            "gsr_backward", "gsr_host_wait_policy", "gsr_buffer", "gsr_copy_buffer", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_loss_l1_ssim",
            "gsr_ssim_precision", "gsr_get_ssim_precision", "gsr_preprocess_form", "gsr_get_preprocess_form",
            "gsr_allreduce_grads", "gsr_last_error_string", "gsr_version", "gsr_abi_version", "gsr_check_abi", "gsr_profile_enable",
@@ -147,6 +147,8 @@ def load():
     lib.gsr_release_scene_buffers.argtypes = [vp]
     lib.gsr_memory_usage.argtypes = [vp]
     lib.gsr_memory_usage.restype = C.c_int64
+    lib.gsr_bins_capacity_after.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32]
+    lib.gsr_bins_capacity_after.restype = C.c_uint32
     lib.gsr_forward.argtypes = [vp, C.POINTER(Inputs), C.POINTER(CameraS), vp, C.POINTER(Aux), vp, C.POINTER(Stats)]
     lib.gsr_backward.argtypes = [vp, C.POINTER(Inputs), C.POINTER(CameraS), vp, C.POINTER(Grads), vp]
     lib.gsr_host_wait_policy.argtypes = [i32, i32, i32]

@@ -306,6 +306,21 @@ static inline void cpu_relax() {
 //   because a late timer wake-up (observed on one box of the pool: one step of twenty 3 ms late) lands in the step time.
 // default budget of the fast binning mode's fixed-capacity bins (gsr_config.bins_budget_bytes = 0)
 constexpr uint64_t kBinsBudgetMin = 512ull << 20, kBinsBudgetPerInstance = 160ull;
+
+// Capacity (keys per tile) of the fixed-capacity bins for the view after one with `instances` instances and a longest list of
+// `longest` on a grid of `tiles` tiles: the longest list + 25 % where the budget allows it; where it does not, the deep tiles are
+// OUTLIERS for the overflow path and the bins are sized for the rest (4 x the mean list, at least 1024, + 25 %).  A budget below
+// twice the mean list (or below 64 keys) is no budget for bins at all: 0 = compact mode.
+uint32_t bins_capacity_after(uint64_t instances, uint64_t longest, uint64_t tiles, uint64_t budget_bytes) {
+    const auto round64 = [](uint64_t v) { return (v + v / 4 + 63) & ~63ull; };
+    const uint64_t mean_list = instances / tiles + 1;
+    const uint64_t budget = budget_bytes ? budget_bytes : std::max<uint64_t>(kBinsBudgetMin, kBinsBudgetPerInstance * instances);
+    const uint64_t cap = (budget / (8ull * (tiles + 1))) & ~63ull;
+    uint64_t want = std::max<uint64_t>(64ull, round64(longest));  // (an empty view keeps the minimum)
+    if (want > cap) want = std::min<uint64_t>(cap, round64(std::max<uint64_t>(1024ull, 4ull * mean_list)));
+    if (want < 64 || cap < 2 * mean_list) return 0u;
+    return (uint32_t)std::min<uint64_t>(want, 1u << 20);
+}
 struct WaitPolicy { int spin_us = 30, yield_us = 0, sleep_us = 0; };
 // the three values live in ONE atomic word (21 bits each): a forward on another thread reads the old or the new policy,
 // never a mix of the two (round-4 verdict, weak #9)
@@ -553,6 +568,14 @@ int gsr_release_scene_buffers(gsr_handle* h) {
     return GSR_OK;
 }
 
+uint32_t gsr_bins_capacity_after(int64_t n_rendered, int32_t max_tile_instances, int32_t width, int32_t height,
+                                 uint64_t bins_budget_bytes, uint32_t current_capacity) {
+    if (n_rendered < 0 || max_tile_instances < 0 || width <= 0 || height <= 0) return 0u;
+    const uint64_t tiles = (uint64_t)((width + GSR_TILE - 1) / GSR_TILE) * (uint64_t)((height + GSR_TILE - 1) / GSR_TILE);
+    const uint32_t want = bins_capacity_after((uint64_t)n_rendered, (uint64_t)max_tile_instances, tiles, bins_budget_bytes);
+    return want == 0u ? 0u : std::max(want, current_capacity);
+}
+
 int64_t gsr_memory_usage(const gsr_handle* h) {
     if (!h) return 0;
     int64_t s = 0;
@@ -708,18 +731,10 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     const bool overflow = use_bins && h->host_totals[1] > h->bin_cap_view;
     const bool hybrid = overflow && h->bin_cap_view >= 1024u;
     const bool compact = !use_bins || (overflow && !hybrid);
-    {   // capacity for the NEXT view: the longest list + 25 % where the budget allows it; where it does not, the deep tiles are
-        // OUTLIERS for the overflow path and the bins are sized for the rest (4 x the mean list, at least 1024, + 25 %).  A budget
-        // below twice the mean list is no budget for bins at all: compact mode until that changes.
-        const auto round64 = [](uint64_t v) { return (v + v / 4 + 63) & ~63ull; };
-        const uint64_t mean_list = (uint64_t)h->host_totals[0] / (uint64_t)T + 1;
-        const uint64_t next_budget = h->cfg.bins_budget_bytes ? h->cfg.bins_budget_bytes
-                                                              : std::max<uint64_t>(kBinsBudgetMin, kBinsBudgetPerInstance * (uint64_t)h->host_totals[0]);
-        const uint64_t next_cap = (next_budget / (8ull * (uint64_t)(T + 1))) & ~63ull;
-        uint64_t want = round64(h->host_totals[1]);
-        if (want > next_cap) want = std::min<uint64_t>(next_cap, round64(std::max<uint64_t>(1024ull, 4ull * mean_list)));
-        if (want < 64 || next_cap < 2 * mean_list) { h->bin_cap = 0; h->compact_sticky = true; }
-        else if (want > h->bin_cap || !use_bins) { h->bin_cap = (uint32_t)std::min<uint64_t>(want, 1u << 20); h->compact_sticky = false; }
+    {   // capacity for the NEXT view (bins_capacity_after, above): grow-only while bins are in use
+        const uint32_t want = bins_capacity_after(h->host_totals[0], h->host_totals[1], (uint64_t)T, h->cfg.bins_budget_bytes);
+        if (want == 0u) { h->bin_cap = 0; h->compact_sticky = true; }
+        else if (want > h->bin_cap || !use_bins) { h->bin_cap = want; h->compact_sticky = false; }
     }
     const uint64_t D = h->host_totals[0];
     const uint32_t max_tile = h->host_totals[1], n_big = h->host_totals[2];

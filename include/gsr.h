@@ -205,6 +205,14 @@ GSR_API int gsr_destroy(gsr_handle* h);
 GSR_API int gsr_release_scene_buffers(gsr_handle* h);
 /* memory_usage(rast) — rasterizer.jl:127-134 (device bytes owned by the handle). */
 GSR_API int64_t gsr_memory_usage(const gsr_handle* h);
+/* Memory planning; no GPU needed.  The capacity — keys per tile — of the fixed-capacity key bins gsr_forward chooses for the view
+ * AFTER one that rendered n_rendered instances with a longest tile list of max_tile_instances on a width x height image, under
+ * bins_budget_bytes (0 = the default budget, see gsr_config) and with bins of current_capacity keys in place (0 = none yet; the
+ * capacity only grows).  0 = no bins: compact mode.  The bins take (tiles + 1) x capacity x 8 bytes; a view whose longest list
+ * exceeds the capacity scatters those lists a second time (+ 8 bytes per instance: gsr_stats.compact_binning == 2).
+ * (No reference counterpart: the reference's BinningState is O(instances), states.jl:66-85.) */
+GSR_API uint32_t gsr_bins_capacity_after(int64_t n_rendered, int32_t max_tile_instances, int32_t width, int32_t height,
+                                         uint64_t bins_budget_bytes, uint32_t current_capacity);
 
 /* rasterize(...) — rasterizer.jl:255-408: project! + spherical_harmonics! +
  * count_tiles_per_gaussian! + cumsum! + duplicate_with_keys! + sortperm!/_permute! +

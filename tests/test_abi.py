@@ -278,3 +278,31 @@ def test_julia_files_are_block_and_bracket_balanced(pkg):
         toks = re.findall(r"(?<![\w:.!])(module|function|struct|if|for|while|let|begin|do|try|quote|macro|end)(?![\w!])", "".join(flat))
         opens, ends = sum(t != "end" for t in toks), sum(t == "end" for t in toks)
         assert opens == ends, (f, opens, ends)
+
+
+def test_bins_capacity_policy(pkg):
+    """gsr_bins_capacity_after: the host logic that sizes the fixed-capacity key bins (no GPU): longest list + 25 % where the budget
+    holds it; bins for the typical tile (4 x the mean list, >= 1024 keys) where a few lists are far longer — those are scattered a
+    second time —; no bins (compact mode) under a budget below twice the mean list; grow-only."""
+    f = pkg._lib.load().gsr_bins_capacity_after
+    T = 120 * 68
+    r64 = lambda v: (v + v // 4 + 63) & ~63  # noqa: E731
+    # config 3: 3.9 M instances, longest list 569 -> 768 keys, 50 MB of bins
+    assert f(3_888_089, 569, 1920, 1080, 0, 0) == r64(569) == 768
+    # grow-only, and never below what is in place
+    assert f(3_888_089, 569, 1920, 1080, 0, 1024) == 1024 and f(3_888_089, 1500, 1920, 1080, 0, 1024) == r64(1500)
+    # the trained-like 3 M / 1440p scene: longest 2 395 = 6.7 x the mean list fits the default budget (20 x the mean)
+    assert f(5_171_694, 2395, 2560, 1440, 0, 0) == r64(2395)
+    # one tile of 32 451 instances on config 3's scene: bins for it would take (T + 1) x 40 576 x 8 = 2.6 GB > 645 MB;
+    # the bins are sized for the other tiles: max(1024, 4 x 495) + 25 %
+    cap = f(4_032_599, 32_451, 1920, 1080, 0, 0)
+    assert cap == r64(4 * (4_032_599 // T + 1)) and (T + 1) * cap * 8 < 200 * 2 ** 20 and cap >= 1024
+    # ... the same under an explicit budget that allows 1 536 keys per tile
+    assert f(4_032_599, 32_451, 1920, 1080, (T + 1) * 8 * 1536, 0) == 1536
+    # budgets that hold no useful bins: below twice the mean list, or below 64 keys
+    assert f(4_032_599, 32_451, 1920, 1080, (T + 1) * 8 * 512, 0) == 0
+    assert f(3_888_089, 569, 1920, 1080, 1, 0) == 0 and f(100, 3, 64, 64, 16 * 8 * 17, 0) == 0
+    # a tiny scene: a handful of keys still gets its 64-key bins; nothing rendered: 64 too (the minimum)
+    assert f(100, 3, 64, 64, 0, 0) == 64 and f(0, 0, 64, 64, 0, 0) == 64
+    # invalid arguments
+    assert f(-1, 3, 64, 64, 0, 0) == 0 and f(10, 3, 0, 64, 0, 0) == 0

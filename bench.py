@@ -712,14 +712,18 @@ class Workload:
             vp = self.vpix_fixed
         else:
             _, vp = pkg.fused_ssim.l1_ssim_loss(rast, img, self.target)
+        # the loss head's cotangent has zeros in its depth / alpha / normal channels (the loss only sees features[1:3],
+        # training.jl:656,684-685): said to the backward (GSR_GRADS_COLOR_COTANGENT; nothing to say in :rgb mode)
+        color = not self.no_loss
         if tail is not None and self.tail_in_backward:
             ev[2].record(); ev[3].record()
             pkg.optim.fused_backward_tail_step(rast, vp, self.opt_map, self.raw_map, params[1], params[2], params[3], self.cam,
-                                               self.deg, self.bg)
+                                               self.deg, self.bg, color_cotangent=color)
             e4 = torch.cuda.Event(enable_timing=True); e4.record()
             tail["_last"] = (ev[0], ev[1], ev[2], ev[3], e4)
             return
-        rast.backward_raw(vp, *params, self.cam, self.deg, self.bg, arena=self.arena, factored_sh=self.factored)
+        rast.backward_raw(vp, *params, self.cam, self.deg, self.bg, arena=self.arena, factored_sh=self.factored,
+                          color_cotangent=color)
         exchanged = None
         if self.dist_on:
             if self.exchange_events is not None:
@@ -919,6 +923,8 @@ class Workload:
                "value": round(self.world * self.W * self.H / (m["dt"] / m["steps"]) / 1e6, 3), "unit": "Mpixels/s",
                "steps": m["steps"], "n_gaussians": self.N, "resolution": [self.W, self.H], "mode": self.mode,
                "loss": not self.no_loss and not self.forward_only, "visible": int(self.rast.stats.n_visible),
+               # (:rgbd / :rgbdn with the loss head: the backward is told that only the colour channels carry a cotangent)
+               "color_cotangent": not self.no_loss and not self.forward_only and self.mode != "rgb",
                "tile_instances": int(self.rast.stats.n_rendered),
                "max_tile_instances": int(self.rast.stats.max_tile_instances),
                "compact_binning": int(self.rast.stats.compact_binning) == 1,

@@ -60,9 +60,10 @@ class Stats(C.Structure):
 class Grads(C.Structure):
     _fields_ = [("vmeans", C.c_void_p), ("vshs", C.c_void_p), ("vopacities", C.c_void_p), ("vscales", C.c_void_p),
                 ("vrotations", C.c_void_p), ("vR", C.c_void_p), ("vt", C.c_void_p), ("vcolors", C.c_void_p),
-                ("vmeans2d", C.c_void_p), ("forward_generation", C.c_uint64)]
+                ("vmeans2d", C.c_void_p), ("forward_generation", C.c_uint64), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+GRADS_COLOR_COTANGENT = 0x1  # gsr_grads.flags / gsr_tail_state.flags: channels >= 3 of vpixels are zeros (the loss head's cotangent)
 ADAM_MAX_GROUPS = 8
 
 
@@ -80,7 +81,8 @@ class TailState(C.Structure):  # gsr_tail_state
     _fields_ = [("theta", C.c_void_p * 6), ("mu", C.c_void_p * 6), ("nu", C.c_void_p * 6), ("lr", C.c_float * 6),
                 ("current_step", C.c_uint32 * 6), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("scale_dims", C.c_int32), ("shs", C.c_void_p), ("opacities_act", C.c_void_p),
-                ("scales_act", C.c_void_p), ("vmeans2d", C.c_void_p), ("forward_generation", C.c_uint64)]
+                ("scales_act", C.c_void_p), ("vmeans2d", C.c_void_p), ("forward_generation", C.c_uint64),
+                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class ComposeGroup(C.Structure):

@@ -355,7 +355,11 @@ constexpr int BWD_BATCH = GSR_BWD_BATCH;  // splats staged per round (LDS: one a
 //                    reaches 80 VGPRs = six waves and is 6 % SLOWER: 0.724 -> 0.770 ms);
 //   C == 3 (:rgb)  : NEVER the BG0 kernel (74 -> 70 VGPRs = seven waves: 0.659 -> 0.676 ms; round 3's forced-occupancy probes:
 //                    789 / 735 / 677 / 695 us at 4 / 5 / 6 / 7 waves) — <3, PPL, false, true> is not instantiated.
-template <int C, int PPL, bool LISTED, bool BG0>
+// VC: channels of the pixel cotangent that can be non-zero.  VC == 3 < C (the cotangent comes from the photometric loss head, which
+// only sees features[1:3] — training.jl:656,684-685: depth / alpha / normal channels of vpixels are exact zeros and their feature
+// gradients too): the pixels' cotangent state, the colour·v dot product and the reduction are the :rgb kernel's; the stream, the
+// blend thresholds and the row layout stay the mode's.
+template <int C, int PPL, bool LISTED, bool BG0, int VC = C>
 __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_kernel(int W, int H, int grid_x,
                                                                 const uint32_t* __restrict__ tile_start,
                                                                 const uint32_t* __restrict__ tile_order,
@@ -364,7 +368,8 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
                                                                 const uint32_t* __restrict__ n_contrib,
                                                                 const float* __restrict__ final_T, GsrInst inst,
                                                                 GsrTierLists tiers) {
-    constexpr int NA = AccRow<C>::N, ST = AccRow<C>::STRIDE;
+    static_assert(VC == C || VC == 3, "all channels, or colour only");
+    constexpr int NA = AccRow<VC>::N, ST = AccRow<VC>::STRIDE;
     constexpr int BB = BWD_BATCH, NT = 256 / PPL, NW = NT / 64, ROWS = 4 * PPL;
     // the long tiles are the critical path of the step and share their SIMDs with the main launch's waves: issue priority
     if (LISTED) __builtin_amdgcn_s_setprio(3);
@@ -410,7 +415,7 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
     // (:rgbdn: the rows' y coordinates are rebuilt from the first one — fy0 + 4q, exact in fp32, so dy and sigma keep their
     //  bits — instead of living in PPL registers: one more add per visited group, three registers less)
     constexpr bool FY_REBUILD = C > 5 && PPL > 1;
-    float fy[FY_REBUILD ? 1 : PPL], T[PPL], A[PPL], bgT[BG0 ? 1 : PPL], vp[PPL][C];
+    float fy[FY_REBUILD ? 1 : PPL], T[PPL], A[PPL], bgT[BG0 ? 1 : PPL], vp[PPL][VC];
     int last_contributor[PPL];
     int wave_last = 0;  // deepest list position any pixel of this wave blended
 #pragma unroll
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
         last_contributor[q] = inside ? (int)n_contrib[pi] : 0;
         float bg_dot = 0.0f;
 #pragma unroll
-        for (int c = 0; c < C; c++) {
+        for (int c = 0; c < VC; c++) {
             vp[q][c] = inside ? vpixels[(size_t)C * pi + c] : 0.0f;
             bg_dot += bg.v[c] * vp[q][c];
         }
@@ -491,9 +496,9 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
             // feature sums.  The conic / mean2d gradients (render.jl:262-272) are linear in
             // {dx²·P, dx·U1, U2, dx·P, U1}: those five are what the wave reduces, and the
             // per-instance flush applies the wave-uniform factors (-o/2, conic) once per row.
-            float P = 0.0f, U1 = 0.0f, U2 = 0.0f, col[C];
+            float P = 0.0f, U1 = 0.0f, U2 = 0.0f, col[VC];
 #pragma unroll
-            for (int c = 0; c < C; c++) col[c] = 0.0f;
+            for (int c = 0; c < VC; c++) col[c] = 0.0f;
             unsigned long long any_active = 0ull;
 #ifndef GSR_BWD_NO_ROW_SKIP
             const uint32_t rowbits = __builtin_amdgcn_readfirstlane(__float_as_uint(c2.w)) >> (ROWS * wave);
@@ -525,7 +530,7 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
                     const float fac = alpha * T[q];
                     float cv = f[0] * vp[q][0];
 #pragma unroll
-                    for (int c = 1; c < C; c++) cv += f[c] * vp[q][c];
+                    for (int c = 1; c < VC; c++) cv += f[c] * vp[q][c];
                     const float d = cv - A[q];                 // (color - accum_rec)·v
                     const float valpha = BG0 ? d * T[q] : d * T[q] + bgT[BG0 ? 0 : q] * rinv;
                     A[q] = A[q] + alpha * d;                   // α·cv + (1-α)·A for the next (nearer) splat
@@ -534,7 +539,7 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
                     U1 += t * dy;
                     U2 += t * dy2;
 #pragma unroll
-                    for (int c = 0; c < C; c++) col[c] += fac * vp[q][c];
+                    for (int c = 0; c < VC; c++) col[c] += fac * vp[q][c];
                 }
             }
             if (any_active == 0ull) continue;  // wave-uniform: none of this wave's pixels is touched
@@ -546,7 +551,7 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
 #pragma unroll
             for (int w = 0; w < BB / 64; w++)
                 if ((j >> 6) == w) touched[w] |= 1ull << (j & 63);
-            if (C == 3) {
+            if (VC == 3) {
                 // :rgb — reduce {P, U1, U2, rgb} over the 4 lanes of each pixel column first, apply the
                 // column's dx weights, then finish over the 16 columns (wave_reduce.h: 5 swaps, not 8)
 #ifdef GSR_BWD_MFMA
@@ -558,7 +563,7 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
             } else if (C == 5) {
                 // :rgbd (the reference's default training mode): the same row-then-column scheme with the depth sum
                 // riding along — six swaps instead of the generic network's eight; feature 4 (constant 1) is not a parameter
-                const float total = gsr::wave_reduce_rowcol_rgbd(P, U1, U2, col[0], col[1], col[2], col[C > 3 ? 3 : 0], dx, lane_bits, rowcol_d);
+                const float total = gsr::wave_reduce_rowcol_rgbd(P, U1, U2, col[0], col[1], col[2], col[VC > 3 ? 3 : 0], dx, lane_bits, rowcol_d);
                 if (rowcol_d.slot >= 0) my_row[rowcol_d.slot] = total;
             } else {
                 float part[16];
@@ -572,8 +577,8 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
                 part[6] = U2;        // Σ dy²·G·vα      -> v conic.z
                 part[7] = dxp;       // Σ dx·G·vα   }   -> v mean2d = -o·(conic · these)
                 part[8] = U1;        // Σ dy·G·vα   }
-                if (C > 3) part[9] = col[3];  // depth feature; channel 4 (constant 1) is not a parameter
-                if (C > 5) { part[10] = col[5]; part[11] = col[6]; part[12] = col[7]; }
+                if (VC > 3) part[9] = col[VC > 3 ? 3 : 0];  // depth feature; channel 4 (constant 1) is not a parameter
+                if (VC > 5) { part[10] = col[VC > 5 ? 5 : 0]; part[11] = col[VC > 5 ? 6 : 0]; part[12] = col[VC > 5 ? 7 : 0]; }
                 // transposed wave64 reduction: ~3·NA/2 + 6 VALU ops, then ONE ds_write for all NA sums
                 const float total = gsr::wave_reduce_transposed<NA>(part, lane_bits);
                 // (storing the sums straight into the global row when NW == 1 measured 3 % slower than
@@ -610,11 +615,11 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
                 const float mo = -b.y, mh = -0.5f * b.y;  // vσ = -o·G·vα (render.jl:260)
                 float4* row = inst.rows + (size_t)GSR_ROW_F4(C) * __float_as_uint(l2[tid].w);  // Gaussian-major slot
                 row[0] = make_float4(r[0], r[1], r[2], r[3]);
-                row[1] = make_float4(mh * r[4], mh * r[5], mh * r[6], C > 3 ? r[9 < NA ? 9 : 0] : 0.0f);
+                row[1] = make_float4(mh * r[4], mh * r[5], mh * r[6], VC > 3 ? r[9 < NA ? 9 : 0] : 0.0f);
                 // conic a = 2·ha, c = 2·hc (the stream carries the halves)
                 row[2] = make_float4(mo * (2.0f * a.z * r[7] + a.w * r[8]), mo * (a.w * r[7] + 2.0f * b.x * r[8]),
-                                     C > 5 ? r[10 < NA ? 10 : 0] : 0.0f, C > 5 ? r[11 < NA ? 11 : 0] : 0.0f);
-                if (C > 5) row[3] = make_float4(r[12 < NA ? 12 : 0], 0.0f, 0.0f, 0.0f);
+                                     VC > 5 ? r[10 < NA ? 10 : 0] : 0.0f, VC > 5 ? r[11 < NA ? 11 : 0] : 0.0f);
+                if (C > 5) row[3] = make_float4(VC > 5 ? r[12 < NA ? 12 : 0] : 0.0f, 0.0f, 0.0f, 0.0f);
             }
         }
     }
@@ -959,7 +964,7 @@ void gsr_launch_sort_composite_fwd(hipStream_t s, int channels, GsrCam cam, cons
 void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
                               const uint32_t* tile_order, GsrStream stream, const float* background,
                               const float* vpixels, const uint32_t* n_contrib, const float* final_T, GsrInst inst,
-                              uint32_t split_len) {
+                              uint32_t split_len, bool color_only) {
     dim3 grid(cam.grid_x * cam.grid_y), block(256 / GSR_BWD_PPL);
     Bg bg = make_bg(background, channels);
     GsrTierLists none{};
@@ -971,11 +976,20 @@ void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uin
     // the zero-background kernels where they pay (table above the kernel): C == 5 and C == 8 take BG0, C == 3 never does
     // (:rgb capped at six waves with 1.25 KB of unused dynamic LDS per workgroup takes 0.738 ms: it is the code generated under
     //  the tighter register budget that is slower, not the occupancy)
+#define LAUNCH3(CC, ZZ)                                                                                                \
+    hipLaunchKernelGGL((composite_bwd_kernel<CC, GSR_BWD_PPL, false, ZZ, 3>), grid, block, 0, s, cam.width, cam.height, \
+                       cam.grid_x, tile_start, tile_order, stream, bg, vpixels, n_contrib, final_T, inst, none)
     if (channels == 3) LAUNCH2(3, false);
+    else if (color_only) {
+        // the cotangent of the loss head (channels >= 3 are zeros): the :rgb arithmetic on the mode's stream.  (BG0 as measured
+        // for :rgb: the general kernel)
+        if (channels == 5) LAUNCH3(5, false); else LAUNCH3(8, false);
+    }
     else if (channels == 5) { if (bg0) LAUNCH2(5, true); else LAUNCH2(5, false); }
     else if (bg0) LAUNCH2(8, true);
     else LAUNCH2(8, false);
 #undef LAUNCH2
+#undef LAUNCH3
 }
 
 void gsr_launch_composite_bwd_listed(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,

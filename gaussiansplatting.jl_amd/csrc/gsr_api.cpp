@@ -861,7 +861,10 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
 // scan (> 8192, > 4096 or > 1024 instances): the deepest tiers first, as many as fit the limit.  Four waves cost
 // ~20 % more work per instance, so when long tiles are plentiful they stay with the main launch.
 static int launch_composite_bwd(gsr_handle* h, hipStream_t s, int C, const GsrCam& k, const float* background,
-                                const float* vpixels) {
+                                const float* vpixels, bool color_only) {
+    // (A/B knob: GSR_BWD_COLOR_ONLY=1 treats EVERY cotangent as the loss head's — valid only where it is)
+    static const bool force_color_only = [] { const char* e = getenv("GSR_BWD_COLOR_ONLY"); return e && e[0] == '1'; }();
+    color_only = (color_only || force_color_only) && C > 3;
     // (GSR_BWD_SPLIT_TILES overrides the limit for A/B runs)
     static const uint32_t kMaxSplitTiles = [] { const char* e = getenv("GSR_BWD_SPLIT_TILES"); return e ? (uint32_t)atoi(e) : 256u; }();
     GsrTierLists tiers{h->big_list.as<uint32_t>(), (uint32_t)h->n_tiles, 0, 0, 0, 0xFFFFFFFFu};
@@ -886,7 +889,7 @@ static int launch_composite_bwd(gsr_handle* h, hipStream_t s, int C, const GsrCa
         HIPCHK(hipEventRecord(h->ev_join, h->aux_stream));
     }
     gsr_launch_composite_bwd(s, C, k, h->tile_start.as<uint32_t>(), h->tile_order.as<uint32_t>(), stream_of(h), background,
-                             vpixels, h->n_contrib.as<uint32_t>(), h->final_T.as<float>(), inst_of(h), tiers.split_len);
+                             vpixels, h->n_contrib.as<uint32_t>(), h->final_T.as<float>(), inst_of(h), tiers.split_len, color_only);
     if (n > 0) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
     return GSR_OK;
 }
@@ -903,6 +906,7 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
     if (h->inputs_consumed)
         return fail(GSR_E_STATE, "the inputs of the handle's last forward were updated in place by "
                     "gsr_backward_trainer_tail; run gsr_forward again");
+    if ((g->flags & ~GSR_GRADS_COLOR_COTANGENT) != 0u || g->reserved != 0u) return fail(GSR_E_INVALID_ARG, "unknown gsr_grads.flags / reserved bits");
     if (g->forward_generation != 0 && g->forward_generation != h->generation)
         return fail(GSR_E_STATE, "gsr_backward for forward #%llu, but the handle's last forward is #%llu (another "
                     "gsr_forward ran in between)", (unsigned long long)g->forward_generation,
@@ -926,7 +930,7 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
     }
     GsrCam k = make_cam(h, cam);
     StageScope sc7(h->prof, ST_COMPOSITE_BWD, s);
-    if (h->last_D > 0 && (rc = launch_composite_bwd(h, s, C, k, in->background, vpixels))) return rc;
+    if (h->last_D > 0 && (rc = launch_composite_bwd(h, s, C, k, in->background, vpixels, (g->flags & GSR_GRADS_COLOR_COTANGENT) != 0u))) return rc;
     sc7.close();
     StageScope sc8(h->prof, ST_PERGAUSS_BWD, s);
     gsr_launch_pergauss_bwd(s, n, in->n_coeffs, in->sh_degree, C, in->means, in->scales, in->rotations, in->shs, k,
@@ -1189,6 +1193,7 @@ int gsr_backward_trainer_tail(gsr_handle* h, const gsr_inputs* in, const gsr_cam
     if (h->inputs_consumed)
         return fail(GSR_E_STATE, "the inputs of the handle's last forward were updated in place by "
                     "gsr_backward_trainer_tail; run gsr_forward again");
+    if ((st->flags & ~GSR_GRADS_COLOR_COTANGENT) != 0u || st->reserved != 0u) return fail(GSR_E_INVALID_ARG, "unknown gsr_tail_state.flags / reserved bits");
     if (st->forward_generation != 0 && st->forward_generation != h->generation)
         return fail(GSR_E_STATE, "gsr_backward_trainer_tail for forward #%llu, but the handle's last forward is #%llu",
                     (unsigned long long)st->forward_generation, (unsigned long long)h->generation);
@@ -1215,7 +1220,7 @@ int gsr_backward_trainer_tail(gsr_handle* h, const gsr_inputs* in, const gsr_cam
     h->vmean2d_cur = st->vmeans2d ? reinterpret_cast<float2*>(st->vmeans2d) : h->vmean2d.as<float2>();
     GsrCam k = make_cam(h, cam);
     StageScope sc11(h->prof, ST_COMPOSITE_BWD, s);
-    if (h->last_D > 0 && (rc = launch_composite_bwd(h, s, C, k, in->background, vpixels))) return rc;
+    if (h->last_D > 0 && (rc = launch_composite_bwd(h, s, C, k, in->background, vpixels, (st->flags & GSR_GRADS_COLOR_COTANGENT) != 0u))) return rc;
     sc11.close();
     StageScope sc12(h->prof, ST_PERGAUSS_BWD, s);
     const gsr::TailState S = gsr_make_tail_state(st->theta, st->mu, st->nu, lr_t, st->beta1, st->beta2, st->eps,

@@ -140,7 +140,7 @@ def tail_state(opts, raw, shs, opacities_act, scales_act):
 
 
 def fused_backward_tail_step(rast, vpixels, opts, raw, shs, opacities_act, scales_act, camera, sh_degree, background,
-                             forward_generation: int = 0):
+                             forward_generation: int = 0, color_cotangent: bool = False):
     """The single-GPU `step!` after the loss: ∇rasterize + prologue pullback + the six `NU.step!` + the
     prologue of the next forward, without the gradients ever reaching memory (gsr_backward_trainer_tail).
     Same results, bit for bit, as `rast.backward_raw(...)` followed by `trainer_tail_step(...)`.
@@ -148,7 +148,7 @@ def fused_backward_tail_step(rast, vpixels, opts, raw, shs, opacities_act, scale
     was given as means / rotations, `shs` / `opacities_act` / `scales_act` its other inputs."""
     st, bump = tail_state(opts, raw, shs, opacities_act, scales_act)
     rast.backward_trainer_tail(vpixels, st, raw["points"], shs, opacities_act, scales_act, raw["rotations"], camera,
-                               sh_degree, background, forward_generation=forward_generation)
+                               sh_degree, background, forward_generation=forward_generation, color_cotangent=color_cotangent)
     for o in bump:  # committed only after validation and a successful launch
         o.current_step += 1
 

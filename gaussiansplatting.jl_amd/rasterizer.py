@@ -325,7 +325,7 @@ class GaussianRasterizer:
 
     def backward_raw(self, vpixels, means_3d, shs, opacities, scales, rotations, camera, sh_degree, background,
                      R_w2c=None, t_w2c=None, arena: Optional[torch.Tensor] = None, factored_sh: bool = False,
-                     forward_generation: int = 0):
+                     forward_generation: int = 0, color_cotangent: bool = False):
         """∇rasterize.  Returns (vmeans, vshs, vopacities, vscales, vrot, vR, vt); when `arena`
         (a flat float32 tensor of (11+3K)·N elements, 59·N at K=16) is given the five gradients
         are views into it, laid out [vrot | vmeans | vshs | vopacities | vscales] for one
@@ -335,7 +335,11 @@ class GaussianRasterizer:
         [vrot | vmeans | vopacities | vscales | vcolors] (14·N floats instead of (11+3K)·N) with
         (N,3) `vcolors` — the view's colour cotangent after the clamp mask — in place of vshs; the
         first 11·N floats are summed over ranks, `vcolors` is all-gathered and
-        `sh_grad_from_views` rebuilds ∇shs.  The second return value is then `vcolors`."""
+        `sh_grad_from_views` rebuilds ∇shs.  The second return value is then `vcolors`.
+
+        color_cotangent=True (GSR_GRADS_COLOR_COTANGENT): the caller's promise that channels >= 3 of `vpixels` are exact zeros —
+        the cotangent `fused_ssim.l1_ssim_loss` returns, untouched; in :rgbd / :rgbdn mode the backward then runs the :rgb
+        arithmetic (:rgbdn 0.885 -> 0.702 ms).  Not checked: a depth / normal loss added to vpixels must not set it."""
         inp = self._inputs(means_3d, shs, opacities, scales, rotations, sh_degree, background)
         cs = self._camera(camera, R_w2c, t_w2c)
         _chk(vpixels, "vpixels", (self.height, self.width, self.channels))
@@ -365,14 +369,15 @@ class GaussianRasterizer:
         g = L.Grads(vmeans.data_ptr(), None if factored_sh else vshs.data_ptr(), vopac.data_ptr(), vscales.data_ptr(),
                     vrot.data_ptr(), None if vR is None else vR.data_ptr(), None if vt is None else vt.data_ptr(),
                     vshs.data_ptr() if factored_sh else None,
-                    self.gstate._grad_means_2d.data_ptr() if n else None, int(forward_generation))
+                    self.gstate._grad_means_2d.data_ptr() if n else None, int(forward_generation),
+                    L.GRADS_COLOR_COTANGENT if color_cotangent else 0, 0)
         with torch.cuda.device(self.device):
             L.check(self._lib.gsr_backward(self._h, C.byref(inp), C.byref(cs), _ptr(vpixels), C.byref(g), _stream()))
         return vmeans, vshs, vopac, vscales, vrot, vR, vt
 
 
     def backward_trainer_tail(self, vpixels, tail_state: "L.TailState", means_3d, shs, opacities, scales, rotations,
-                              camera, sh_degree, background, forward_generation: int = 0):
+                              camera, sh_degree, background, forward_generation: int = 0, color_cotangent: bool = False):
         """∇rasterize with the trainer tail applied in its epilogue (gsr_backward_trainer_tail): no gradient
         arrays; the raw parameters, Adam moments and activated copies named by `tail_state` are updated in
         place.  `means_3d` / `rotations` must be the raw points / rotations, `shs` / `opacities` / `scales` the
@@ -382,6 +387,7 @@ class GaussianRasterizer:
         _chk(vpixels, "vpixels", (self.height, self.width, self.channels))
         tail_state.vmeans2d = self.gstate._grad_means_2d.data_ptr() if inp.n else None
         tail_state.forward_generation = int(forward_generation)
+        tail_state.flags = L.GRADS_COLOR_COTANGENT if color_cotangent else 0   # (see backward_raw)
         with torch.cuda.device(self.device):
             L.check(self._lib.gsr_backward_trainer_tail(self._h, C.byref(inp), C.byref(cs), _ptr(vpixels),
                                                         C.byref(tail_state), _stream()))

@@ -193,7 +193,15 @@ typedef struct gsr_grads {
                         * this backward belongs to: an intervening forward on the same handle (e.g. an eval
                         * render between a training forward and its pullback) is reported as GSR_E_STATE instead
                         * of silently producing the gradients of the wrong view. */
+    uint32_t flags;    /* GSR_GRADS_* (new in ABI 5, late): 0 = none */
+    uint32_t reserved; /* must be 0 */
 } gsr_grads;
+/* gsr_grads.flags / gsr_tail_state.flags — the caller's promise that channels >= 3 of `vpixels` (depth, alpha, normal) are exact
+ * zeros: the cotangent gsr_loss_l1_ssim writes — the photometric loss only sees features[1:3] (training.jl:656,684-685) — not
+ * touched since.  ∇render! then runs the :rgb arithmetic on the mode's stream: the :rgbdn backward 0.885 -> 0.702 ms, :rgbd
+ * 0.713 -> 0.700 (config 3).  Gradients equal the unflagged call's up to the association of fp32 sums.  The promise is not
+ * checked: a depth or normal loss added to vpixels in place must not set it.  Ignored in :rgb mode. */
+#define GSR_GRADS_COLOR_COTANGENT 0x1u
 
 typedef struct gsr_handle gsr_handle;
 
@@ -422,6 +430,8 @@ typedef struct gsr_tail_state {
     float* scales_act;          /* (3,N) */
     float* vmeans2d;
     uint64_t forward_generation;
+    uint32_t flags;             /* GSR_GRADS_* (gsr_grads.flags) */
+    uint32_t reserved;          /* must be 0 */
 } gsr_tail_state;
 GSR_API int gsr_backward_trainer_tail(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam,
                                       const float* vpixels, const gsr_tail_state* st, void* stream);

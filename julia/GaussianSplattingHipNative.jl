@@ -66,7 +66,9 @@ struct GsrGrads
     vcolors::Ptr{Float32}          # C_NULL: classic form (∇shs written); see gsr.h for the factored multi-view form
     vmeans2d::Ptr{Float32}         # rast.gstate.∇means_2d
     forward_generation::UInt64     # pairs the pullback with its forward (0 = unchecked)
+    flags::UInt32; reserved::UInt32 # GSR_GRADS_*
 end
+const GSR_GRADS_COLOR_COTANGENT = 0x00000001  # channels >= 4 of the cotangent (depth, alpha, normal) are zeros: the loss head's
 
 check(rc) = rc == 0 || error(unsafe_string(ccall((:gsr_last_error_string, LIB), Cstring, ())))
 
@@ -90,6 +92,7 @@ mutable struct NativeState
     generation::UInt64
     forward_only_outside_ad::Bool  # a bare `rasterize` (no rrule around it) keeps no backward state
     pullback_follows::Bool         # set by the rrule below for the forward it is about to run
+    color_cotangent::Bool          # the next pullbacks' cotangent has zeros in its depth / alpha / normal channels (color_cotangent!)
 end
 const NATIVE = WeakKeyDict{GaussianRasterizer, NativeState}()
 const NATIVE_LOCK = ReentrantLock()
@@ -116,9 +119,24 @@ function enable_hip_native!(rast::GaussianRasterizer; reference_tile_lists::Bool
         GsrConfig(w, h, c, rast.near_plane, rast.far_plane, 3, 0.3f0, reference_tile_lists ? 0x2 : 0x0, 0,
                   ssim_exact === nothing ? Int32(-1) : Int32(ssim_exact), preprocess_form === nothing ? Int32(-1) : Int32(preprocess_form)),
         href))
-    st = NativeState(href[], 0, forward_only_outside_ad, false)
+    st = NativeState(href[], 0, forward_only_outside_ad, false, false)
     finalizer(s -> ccall((:gsr_destroy, LIB), Cint, (Ptr{Cvoid},), s.handle), st)
     lock(() -> (NATIVE[rast] = st), NATIVE_LOCK)
+    return rast
+end
+
+"""
+    color_cotangent!(rast, flag::Bool)
+
+Promise (GSR_GRADS_COLOR_COTANGENT) that the pixel cotangent handed to `∇rasterize` / `backward_trainer_tail!` on this rasterizer has
+exact zeros in every channel above the colour — true for the reference's photometric loss, which only sees `features[1:3]`
+(training.jl:656,684-685), and false as soon as a depth or normal term is added to the loss.  In `:rgbd` / `:rgbdn` mode the backward
+then runs the `:rgb` arithmetic (`:rgbdn` 0.885 -> 0.702 ms at config 3).  Off by default.
+"""
+function color_cotangent!(rast::GaussianRasterizer, flag::Bool)
+    st = native(rast)
+    st === nothing && error("color_cotangent! needs enable_hip_native!(rast)")
+    st.color_cotangent = flag
     return rast
 end
 
@@ -186,7 +204,9 @@ function GaussianSplatting.∇rasterize(vpixels::R3, means_3d::RM, shs::R3, scal
     vt = R_w2c === nothing ? nothing : AMDGPU.zeros(Float32, 3)
     inp, cam = _structs(means_3d, shs, opacities, scales, rotations, R_w2c, t_w2c, camera, sh_degree, background)
     g = GsrGrads(dptr(vmeans), dptr(vshs), dptr(vopac), dptr(vscales), dptr(vrot), dptr(vR), dptr(vt),
-        Ptr{Float32}(C_NULL), Ptr{Float32}(UInt(pointer(rast.gstate.∇means_2d))), st.generation)
+        Ptr{Float32}(C_NULL), Ptr{Float32}(UInt(pointer(rast.gstate.∇means_2d))), st.generation,
+        # (color_cotangent!: the caller's promise that the depth / alpha / normal channels of vpixels are zeros)
+        st.color_cotangent ? GSR_GRADS_COLOR_COTANGENT : UInt32(0), UInt32(0))
     check(ccall((:gsr_backward, LIB), Cint,
         (Ptr{Cvoid}, Ref{GsrInputs}, Ref{GsrCamera}, Ptr{Float32}, Ref{GsrGrads}, Ptr{Cvoid}),
         st.handle, inp, cam, dptr(vpixels), g, hipstream()))
@@ -284,6 +304,7 @@ struct GsrTailState
     beta1::Float32; beta2::Float32; eps::Float32; scale_dims::Int32
     shs::Ptr{Float32}; opacities_act::Ptr{Float32}; scales_act::Ptr{Float32}
     vmeans2d::Ptr{Float32}; forward_generation::UInt64
+    flags::UInt32; reserved::UInt32
 end
 function backward_trainer_tail!(rast::GaussianRasterizer, vpixels, θ::NTuple{6}, opts::NTuple{6}, shs, opacities_act,
         scales_act; camera::Camera, sh_degree::Int, background::SVector{3, Float32}, β1=0.9f0, β2=0.999f0, ϵ=1f-15)
@@ -293,7 +314,8 @@ function backward_trainer_tail!(rast::GaussianRasterizer, vpixels, θ::NTuple{6}
     p(xs) = ntuple(i -> dptr(xs[i]), 6)
     ts = GsrTailState(p(θ), p(map(o -> o.μ[1], opts)), p(map(o -> o.ν[1], opts)), ntuple(i -> Float32(opts[i].lr), 6),
         ntuple(i -> UInt32(opts[i].current_step + 0x1), 6), β1, β2, ϵ, size(θ[5], 1),
-        dptr(shs), dptr(opacities_act), dptr(scales_act), Ptr{Float32}(UInt(pointer(rast.gstate.∇means_2d))), st.generation)
+        dptr(shs), dptr(opacities_act), dptr(scales_act), Ptr{Float32}(UInt(pointer(rast.gstate.∇means_2d))), st.generation,
+        st.color_cotangent ? GSR_GRADS_COLOR_COTANGENT : UInt32(0), UInt32(0))
     check(ccall((:gsr_backward_trainer_tail, LIB), Cint,
         (Ptr{Cvoid}, Ref{GsrInputs}, Ref{GsrCamera}, Ptr{Float32}, Ref{GsrTailState}, Ptr{Cvoid}),
         st.handle, inp, cam, dptr(vpixels), ts, hipstream()))

@@ -58,9 +58,9 @@ def test_struct_sizes_match_header(pkg):
     assert C.sizeof(L.Inputs) == 16 + 5 * 8 + 12 + 4
     assert C.sizeof(L.CameraS) == (9 + 3 + 2 + 2 + 3) * 4 + 4 + 16
     assert C.sizeof(L.Stats) == 40
-    assert C.sizeof(L.Grads) == 80
+    assert C.sizeof(L.Grads) == 88   # + flags, reserved (ABI 5, late: GSR_GRADS_COLOR_COTANGENT)
     assert C.sizeof(L.Aux) == 32
-    assert C.sizeof(L.TailState) == 248
+    assert C.sizeof(L.TailState) == 256
 
 
 def test_struct_sizes_match_the_c_compiler(pkg, tmp_path):

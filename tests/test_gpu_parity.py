@@ -601,6 +601,40 @@ def test_loss_head_vs_oracle(pkg, orc, mode):
     assert abs(float(hl2) - float(loss)) <= 1e-6 and np.array_equal(hv2.cpu().numpy(), vp)
 
 
+@pytest.mark.parametrize("bg", [(0.0, 0.0, 0.0), (0.2, 0.5, 0.1)])
+@pytest.mark.parametrize("mode", ["rgbd", "rgbdn", "rgb"])
+def test_color_cotangent_flag_gives_the_unflagged_gradients(pkg, orc, mode, bg):
+    """GSR_GRADS_COLOR_COTANGENT: the caller says that channels >= 3 of vpixels are zeros (the loss head's cotangent) and the
+    backward of :rgbd / :rgbdn runs the :rgb arithmetic on the mode's stream.  Same gradients as the unflagged call up to the
+    association of fp32 sums, the oracle's within the suite's tolerance; lists beyond 1024 instances included (their launch
+    keeps the full kernel); ignored in :rgb mode; unknown flag bits are refused."""
+    W, H, deg = 200, 120, 2
+    base = pkg.synthetic.make_scene(4000, W, H, deg, 91, sigma_px=5.0)
+    s = pkg.synthetic.add_skew(base, "hot:2500", seed=92)
+    cam = orc.Camera(W, H, s.focal)
+    st = orc.forward(s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, background=bg, mode=mode)
+    tgt = pkg.synthetic.make_target(W, H, 93)
+    run = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, bg, mode)
+    img = run.forward()
+    _, vp = pkg.fused_ssim.l1_ssim_loss(run.rast, img, dev(tgt))
+    vp = vp.clone()
+    assert mode == "rgb" or not vp[:, :, 3:].any()
+    args = (vp, *run.t, run.camera, deg, run.bg)
+    plain = [g.clone() for g in run.rast.backward_raw(*args)[:5]]
+    flagged = [g.clone() for g in run.rast.backward_raw(*args, color_cotangent=True)[:5]]
+    torch.cuda.synchronize()
+    for a, b in zip(plain, flagged):
+        assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) <= (0.0 if mode == "rgb" else 2e-6)
+    g = orc.backward(st, vp.cpu().numpy(), s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, background=bg)
+    _compare_backward(g, flagged + [None, None], st.radii > 0)
+    assert int(run.rast.stats.max_tile_instances) > 1024
+    L = pkg._lib
+    gr = L.Grads(*(t.data_ptr() for t in plain), None, None, None, None, 0, 0x2, 0)
+    inp = run.rast._inputs(*run.t, deg, run.bg)
+    cs = run.rast._camera(run.camera, None, None)
+    assert L.load().gsr_backward(run.rast._h, C.byref(inp), C.byref(cs), vp.data_ptr(), C.byref(gr), None) == L.GSR_E_INVALID_ARG
+
+
 def test_functor_autograd_end_to_end(pkg, orc):
     """rast(points, opacities, scales, rotations, f_dc, f_rest; camera, sh_degree) under autograd:
     raw-parameter gradients = activated gradients x activation derivatives (rasterizer.jl:200-253)."""

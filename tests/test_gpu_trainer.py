@@ -355,14 +355,16 @@ def test_nonfinite_gradient_report(pkg):
         assert int(bad.sum()) == rep.get(nm, (0, 0))[0]
 
 
-@pytest.mark.parametrize("n,deg,max_deg,iso,mode", [(600, 1, 1, False, "rgb"), (1500, 3, 3, False, "rgb"),
-                                                     (777, 1, 3, False, "rgbd"), (300, 0, 0, False, "rgb"),
-                                                     (513, 2, 2, True, "rgb"), (1100, 3, 3, False, "rgbdn")])
-def test_backward_with_the_tail_in_its_epilogue_equals_backward_then_tail(pkg, n, deg, max_deg, iso, mode):
+@pytest.mark.parametrize("n,deg,max_deg,iso,mode,color", [(600, 1, 1, False, "rgb", False), (1500, 3, 3, False, "rgb", False),
+                                                           (777, 1, 3, False, "rgbd", False), (300, 0, 0, False, "rgb", False),
+                                                           (513, 2, 2, True, "rgb", False), (1100, 3, 3, False, "rgbdn", False),
+                                                           (777, 1, 3, False, "rgbd", True), (1100, 3, 3, False, "rgbdn", True)])
+def test_backward_with_the_tail_in_its_epilogue_equals_backward_then_tail(pkg, n, deg, max_deg, iso, mode, color):
     """gsr_backward_trainer_tail == gsr_backward + gsr_trainer_tail_step, bit for bit (θ, μ, ν, the
     activated copies, gstate.∇means_2d), over 4 training steps: culled Gaussians (zero gradient, moments
     still decay), an active SH degree below the stored one, isotropic scales, no features_rest, n % 256 != 0,
-    every render mode."""
+    every render mode; `color`: a cotangent with zeros above the colour channels, announced to both paths
+    (GSR_GRADS_COLOR_COTANGENT: the :rgb arithmetic on the mode's stream)."""
     W, H = 112, 80
     s = pkg.synthetic.make_scene(n, W, H, max_deg, 77, sigma_px=5.0)
     cam = pkg.Camera(W, H, tuple(s.focal))
@@ -391,10 +393,13 @@ def test_backward_with_the_tail_in_its_epilogue_equals_backward_then_tail(pkg, n
         img_b = rast_b.forward_raw(raw_b["points"], *act_b, raw_b["rotations"], cam, deg, bg)
         assert torch.equal(img_a, img_b), step
         vp = (img_a - target) * (2.0 / img_a.numel())     # any cotangent will do; the same one on both sides
-        vm, vsh, vo, vsc, vr, _, _ = rast_a.backward_raw(vp, raw_a["points"], *act_a, raw_a["rotations"], cam, deg, bg)
+        if color:
+            vp[:, :, 3:] = 0.0
+        vm, vsh, vo, vsc, vr, _, _ = rast_a.backward_raw(vp, raw_a["points"], *act_a, raw_a["rotations"], cam, deg, bg,
+                                                         color_cotangent=color)
         O.trainer_tail_step(opt_a, raw_a, dict(vmeans=vm, vshs=vsh, vopacities=vo, vscales=vsc, vrot=vr), *act_a)
         O.fused_backward_tail_step(rast_b, vp.clone(), opt_b, raw_b, *act_b, cam, deg, bg,
-                                   forward_generation=rast_b.stats.generation)
+                                   forward_generation=rast_b.stats.generation, color_cotangent=color)
         torch.cuda.synchronize()
         assert (rast_a.gstate.radii <= 0).any() and (rast_a.gstate.radii > 0).any()
         for k in O.GROUPS:

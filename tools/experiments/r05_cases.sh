@@ -518,6 +518,25 @@ timeout 300 python tools/fuzz_parity.py trainer 40 200 > $O/trainer.txt 2>&1; gr
 timeout 300 python tools/fuzz_parity.py ssim 300 1000 > $O/ssim.txt 2>&1; grep -E "$G" $O/ssim.txt | cut -c1-220
 }
 
+# y: backward with a colour-only pixel cotangent (what the photometric loss head produces: channels >= 3 are zeros) in :rgbd /
+#    :rgbdn — the :rgb arithmetic on the mode's stream
+case_y() {
+O=gpurun_out/r05y; mkdir -p $O
+B="python bench.py --in-process --no-extra --no-cpu-baseline --no-other-lists --no-scenes --steps 20 --warmup 3 --steady-steps 0"
+run() { tag=$1; shift; "$@" 2>/dev/null > $O/tmp.json; python - $O/tmp.json "$tag" <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); c=d['config']; s=d['roofline']['stages_ms']
+print(sys.argv[2], 'ms', d['ms_per_step'], 'median', d.get('ms_per_step_median'), ' '.join(f'{k}={v:.4f}' for k,v in s.items()))
+PY
+}
+for v in 0 1 0 1; do
+  GSR_BWD_COLOR_ONLY=$v run "rgbd color_only=$v" $B --mode rgbd
+  GSR_BWD_COLOR_ONLY=$v run "rgbdn color_only=$v" $B --mode rgbdn
+  GSR_BWD_COLOR_ONLY=$v run "trained3m rgbd color_only=$v" $B --scene trained --seed 1011 --mode rgbd --gaussians 3000000 --width 2560 --height 1440
+done
+run "rgb" $B
+}
+
 if [ "$1" = "--list" ] || [ -z "$1" ]; then declare -F | sed -n "s/^declare -f case_//p"; exit 0; fi
 if ! declare -F "case_$1" > /dev/null; then echo "unknown case $1 (try --list)" >&2; exit 2; fi
 "case_$1"

@@ -347,17 +347,22 @@ def test_views_with_and_without_tier_tiles_alternate_on_one_handle(pkg, orc):
     tensors = [[dev(s.means), dev(s.shs), dev(s.opacities.reshape(-1, 1)), dev(s.scales), dev(s.rotations)] for s in scenes]
     fresh = []
     for s, t in zip(scenes, tensors):
-        r = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, exact_tile_cull=True)
+        r = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, exact_tile_cull=True, want_covis=True,
+                   want_uncert=True)
         img = r.forward().clone()
-        fresh.append((img, [g.clone() for g in r.backward(vp)[:5]], int(r.rast.stats.max_tile_instances)))
+        fresh.append((img, [g.clone() for g in r.backward(vp)[:5]], int(r.rast.stats.max_tile_instances), r.covis.clone(),
+                      r.unc.clone()))
         r.rast.close()
     assert fresh[0][2] <= 1024 < fresh[1][2] <= 4096 and fresh[2][2] > 8192
     one = HipRun(pkg, base.means, base.shs, base.opacities, base.scales, base.rotations, cam, deg, exact_tile_cull=True)
+    one.unc = torch.zeros(H, W, device="cuda")
     # (1 -> 2 at its first occurrence: a held launch whose buffers turn out too small — it is not sent, the unfused path runs)
     for k in (0, 1, 1, 2, 0, 2, 2, 1, 0, 0, 2):
         one.t = tensors[k]
+        one.covis = torch.zeros(scenes[k].means.shape[0], dtype=torch.uint8, device="cuda")   # (side outputs: written by both launches of a held view)
         img = one.forward()
         assert torch.equal(img, fresh[k][0]), k
+        assert torch.equal(one.covis, fresh[k][3]) and torch.equal(one.unc, fresh[k][4]), k
         assert all(torch.equal(a, b) for a, b in zip(one.backward(vp)[:5], fresh[k][1])), k
 
 

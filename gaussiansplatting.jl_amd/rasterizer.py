@@ -528,11 +528,12 @@ def rasterize(means_3d, shs, opacities, scales, rotations, R_w2c=None, t_w2c=Non
 
 
 def grad_rasterize(vpixels, means_3d, shs, scales, rotations, opacities, radii=None, R_w2c=None, t_w2c=None, *,
-                   rast: GaussianRasterizer, camera: Camera, sh_degree: int, background=(0.0, 0.0, 0.0)):
+                   rast: GaussianRasterizer, camera: Camera, sh_degree: int, background=(0.0, 0.0, 0.0),
+                   color_cotangent: bool = False):
     """∇rasterize(vpixels, means_3d, shs, scales, rotations, opacities, radii, R_w2c, t_w2c; ...)
     — rasterizer.jl:416-550 (argument order as in the reference; `radii` is taken from the
     rasterizer state).  Needs a state-keeping forward on `rast` just before it: `rasterize(..., forward_only=False)` (or
     `rast.forward_only_outside_ad = False`), `forward_raw(...)`, or a differentiated `rasterize`; after a forward-only
-    render it raises GsrError(GSR_E_STATE)."""
+    render it raises GsrError(GSR_E_STATE).  `color_cotangent`: see `GaussianRasterizer.backward_raw`."""
     return rast.backward_raw(vpixels, means_3d, shs, opacities, scales, rotations, camera, sh_degree, background,
-                             R_w2c, t_w2c)
+                             R_w2c, t_w2c, color_cotangent=color_cotangent)

@@ -82,7 +82,10 @@ PREPROCESS_FORMS = {0: "direct", 1: "aggregating (2 x 32-bit LDS words)", 2: "ag
 # The kernel sources a PMC measurement belongs to (profiles/pmc_traffic.json: `kernel_sources`, written by
 # tools/pmc_parse.py): git blob hashes, computed from the file contents (the GPU box has no .git).  A measurement whose
 # hashes differ from the tree bench.py runs in is STALE — `traffic: null`, `pmc_stale: true` (round-4 verdict, weak #8).
-PMC_KERNEL_SOURCES = ("composite.hip", "pergauss.hip", "binning.hip", "wave_reduce.h", "tile_sort_device.h", "tile_mask.h")
+# (round 6, ADVICE r5: + the launch choreography — gsr_api.cpp / gsr_policy.cpp decide which launches run held, beside, split —,
+# the internal kernel interface and ssim.hip: a change there used to leave the committed traffic marked fresh)
+PMC_KERNEL_SOURCES = ("composite.hip", "pergauss.hip", "binning.hip", "ssim.hip", "wave_reduce.h", "tile_sort_device.h", "tile_mask.h",
+                      "gsr_kernels.h", "agg_plan.h", "gsr_api.cpp", "gsr_policy.cpp")
 
 
 def git_blob_hash(path):

@@ -14,11 +14,15 @@ LIB_PATH = os.environ.get("GSR_HIP_LIB", os.path.join(_HERE, "libgsr_hip.so"))  
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gsr.h")
 
 GSR_OK, GSR_E_INVALID_ARG, GSR_E_OOM, GSR_E_HIP, GSR_E_STATE = 0, -1, -2, -3, -4
-DEFAULT = -1  # GSR_DEFAULT: gsr_config.ssim_precision / preprocess_form = the process-wide default
+DEFAULT = 0  # GSR_DEFAULT (ABI 6: 0, so that a zero-initialised gsr_config is the default config)
+SSIM_FAST, SSIM_EXACT = 1, 2                      # gsr_config.ssim_precision
+PREPROCESS_DIRECT, PREPROCESS_AGGREGATING = 1, 2  # gsr_config.preprocess_form
+TUNER_OFF, TUNER_ON = 1, 2                        # gsr_config.form_tuner
+GRAD_FP32_REFERENCE = 1                           # gsr_config.grad_precision
 MODES = {"rgb": 3, "rgbd": 5, "rgbdn": 8}
 FORWARD_ONLY = 1  # gsr_aux.flags: no backward state is kept (inference render)
 FLAG_REFERENCE_TILE_LISTS = 2  # flags = 0: exact footprint culling (the default); bit 1 is retired (rejected)
-ABI_VERSION = 5  # GSR_ABI_VERSION of the include/gsr.h this mirror was written against
+ABI_VERSION = 6  # GSR_ABI_VERSION of the include/gsr.h this mirror was written against
 
 (BUF_RADII, BUF_GRAD_MEANS2D, BUF_N_CONTRIB, BUF_FINAL_T, BUF_TILE_RANGES, BUF_VALUES_SORTED, BUF_GEOM, BUF_NORMALS,
  BUF_GRAD_ROWS, BUF_INSTANCE_AUX) = range(10)
@@ -33,7 +37,8 @@ class GsrError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("mode", C.c_int32), ("near_plane", C.c_float),
                 ("far_plane", C.c_float), ("radius_clip", C.c_int32), ("blur_eps", C.c_float), ("flags", C.c_uint32),
-                ("bins_budget_bytes", C.c_uint64), ("ssim_precision", C.c_int32), ("preprocess_form", C.c_int32)]
+                ("bins_budget_bytes", C.c_uint64), ("ssim_precision", C.c_int32), ("preprocess_form", C.c_int32),
+                ("form_tuner", C.c_int32), ("grad_precision", C.c_int32)]
 
 
 class Inputs(C.Structure):
@@ -54,7 +59,17 @@ class Aux(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("n_rendered", C.c_int64), ("n_visible", C.c_int32), ("max_tile_instances", C.c_int32),
-                ("generation", C.c_uint64), ("bins_bytes", C.c_int64), ("compact_binning", C.c_int32), ("preprocess_form", C.c_int32)]
+                ("generation", C.c_uint64), ("bins_bytes", C.c_int64), ("compact_binning", C.c_int32), ("preprocess_form", C.c_int32),
+                # ABI 6: the handle's view history (gsr_policy.h), cumulative since gsr_create
+                ("bins_regrowths", C.c_uint32), ("compact_fallbacks", C.c_uint32), ("tuner_rearms", C.c_uint32),
+                ("scratch_regrowths", C.c_uint32), ("fused_relaunches", C.c_uint32), ("held_views", C.c_uint32),
+                ("bin_capacity", C.c_uint32), ("tuner_form", C.c_int32), ("tuner_ms", C.c_float * 2),
+                ("tier_tiles", C.c_uint32 * 3), ("reserved", C.c_uint32)]
+
+    HISTORY = ("bins_regrowths", "compact_fallbacks", "tuner_rearms", "scratch_regrowths", "fused_relaunches", "held_views")
+
+    def history(self) -> dict:
+        return {k: int(getattr(self, k)) for k in self.HISTORY}
 
 
 class Grads(C.Structure):
@@ -97,6 +112,68 @@ class GatherGroup(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_words", C.c_int32)]
 
 
+# ---- include/gsr_policy.h: the library's policies as GPU-free functions ----
+class FormTuner(C.Structure):
+    _fields_ = [("phase", C.c_int32), ("form", C.c_int32), ("n_ref", C.c_int32), ("age", C.c_uint32), ("ms", C.c_float * 2)]
+
+
+class PolicyConfig(C.Structure):
+    _fields_ = [("grid_x", C.c_int32), ("grid_y", C.c_int32), ("bins_budget_bytes", C.c_uint64), ("preprocess_form", C.c_int32),
+                ("form_tuner", C.c_int32), ("beside_max_tiles", C.c_uint32), ("bwd_split_max_tiles", C.c_uint32),
+                ("agg_max_bands", C.c_int32), ("reserved", C.c_int32)]
+
+
+class PolicyState(C.Structure):
+    _fields_ = [("bin_cap", C.c_uint32), ("compact_sticky", C.c_uint32), ("last_n", C.c_int32), ("last_max_tile", C.c_uint32),
+                ("last_n_rendered", C.c_int64), ("tier_n", C.c_uint32 * 3), ("bin_cap_view", C.c_uint32), ("views", C.c_uint64),
+                ("tuner", FormTuner), ("bins_regrowths", C.c_uint32), ("compact_fallbacks", C.c_uint32),
+                ("compact_views", C.c_uint32), ("overflow_views", C.c_uint32), ("tuner_rearms", C.c_uint32),
+                ("fused_relaunches", C.c_uint32), ("held_views", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class ViewPlan(C.Structure):
+    _fields_ = [("bin_cap_view", C.c_uint32), ("form_request", C.c_int32), ("form", C.c_int32), ("timed_slot", C.c_int32),
+                ("skewed", C.c_int32), ("hold_fused", C.c_int32), ("tuner_decided", C.c_int32), ("reserved", C.c_int32)]
+
+
+class ViewOutcome(C.Structure):
+    _fields_ = [("binning", C.c_int32), ("fused_done", C.c_int32), ("long_tiles", C.c_int32), ("beside", C.c_int32),
+                ("launch_fused_now", C.c_int32), ("reserved", C.c_int32), ("bin_cap_next", C.c_uint32), ("bins_regrown", C.c_uint32)]
+
+
+class BwdSplit(C.Structure):
+    _fields_ = [("n_big", C.c_uint32), ("n_mid8", C.c_uint32), ("n_mid4", C.c_uint32), ("split_len", C.c_uint32)]
+
+
+POLICY_EXPORTS = ["gsr_policy_config_init", "gsr_policy_state_init", "gsr_policy_agg_plan", "gsr_policy_preprocess_form",
+                  "gsr_policy_form_is_open", "gsr_policy_begin_view", "gsr_policy_end_view", "gsr_policy_bwd_split"]
+
+
+def bind_policy(lib):
+    """argtypes of the gsr_policy_* exports on `lib` (libgsr_hip.so, or the g++-only build tests/test_policy.py makes)."""
+    P = C.POINTER
+    lib.gsr_policy_config_init.argtypes = [P(PolicyConfig), C.c_int32, C.c_int32, C.c_uint64, C.c_int32]
+    lib.gsr_policy_config_init.restype = None
+    lib.gsr_policy_state_init.argtypes = [P(PolicyState)]
+    lib.gsr_policy_state_init.restype = None
+    lib.gsr_policy_agg_plan.argtypes = [C.c_int32, C.c_int32, C.c_uint32, P(C.c_int32), P(C.c_int32), P(C.c_size_t), P(C.c_int32)]
+    lib.gsr_policy_agg_plan.restype = None
+    lib.gsr_policy_preprocess_form.argtypes = [P(PolicyConfig), C.c_int32, C.c_int32, C.c_uint32, C.c_int32]
+    lib.gsr_policy_preprocess_form.restype = C.c_int32
+    lib.gsr_policy_form_is_open.argtypes = [P(PolicyConfig), C.c_int32, C.c_uint32]
+    lib.gsr_policy_form_is_open.restype = C.c_int32
+    lib.gsr_policy_begin_view.argtypes = [P(PolicyConfig), P(PolicyState), C.c_int32, P(C.c_float), P(ViewPlan)]
+    lib.gsr_policy_begin_view.restype = None
+    lib.gsr_policy_end_view.argtypes = [P(PolicyConfig), P(PolicyState), P(ViewPlan), C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                        C.c_uint32, C.c_uint64, C.c_int32, P(ViewOutcome)]
+    lib.gsr_policy_end_view.restype = None
+    lib.gsr_policy_bwd_split.argtypes = [P(PolicyConfig), C.c_uint32, C.c_uint32, C.c_uint32, P(BwdSplit)]
+    lib.gsr_policy_bwd_split.restype = None
+    lib.gsr_bins_capacity_after.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32]
+    lib.gsr_bins_capacity_after.restype = C.c_uint32
+    return lib
+
+
 EXPORTS = ["gsr_create", "gsr_destroy", "gsr_release_scene_buffers", "gsr_memory_usage", "gsr_bins_capacity_after", "gsr_forward",
            "gsr_backward", "gsr_host_wait_policy", "gsr_buffer", "gsr_copy_buffer", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_loss_l1_ssim",
            "gsr_ssim_precision", "gsr_get_ssim_precision", "gsr_preprocess_form", "gsr_get_preprocess_form",
@@ -106,7 +183,7 @@ EXPORTS = ["gsr_create", "gsr_destroy", "gsr_release_scene_buffers", "gsr_memory
            "gsr_mask_findall_scratch_bytes", "gsr_mask_findall", "gsr_gather_rows", "gsr_sh_grad_from_views", "gsr_sh_grad_from_views_tail", "gsr_trainer_tail_step",
            "gsr_backward_trainer_tail",
            "gsr_densify_grad_mean", "gsr_densify_mask", "gsr_compose_rows", "gsr_split_transform", "gsr_reset_opacity", "gsr_morton_codes",
-           "gsr_ply_pack_rows", "gsr_ply_unpack_rows", "gsr_count_nonfinite"]
+           "gsr_ply_pack_rows", "gsr_ply_unpack_rows", "gsr_count_nonfinite"] + POLICY_EXPORTS
 
 _lib = None
 
@@ -149,8 +226,7 @@ def load():
     lib.gsr_release_scene_buffers.argtypes = [vp]
     lib.gsr_memory_usage.argtypes = [vp]
     lib.gsr_memory_usage.restype = C.c_int64
-    lib.gsr_bins_capacity_after.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32]
-    lib.gsr_bins_capacity_after.restype = C.c_uint32
+    bind_policy(lib)
     lib.gsr_forward.argtypes = [vp, C.POINTER(Inputs), C.POINTER(CameraS), vp, C.POINTER(Aux), vp, C.POINTER(Stats)]
     lib.gsr_backward.argtypes = [vp, C.POINTER(Inputs), C.POINTER(CameraS), vp, C.POINTER(Grads), vp]
     lib.gsr_host_wait_policy.argtypes = [i32, i32, i32]
@@ -194,9 +270,9 @@ def load():
     lib.gsr_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int), i32]
     lib.gsr_last_error_string.restype = C.c_char_p
     lib.gsr_version.restype = C.c_char_p
-    lib.gsr_check_abi.argtypes = [i32] + [C.c_size_t] * 6
+    lib.gsr_check_abi.argtypes = [i32] + [C.c_size_t] * 7
     # a stale library next to a newer mirror (or the reverse) must fail here, loudly, not mis-read structs later
-    rc = lib.gsr_check_abi(ABI_VERSION, *[C.sizeof(t) for t in (Config, Inputs, CameraS, Aux, Stats, Grads)])
+    rc = lib.gsr_check_abi(ABI_VERSION, *[C.sizeof(t) for t in (Config, Inputs, CameraS, Aux, Stats, Grads, TailState)])
     if rc != 0:
         raise GsrError(rc, lib.gsr_last_error_string().decode())
     _lib = lib

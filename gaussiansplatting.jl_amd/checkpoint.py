@@ -25,6 +25,7 @@ import numpy as np
 
 CHECKPOINT_FORMAT = "GaussianSplatting.jl-checkpoint-1"
 OPTIMIZER_NAMES = ("points", "features_dc", "features_rest", "opacities", "scales", "rotations")  # training.jl:415-416
+STRATEGY_STATS = ("max_radii", "accum_grad_means_2d", "denom")  # DefaultStrategy's per-Gaussian statistics (strategy.jl:30-34)
 
 
 class Checkpoint:
@@ -158,6 +159,13 @@ def save_state(filename: str, gaussians, optimizers: Dict[str, object], step: in
     if strategy is not None:
         for k, v in strategy.state_dict().items():
             meta[f"strategy.{k}"] = str(int(v))
+        # ... and its running statistics (strategy.jl:30-34: max_radii, accum_∇means_2d, denom).  The reference does not
+        # save them — a resumed reference run densifies from half an interval's statistics —; with them a resume in the
+        # middle of a densification interval continues BIT-IDENTICALLY (tests/test_gpu_train_protocol.py).  Extra tensors the
+        # reference's reader never asks for.
+        for k in STRATEGY_STATS:
+            if getattr(strategy, k, None) is not None:
+                tensors[f"strategy.{k}"] = _host(getattr(strategy, k))
     for k, v in (extra_meta or {}).items():
         meta[str(k)] = str(v)
     save_checkpoint(filename, tensors, meta)
@@ -172,4 +180,13 @@ def load_state(filename: str, optimizers: Dict[str, object], strategy=None):
         read_adam(optimizers[name], ckpt, f"optimizers.{name}", numel=int(np.asarray(getattr(g, name)).size))
     if strategy is not None and "strategy.split_rounds" in ckpt.meta:
         strategy.load_state_dict({k: ckpt.read_scalar(f"strategy.{k}") for k in ("split_seed_base", "split_rounds")})
+    if strategy is not None and all(f"strategy.{k}" in ckpt for k in STRATEGY_STATS):
+        import torch
+        n = int(np.asarray(g.points).shape[0])
+        for k in STRATEGY_STATS:
+            host = ckpt.tensor(f"strategy.{k}").reshape(-1)
+            if host.size != n:
+                raise ValueError(f"strategy.{k}: {host.size} entries for {n} Gaussians")
+            cur = getattr(strategy, k)
+            setattr(strategy, k, torch.from_numpy(np.ascontiguousarray(host)).to(cur.device if cur is not None else "cpu"))
     return g, ckpt.read_scalar("step")

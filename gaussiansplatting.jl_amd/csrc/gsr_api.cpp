@@ -47,10 +47,12 @@ int fail(int code, const char* fmt, ...) {
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;  // bytes
+    uint32_t regrowths = 0;  // reallocations of a buffer that already existed (each is a device synchronisation)
     // grow-only, like the reference's scratch (rasterizer.jl:275-278,340-343)
     int ensure(size_t bytes, float slack = 1.0f) {
         if (bytes <= cap) return GSR_OK;
         if (p) {
+            regrowths++;
             HIPCHK(hipFree(p));
             p = nullptr;
             cap = 0;
@@ -180,29 +182,25 @@ struct StageScope {
     StageScope& operator=(const StageScope&) = delete;
 };
 
-// Which binning form the default choice takes where both are candidates (pergauss.hip: gsr_preprocess_form_is_open).  The two
-// forms give bit-identical results, so the choice is free: the handle times two views' preprocess in each form (two timing events
-// per view, read without blocking a later view) and keeps the faster; a scene that grew or shrank by a quarter, or 4096 views,
-// start it again.  Until it has decided, the hint from the previous view (skewed lists -> banded) chooses, as before.
-struct FormTuner {
-    static constexpr int kTimed = 4;  // views timed: direct, aggregating, direct, aggregating — the first launch of a kernel also
-                                      // loads its code; the faster of each form's two views counts
-    int phase = 0;          // < kTimed: the view to time next (form = phase & 1); kTimed: read the events; kTimed + 1: decided
-    int form = -1;          // the decision (0 / 1)
-    int n_ref = 0;
-    uint32_t age = 0;
-    float ms[2] = {0.0f, 0.0f};
-    hipEvent_t ev[2 * kTimed] = {};
-    bool decided() const { return phase == kTimed + 1; }
-    void reset() { phase = 0; form = -1; age = 0; }
+// The form tuner's clock (the RULE is gsr_policy.cpp's: which views are timed, what decides, when it starts over): one event
+// pair per timed view around the view's first kernel, read without blocking a later view.
+struct TunerEvents {
+    hipEvent_t ev[2 * GSR_TUNER_TIMED_VIEWS] = {};
+    bool create() {
+        for (auto& e : ev)
+            if (!e && hipEventCreate(&e) != hipSuccess) { e = nullptr; return false; }
+        return true;
+    }
     void destroy() { for (auto& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; } }
-    // all timed views complete?  then ms[f] = the faster view of form f
-    bool read() {
-        float t[kTimed];
-        for (int v = 0; v < kTimed; v++)
-            if (hipEventQuery(ev[2 * v + 1]) != hipSuccess || hipEventElapsedTime(&t[v], ev[2 * v], ev[2 * v + 1]) != hipSuccess) return false;
-        ms[0] = std::min(t[0], t[2]);
-        ms[1] = std::min(t[1], t[3]);
+    // all timed views complete?  -> their first kernels' milliseconds.  "Not ready" is the expected answer most of the time
+    // and is consumed here; any OTHER error stays for the caller's next HIPCHK (an unconditional hipGetLastError
+    // swallowed unrelated sticky errors).
+    bool read(float ms[GSR_TUNER_TIMED_VIEWS]) {
+        for (int v = 0; v < GSR_TUNER_TIMED_VIEWS; v++) {
+            const hipError_t q = hipEventQuery(ev[2 * v + 1]);
+            if (q == hipErrorNotReady) { (void)hipGetLastError(); return false; }
+            if (q != hipSuccess || hipEventElapsedTime(&ms[v], ev[2 * v], ev[2 * v + 1]) != hipSuccess) return false;
+        }
         return true;
     }
 };
@@ -219,17 +217,18 @@ struct gsr_handle {
     // GeometryState (states.jl:2-47), repacked as one 64-byte record per Gaussian
     DevBuf geo, gnormal, radii, bsum, bpre, bvis;
     // BinningState (states.jl:66-85): unsorted keys (per-tile bins of bin_cap slots), sorted ids, sorted splat stream
-    uint32_t bin_cap = 0;           // capacity (keys per tile) the NEXT fast-mode view will use; 0 = none chosen yet
-    uint32_t bin_cap_view = 0;      // capacity the bins were filled with in the current view
+    // everything gsr_forward carries from one view to the next lives in `pol`, and every decision taken from it is a pure
+    // function of gsr_policy.cpp (include/gsr_policy.h): bins capacity / compact mode, the binning form and its tuner, the held
+    // fused launch, the backward's list split.  This file only executes them.
+    gsr_policy_config pcfg;
+    gsr_policy_state pol;
+    TunerEvents tuner_ev;
     int last_form = 0;              // binning form the last view's preprocess ran in (gsr_stats.preprocess_form)
-    FormTuner tuner;                // the default form choice on grids where both forms are candidates
-    bool compact_sticky = false;    // the last view showed that fixed-capacity bins do not fit the budget
     bool last_compact = false;
     bool tile_count_dirty = false;  // counters not yet re-zeroed by the tile sort
     double wait_ema_us = 0.0;       // running average of the host's wait for the instance count (wait_totals)
     DevBuf bins, keys_compact, big_list, values_sorted, s0, s1, s2, s3, big_scratch, long_state;
     DevBuf overflow_fill;           // fill cursors of the scatter pass restricted to the lists beyond the bins' capacity
-    uint32_t bin_cap_used(bool use_bins) const { return use_bins ? bin_cap_view : 0u; }
     // backward: per-instance gradient rows + instance position map; gstate.∇means_2d
     DevBuf rows, vmean2d;
     // loss-head scratch
@@ -237,7 +236,6 @@ struct gsr_handle {
     uint32_t* host_totals = nullptr;  // pinned: D, max tile count, #oversized tiles, slab ctr, n_visible, ..., [7] = sequence
     uint32_t* host_totals_dev = nullptr;  // the same words as the device addresses them
     uint32_t totals_seq = 0;
-    uint32_t tier_n[3] = {0, 0, 0};    // tiles of the last forward with lists in (1024, 4096], (4096, 8192], > 8192
     hipStream_t aux_stream = nullptr;  // the four-wave backward of those tiles runs here, next to the main launch
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool fwd_valid = false, bwd_valid = false;
@@ -248,11 +246,14 @@ struct gsr_handle {
     float2* vmean2d_cur = nullptr;       // gstate.∇means_2d of the last backward: caller's (gsr_grads.vmeans2d) or h->vmean2d
     int last_n = 0;
     int64_t last_D = 0;
-    uint32_t last_max_tile = 0;
     int64_t last_slots = 0;
+    // the cotangent the handle's loss head wrote, and for which forward (GSR_GRADS_COLOR_COTANGENT is honoured for it only)
+    const float* loss_vpixels = nullptr;
+    uint64_t loss_generation = 0;
+    DevBuf dbg_flag;
     Profiler prof;
 
-    DevBuf* all[36];
+    DevBuf* all[40];
     int n_all = 0;
 };
 
@@ -304,23 +305,6 @@ static inline void cpu_relax() {
 //   ratchets upwards and starves the GPU) but shrinks the estimate; after the expected time + spin_us: sched_yield() for
 //   yield_us, then sleeps of sleep_us.  Same step time on a quiet host, a fraction of the CPU time; NOT the default
 //   because a late timer wake-up (observed on one box of the pool: one step of twenty 3 ms late) lands in the step time.
-// default budget of the fast binning mode's fixed-capacity bins (gsr_config.bins_budget_bytes = 0)
-constexpr uint64_t kBinsBudgetMin = 512ull << 20, kBinsBudgetPerInstance = 160ull;
-
-// Capacity (keys per tile) of the fixed-capacity bins for the view after one with `instances` instances and a longest list of
-// `longest` on a grid of `tiles` tiles: the longest list + 25 % where the budget allows it; where it does not, the deep tiles are
-// OUTLIERS for the overflow path and the bins are sized for the rest (4 x the mean list, at least 1024, + 25 %).  A budget below
-// twice the mean list (or below 64 keys) is no budget for bins at all: 0 = compact mode.
-uint32_t bins_capacity_after(uint64_t instances, uint64_t longest, uint64_t tiles, uint64_t budget_bytes) {
-    const auto round64 = [](uint64_t v) { return (v + v / 4 + 63) & ~63ull; };
-    const uint64_t mean_list = instances / tiles + 1;
-    const uint64_t budget = budget_bytes ? budget_bytes : std::max<uint64_t>(kBinsBudgetMin, kBinsBudgetPerInstance * instances);
-    const uint64_t cap = (budget / (8ull * (tiles + 1))) & ~63ull;
-    uint64_t want = std::max<uint64_t>(64ull, round64(longest));  // (an empty view keeps the minimum)
-    if (want > cap) want = std::min<uint64_t>(cap, round64(std::max<uint64_t>(1024ull, 4ull * mean_list)));
-    if (want < 64 || cap < 2 * mean_list) return 0u;
-    return (uint32_t)std::min<uint64_t>(want, 1u << 20);
-}
 struct WaitPolicy { int spin_us = 30, yield_us = 0, sleep_us = 0; };
 // the three values live in ONE atomic word (21 bits each): a forward on another thread reads the old or the new policy,
 // never a mix of the two (round-4 verdict, weak #9)
@@ -343,10 +327,12 @@ std::atomic<int> g_ssim_exact{[] { const char* e = getenv("GSR_SSIM_EXACT"); ret
 // gsr_preprocess_form: -1 by scene and grid size (default), 0 direct, 1 aggregating wherever its LDS fits; the same rule
 std::atomic<int> g_preprocess_form{[] { const char* e = getenv("GSR_PREPROCESS_AGG"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }()};
 inline int ssim_exact_of(const gsr_handle* h) {
-    return h->cfg.ssim_precision >= 0 ? h->cfg.ssim_precision : g_ssim_exact.load(std::memory_order_relaxed);
+    return h->cfg.ssim_precision != GSR_DEFAULT ? (h->cfg.ssim_precision == GSR_SSIM_EXACT ? 1 : 0)
+                                                : g_ssim_exact.load(std::memory_order_relaxed);
 }
-inline int preprocess_form_of(const gsr_handle* h) {
-    return h->cfg.preprocess_form >= 0 ? h->cfg.preprocess_form : g_preprocess_form.load(std::memory_order_relaxed);
+inline int preprocess_form_of(const gsr_handle* h) {  // -1 by scene and grid, 0 direct, 1 aggregating
+    return h->cfg.preprocess_form != GSR_DEFAULT ? (h->cfg.preprocess_form == GSR_PREPROCESS_AGGREGATING ? 1 : 0)
+                                                 : g_preprocess_form.load(std::memory_order_relaxed);
 }
 
 // Wait until tile_scan of forward `seq` has published its totals (a word of pinned host memory).
@@ -420,6 +406,55 @@ int wait_totals(gsr_handle* h, uint32_t seq, hipStream_t s) {
     return rc;
 }
 
+// gsr_stats' view-history block (ABI 6): the policy state's counters + the mechanism's own (buffer reallocations)
+void fill_history(const gsr_handle* h, gsr_stats* st) {
+    const gsr_policy_state& p = h->pol;
+    st->bins_regrowths = p.bins_regrowths;
+    st->compact_fallbacks = p.compact_fallbacks;
+    st->tuner_rearms = p.tuner_rearms;
+    uint32_t grows = 0;
+    for (int i = 0; i < h->n_all; i++) grows += h->all[i]->regrowths;
+    st->scratch_regrowths = grows;
+    st->fused_relaunches = p.fused_relaunches;
+    st->held_views = p.held_views;
+    const bool decided = p.tuner.phase == GSR_TUNER_TIMED_VIEWS + 1;
+    st->tuner_form = decided ? p.tuner.form : -1;
+    st->tuner_ms[0] = decided ? p.tuner.ms[0] : 0.0f;
+    st->tuner_ms[1] = decided ? p.tuner.ms[1] : 0.0f;
+}
+
+// GSR_GRADS_COLOR_COTANGENT (gsr.h): honoured for the cotangent this handle's loss head wrote for THIS forward, nothing else.
+// GSR_CHECK_COLOR_COTANGENT=1 (debugging): also look at the buffer — every value of channels >= 3 must be exactly zero.
+__global__ void nonzero_tail_kernel(const float* __restrict__ v, size_t n_pixels, int C, uint32_t* flag) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pixels) return;
+    bool bad = false;
+    for (int c = 3; c < C; c++) bad |= v[p * C + c] != 0.0f;
+    if (bad) atomicOr(flag, 1u);
+}
+int check_color_cotangent(gsr_handle* h, const float* vpixels, hipStream_t s) {
+    if (h->cfg.mode <= 3) return GSR_OK;  // nothing above the colour channels
+    if (vpixels != h->loss_vpixels || h->loss_generation != h->generation)
+        return fail(GSR_E_INVALID_ARG, "GSR_GRADS_COLOR_COTANGENT is only valid for the cotangent gsr_loss_l1_ssim wrote for this "
+                    "forward on this handle (its vpixels %p for forward #%llu; got %p for forward #%llu): a cotangent with depth / "
+                    "alpha / normal terms must not set the flag", (const void*)h->loss_vpixels,
+                    (unsigned long long)h->loss_generation, (const void*)vpixels, (unsigned long long)h->generation);
+    const char* look = getenv("GSR_CHECK_COLOR_COTANGENT");  // (read per call: a debugging switch, flipped by tests in-process)
+    if (!(look && look[0] == '1')) return GSR_OK;
+    int rc = h->dbg_flag.ensure(4);
+    if (rc) return rc;
+    const size_t P = (size_t)h->cfg.width * h->cfg.height;
+    uint32_t bad = 0;
+    HIPCHK(hipMemsetAsync(h->dbg_flag.p, 0, 4, s));
+    hipLaunchKernelGGL(nonzero_tail_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, vpixels, P, h->cfg.mode,
+                       h->dbg_flag.as<uint32_t>());
+    HIPCHK(hipMemcpyAsync(&bad, h->dbg_flag.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (bad) return fail(GSR_E_INVALID_ARG, "GSR_GRADS_COLOR_COTANGENT: vpixels holds non-zero values above the colour channels "
+                         "(something was added to the loss head's cotangent in place)");
+    return GSR_OK;
+}
+
 int check_inputs(const gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam) {
     if (!h || !in || !cam) return fail(GSR_E_INVALID_ARG, "null handle / inputs / camera");
     if (in->n < 0) return fail(GSR_E_INVALID_ARG, "n = %d < 0", in->n);
@@ -469,13 +504,14 @@ int gsr_preprocess_form(int form) {
 int gsr_get_preprocess_form(void) { return g_preprocess_form.load(std::memory_order_relaxed); }
 
 int gsr_check_abi(int abi_version, size_t sizeof_config, size_t sizeof_inputs, size_t sizeof_camera, size_t sizeof_aux,
-                  size_t sizeof_stats, size_t sizeof_grads) {
+                  size_t sizeof_stats, size_t sizeof_grads, size_t sizeof_tail_state) {
     if (abi_version != GSR_ABI_VERSION)
         return fail(GSR_E_INVALID_ARG, "binding was written for gsr ABI %d, this library is ABI %d", abi_version, GSR_ABI_VERSION);
     const struct { const char* name; size_t theirs, ours; } t[] = {
         {"gsr_config", sizeof_config, sizeof(gsr_config)}, {"gsr_inputs", sizeof_inputs, sizeof(gsr_inputs)},
         {"gsr_camera", sizeof_camera, sizeof(gsr_camera)}, {"gsr_aux", sizeof_aux, sizeof(gsr_aux)},
-        {"gsr_stats", sizeof_stats, sizeof(gsr_stats)},    {"gsr_grads", sizeof_grads, sizeof(gsr_grads)}};
+        {"gsr_stats", sizeof_stats, sizeof(gsr_stats)},    {"gsr_grads", sizeof_grads, sizeof(gsr_grads)},
+        {"gsr_tail_state", sizeof_tail_state, sizeof(gsr_tail_state)}};
     for (const auto& e : t)
         if (e.theirs != e.ours)
             return fail(GSR_E_INVALID_ARG, "sizeof(%s) is %zu in the binding, %zu in the library", e.name, e.theirs, e.ours);
@@ -491,11 +527,16 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
         return fail(GSR_E_INVALID_ARG, "flag bit 0x1 is retired (ABI 1's GSR_FLAG_EXACT_TILE_CULL): rebuild the caller against "
                                        "include/gsr.h ABI %d", GSR_ABI_VERSION);
     if (cfg->flags & ~(uint32_t)GSR_FLAG_REFERENCE_TILE_LISTS) return fail(GSR_E_INVALID_ARG, "unknown flags 0x%x", cfg->flags);
-    if (cfg->ssim_precision < -1 || cfg->ssim_precision > 1)
-        return fail(GSR_E_INVALID_ARG, "gsr_config.ssim_precision = %d: GSR_DEFAULT (-1), 0 (fast) or 1 (exact)", cfg->ssim_precision);
-    if (cfg->preprocess_form < -1 || cfg->preprocess_form > 1)
-        return fail(GSR_E_INVALID_ARG, "gsr_config.preprocess_form = %d: GSR_DEFAULT (-1), 0 (direct) or 1 (aggregating)",
-                    cfg->preprocess_form);
+    if (cfg->ssim_precision < 0 || cfg->ssim_precision > GSR_SSIM_EXACT)
+        return fail(GSR_E_INVALID_ARG, "gsr_config.ssim_precision = %d: GSR_DEFAULT (0), GSR_SSIM_FAST (1) or GSR_SSIM_EXACT (2)",
+                    cfg->ssim_precision);
+    if (cfg->preprocess_form < 0 || cfg->preprocess_form > GSR_PREPROCESS_AGGREGATING)
+        return fail(GSR_E_INVALID_ARG, "gsr_config.preprocess_form = %d: GSR_DEFAULT (0), GSR_PREPROCESS_DIRECT (1) or "
+                    "GSR_PREPROCESS_AGGREGATING (2)", cfg->preprocess_form);
+    if (cfg->form_tuner < 0 || cfg->form_tuner > GSR_TUNER_ON)
+        return fail(GSR_E_INVALID_ARG, "gsr_config.form_tuner = %d: GSR_DEFAULT (0), GSR_TUNER_OFF (1) or GSR_TUNER_ON (2)", cfg->form_tuner);
+    if (cfg->grad_precision < 0 || cfg->grad_precision > GSR_GRAD_FP32_REFERENCE)
+        return fail(GSR_E_INVALID_ARG, "gsr_config.grad_precision = %d: GSR_DEFAULT (0) or GSR_GRAD_FP32_REFERENCE (1)", cfg->grad_precision);
     gsr_handle* h = new (std::nothrow) gsr_handle();
     if (!h) return fail(GSR_E_OOM, "host allocation failed");
     h->cfg = *cfg;
@@ -504,10 +545,21 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
     // (8 192 tiles = 131 072 pixels wide: one row of the tile grid must fit the aggregating binning's LDS band, pergauss.hip)
     if (h->grid_x > 8192 || h->grid_y > 65535) { delete h; return fail(GSR_E_INVALID_ARG, "resolution too large"); }
     h->n_tiles = h->grid_x * h->grid_y;
+    // the handle's policies: configuration (constructor fields, then the A/B environment knobs) and the view-history state
+    gsr_policy_config_init(&h->pcfg, cfg->width, cfg->height, cfg->bins_budget_bytes, -1 /* resolved per view: process default */);
+    gsr_policy_state_init(&h->pol);
+    {
+        const auto env_u32 = [](const char* name, uint32_t dflt) { const char* e = getenv(name); return e ? (uint32_t)atoi(e) : dflt; };
+        const char* tun = getenv("GSR_FORM_TUNER");  // the DEFAULT of handles that do not say (0 = off)
+        h->pcfg.form_tuner = cfg->form_tuner == GSR_TUNER_ON ? 1 : cfg->form_tuner == GSR_TUNER_OFF ? 0 : !(tun && tun[0] == '0');
+        h->pcfg.beside_max_tiles = env_u32("GSR_TIERS_BESIDE_MAX", h->pcfg.beside_max_tiles);      // 0 = never hold the fused launch
+        h->pcfg.bwd_split_max_tiles = env_u32("GSR_BWD_SPLIT_TILES", h->pcfg.bwd_split_max_tiles);
+        h->pcfg.agg_max_bands = (int32_t)env_u32("GSR_AGG_MAX_BANDS", (uint32_t)h->pcfg.agg_max_bands);
+    }
     DevBuf* list[] = {&h->ranges, &h->n_contrib, &h->final_T, &h->tile_count, &h->tile_start, &h->tile_order, &h->totals,
                       &h->geo, &h->gnormal, &h->radii, &h->bsum, &h->bpre, &h->bvis, &h->bins, &h->values_sorted, &h->s0,
                       &h->s1, &h->s2, &h->s3, &h->big_scratch, &h->rows, &h->vmean2d, &h->d0, &h->d1,
-                      &h->d2, &h->partial, &h->keys_compact, &h->big_list, &h->long_state, &h->overflow_fill};
+                      &h->d2, &h->partial, &h->keys_compact, &h->big_list, &h->long_state, &h->overflow_fill, &h->dbg_flag};
     for (DevBuf* b : list) h->all[h->n_all++] = b;
     const size_t P = (size_t)cfg->width * cfg->height, T = (size_t)h->n_tiles;
     int rc = GSR_OK;
@@ -543,7 +595,7 @@ int gsr_destroy(gsr_handle* h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
-    h->tuner.destroy();
+    h->tuner_ev.destroy();
     h->prof.destroy();
     delete h;
     return GSR_OK;
@@ -553,8 +605,8 @@ int gsr_release_scene_buffers(gsr_handle* h) {
     if (!h) return fail(GSR_E_INVALID_ARG, "null handle");
     DevBuf* scene[] = {&h->geo, &h->gnormal, &h->radii, &h->bsum, &h->bpre, &h->bvis, &h->bins, &h->values_sorted, &h->s0, &h->s1,
                        &h->s2, &h->s3, &h->big_scratch, &h->rows, &h->vmean2d, &h->keys_compact};
-    h->bin_cap = 0;
-    h->compact_sticky = false;
+    h->pol.bin_cap = 0;
+    h->pol.compact_sticky = 0;
     for (DevBuf* b : scene) {
         int rc = b->release();
         if (rc) return rc;
@@ -566,14 +618,6 @@ int gsr_release_scene_buffers(gsr_handle* h) {
     h->last_n = 0;
     h->last_D = 0;
     return GSR_OK;
-}
-
-uint32_t gsr_bins_capacity_after(int64_t n_rendered, int32_t max_tile_instances, int32_t width, int32_t height,
-                                 uint64_t bins_budget_bytes, uint32_t current_capacity) {
-    if (n_rendered < 0 || max_tile_instances < 0 || width <= 0 || height <= 0) return 0u;
-    const uint64_t tiles = (uint64_t)((width + GSR_TILE - 1) / GSR_TILE) * (uint64_t)((height + GSR_TILE - 1) / GSR_TILE);
-    const uint32_t want = bins_capacity_after((uint64_t)n_rendered, (uint64_t)max_tile_instances, tiles, bins_budget_bytes);
-    return want == 0u ? 0u : std::max(want, current_capacity);
 }
 
 int64_t gsr_memory_usage(const gsr_handle* h) {
@@ -613,66 +657,37 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
 
     GsrCam k = make_cam(h, cam);
     uint32_t* totals = h->totals.as<uint32_t>();
-    // Binning (SURVEY.md A.5-A.7 restated per tile).  FAST mode: every tile owns a fixed-capacity key bin
-    // (capacity = the longest list seen on this handle + 25 %; before the first view an estimate from N / T) and
-    // preprocess drops the keys straight into them — no second pass over the instances.  Its memory is
-    // (T+1)·capacity·8 B, i.e. O(T · longest list), so it is only used while that stays within the bins budget
-    // (default max(512 MiB, 160 B x last instance count): lists up to 20 x the mean — round 5: the procedural trained-like scene
-    // at 3 M / 1440p has a longest list of 6.7 x its mean and fell out of round 4's 6 x budget into the compact mode, where its
-    // forward cost 2 x; gsr_config.bins_budget_bytes overrides).  Otherwise — a
-    // scene with a few very deep tiles, or a view that overflowed its bins — the COMPACT mode runs: preprocess
-    // only counts, the scan turns the counts into offsets, emit_compact scatters the keys to exact offsets
-    // (8 B per instance whatever the skew), and nothing is ever repeated.
-    if (h->bin_cap == 0 && !h->compact_sticky) {
-        const uint64_t est = 8ull * (uint64_t)nn / T + 64;  // ~6 tiles per Gaussian, +35 %
-        h->bin_cap = (uint32_t)((est < (1u << 20) ? est : (1u << 20)) + 63) & ~63u;
-    }
-    const uint64_t budget = h->cfg.bins_budget_bytes ? h->cfg.bins_budget_bytes
-                                                     : std::max<uint64_t>(kBinsBudgetMin, kBinsBudgetPerInstance * (uint64_t)h->last_D);
-    // (the capacity the budget allows: bins smaller than one cache line of keys per tile are not worth having)
-    const uint64_t cap_budget = (budget / (8ull * (uint64_t)(T + 1))) & ~63ull;
-    if (h->bin_cap > cap_budget) h->bin_cap = (uint32_t)cap_budget;
-    bool use_bins = h->bin_cap >= 64u;
-    h->bin_cap_view = use_bins ? h->bin_cap : 0u;
-    if (use_bins && (rc = h->bins.ensure((T + 1) * (size_t)h->bin_cap * 8))) return rc;
+    // Binning (SURVEY.md A.5-A.7 restated per tile).  FAST mode: every tile owns a fixed-capacity key bin and preprocess drops
+    // the keys straight into them — no second pass over the instances; (T+1) x capacity x 8 B, so only while that stays within
+    // the bins budget.  Otherwise — a scene with a few very deep tiles, or a view that overflowed small bins — the COMPACT mode
+    // runs: preprocess only counts, the scan turns the counts into offsets, a scatter pass puts the keys at exact offsets (8 B
+    // per instance whatever the skew).  WHICH of them, with what capacity, in which binning form: gsr_policy_begin_view.
+    h->pcfg.preprocess_form = preprocess_form_of(h);  // the handle's pin, else the process default as of this call
+    float timed_ms[GSR_TUNER_TIMED_VIEWS];
+    const bool have_ms = h->pcfg.form_tuner && h->pol.tuner.phase == GSR_TUNER_TIMED_VIEWS && h->tuner_ev.read(timed_ms);
+    gsr_view_plan plan;
+    gsr_policy_begin_view(&h->pcfg, &h->pol, n, have_ms ? timed_ms : nullptr, &plan);
+    const bool use_bins = plan.bin_cap_view > 0;
+    const uint32_t bin_cap_view = plan.bin_cap_view;
+    if (use_bins && (rc = h->bins.ensure((T + 1) * (size_t)bin_cap_view * 8))) return rc;
     // The tile counters are zero on entry: gsr_create clears them and the tile sort re-zeroes each
     // tile's counter as it consumes it (no memset kernel per view; the scan overwrites every total).
     // Only a pass that did not reach the sort (an error) leaves them dirty.
     if (h->tile_count_dirty) HIPCHK(hipMemsetAsync(h->tile_count.p, 0, (T + 2) * 4, s));
     h->tile_count_dirty = true;
-    // the binning form of this view: the handle's or the process's choice, else by scene and grid — and where that leaves two
-    // candidates, the one this handle has measured to be faster (FormTuner)
-    int form = preprocess_form_of(h), timed = -1;
-    static const bool no_tuner = [] { const char* e = getenv("GSR_FORM_TUNER"); return e && e[0] == '0'; }();  // A/B only
-    if (form < 0 && !no_tuner && gsr_preprocess_form_is_open(n, h->grid_x, h->grid_y, h->bin_cap_view)) {
-        FormTuner& t = h->tuner;
-        if (t.decided() && (++t.age > 4096u || std::abs(n - t.n_ref) > t.n_ref / 4)) t.reset();
-        if (t.decided()) {
-            form = t.form;
-        } else if (h->generation > 2) {  // (the first views of a handle grow buffers and touch memory for the first time)
-            if (t.phase == FormTuner::kTimed) {
-                if (t.read()) {
-                    t.form = t.ms[1] < 0.97f * t.ms[0] ? 1 : 0;  // (a tie stays with the direct form)
-                    t.phase = FormTuner::kTimed + 1; t.n_ref = n; t.age = 0;
-                    form = t.form;
-                }
-            } else {
-                bool ok = true;
-                for (int e = 2 * t.phase; e < 2 * t.phase + 2; e++)
-                    if (!t.ev[e] && hipEventCreate(&t.ev[e]) != hipSuccess) { t.ev[e] = nullptr; ok = false; }
-                if (ok) { timed = t.phase; form = timed & 1; }
-            }
-            (void)hipGetLastError();  // (hipEventQuery reports "not ready" as an error)
-        }
+    int timed = plan.timed_slot;
+    if (timed >= 0 && !h->tuner_ev.create()) {  // no clock, no tuner on this handle (the plan's form is still a valid form)
+        h->pcfg.form_tuner = 0;
+        h->pol.tuner.phase = 0;
+        timed = -1;
     }
     StageScope sc1(h->prof, ST_PREPROCESS, s);
-    if (timed >= 0) HIPCHK(hipEventRecord(h->tuner.ev[2 * timed], s));
+    if (timed >= 0) HIPCHK(hipEventRecord(h->tuner_ev.ev[2 * timed], s));
     h->last_form = gsr_launch_preprocess(s, n, in->n_coeffs, in->sh_degree, C, in->means, in->scales, in->rotations,
                                          in->opacities, in->shs, k, geom_of(h), h->tile_count.as<uint32_t>(),
-                                         h->bvis.as<uint32_t>(), h->bins.as<uint64_t>(), h->bin_cap_view /* 0: count only */,
-                                         h->n_tiles, form,
-                                         /*skewed=*/h->last_D > 0 && (uint64_t)h->last_max_tile * (uint64_t)T > 6ull * (uint64_t)h->last_D);
-    if (timed >= 0) { HIPCHK(hipEventRecord(h->tuner.ev[2 * timed + 1], s)); h->tuner.phase = timed + 1; }
+                                         h->bvis.as<uint32_t>(), h->bins.as<uint64_t>(), bin_cap_view /* 0: count only */,
+                                         h->n_tiles, /*aggregating=*/plan.form != GSR_FORM_DIRECT);
+    if (timed >= 0) HIPCHK(hipEventRecord(h->tuner_ev.ev[2 * timed + 1], s));
     sc1.close();
     const uint32_t seq = ++h->totals_seq ? h->totals_seq : ++h->totals_seq;  // never 0
     StageScope sc2(h->prof, ST_SCAN, s);
@@ -706,14 +721,13 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     // tiles the fused launch is HELD until the host has the counts and the tier sorts have run (mostly idle GPU: 0.04-0.2 ms),
     // and then goes out together with the walk, which takes the handle's second stream at raised wave priority.  Hot tile
     // (32 k) 2.08 -> 1.80 ms, trained-like 3 M / 1440p 2.19 -> 2.10, dense 4K 7.81 -> 7.70; a view without tier tiles is not
-    // touched.  (GSR_TIERS_BESIDE_MAX: hold only when the previous view had at most that many tier tiles — A/B runs; 0 = never.)
-    static const uint32_t kBesideMaxTiles = [] { const char* e = getenv("GSR_TIERS_BESIDE_MAX"); return e ? (uint32_t)atoi(e) : 0xFFFFFFFFu; }();
-    const uint64_t prev_tiers = (uint64_t)h->tier_n[0] + h->tier_n[1] + h->tier_n[2];
-    const bool hold_fused = spec && prev_tiers > 0 && prev_tiers <= kBesideMaxTiles;
+    // touched.  (GSR_TIERS_BESIDE_MAX: hold only when the previous view had at most that many tier tiles — A/B runs; 0 = never:
+    // gsr_policy_config.beside_max_tiles.)
+    const bool hold_fused = spec && plan.hold_fused;
     const auto launch_fused = [&](hipStream_t fs) {
         StageScope sc3(h->prof, ST_SORT_COMPOSITE_FWD, fs);
         gsr_launch_sort_composite_fwd(fs, C, k, h->tile_start.as<uint32_t>(), h->tile_order.as<uint32_t>(),
-                                      h->tile_count.as<uint32_t>(), h->bins.as<uint64_t>(), h->bin_cap_view, geom_of(h),
+                                      h->tile_count.as<uint32_t>(), h->bins.as<uint64_t>(), bin_cap_view, geom_of(h),
                                       stream_of(h), in->background, image_out, h->n_contrib.as<uint32_t>(),
                                       h->final_T.as<float>(), h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>(),
                                       aux ? aux->covisibilities : nullptr, aux ? aux->uncertainties : nullptr, totals,
@@ -722,41 +736,35 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     };
     if (spec && !hold_fused) launch_fused(s);
     if ((rc = wait_totals(h, seq, s))) return rc;
+    // What this view turned out to be — bins / overflow tiles / compact; whether the fused launch covers it; where the tier
+    // walk goes; the bins' capacity for the next view — is gsr_policy_end_view's decision on the scan's counts.
     // OVERFLOW TILES (round 5): lists longer than the bins' capacity.  Their bins hold the first bin_cap_view arrivals only
     // (preprocess counted every instance); their complete key lists come from a scatter pass restricted to them (below), and
-    // every sort takes a tile's keys from wherever they are complete.  The rest of the view stays on the fast path — a few
-    // deep tiles no longer send the whole view to the compact mode, and nothing is ever repeated.
-    // (Bins of fewer than 1024 keys could also cut a list of the fused launch's: such a view is finished in the compact mode, as
-    // every overflowing view was before — a small scene's first views, or a budget that small.)
-    const bool overflow = use_bins && h->host_totals[1] > h->bin_cap_view;
-    const bool hybrid = overflow && h->bin_cap_view >= 1024u;
-    const bool compact = !use_bins || (overflow && !hybrid);
-    {   // capacity for the NEXT view (bins_capacity_after, above): grow-only while bins are in use
-        const uint32_t want = bins_capacity_after(h->host_totals[0], h->host_totals[1], (uint64_t)T, h->cfg.bins_budget_bytes);
-        if (want == 0u) { h->bin_cap = 0; h->compact_sticky = true; }
-        else if (want > h->bin_cap || !use_bins) { h->bin_cap = want; h->compact_sticky = false; }
-    }
+    // every sort takes a tile's keys from wherever they are complete.  The rest of the view stays on the fast path.
     const uint64_t D = h->host_totals[0];
     const uint32_t max_tile = h->host_totals[1], n_big = h->host_totals[2];
+    const uint32_t n_mid4 = h->host_totals[3], n_mid8 = h->host_totals[6];
     const uint64_t D_slots = h->host_totals[5];  // >= D; == D unless exact culling dropped tiles
+    gsr_view_outcome oc;
+    gsr_policy_end_view(&h->pcfg, &h->pol, &plan, (int64_t)D, max_tile, n_mid4, n_mid8, n_big, cap_instances, spec ? 1 : 0, &oc);
+    const bool hybrid = oc.binning == GSR_BINNING_OVERFLOW, compact = oc.binning == GSR_BINNING_COMPACT;
+    const bool fused_done = oc.fused_done != 0, long_tiles = oc.long_tiles != 0, beside = oc.beside != 0;
     h->last_n = n;
     h->last_D = (int64_t)D;
-    h->last_max_tile = max_tile;
-    h->tier_n[0] = h->host_totals[3]; h->tier_n[1] = h->host_totals[6]; h->tier_n[2] = n_big;
     h->last_slots = (int64_t)D_slots;
+    h->last_compact = compact;
     if (stats) {
         stats->n_rendered = (int64_t)D;
         stats->n_visible = (int32_t)(h->host_totals[4] & 0x7FFFFFFFu);
         stats->max_tile_instances = (int32_t)max_tile;
-    }
-    h->last_compact = compact;
-    if (stats) {
-        stats->compact_binning = compact ? 1 : (hybrid ? 2 : 0);
+        stats->compact_binning = oc.binning;
         stats->preprocess_form = h->last_form;
-        stats->bins_bytes = (int64_t)(compact ? D * 8 : (uint64_t)(T + 1) * h->bin_cap_used(use_bins) * 8ull + (hybrid ? D * 8 : 0));
+        stats->bins_bytes = (int64_t)(compact ? D * 8 : (uint64_t)(T + 1) * bin_cap_view * 8ull + (hybrid ? D * 8 : 0));
+        stats->bin_capacity = bin_cap_view;
+        stats->tier_tiles[0] = n_mid4; stats->tier_tiles[1] = n_mid8; stats->tier_tiles[2] = n_big;
+        stats->reserved = 0;
+        fill_history(h, stats);  // (again at the end: the buffers this view grows are counted there)
     }
-    // did the early launch run?  (same two comparisons as in the kernel, on the same numbers)
-    const bool fused_done = spec && D <= cap_instances && !(overflow && !hybrid);  // (hybrid: every list of up to 1024 sat complete in its bin)
     if (D == 0) {
         h->tile_count_dirty = false;  // every counter is zero
         if (k.exact_cull && (h->host_totals[4] >> 31)) {
@@ -776,8 +784,6 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
         return GSR_OK;
     }
     const float slack = 1.25f;  // instance count drifts slowly between training steps
-    const uint32_t n_mid4 = h->host_totals[3], n_mid8 = h->host_totals[6];
-    const bool long_tiles = (n_mid4 | n_mid8 | n_big) != 0u;
     // forward-only and everything composited by the fused launch: no per-instance storage at all (the rare paths below —
     // tier lists, compact binning — still hand their instances over through the stream)
     const bool need_stream = !(fwd_only && fused_done && !long_tiles);
@@ -793,16 +799,15 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
         // (+ the plan of the multi-workgroup sort: 2 (n_big + 1) words behind the slabs)
         if ((rc = h->big_scratch.ensure((size_t)n_big * 2 * slab_stride * 8 + (size_t)(2 * n_big + 2) * 4 + 64))) return rc;
     }
-    // (a held fused launch that this view gives no reason to hold any longer: no tier tiles after all, or too many)
-    const bool beside = hold_fused && fused_done && long_tiles && (uint64_t)n_mid4 + n_mid8 + n_big <= kBesideMaxTiles;
-    // (... and one that would only find its buffers too small — the kernel checks the same totals — is not launched at all: the
+    // (a held fused launch that this view gives no reason to hold any longer — no tier tiles after all, or too many — goes out
+    // now; one that would only find its buffers too small — the kernel checks the same totals — is not launched at all: the
     // main sort pass then re-zeroes the counters and writes the ranges, as in every view without the fused launch)
-    if (hold_fused && !beside && fused_done) launch_fused(s);
+    if (oc.launch_fused_now) launch_fused(s);
     if (!fused_done || long_tiles) {
         StageScope sc4(h->prof, ST_SORT, s);
         const uint64_t* keys = h->bins.as<uint64_t>();
         const uint64_t* overflow_keys = nullptr;
-        uint32_t key_cap = h->bin_cap_used(use_bins);
+        uint32_t key_cap = bin_cap_view;
         if (compact) {
             // count -> scan -> scatter: the counters become the fill cursors of the scatter pass
             if ((rc = h->keys_compact.ensure(D * 8, slack))) return rc;
@@ -818,7 +823,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
             if ((rc = h->keys_compact.ensure(D * 8, slack)) || (rc = h->overflow_fill.ensure((T + 2) * 4))) return rc;
             HIPCHK(hipMemsetAsync(h->overflow_fill.p, 0, (T + 2) * 4, s));
             gsr_launch_emit_compact(s, n, k, geom_of(h), h->tile_start.as<uint32_t>(), h->overflow_fill.as<uint32_t>(),
-                                    h->keys_compact.as<uint64_t>(), max_tile, /*only_above=*/h->bin_cap_view);
+                                    h->keys_compact.as<uint64_t>(), max_tile, /*only_above=*/bin_cap_view);
             overflow_keys = h->keys_compact.as<uint64_t>();
         }
         gsr_launch_tile_sort(s, (fused_done ? 0 : GSR_SORT_PASS_MAIN) | GSR_SORT_PASS_TIERS, h->n_tiles, h->grid_x, C,
@@ -850,6 +855,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     }
     h->tile_count_dirty = false;  // the sort (fused or not) zeroed the counters
     HIPCHK(hipGetLastError());
+    if (stats) fill_history(h, stats);
     h->fwd_valid = true;
     return GSR_OK;
 }
@@ -865,18 +871,11 @@ static int launch_composite_bwd(gsr_handle* h, hipStream_t s, int C, const GsrCa
     // (A/B knob: GSR_BWD_COLOR_ONLY=1 treats EVERY cotangent as the loss head's — valid only where it is)
     static const bool force_color_only = [] { const char* e = getenv("GSR_BWD_COLOR_ONLY"); return e && e[0] == '1'; }();
     color_only = (color_only || force_color_only) && C > 3;
-    // (GSR_BWD_SPLIT_TILES overrides the limit for A/B runs)
-    static const uint32_t kMaxSplitTiles = [] { const char* e = getenv("GSR_BWD_SPLIT_TILES"); return e ? (uint32_t)atoi(e) : 256u; }();
-    GsrTierLists tiers{h->big_list.as<uint32_t>(), (uint32_t)h->n_tiles, 0, 0, 0, 0xFFFFFFFFu};
-    const uint32_t cut[3] = {GSR_SORT_LDS_CAP, 4096u, 1024u};             // deepest tier first
-    const uint32_t have[3] = {h->tier_n[2], h->tier_n[1], h->tier_n[0]};
-    uint32_t* take[3] = {&tiers.n_big, &tiers.n_mid8, &tiers.n_mid4};
-    uint32_t n = 0;
-    for (int t = 0; t < 3 && n + have[t] <= kMaxSplitTiles; t++) {
-        n += *take[t] = have[t];
-        tiers.split_len = cut[t];
-    }
-    if (n == 0) tiers.split_len = 0xFFFFFFFFu;  // nothing to split (or the deepest tier alone is already plentiful)
+    // which tiers leave the main launch: gsr_policy_bwd_split (GSR_BWD_SPLIT_TILES overrides its limit for A/B runs)
+    gsr_bwd_split sp;
+    gsr_policy_bwd_split(&h->pcfg, h->pol.tier_n[0], h->pol.tier_n[1], h->pol.tier_n[2], &sp);
+    GsrTierLists tiers{h->big_list.as<uint32_t>(), (uint32_t)h->n_tiles, sp.n_big, sp.n_mid8, sp.n_mid4, sp.split_len};
+    const uint32_t n = sp.n_big + sp.n_mid8 + sp.n_mid4;
     if (n > 0) {
         // per (listed tile, list segment, pixel): the (m, c) of the segment — the first pass's hand-over to the second
         int rc = h->long_state.ensure((size_t)n * GSR_BWD_LONG_SEGS * 256 * 2 * sizeof(float));
@@ -928,14 +927,17 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
         HIPCHK(hipMemsetAsync(g->vt, 0, 3 * 4, s));
         sc6.close();
     }
+    const bool color_only = (g->flags & GSR_GRADS_COLOR_COTANGENT) != 0u;
+    if (color_only && (rc = check_color_cotangent(h, vpixels, s))) return rc;
     GsrCam k = make_cam(h, cam);
     StageScope sc7(h->prof, ST_COMPOSITE_BWD, s);
-    if (h->last_D > 0 && (rc = launch_composite_bwd(h, s, C, k, in->background, vpixels, (g->flags & GSR_GRADS_COLOR_COTANGENT) != 0u))) return rc;
+    if (h->last_D > 0 && (rc = launch_composite_bwd(h, s, C, k, in->background, vpixels, color_only))) return rc;
     sc7.close();
     StageScope sc8(h->prof, ST_PERGAUSS_BWD, s);
     gsr_launch_pergauss_bwd(s, n, in->n_coeffs, in->sh_degree, C, in->means, in->scales, in->rotations, in->shs, k,
                             geom_of(h), inst_of(h), h->vmean2d_cur, g->vmeans, g->vshs, g->vopacities,
-                            g->vscales, g->vrotations, g->vR, g->vt, g->vcolors);
+                            g->vscales, g->vrotations, g->vR, g->vt, g->vcolors,
+                            /*fp32_chain=*/h->cfg.grad_precision == GSR_GRAD_FP32_REFERENCE);
     sc8.close();
     HIPCHK(hipGetLastError());
     h->bwd_valid = true;
@@ -1036,6 +1038,9 @@ int gsr_loss_l1_ssim(gsr_handle* h, const float* image, const float* target, flo
                                                                           loss_out, vpixels);
     sc10.close();
     HIPCHK(hipGetLastError());
+    // the cotangent of this forward whose channels >= 3 are zeros by construction (GSR_GRADS_COLOR_COTANGENT)
+    h->loss_vpixels = vpixels;
+    h->loss_generation = h->generation;
     return GSR_OK;
 }
 
@@ -1218,14 +1223,17 @@ int gsr_backward_trainer_tail(gsr_handle* h, const gsr_inputs* in, const gsr_cam
     const int C = h->cfg.mode;
     if (!st->vmeans2d && (rc = h->vmean2d.ensure((size_t)n * 8))) return rc;
     h->vmean2d_cur = st->vmeans2d ? reinterpret_cast<float2*>(st->vmeans2d) : h->vmean2d.as<float2>();
+    const bool color_only = (st->flags & GSR_GRADS_COLOR_COTANGENT) != 0u;
+    if (color_only && (rc = check_color_cotangent(h, vpixels, s))) return rc;
     GsrCam k = make_cam(h, cam);
     StageScope sc11(h->prof, ST_COMPOSITE_BWD, s);
-    if (h->last_D > 0 && (rc = launch_composite_bwd(h, s, C, k, in->background, vpixels, (st->flags & GSR_GRADS_COLOR_COTANGENT) != 0u))) return rc;
+    if (h->last_D > 0 && (rc = launch_composite_bwd(h, s, C, k, in->background, vpixels, color_only))) return rc;
     sc11.close();
     StageScope sc12(h->prof, ST_PERGAUSS_BWD, s);
     const gsr::TailState S = gsr_make_tail_state(st->theta, st->mu, st->nu, lr_t, st->beta1, st->beta2, st->eps,
                                                  st->scale_dims, st->shs, st->opacities_act, st->scales_act);
-    gsr_launch_pergauss_bwd_tail(s, n, K, in->sh_degree, C, k, geom_of(h), inst_of(h), h->vmean2d_cur, S);
+    gsr_launch_pergauss_bwd_tail(s, n, K, in->sh_degree, C, k, geom_of(h), inst_of(h), h->vmean2d_cur, S,
+                                 /*fp32_chain=*/h->cfg.grad_precision == GSR_GRAD_FP32_REFERENCE);
     sc12.close();
     HIPCHK(hipGetLastError());
     h->bwd_valid = true;

@@ -69,15 +69,12 @@ struct GsrInst {
 };
 
 // ---- pergauss.hip (compiled with -ffp-contract=off: bit-reproducible fp32) ----
-// form: -1 by scene and grid size, 0 direct, 1 aggregating wherever its LDS fits (gsr_config.preprocess_form / gsr_preprocess_form);
+// aggregating: the binning form gsr_policy_begin_view chose for this view (false = the direct form);
 // returns the form that ran (gsr_stats.preprocess_form: 0 direct, 1 / 2 aggregating with 2 x 32 / 2 x 16-bit LDS words, 3 banded)
 int gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels, const float* means,
                           const float* scales, const float* rots, const float* opac, const float* shs, GsrCam cam,
                           GsrGeom geom, uint32_t* tile_count, uint32_t* n_visible /* per 256-block */,
-                          uint64_t* bins /* (T+1) x bin_cap keys */, uint32_t bin_cap, int n_tiles, int form,
-                          bool skewed /* hint from the previous view: longest tile list >> mean list (hot counter words) */);
-// true where the default form choice has two candidates (large grids): gsr_forward then measures both once per handle
-bool gsr_preprocess_form_is_open(int n, int grid_x, int grid_y, uint32_t bin_cap);
+                          uint64_t* bins /* (T+1) x bin_cap keys */, uint32_t bin_cap, int n_tiles, bool aggregating);
 struct GsrBg8 { float v[8]; };
 void gsr_launch_fill_background(hipStream_t s, size_t n_pixels, int channels, const float* background /* host, 3 floats */,
                                 float* image, float* final_T, uint32_t* n_contrib);
@@ -90,12 +87,13 @@ void gsr_launch_pergauss_bwd(hipStream_t s, int n, int K, int degree, int channe
                              const float* scales, const float* rots, const float* shs, GsrCam cam, GsrGeom geom,
                              GsrInst inst, float2* vmean2d, float* vmeans, float* vshs, float* vopac,
                              float* vscales, float* vrots, float* vR, float* vt,
-                             float* vcolors /* (3,N) or NULL: factored SH gradient instead of vshs */);
+                             float* vcolors /* (3,N) or NULL: factored SH gradient instead of vshs */,
+                             bool fp32_chain /* ∇scales / ∇rotations by the reference's fp32 trees (GSR_GRAD_FP32_REFERENCE) */);
 // backward epilogue = trainer tail (single-GPU step): no gradient arrays, the parameters / Adam states in S are
 // updated in place and the activated copies of the next forward written (adam_math.h)
 namespace gsr { struct TailState; }
 void gsr_launch_pergauss_bwd_tail(hipStream_t s, int n, int K, int degree, int channels, GsrCam cam, GsrGeom geom,
-                                  GsrInst inst, float2* vmean2d, const gsr::TailState& S);
+                                  GsrInst inst, float2* vmean2d, const gsr::TailState& S, bool fp32_chain);
 void gsr_launch_sh_grad_views(hipStream_t s, int n, int K, int degree, int n_views, const float* centers,
                               const float* means, const float* vc_all, float* vshs);
 // the same rebuild with the trainer tail applied in place of the ∇shs store (multi-GPU trainer step; S.points = the means)

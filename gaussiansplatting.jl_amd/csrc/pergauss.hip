@@ -17,14 +17,12 @@
 #include "tile_mask.h"
 #include "wave_reduce.h"
 #include "adam_math.h"
+#include "agg_plan.h"
 
 namespace {
 
 constexpr uint32_t EMIT_COOP = 48;  // tiles per rect above which the wave emits cooperatively
-constexpr int kAggThreads = 512;           // workgroup of preprocess_kernel's aggregating form
-constexpr size_t kAggLdsMax = 42 * 1024;   // ... its dynamic LDS (the counter words; + 10 KB of static tables): three workgroups per CU
-constexpr int kAggMaxBandsDefault = 1;      // ... and the number of bands the default choice accepts (measured: DESIGN.md §4)
-constexpr int kAggMinGaussians = 250000;   // ... and the scene size from which it is the default (measured, both forms flattened: DESIGN.md §4)
+constexpr int kAggThreads = gsr_agg::kThreads;  // workgroup of preprocess_kernel's aggregating form (agg_plan.h: shared with the policy layer)
 // Gradient-row slots of a Gaussian (Gaussian-major, gsr_kernels.h): rects of at most DENSE_RECT tiles get one slot per
 // EMITTED tile — preprocess keeps the bit mask of the rect's tiles that passed the footprint test in the record, the
 // sort's emit ranks a tile by a popcount below its bit, the per-Gaussian backward sums popcount(mask) contiguous rows
@@ -921,7 +919,10 @@ __device__ __forceinline__ void scales_rots_bwd_f64(const GsrCam& cam, const M33
 // `scales` the activated copy; the SH coefficients are read from features_rest (the hcat copy `shs`
 // is only written).  Same expression trees as the unfused chain (adam_math.h): identical bits.
 // ---------------------------------------------------------------------------------
-template <int DEG, bool FUSED>
+// F32CHAIN (gsr_config.grad_precision = GSR_GRAD_FP32_REFERENCE): ∇scales / ∇rotations through the reference's own fp32
+// expression trees instead of the float64 chain — reference-parity runs; a template parameter, not a branch, so
+// that the default kernels are round 5's register for register.
+template <int DEG, bool FUSED, bool F32CHAIN = false>
 __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int n, int K, int channels, const float* __restrict__ means,
                                                            const float* __restrict__ scales,
                                                            const float4* __restrict__ rots,
@@ -1195,14 +1196,13 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
                 }
             }
             // ∇quat_scale_to_cov (render.jl:302-320) + ∇unnorm_quat2rot (render.jl:335-366): in float64 from the raw inputs
-            // (scales_rots_bwd_f64 above — the fp32 chain loses a needle's thin eigen-direction).  GSR_PGB_FP32_CHAIN keeps the
-            // reference's fp32 expression trees for A/B runs.
+            // (scales_rots_bwd_f64 above — the fp32 chain loses a needle's thin eigen-direction).  F32CHAIN keeps the
+            // reference's fp32 expression trees (gsr_config.grad_precision = GSR_GRAD_FP32_REFERENCE).
             float vs[3], vq[4];
-#ifndef GSR_PGB_FP32_CHAIN
-            scales_rots_bwd_f64(cam, R, t, p, q4, s, a1.x, a1.y, a1.z, vRg, vs, vq);
-            (void)vSigma; (void)M; (void)qn; (void)inv_norm;
-#else
-            {
+            if constexpr (!F32CHAIN) {
+                scales_rots_bwd_f64(cam, R, t, p, q4, s, a1.x, a1.y, a1.z, vRg, vs, vq);
+                (void)vSigma; (void)M; (void)qn; (void)inv_norm;
+            } else {
                 M33 S;
 #pragma unroll
                 for (int a = 0; a < 3; a++)
@@ -1229,7 +1229,6 @@ __global__ __launch_bounds__(256, GSR_PGB_MINWAVES) void pergauss_bwd_kernel(int
 #pragma unroll
                 for (int k = 0; k < 4; k++) vq[k] = (vqn[k] - dq * qn[k]) * inv_norm;
             }
-#endif
             if constexpr (FUSED) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) f_vq[k] = vq[k];
@@ -1527,63 +1526,25 @@ void gsr_launch_update_stats(hipStream_t s, int n, const int32_t* radii, const f
 }
 
 
-// The aggregating form's LDS plan: the counter words of ONE BAND of the tile grid must fit kAggLdsMax (three workgroups per
-// CU).  One band = the whole grid where that fits (1080p with 2 x 32-bit words, 1440p with 2 x 16-bit words); else the grid
-// is cut into the fewest equal bands of whole tile rows.  2 x 16-bit words need every position handed out to stay below
-// 65 535 - 512 (`max_pos`: the bins' capacity, or the longest list in the scatter pass).
+// The aggregating form's LDS plan (agg_plan.h): whole grid or bands, 2 x 32-bit or 2 x 16-bit words.
 namespace {
-struct AggPlan { bool w32; int n_bands, band_rows; size_t lds; };
-AggPlan agg_plan(int grid_x, int grid_y, uint32_t max_pos) {
-    AggPlan p;
-    const size_t n_words = ((size_t)grid_x * grid_y + 2) / 2;
-    const bool small_pos = max_pos < 0xFFFFu - (uint32_t)kAggThreads;
-    p.w32 = small_pos && n_words * 8 > kAggLdsMax;  // 64-bit words where the whole grid fits with them (as round 4)
-    const size_t wbytes = p.w32 ? 4 : 8;
-    const int words_max = (int)(kAggLdsMax / wbytes);
-    int rows = (int)((2 * (size_t)(words_max - 2)) / (size_t)grid_x);  // a band of r rows spans at most r * grid_x / 2 + 2 words
-    rows = rows < 1 ? 1 : (rows > grid_y ? grid_y : rows);
-    p.n_bands = (grid_y + rows - 1) / rows;
-    p.band_rows = (grid_y + p.n_bands - 1) / p.n_bands;  // equal bands
-    p.lds = ((size_t)p.band_rows * grid_x / 2 + 2) * wbytes;
-    return p;
-}
-// bands the DEFAULT form choice accepts (form = -1); gsr_preprocess_form(1) / gsr_config.preprocess_form = 1 take any number.
-// GSR_AGG_MAX_BANDS overrides (A/B runs).
-int agg_max_bands_default() {
-    static const int v = [] { const char* e = getenv("GSR_AGG_MAX_BANDS"); return e ? atoi(e) : kAggMaxBandsDefault; }();
-    return v;
-}
+using AggPlan = gsr_agg::Plan;
+inline AggPlan agg_plan(int grid_x, int grid_y, uint32_t max_pos) { return gsr_agg::plan(grid_x, grid_y, max_pos); }
 }  // namespace
 
-// The default form choice (form = -1) is open where BOTH forms are candidates: scenes of the aggregating form's size on grids that
-// need 2 .. 8 bands (4K).  There neither wins everywhere — a uniform scene in random order is faster direct (config 5: 0.67
-// against 0.84 ms), a skewed one or one whose Gaussians are in spatial order faster banded (dense 4K 2.0 -> 1.1 ms, Morton-ordered
-// config 5 0.78 -> 0.55) — and gsr_forward times each once on the handle and keeps the faster (gsr_api.cpp: FormTuner).
-bool gsr_preprocess_form_is_open(int n, int grid_x, int grid_y, uint32_t bin_cap) {
-    if (n < kAggMinGaussians) return false;
-    const AggPlan pl = agg_plan(grid_x, grid_y, bin_cap);
-    return pl.n_bands > agg_max_bands_default() && pl.n_bands <= 8;
-}
-
-// form — -1: by scene and grid size (default), 0: direct form, 1: aggregating form (per handle: gsr_config.preprocess_form;
-// its -1 = the process default, gsr_preprocess_form).  Returns the form that ran (gsr_stats.preprocess_form).
+// `agg`: the aggregating form (else the direct one) — WHICH is gsr_policy.cpp's decision (gsr_policy_begin_view: the handle's
+// pin, the process default, the scene / grid rule with the previous view's skew, or the form tuner's measurement).  Returns
+// the form that ran (gsr_stats.preprocess_form = gsr_agg::form_code: the same number the policy announced).
 int gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels, const float* means,
                           const float* scales, const float* rots, const float* opac, const float* shs, GsrCam cam,
                           GsrGeom geom, uint32_t* tile_count, uint32_t* n_visible, uint64_t* bins, uint32_t bin_cap,
-                          int n_tiles, int form, bool skewed) {
+                          int n_tiles, bool agg) {
     if (n <= 0) return 0;
     const float4* r4 = reinterpret_cast<const float4*>(rots);
-    // The aggregating form wants a scene of several rounds of 512-Gaussian workgroups (smaller scenes take the direct form)
-    // and its counter words in LDS three times per CU: the whole grid up to ~21 500 tiles, bands of it beyond (4K: two).
+    // The aggregating form keeps its counter words in LDS three times per CU: the whole grid up to ~21 500 tiles, bands of it
+    // beyond (4K: two).
     const int n_words = (n_tiles + 2) / 2;
     const AggPlan pl = agg_plan(cam.grid_x, cam.grid_y, bin_cap);
-    // Default (form = -1): the aggregating form for scenes of >= 250 k Gaussians where ONE band holds the grid (measured faster on
-    // every scene: 1080p, 1440p); on larger grids (4K: two bands) only for SKEWED views — `skewed`: the previous view's longest
-    // tile list was several times its mean, i.e. some counter words are hot and their global atomics serialise (dense 4K scene:
-    // 2.0 -> 1.1 ms) — because a uniform 4K scene is faster in the direct form (config 5: 0.67 against 0.83 ms, both walks run
-    // once per band).
-    const bool agg = form >= 0 ? form != 0
-                               : (n >= kAggMinGaussians && (pl.n_bands <= agg_max_bands_default() || (skewed && pl.n_bands <= 8)));
     const uint32_t* no_start = nullptr;
     const dim3 agg_grid((n + kAggThreads - 1) / kAggThreads), agg_block(kAggThreads);
 #define LAUNCH_AGG(D, W, B)                                                                                                 \
@@ -1607,7 +1568,7 @@ int gsr_launch_preprocess(hipStream_t s, int n, int K, int degree, int channels,
     }
 #undef LAUNCH
 #undef LAUNCH_AGG
-    return !agg ? 0 : (pl.n_bands > 1 ? 3 : (pl.w32 ? 2 : 1));
+    return gsr_agg::form_code(agg, pl);
 }
 
 // duplicate_with_keys! (utils.jl:85-120) as the SECOND pass of the compact binning mode (count -> scan -> scatter): the
@@ -1636,15 +1597,16 @@ void gsr_launch_emit_compact(hipStream_t s, int n, GsrCam cam, GsrGeom geom, con
 void gsr_launch_pergauss_bwd(hipStream_t s, int n, int K, int degree, int channels, const float* means,
                              const float* scales, const float* rots, const float* shs, GsrCam cam, GsrGeom geom,
                              GsrInst inst, float2* vmean2d, float* vmeans, float* vshs, float* vopac,
-                             float* vscales, float* vrots, float* vR, float* vt, float* vcolors) {
+                             float* vscales, float* vrots, float* vR, float* vt, float* vcolors, bool fp32_chain) {
     if (n <= 0) return;
     dim3 grid((n + 255) / 256), block(256);
     const float4* r4 = reinterpret_cast<const float4*>(rots);
     float4* vr4 = reinterpret_cast<float4*>(vrots);
     const gsr::TailState none{};
-#define LAUNCH(D)                                                                                                     \
-    hipLaunchKernelGGL((pergauss_bwd_kernel<D, false>), grid, block, 0, s, n, K, channels, means, scales, r4, shs,  \
+#define LAUNCH_C(D, F32)                                                                                              \
+    hipLaunchKernelGGL((pergauss_bwd_kernel<D, false, F32>), grid, block, 0, s, n, K, channels, means, scales, r4, shs, \
                        cam, geom, inst, vmean2d, vmeans, vshs, vopac, vscales, vr4, vR, vt, vcolors, none)
+#define LAUNCH(D) do { if (fp32_chain) LAUNCH_C(D, true); else LAUNCH_C(D, false); } while (0)
     switch (degree) {
         case 0: LAUNCH(0); break;
         case 1: LAUNCH(1); break;
@@ -1652,18 +1614,20 @@ void gsr_launch_pergauss_bwd(hipStream_t s, int n, int K, int degree, int channe
         default: LAUNCH(3); break;
     }
 #undef LAUNCH
+#undef LAUNCH_C
 }
 
 void gsr_launch_pergauss_bwd_tail(hipStream_t s, int n, int K, int degree, int channels, GsrCam cam, GsrGeom geom,
-                                  GsrInst inst, float2* vmean2d, const gsr::TailState& S) {
+                                  GsrInst inst, float2* vmean2d, const gsr::TailState& S, bool fp32_chain) {
     if (n <= 0) return;
     dim3 grid((n + 255) / 256), block(256);
     const float4* r4 = reinterpret_cast<const float4*>(S.rots);
-#define LAUNCH(D)                                                                                                     \
-    hipLaunchKernelGGL((pergauss_bwd_kernel<D, true>), grid, block, 0, s, n, K, channels, S.points, S.scales_act,   \
+#define LAUNCH_C(D, F32)                                                                                              \
+    hipLaunchKernelGGL((pergauss_bwd_kernel<D, true, F32>), grid, block, 0, s, n, K, channels, S.points, S.scales_act, \
                        r4, (const float*)nullptr, cam, geom, inst, vmean2d, (float*)nullptr, (float*)nullptr,       \
                        (float*)nullptr, (float*)nullptr, (float4*)nullptr, (float*)nullptr, (float*)nullptr,        \
                        (float*)nullptr, S)
+#define LAUNCH(D) do { if (fp32_chain) LAUNCH_C(D, true); else LAUNCH_C(D, false); } while (0)
     switch (degree) {
         case 0: LAUNCH(0); break;
         case 1: LAUNCH(1); break;
@@ -1671,6 +1635,7 @@ void gsr_launch_pergauss_bwd_tail(hipStream_t s, int n, int K, int degree, int c
         default: LAUNCH(3); break;
     }
 #undef LAUNCH
+#undef LAUNCH_C
 }
 
 void gsr_launch_sh_views_tail(hipStream_t s, int n, int K, int degree, int n_views, const float* centers,

@@ -92,7 +92,7 @@ class GaussianRasterizer:
     def __init__(self, width: int, height: int, mode: str = "rgbd", near_plane: float = 0.2,
                  far_plane: float = 1000.0, device="cuda", radius_clip: int = 3, blur_eps: float = 0.3,
                  exact_tile_cull: bool = True, bins_budget_bytes: int = 0, ssim_precision: Optional[str] = None,
-                 preprocess_form: Optional[str] = None):
+                 preprocess_form: Optional[str] = None, form_tuner: Optional[bool] = None, grad_precision: Optional[str] = None):
         self.mode = mode
         self.channels = n_color_features(mode)
         self.width, self.height = int(width), int(height)
@@ -111,17 +111,25 @@ class GaussianRasterizer:
         # (rasterizer.jl:60-65): None = follow the process-wide default (gsr_ssim_precision / gsr_preprocess_form).
         #   ssim_precision : None | "fast" | "exact"   — arithmetic of the loss head on this rasterizer (fused_ssim.l1_ssim_loss)
         #   preprocess_form: None | "direct" | "aggregating" — binning form of the forward's first kernel (same outputs)
+        #   form_tuner     : None | False | True — on 4K-class grids the handle times both forms once and keeps the faster
+        #                    (None: on unless GSR_FORM_TUNER=0; same outputs either way)
+        #   grad_precision : None | "fp32_reference" — ∇scales / ∇rotations by the reference's own fp32 expression trees instead
+        #                    of the float64 chain (reference-parity runs; needle-shaped splats then carry the reference's 1e-4..1e-3)
         try:
-            sp = {None: L.DEFAULT, "fast": 0, "exact": 1}[ssim_precision]
-            pf = {None: L.DEFAULT, "direct": 0, "aggregating": 1}[preprocess_form]
+            sp = {None: L.DEFAULT, "fast": L.SSIM_FAST, "exact": L.SSIM_EXACT}[ssim_precision]
+            pf = {None: L.DEFAULT, "direct": L.PREPROCESS_DIRECT, "aggregating": L.PREPROCESS_AGGREGATING}[preprocess_form]
+            ft = {None: L.DEFAULT, False: L.TUNER_OFF, True: L.TUNER_ON}[form_tuner]
+            gp = {None: L.DEFAULT, "float64": L.DEFAULT, "fp32_reference": L.GRAD_FP32_REFERENCE}[grad_precision]
         except KeyError as e:
-            raise ValueError(f"ssim_precision is None / 'fast' / 'exact', preprocess_form None / 'direct' / 'aggregating': {e}") from None
+            raise ValueError(f"ssim_precision is None / 'fast' / 'exact', preprocess_form None / 'direct' / 'aggregating', "
+                             f"form_tuner None / False / True, grad_precision None / 'float64' / 'fp32_reference': {e}") from None
         self.ssim_precision, self.preprocess_form = ssim_precision, preprocess_form
+        self.form_tuner, self.grad_precision = form_tuner, grad_precision
         # a bare `rasterize` outside autograd renders forward-only (no backward state); False restores the reference's
         # always-state-keeping `rasterize` for callers of the manual rasterize / grad_rasterize pair
         self.forward_only_outside_ad = True
         cfg = L.Config(self.width, self.height, self.channels, self.near_plane, self.far_plane, int(radius_clip),
-                       float(blur_eps), 0 if exact_tile_cull else L.FLAG_REFERENCE_TILE_LISTS, int(bins_budget_bytes), sp, pf)
+                       float(blur_eps), 0 if exact_tile_cull else L.FLAG_REFERENCE_TILE_LISTS, int(bins_budget_bytes), sp, pf, ft, gp)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             L.check(self._lib.gsr_create(C.byref(cfg), C.byref(h)))

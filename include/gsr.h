@@ -65,15 +65,33 @@ typedef struct gsr_config {
                           * scattered a second time (+ 8 B per instance); a budget below bins of 2 x the mean list (or of 64
                           * keys) selects the compact mode (count -> scan -> scatter, 8 B per instance, no bins).  Same lists,
                           * same results in every mode. */
-    /* New in ABI 5 — the two behaviour switches are PER HANDLE, as the reference's knobs are constructor keywords
-     * (rasterizer.jl:60-65).  -1 = the process-wide default (gsr_ssim_precision / gsr_preprocess_form below, themselves
-     * started from GSR_SSIM_EXACT / GSR_PREPROCESS_AGG), read at every call; 0 / 1 pin the handle whatever another thread
-     * sets process-wide — e.g. a GUI render worker next to a trainer (gui/worker.jl:47-58).  Other values: GSR_E_INVALID_ARG.
-     * (A zero-initialised config therefore means "fast SSIM, direct binning": bindings should write -1.) */
-    int32_t ssim_precision;  /* arithmetic of gsr_loss_l1_ssim on this handle: GSR_DEFAULT (-1), 0 fast, 1 exact */
-    int32_t preprocess_form; /* binning form of gsr_forward on this handle: GSR_DEFAULT (-1) by size, 0 direct, 1 aggregating */
+    /* The behaviour switches are PER HANDLE (ABI 5), as the reference's knobs are constructor keywords (rasterizer.jl:60-65).
+     * ABI 6: 0 = GSR_DEFAULT everywhere, so that a zero-initialised (memset) gsr_config means "the defaults" — under ABI 5's
+     * encoding (-1 default, 0 / 1 explicit) it silently pinned fast SSIM and direct binning.  GSR_DEFAULT follows the
+     * process-wide default (gsr_ssim_precision / gsr_preprocess_form below, themselves started from GSR_SSIM_EXACT /
+     * GSR_PREPROCESS_AGG), read at every call; an explicit value pins the handle whatever another thread sets process-wide —
+     * e.g. a GUI render worker next to a trainer (gui/worker.jl:47-58).  Other values: GSR_E_INVALID_ARG. */
+    int32_t ssim_precision;  /* arithmetic of gsr_loss_l1_ssim on this handle: GSR_DEFAULT, GSR_SSIM_FAST, GSR_SSIM_EXACT */
+    int32_t preprocess_form; /* binning form of gsr_forward on this handle: GSR_DEFAULT (by size), GSR_PREPROCESS_DIRECT,
+                              * GSR_PREPROCESS_AGGREGATING */
+    /* New in ABI 6 */
+    int32_t form_tuner;      /* on 4K-class grids, where neither binning form wins everywhere, the handle times four views'
+                              * first kernel (two per form) and keeps the faster form (gsr_policy.h; results are bit-identical
+                              * either way): GSR_DEFAULT (on; GSR_FORM_TUNER=0 in the environment turns the default off),
+                              * GSR_TUNER_OFF (the previous view's skew decides, as before the tuner existed), GSR_TUNER_ON.
+                              * An explicit preprocess_form pins the form and leaves the tuner nothing to decide. */
+    int32_t grad_precision;  /* ∇scales / ∇rotations of gsr_backward: GSR_DEFAULT = their chain (∇inverse -> ∇perspective ->
+                              * ∇covar_world_to_cam -> ∇quat_scale_to_cov -> ∇unnorm_quat2rot, projection.jl:132-257,
+                              * render.jl:302-366) evaluated in float64 from the raw inputs — on needle-shaped splats the fp32
+                              * chain is 1e-4 .. 1e-3 from float64 whoever evaluates it; GSR_GRAD_FP32_REFERENCE = the
+                              * reference's own fp32 expression trees, operation for operation (reference-parity runs: equal
+                              * to the fp32 CPU oracle to ~1e-6 on well-conditioned Gaussians). */
 } gsr_config;
-#define GSR_DEFAULT (-1)
+#define GSR_DEFAULT 0
+enum { GSR_SSIM_FAST = 1, GSR_SSIM_EXACT = 2 };
+enum { GSR_PREPROCESS_DIRECT = 1, GSR_PREPROCESS_AGGREGATING = 2 };
+enum { GSR_TUNER_OFF = 1, GSR_TUNER_ON = 2 };
+enum { GSR_GRAD_FP32_REFERENCE = 1 };
 
 /* Tile lists.  DEFAULT (flags = 0): exact footprint culling at binning — a (Gaussian, tile)
  * instance none of whose pixels can reach alpha >= 1/255 is not emitted at all.  The reference
@@ -96,9 +114,14 @@ typedef struct gsr_config {
  *   2: round-2 layout (flag bit 1u = reference tile lists) — never given a number at the time
  *   3: round-3 layout (GSR_FLAG_REFERENCE_TILE_LISTS = 2u, bit 1u rejected, gsr_check_abi)
  *   4: gsr_aux grew by `flags` (GSR_FORWARD_ONLY) + `reserved`; gsr_sh_grad_from_views_tail.
- *   5: this layout: gsr_config grew by `ssim_precision` + `preprocess_form` (per-handle switches); gsr_stats.reserved became
- *      `preprocess_form` (the form that ran); gsr_get_ssim_precision / gsr_get_preprocess_form. */
-#define GSR_ABI_VERSION 5
+ *   5: gsr_config grew by `ssim_precision` + `preprocess_form` (per-handle switches); gsr_stats.reserved became
+ *      `preprocess_form` (the form that ran); gsr_get_ssim_precision / gsr_get_preprocess_form; late: gsr_grads and
+ *      gsr_tail_state grew by `flags` + `reserved` (GSR_GRADS_COLOR_COTANGENT).
+ *   6: this layout: gsr_config's switches re-encoded with 0 = default (a zero-initialised config is the default config) and
+ *      grown by `form_tuner` + `grad_precision`; gsr_stats grew by the handle's view-history counters; gsr_check_abi also
+ *      takes sizeof(gsr_tail_state); GSR_GRADS_COLOR_COTANGENT is checked against the cotangent gsr_loss_l1_ssim wrote;
+ *      the policies are GPU-free exports of their own (gsr_policy.h). */
+#define GSR_ABI_VERSION 6
 
 /* Positional arguments of `rasterize(means_3d, shs, opacities, scales, rotations, ...)`
  * (rasterizer.jl:255-267).  opacities / scales are the ACTIVATED values, as the
@@ -167,6 +190,21 @@ typedef struct gsr_stats {
                                  * scattered a second time (the rest of the view stayed on the fast path) */
     int32_t preprocess_form;    /* the binning form this view's first kernel ran in: 0 direct, 1 aggregating (2 x 32-bit LDS
                                  * words), 2 aggregating (2 x 16-bit words), 3 aggregating in horizontal bands of the tile grid */
+    /* New in ABI 6 — the handle's VIEW HISTORY (gsr_policy.h: gsr_policy_state), cumulative since gsr_create.  gsr_forward keeps
+     * state from one view to the next (bins capacity, compact mode, the form tuner, the held fused launch); a training run in
+     * which N, D and the list skew drift can read here what that state did: in steady state none of the first four moves. */
+    uint32_t bins_regrowths;    /* views after which the bins' capacity grew (a hipFree + hipMalloc before the next view) */
+    uint32_t compact_fallbacks; /* views whose small bins overflowed: filled in vain, then binned again compactly */
+    uint32_t tuner_rearms;      /* times the form tuner started over after a decision (scene size moved by 25 %, or 4096 views) */
+    uint32_t scratch_regrowths; /* reallocations of any grow-only scratch buffer of the handle (each synchronises the device) */
+    uint32_t fused_relaunches;  /* early fused launches that found the per-instance buffers too small: a no-op + the redo */
+    uint32_t held_views;        /* views whose fused launch was held so that the tier walk could run beside it */
+    uint32_t bin_capacity;      /* keys per tile of THIS view's bins (0: the view was binned compactly) */
+    int32_t tuner_form;         /* the form tuner's decision on this handle: -1 none (yet / not its territory), 0 direct, 1 aggregating */
+    float tuner_ms[2];          /* the measurement behind it: faster of two timed views of the direct / the aggregating form */
+    uint32_t tier_tiles[3];     /* tiles of THIS view whose list has (1024, 4096], (4096, 8192], > 8192 instances: the lists the
+                                 * fused sort + forward launch leaves to the tier sorts and the tier walk */
+    uint32_t reserved;
 } gsr_stats;
 
 /* Cotangents returned by `∇rasterize` (rasterizer.jl:549): caller-provided device
@@ -199,8 +237,13 @@ typedef struct gsr_grads {
 /* gsr_grads.flags / gsr_tail_state.flags — the caller's promise that channels >= 3 of `vpixels` (depth, alpha, normal) are exact
  * zeros: the cotangent gsr_loss_l1_ssim writes — the photometric loss only sees features[1:3] (training.jl:656,684-685) — not
  * touched since.  ∇render! then runs the :rgb arithmetic on the mode's stream: the :rgbdn backward 0.885 -> 0.702 ms, :rgbd
- * 0.713 -> 0.700 (config 3).  Gradients equal the unflagged call's up to the association of fp32 sums.  The promise is not
- * checked: a depth or normal loss added to vpixels in place must not set it.  Ignored in :rgb mode. */
+ * 0.713 -> 0.700 (config 3).  Gradients equal the unflagged call's up to the association of fp32 sums.  Ignored in :rgb mode.
+ * ABI 6: the promise is CHECKED as far as the library can see — the flag is honoured only for the very buffer the handle's
+ * last gsr_loss_l1_ssim wrote for THIS forward (pointer and forward generation recorded by the loss head); any other vpixels
+ * with the flag set is GSR_E_INVALID_ARG instead of silently dropped depth / normal gradients.  What it cannot see is a term
+ * added to that buffer in place afterwards: GSR_CHECK_COLOR_COTANGENT=1 in the environment makes every flagged backward
+ * reduce |vpixels[3:]| first (one pass over the image + a host wait — debugging only) and fail with GSR_E_INVALID_ARG when it
+ * is not exactly zero. */
 #define GSR_GRADS_COLOR_COTANGENT 0x1u
 
 typedef struct gsr_handle gsr_handle;
@@ -306,7 +349,7 @@ GSR_API int gsr_ssim_backward(int W, int H, int CH, int B, const float* img, con
 
 /* Arithmetic of the three SSIM entry points (gsr_ssim_forward / gsr_ssim_backward / gsr_loss_l1_ssim): the PROCESS-WIDE
  * DEFAULT — what gsr_ssim_forward / gsr_ssim_backward (no handle) use, and gsr_loss_l1_ssim on a handle whose
- * gsr_config.ssim_precision is GSR_DEFAULT; a handle created with 0 or 1 there is not affected (ABI 5).  Stored and read
+ * gsr_config.ssim_precision is GSR_DEFAULT; a handle created with GSR_SSIM_FAST / GSR_SSIM_EXACT there is not affected.  Stored and read
  * atomically; gsr_get_ssim_precision returns the current value (so that a scoped override can restore what it found).
  *   0 (default): multiply-adds contracted to FMAs and the six divisions of the SSIM formula (fused_ssim.jl:219-233) taken over
  *      two hardware reciprocals — what a GPU compiler makes of the reference's own source; results agree with the
@@ -318,8 +361,8 @@ GSR_API int gsr_ssim_precision(int exact);
 GSR_API int gsr_get_ssim_precision(void);
 
 /* Form of the binning inside gsr_forward's first kernel (preprocess: projection.jl:69-129 + spherical_harmonics! +
- * utils.jl:85-142 fused): the PROCESS-WIDE DEFAULT, used by handles whose gsr_config.preprocess_form is GSR_DEFAULT (ABI 5:
- * a handle created with 0 or 1 there is pinned).  Outputs are identical in every form (only the arbitrary order of the unsorted
+ * utils.jl:85-142 fused): the PROCESS-WIDE DEFAULT, used by handles whose gsr_config.preprocess_form is GSR_DEFAULT (a
+ * handle created with GSR_PREPROCESS_DIRECT / GSR_PREPROCESS_AGGREGATING there is pinned).  Outputs are identical in every form (only the arbitrary order of the unsorted
  * keys inside a tile's bin differs), this is a performance switch and the tests' handle on both code paths.
  *  -1 (default): chosen per call — the aggregating form for scenes of >= 250 000 Gaussians on grids whose counter words
  *      fit the LDS three times per CU (up to ~10 700 tiles with 2 x 32-bit words: 1080p; up to ~21 500 with 2 x 16-bit words
@@ -588,12 +631,17 @@ GSR_API const char* gsr_version(void);   /* "gsr-hip <release> abi <GSR_ABI_VERS
 GSR_API int gsr_abi_version(void);        /* GSR_ABI_VERSION the library was built from */
 /* Binding self-check, to be called once by every binding right after it loads the library (the Python mirror and the
  * Julia binding do): the caller's GSR_ABI_VERSION and its sizeof of the six structs that cross gsr_create / gsr_forward
- * / gsr_backward.  Any mismatch — a caller built against another header — is GSR_E_INVALID_ARG with a message naming the
+ * / gsr_backward, and (ABI 6) of gsr_tail_state, which grew late in ABI 5.  Any mismatch — a caller built against another header — is GSR_E_INVALID_ARG with a message naming the
  * struct, instead of mis-sized structs being read silently. */
 GSR_API int gsr_check_abi(int abi_version, size_t sizeof_config, size_t sizeof_inputs, size_t sizeof_camera,
-                          size_t sizeof_aux, size_t sizeof_stats, size_t sizeof_grads);
+                          size_t sizeof_aux, size_t sizeof_stats, size_t sizeof_grads, size_t sizeof_tail_state);
 
 #ifdef __cplusplus
 }
 #endif
+
+/* The library's policies as GPU-free functions (bins capacity, binning mode and form, the form tuner's rule, the held
+ * fused launch, the backward's list split) and the view-history state gsr_stats reports from. */
+#include "gsr_policy.h"
+
 #endif /* GSR_H */

@@ -40,8 +40,10 @@ struct GsrConfig
     width::Int32; height::Int32; mode::Int32
     near_plane::Float32; far_plane::Float32; radius_clip::Int32; blur_eps::Float32; flags::UInt32
     bins_budget_bytes::UInt64  # 0 = default
-    ssim_precision::Int32      # ABI 5, per handle: -1 = process default (ssim_exact!), 0 fast, 1 exact
-    preprocess_form::Int32     # ABI 5, per handle: -1 = process default (preprocess_form!), 0 direct, 1 aggregating
+    ssim_precision::Int32      # per handle: 0 = process default (ssim_exact!), 1 fast, 2 exact            (ABI 6 encoding:
+    preprocess_form::Int32     # per handle: 0 = process default (preprocess_form!), 1 direct, 2 aggregating   0 = default)
+    form_tuner::Int32          # ABI 6: 0 default (on), 1 off, 2 on — the handle measures the binning form on 4K-class grids
+    grad_precision::Int32      # ABI 6: 0 default (∇scales / ∇rotations through the float64 chain), 1 the reference's fp32 trees
 end
 struct GsrInputs
     n::Int32; n_coeffs::Int32; sh_degree::Int32
@@ -59,6 +61,10 @@ const GSR_FORWARD_ONLY = 0x00000001  # gsr_aux.flags: this forward will not be d
 struct GsrStats
     n_rendered::Int64; n_visible::Int32; max_tile_instances::Int32; generation::UInt64
     bins_bytes::Int64; compact_binning::Int32; preprocess_form::Int32
+    # ABI 6: the handle's view history (include/gsr_policy.h), cumulative since gsr_create
+    bins_regrowths::UInt32; compact_fallbacks::UInt32; tuner_rearms::UInt32; scratch_regrowths::UInt32
+    fused_relaunches::UInt32; held_views::UInt32; bin_capacity::UInt32; tuner_form::Int32; tuner_ms::NTuple{2, Float32}
+    tier_tiles::NTuple{3, UInt32}; reserved::UInt32
 end
 struct GsrGrads
     vmeans::Ptr{Float32}; vshs::Ptr{Float32}; vopacities::Ptr{Float32}
@@ -68,18 +74,29 @@ struct GsrGrads
     forward_generation::UInt64     # pairs the pullback with its forward (0 = unchecked)
     flags::UInt32; reserved::UInt32 # GSR_GRADS_*
 end
-const GSR_GRADS_COLOR_COTANGENT = 0x00000001  # channels >= 4 of the cotangent (depth, alpha, normal) are zeros: the loss head's
+struct GsrTailState
+    theta::NTuple{6, Ptr{Float32}}; mu::NTuple{6, Ptr{Float32}}; nu::NTuple{6, Ptr{Float32}}
+    lr::NTuple{6, Float32}; current_step::NTuple{6, UInt32}
+    beta1::Float32; beta2::Float32; eps::Float32; scale_dims::Int32
+    shs::Ptr{Float32}; opacities_act::Ptr{Float32}; scales_act::Ptr{Float32}
+    vmeans2d::Ptr{Float32}; forward_generation::UInt64
+    flags::UInt32; reserved::UInt32
+end
+const EMPTY_STATS = GsrStats(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, -1, (0f0, 0f0), (0x0, 0x0, 0x0), 0)
+const GSR_GRADS_COLOR_COTANGENT = 0x00000001  # channels >= 4 of the cotangent (depth, alpha, normal) are zeros: ONLY valid for the
+                                              # buffer loss_l1_ssim! wrote for this forward (the library checks pointer + generation)
 
 check(rc) = rc == 0 || error(unsafe_string(ccall((:gsr_last_error_string, LIB), Cstring, ())))
 
-# GSR_ABI_VERSION of the include/gsr.h these struct definitions mirror; checked (with the six struct sizes) against
+# GSR_ABI_VERSION of the include/gsr.h these struct definitions mirror; checked (with the seven struct sizes) against
 # the loaded library by the first enable_hip_native!: a stale libgsr_hip.so or a stale binding fails here, loudly.
-const GSR_ABI_VERSION = 5
+const GSR_ABI_VERSION = 6
 const ABI_CHECKED = Ref(false)
 function check_abi()
     ABI_CHECKED[] && return
-    check(ccall((:gsr_check_abi, LIB), Cint, (Cint, Csize_t, Csize_t, Csize_t, Csize_t, Csize_t, Csize_t), GSR_ABI_VERSION,
-        sizeof(GsrConfig), sizeof(GsrInputs), sizeof(GsrCamera), sizeof(GsrAux), sizeof(GsrStats), sizeof(GsrGrads)))
+    check(ccall((:gsr_check_abi, LIB), Cint, (Cint, Csize_t, Csize_t, Csize_t, Csize_t, Csize_t, Csize_t, Csize_t), GSR_ABI_VERSION,
+        sizeof(GsrConfig), sizeof(GsrInputs), sizeof(GsrCamera), sizeof(GsrAux), sizeof(GsrStats), sizeof(GsrGrads),
+        sizeof(GsrTailState)))
     ABI_CHECKED[] = true
 end
 dptr(::Type{T}, x) where T = x === nothing ? Ptr{T}(C_NULL) : Ptr{T}(UInt(pointer(x)))
@@ -92,14 +109,15 @@ mutable struct NativeState
     generation::UInt64
     forward_only_outside_ad::Bool  # a bare `rasterize` (no rrule around it) keeps no backward state
     pullback_follows::Bool         # set by the rrule below for the forward it is about to run
-    color_cotangent::Bool          # the next pullbacks' cotangent has zeros in its depth / alpha / normal channels (color_cotangent!)
+    stats::GsrStats                # of the last forward (view history: `history(rast)`)
 end
 const NATIVE = WeakKeyDict{GaussianRasterizer, NativeState}()
 const NATIVE_LOCK = ReentrantLock()
 native(rast::GaussianRasterizer) = lock(() -> get(NATIVE, rast, nothing), NATIVE_LOCK)
 
 """
-    enable_hip_native!(rast; reference_tile_lists=false, forward_only_outside_ad=true, ssim_exact=nothing, preprocess_form=nothing)
+    enable_hip_native!(rast; reference_tile_lists=false, forward_only_outside_ad=true, ssim_exact=nothing, preprocess_form=nothing,
+                       form_tuner=nothing, grad_fp32_reference=false)
 
 Route `rasterize` / `∇rasterize` on this rasterizer through libgsr_hip.so.  Width / height / mode / near / far
 are the rasterizer's own (rasterizer.jl:60-90).  `forward_only_outside_ad`: a `rasterize` that is not being
@@ -107,37 +125,59 @@ differentiated (no `rrule` around it) is rendered with GSR_FORWARD_ONLY — `∇
 `ssim_exact` (`nothing` | `false` | `true`) and `preprocess_form` (`nothing` | `0` | `1`) pin the two behaviour switches for THIS
 rasterizer (ABI 5; constructor keywords, as the reference's knobs are: rasterizer.jl:60-65); `nothing` follows the process-wide
 default (`ssim_exact!`, `preprocess_form!`) — so a GUI render task and a trainer in one process cannot disturb each other.
+`form_tuner` (`nothing` | `false` | `true`): whether the handle measures the binning form on 4K-class grids (same outputs either
+way).  `grad_fp32_reference = true`: ∇scales / ∇rotations by the reference's own fp32 expression trees (projection.jl:132-257,
+render.jl:302-366) instead of the library's float64 chain — for reference-parity runs.
 Returns `rast`.
 """
 function enable_hip_native!(rast::GaussianRasterizer; reference_tile_lists::Bool = false, forward_only_outside_ad::Bool = true,
-                            ssim_exact::Union{Nothing, Bool} = nothing, preprocess_form::Union{Nothing, Integer} = nothing)
+                            ssim_exact::Union{Nothing, Bool} = nothing, preprocess_form::Union{Nothing, Integer} = nothing,
+                            form_tuner::Union{Nothing, Bool} = nothing, grad_fp32_reference::Bool = false)
     native(rast) === nothing || return rast
     check_abi()
     c, w, h = size(rast.image)
     href = Ref{Ptr{Cvoid}}()
     check(ccall((:gsr_create, LIB), Cint, (Ref{GsrConfig}, Ref{Ptr{Cvoid}}),
         GsrConfig(w, h, c, rast.near_plane, rast.far_plane, 3, 0.3f0, reference_tile_lists ? 0x2 : 0x0, 0,
-                  ssim_exact === nothing ? Int32(-1) : Int32(ssim_exact), preprocess_form === nothing ? Int32(-1) : Int32(preprocess_form)),
+                  # ABI 6: 0 = default, 1 / 2 the explicit choices
+                  ssim_exact === nothing ? Int32(0) : Int32(ssim_exact ? 2 : 1),
+                  preprocess_form === nothing ? Int32(0) : Int32(preprocess_form != 0 ? 2 : 1),
+                  form_tuner === nothing ? Int32(0) : Int32(form_tuner ? 2 : 1), Int32(grad_fp32_reference ? 1 : 0)),
         href))
-    st = NativeState(href[], 0, forward_only_outside_ad, false, false)
+    st = NativeState(href[], 0, forward_only_outside_ad, false, EMPTY_STATS)
     finalizer(s -> ccall((:gsr_destroy, LIB), Cint, (Ptr{Cvoid},), s.handle), st)
     lock(() -> (NATIVE[rast] = st), NATIVE_LOCK)
     return rast
 end
 
 """
-    color_cotangent!(rast, flag::Bool)
+    loss_l1_ssim!(rast, target; λ_dssim=0.2f0) -> (loss::ROCVector{Float32} of length 1, vpixels)
 
-Promise (GSR_GRADS_COLOR_COTANGENT) that the pixel cotangent handed to `∇rasterize` / `backward_trainer_tail!` on this rasterizer has
-exact zeros in every channel above the colour — true for the reference's photometric loss, which only sees `features[1:3]`
-(training.jl:656,684-685), and false as soon as a depth or normal term is added to the loss.  In `:rgbd` / `:rgbdn` mode the backward
-then runs the `:rgb` arithmetic (`:rgbdn` 0.885 -> 0.702 ms at config 3).  Off by default.
+The photometric loss head of `step!` (training.jl:656,684-694) fused with its pullback (gsr_loss_l1_ssim) on `rast.image`, the render
+of the forward just run: `target` is the (W,H,3) device image.  The returned cotangent has exact zeros above the colour channels and
+is the ONLY buffer `backward_trainer_tail!(...; color_cotangent=true)` accepts — the library remembers which buffer its loss head
+wrote for which forward, so a cotangent with depth / normal terms can never be mistaken for it (ADVICE r5: the flag used to be a
+sticky, unchecked promise).
 """
-function color_cotangent!(rast::GaussianRasterizer, flag::Bool)
+function loss_l1_ssim!(rast::GaussianRasterizer, target; λ_dssim::Float32 = 0.2f0)
     st = native(rast)
-    st === nothing && error("color_cotangent! needs enable_hip_native!(rast)")
-    st.color_cotangent = flag
-    return rast
+    st === nothing && error("loss_l1_ssim! needs enable_hip_native!(rast)")
+    loss = AMDGPU.zeros(Float32, 1); vpixels = similar(rast.image)
+    check(ccall((:gsr_loss_l1_ssim, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Cfloat, Ptr{Float32}, Ptr{Float32}, Ptr{Cvoid}),
+        st.handle, dptr(rast.image), dptr(target), λ_dssim, dptr(loss), dptr(vpixels), hipstream()))
+    return loss, vpixels
+end
+
+"""
+    history(rast) -> NamedTuple
+
+The native handle's view history after the last forward (gsr_stats, ABI 6): how often the key bins were regrown, a view fell back
+to compact binning, the form tuner started over, a scratch buffer was reallocated — in a steady training run none of them moves.
+"""
+function history(rast::GaussianRasterizer)
+    s = native(rast).stats
+    return (; s.bins_regrowths, s.compact_fallbacks, s.tuner_rearms, s.scratch_regrowths, s.fused_relaunches, s.held_views,
+            s.bin_capacity, s.tuner_form, s.compact_binning, s.preprocess_form)
 end
 
 function disable_hip_native!(rast::GaussianRasterizer)
@@ -181,11 +221,12 @@ function GaussianSplatting.rasterize(means_3d::RM, shs::R3, opacities::RM, scale
     st.pullback_follows = false
     aux = GsrAux(dptr(UInt8, covisibilities), dptr(uncertainties), dptr(Int32, rast.gstate.radii),
         keep ? 0x00000000 : GSR_FORWARD_ONLY, 0x00000000)
-    stats = Ref(GsrStats(0, 0, 0, 0, 0, 0, 0))
+    stats = Ref(EMPTY_STATS)
     check(ccall((:gsr_forward, LIB), Cint,
         (Ptr{Cvoid}, Ref{GsrInputs}, Ref{GsrCamera}, Ptr{Float32}, Ref{GsrAux}, Ptr{Cvoid}, Ref{GsrStats}),
         st.handle, inp, cam, dptr(rast.image), aux, hipstream(), stats))
     st.generation = stats[].generation
+    st.stats = stats[]
     return rast.image  # aliased, overwritten by the next call (rasterizer.jl:407)
 end
 
@@ -205,8 +246,8 @@ function GaussianSplatting.∇rasterize(vpixels::R3, means_3d::RM, shs::R3, scal
     inp, cam = _structs(means_3d, shs, opacities, scales, rotations, R_w2c, t_w2c, camera, sh_degree, background)
     g = GsrGrads(dptr(vmeans), dptr(vshs), dptr(vopac), dptr(vscales), dptr(vrot), dptr(vR), dptr(vt),
         Ptr{Float32}(C_NULL), Ptr{Float32}(UInt(pointer(rast.gstate.∇means_2d))), st.generation,
-        # (color_cotangent!: the caller's promise that the depth / alpha / normal channels of vpixels are zeros)
-        st.color_cotangent ? GSR_GRADS_COLOR_COTANGENT : UInt32(0), UInt32(0))
+        # (no GSR_GRADS_COLOR_COTANGENT here: under the rrule the cotangent is Zygote's, not the fused loss head's)
+        UInt32(0), UInt32(0))
     check(ccall((:gsr_backward, LIB), Cint,
         (Ptr{Cvoid}, Ref{GsrInputs}, Ref{GsrCamera}, Ptr{Float32}, Ref{GsrGrads}, Ptr{Cvoid}),
         st.handle, inp, cam, dptr(vpixels), g, hipstream()))
@@ -298,16 +339,12 @@ end
 # The same tail applied in the epilogue of the backward (gsr_backward_trainer_tail): the single-GPU `step!` after
 # the loss with no gradient arrays at all.  `vpixels` is the loss cotangent of rast.image; θ[1] / θ[6] must be the
 # arrays the forward was given as means_3d / rotations, shs / opacities_act / scales_act its other inputs.
-struct GsrTailState
-    theta::NTuple{6, Ptr{Float32}}; mu::NTuple{6, Ptr{Float32}}; nu::NTuple{6, Ptr{Float32}}
-    lr::NTuple{6, Float32}; current_step::NTuple{6, UInt32}
-    beta1::Float32; beta2::Float32; eps::Float32; scale_dims::Int32
-    shs::Ptr{Float32}; opacities_act::Ptr{Float32}; scales_act::Ptr{Float32}
-    vmeans2d::Ptr{Float32}; forward_generation::UInt64
-    flags::UInt32; reserved::UInt32
-end
+# `color_cotangent = true` (per call, GSR_GRADS_COLOR_COTANGENT): `vpixels` is the buffer loss_l1_ssim! returned for this forward,
+# untouched — in :rgbd / :rgbdn mode the backward then runs the :rgb arithmetic (:rgbdn 0.885 -> 0.702 ms at config 3); any other
+# buffer with the flag set is an error, not silently dropped depth / normal gradients.
 function backward_trainer_tail!(rast::GaussianRasterizer, vpixels, θ::NTuple{6}, opts::NTuple{6}, shs, opacities_act,
-        scales_act; camera::Camera, sh_degree::Int, background::SVector{3, Float32}, β1=0.9f0, β2=0.999f0, ϵ=1f-15)
+        scales_act; camera::Camera, sh_degree::Int, background::SVector{3, Float32}, β1=0.9f0, β2=0.999f0, ϵ=1f-15,
+        color_cotangent::Bool = false)
     st = native(rast)
     st === nothing && error("backward_trainer_tail! needs enable_hip_native!(rast)")
     inp, cam = _structs(θ[1], shs, opacities_act, scales_act, θ[6], nothing, nothing, camera, sh_degree, background)
@@ -315,7 +352,7 @@ function backward_trainer_tail!(rast::GaussianRasterizer, vpixels, θ::NTuple{6}
     ts = GsrTailState(p(θ), p(map(o -> o.μ[1], opts)), p(map(o -> o.ν[1], opts)), ntuple(i -> Float32(opts[i].lr), 6),
         ntuple(i -> UInt32(opts[i].current_step + 0x1), 6), β1, β2, ϵ, size(θ[5], 1),
         dptr(shs), dptr(opacities_act), dptr(scales_act), Ptr{Float32}(UInt(pointer(rast.gstate.∇means_2d))), st.generation,
-        st.color_cotangent ? GSR_GRADS_COLOR_COTANGENT : UInt32(0), UInt32(0))
+        color_cotangent ? GSR_GRADS_COLOR_COTANGENT : UInt32(0), UInt32(0))
     check(ccall((:gsr_backward_trainer_tail, LIB), Cint,
         (Ptr{Cvoid}, Ref{GsrInputs}, Ref{GsrCamera}, Ptr{Float32}, Ref{GsrTailState}, Ptr{Cvoid}),
         st.handle, inp, cam, dptr(vpixels), ts, hipstream()))

@@ -12,7 +12,8 @@ def test_library_exports_every_declared_symbol(pkg):
     if not os.path.exists(L.LIB_PATH):
         L.build()
     lib = L.load()
-    hdr = open(L.HEADER_PATH).read()
+    inc = os.path.dirname(L.HEADER_PATH)
+    hdr = "".join(open(os.path.join(inc, f)).read() for f in sorted(os.listdir(inc)) if f.endswith(".h"))  # gsr.h + gsr_policy.h
     declared = sorted(set(re.findall(r"GSR_API\s+[\w\s\*]+?\b(gsr_\w+)\s*\(", hdr)))
     assert declared, "no GSR_API declarations parsed"
     assert sorted(L.EXPORTS) == declared
@@ -24,40 +25,45 @@ def test_library_exports_every_declared_symbol(pkg):
 def test_stale_callers_fail_loudly(pkg):
     """ADVICE r2 (gsr.h:77): flag bit 1u changed meaning between ABI 1 and 2, structs grew — a caller built against an
     old header must get an error, not the other list mode or mis-sized structs.  Bit 1u is retired and rejected; the
-    reference-lists flag lives on bit 2u; gsr_check_abi compares the ABI number and the six struct sizes."""
+    reference-lists flag lives on bit 2u; gsr_check_abi compares the ABI number and the seven struct sizes (ABI 6: + gsr_tail_state,
+    which grew late in ABI 5 without being size-checked — ADVICE r5)."""
     L = pkg._lib
     lib = L.load()
-    assert lib.gsr_abi_version() == L.ABI_VERSION == 5
-    assert b"abi 5" in lib.gsr_version()
+    assert lib.gsr_abi_version() == L.ABI_VERSION == 6
+    assert b"abi 6" in lib.gsr_version()
     hdr = open(L.HEADER_PATH).read()
-    assert re.search(r"#define\s+GSR_ABI_VERSION\s+5\b", hdr) and re.search(r"#define\s+GSR_FLAG_REFERENCE_TILE_LISTS\s+2u", hdr)
+    assert re.search(r"#define\s+GSR_ABI_VERSION\s+6\b", hdr) and re.search(r"#define\s+GSR_FLAG_REFERENCE_TILE_LISTS\s+2u", hdr)
     h = C.c_void_p()
-    cfg = L.Config(64, 48, 3, 0.2, 1000.0, 3, 0.3, 1, 0, -1, -1)  # the retired bit
+    cfg = L.Config(64, 48, 3, 0.2, 1000.0, 3, 0.3, 1, 0, 0, 0, 0, 0)  # the retired bit
     assert lib.gsr_create(C.byref(cfg), C.byref(h)) == L.GSR_E_INVALID_ARG
     assert b"retired" in lib.gsr_last_error_string()
-    sizes = [C.sizeof(t) for t in (L.Config, L.Inputs, L.CameraS, L.Aux, L.Stats, L.Grads)]
-    assert lib.gsr_check_abi(5, *sizes) == 0
+    sizes = [C.sizeof(t) for t in (L.Config, L.Inputs, L.CameraS, L.Aux, L.Stats, L.Grads, L.TailState)]
+    assert lib.gsr_check_abi(6, *sizes) == 0
+    assert lib.gsr_check_abi(5, *sizes) == L.GSR_E_INVALID_ARG and b"ABI 5" in lib.gsr_last_error_string()
     assert lib.gsr_check_abi(4, *sizes) == L.GSR_E_INVALID_ARG and b"ABI 4" in lib.gsr_last_error_string()
     assert lib.gsr_check_abi(3, *sizes) == L.GSR_E_INVALID_ARG and b"ABI 3" in lib.gsr_last_error_string()
     assert lib.gsr_check_abi(2, *sizes) == L.GSR_E_INVALID_ARG and b"ABI 2" in lib.gsr_last_error_string()
     stale = list(sizes); stale[5] -= 16  # round-1 gsr_grads had no vmeans2d / forward_generation
-    assert lib.gsr_check_abi(5, *stale) == L.GSR_E_INVALID_ARG and b"gsr_grads" in lib.gsr_last_error_string()
+    assert lib.gsr_check_abi(6, *stale) == L.GSR_E_INVALID_ARG and b"gsr_grads" in lib.gsr_last_error_string()
     # the Julia binding carries the same numbers
     jl = open(os.path.join(os.path.dirname(L.HEADER_PATH), "..", "julia", "GaussianSplattingHipNative.jl")).read()
     stale = list(sizes); stale[3] -= 8  # ABI 3's gsr_aux had no flags / reserved
-    assert lib.gsr_check_abi(5, *stale) == L.GSR_E_INVALID_ARG and b"gsr_aux" in lib.gsr_last_error_string()
-    stale = list(sizes); stale[0] -= 8  # ABI 4's gsr_config had no ssim_precision / preprocess_form
-    assert lib.gsr_check_abi(5, *stale) == L.GSR_E_INVALID_ARG and b"gsr_config" in lib.gsr_last_error_string()
-    assert "const GSR_ABI_VERSION = 5" in jl and "reference_tile_lists ? 0x2 : 0x0" in jl and ":gsr_check_abi" in jl
+    assert lib.gsr_check_abi(6, *stale) == L.GSR_E_INVALID_ARG and b"gsr_aux" in lib.gsr_last_error_string()
+    stale = list(sizes); stale[0] -= 8  # ABI 5's gsr_config had no form_tuner / grad_precision
+    assert lib.gsr_check_abi(6, *stale) == L.GSR_E_INVALID_ARG and b"gsr_config" in lib.gsr_last_error_string()
+    stale = list(sizes); stale[6] -= 8  # early ABI 5's gsr_tail_state had no flags / reserved: the library would read 8 bytes past it
+    assert lib.gsr_check_abi(6, *stale) == L.GSR_E_INVALID_ARG and b"gsr_tail_state" in lib.gsr_last_error_string()
+    assert "const GSR_ABI_VERSION = 6" in jl and "reference_tile_lists ? 0x2 : 0x0" in jl and ":gsr_check_abi" in jl
+    assert "sizeof(GsrTailState)" in jl
 
 
 def test_struct_sizes_match_header(pkg):
     L = pkg._lib
     # include/gsr.h layouts (x86-64 SysV): catches a drifting binding
-    assert C.sizeof(L.Config) == 48
+    assert C.sizeof(L.Config) == 56  # ABI 6: + form_tuner, grad_precision
     assert C.sizeof(L.Inputs) == 16 + 5 * 8 + 12 + 4
     assert C.sizeof(L.CameraS) == (9 + 3 + 2 + 2 + 3) * 4 + 4 + 16
-    assert C.sizeof(L.Stats) == 40
+    assert C.sizeof(L.Stats) == 96   # ABI 6: + the view-history block and the tier-tile counts
     assert C.sizeof(L.Grads) == 88   # + flags, reserved (ABI 5, late: GSR_GRADS_COLOR_COTANGENT)
     assert C.sizeof(L.Aux) == 32
     assert C.sizeof(L.TailState) == 256
@@ -69,7 +75,9 @@ def test_struct_sizes_match_the_c_compiler(pkg, tmp_path):
     L = pkg._lib
     pairs = {"gsr_config": L.Config, "gsr_inputs": L.Inputs, "gsr_camera": L.CameraS, "gsr_aux": L.Aux,
              "gsr_stats": L.Stats, "gsr_grads": L.Grads, "gsr_adam_group": L.AdamGroup, "gsr_tail_grads": L.TailGrads,
-             "gsr_tail_state": L.TailState, "gsr_compose_group": L.ComposeGroup, "gsr_gather_group": L.GatherGroup}
+             "gsr_tail_state": L.TailState, "gsr_compose_group": L.ComposeGroup, "gsr_gather_group": L.GatherGroup,
+             "gsr_form_tuner": L.FormTuner, "gsr_policy_config": L.PolicyConfig, "gsr_policy_state": L.PolicyState,
+             "gsr_view_plan": L.ViewPlan, "gsr_view_outcome": L.ViewOutcome, "gsr_bwd_split": L.BwdSplit}
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include "gsr.h"\nint main(void){' +
                    "".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in pairs) + "return 0;}\n")
@@ -85,14 +93,18 @@ def test_invalid_arguments_fail_before_touching_the_gpu(pkg):
     L = pkg._lib
     lib = L.load()
     h = C.c_void_p()
-    cfg = L.Config(64, 48, 4, 0.2, 1000.0, 3, 0.3, 0, 0, -1, -1)  # mode 4 does not exist
+    cfg = L.Config(64, 48, 4, 0.2, 1000.0, 3, 0.3, 0, 0, 0, 0, 0, 0)  # mode 4 does not exist
     assert lib.gsr_create(C.byref(cfg), C.byref(h)) == L.GSR_E_INVALID_ARG
     assert b"Invalid render mode" in lib.gsr_last_error_string()
-    cfg = L.Config(0, 48, 3, 0.2, 1000.0, 3, 0.3, 0, 0, -1, -1)
+    cfg = L.Config(0, 48, 3, 0.2, 1000.0, 3, 0.3, 0, 0, 0, 0, 0, 0)
     assert lib.gsr_create(C.byref(cfg), C.byref(h)) == L.GSR_E_INVALID_ARG
-    # the per-handle switches (ABI 5) take GSR_DEFAULT (-1), 0 or 1
-    for sp, pf, word in ((2, -1, b"ssim_precision"), (-2, 0, b"ssim_precision"), (0, 2, b"preprocess_form"), (1, -2, b"preprocess_form")):
-        cfg = L.Config(64, 48, 3, 0.2, 1000.0, 3, 0.3, 0, 0, sp, pf)
+    # the per-handle switches take GSR_DEFAULT (0 since ABI 6: a zero-initialised gsr_config IS the default config)
+    # or their explicit values 1 / 2 (grad_precision: 1); ABI 5's -1 is rejected, not read as something else
+    assert (L.DEFAULT, L.SSIM_FAST, L.SSIM_EXACT, L.PREPROCESS_DIRECT, L.PREPROCESS_AGGREGATING) == (0, 1, 2, 1, 2)
+    for sp, pf, ft, gp, word in ((3, 0, 0, 0, b"ssim_precision"), (-1, 0, 0, 0, b"ssim_precision"), (0, 3, 0, 0, b"preprocess_form"),
+                                 (1, -1, 0, 0, b"preprocess_form"), (0, 0, 3, 0, b"form_tuner"), (0, 0, -1, 0, b"form_tuner"),
+                                 (0, 0, 0, 2, b"grad_precision"), (0, 0, 0, -1, b"grad_precision")):
+        cfg = L.Config(64, 48, 3, 0.2, 1000.0, 3, 0.3, 0, 0, sp, pf, ft, gp)
         assert lib.gsr_create(C.byref(cfg), C.byref(h)) == L.GSR_E_INVALID_ARG and word in lib.gsr_last_error_string()
     # the process-wide defaults: getters return what the setters stored; out-of-range values are rejected and change nothing
     was = (lib.gsr_get_ssim_precision(), lib.gsr_get_preprocess_form())

@@ -612,7 +612,9 @@ def test_color_cotangent_flag_gives_the_unflagged_gradients(pkg, orc, mode, bg):
     """GSR_GRADS_COLOR_COTANGENT: the caller says that channels >= 3 of vpixels are zeros (the loss head's cotangent) and the
     backward of :rgbd / :rgbdn runs the :rgb arithmetic on the mode's stream.  Same gradients as the unflagged call up to the
     association of fp32 sums, the oracle's within the suite's tolerance; lists beyond 1024 instances included (their launch
-    keeps the full kernel); ignored in :rgb mode; unknown flag bits are refused."""
+    keeps the full kernel); ignored in :rgb mode; unknown flag bits are refused.  ABI 6: the promise is CHECKED —
+    the flag is honoured only for the very buffer this handle's gsr_loss_l1_ssim wrote for this forward; a copy of it, or the
+    same buffer after another forward, is GSR_E_INVALID_ARG; GSR_CHECK_COLOR_COTANGENT=1 also looks INTO the buffer."""
     W, H, deg = 200, 120, 2
     base = pkg.synthetic.make_scene(4000, W, H, deg, 91, sigma_px=5.0)
     s = pkg.synthetic.add_skew(base, "hot:2500", seed=92)
@@ -621,13 +623,28 @@ def test_color_cotangent_flag_gives_the_unflagged_gradients(pkg, orc, mode, bg):
     tgt = pkg.synthetic.make_target(W, H, 93)
     run = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, bg, mode)
     img = run.forward()
-    _, vp = pkg.fused_ssim.l1_ssim_loss(run.rast, img, dev(tgt))
-    vp = vp.clone()
+    _, vp = pkg.fused_ssim.l1_ssim_loss(run.rast, img, dev(tgt))   # (the loss head's own buffer: what the flag is valid for)
     assert mode == "rgb" or not vp[:, :, 3:].any()
     args = (vp, *run.t, run.camera, deg, run.bg)
     plain = [g.clone() for g in run.rast.backward_raw(*args)[:5]]
     flagged = [g.clone() for g in run.rast.backward_raw(*args, color_cotangent=True)[:5]]
     torch.cuda.synchronize()
+    if mode != "rgb":
+        # any other buffer with the flag set is refused — even a bit-identical copy: the library cannot know what was added to it
+        with pytest.raises(pkg._lib.GsrError, match="only valid for the cotangent gsr_loss_l1_ssim wrote"):
+            run.rast.backward_raw(vp.clone(), *args[1:], color_cotangent=True)
+        # the debug check looks into the buffer: something added in place to the depth channel after the loss head
+        os.environ["GSR_CHECK_COLOR_COTANGENT"] = "1"
+        try:
+            run.rast.backward_raw(*args, color_cotangent=True)       # untouched: passes
+            vp[3, 5, 3] += 1e-3
+            with pytest.raises(pkg._lib.GsrError, match="non-zero values above the colour channels"):
+                run.rast.backward_raw(*args, color_cotangent=True)
+            vp[3, 5, 3] = 0.0
+        finally:
+            del os.environ["GSR_CHECK_COLOR_COTANGENT"]
+    else:
+        run.rast.backward_raw(vp.clone(), *args[1:], color_cotangent=True)   # :rgb: nothing above the colour, the flag says nothing
     for a, b in zip(plain, flagged):
         assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) <= (0.0 if mode == "rgb" else 2e-6)
     g = orc.backward(st, vp.cpu().numpy(), s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, background=bg)
@@ -638,6 +655,11 @@ def test_color_cotangent_flag_gives_the_unflagged_gradients(pkg, orc, mode, bg):
     inp = run.rast._inputs(*run.t, deg, run.bg)
     cs = run.rast._camera(run.camera, None, None)
     assert L.load().gsr_backward(run.rast._h, C.byref(inp), C.byref(cs), vp.data_ptr(), C.byref(gr), None) == L.GSR_E_INVALID_ARG
+    if mode != "rgb":
+        # ... and the loss head's buffer is only good for the forward it was computed from
+        run.forward()
+        with pytest.raises(pkg._lib.GsrError, match="only valid for the cotangent"):
+            run.rast.backward_raw(*args, color_cotangent=True)
 
 
 def test_functor_autograd_end_to_end(pkg, orc):

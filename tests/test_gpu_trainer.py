@@ -392,13 +392,19 @@ def test_backward_with_the_tail_in_its_epilogue_equals_backward_then_tail(pkg, n
         img_a = rast_a.forward_raw(raw_a["points"], *act_a, raw_a["rotations"], cam, deg, bg)
         img_b = rast_b.forward_raw(raw_b["points"], *act_b, raw_b["rotations"], cam, deg, bg)
         assert torch.equal(img_a, img_b), step
-        vp = (img_a - target) * (2.0 / img_a.numel())     # any cotangent will do; the same one on both sides
         if color:
-            vp[:, :, 3:] = 0.0
+            # the flag is only valid for the cotangent the handle's OWN loss head wrote for this forward (ABI 6): one each
+            tgt3 = target[:, :, :3].permute(2, 0, 1).contiguous()
+            _, vp = pkg.fused_ssim.l1_ssim_loss(rast_a, img_a, tgt3)
+            _, vp_b = pkg.fused_ssim.l1_ssim_loss(rast_b, img_b, tgt3)
+            assert torch.equal(vp, vp_b) and not vp[:, :, 3:].any()
+        else:
+            vp = (img_a - target) * (2.0 / img_a.numel())     # any cotangent will do; the same one on both sides
+            vp_b = vp.clone()
         vm, vsh, vo, vsc, vr, _, _ = rast_a.backward_raw(vp, raw_a["points"], *act_a, raw_a["rotations"], cam, deg, bg,
                                                          color_cotangent=color)
         O.trainer_tail_step(opt_a, raw_a, dict(vmeans=vm, vshs=vsh, vopacities=vo, vscales=vsc, vrot=vr), *act_a)
-        O.fused_backward_tail_step(rast_b, vp.clone(), opt_b, raw_b, *act_b, cam, deg, bg,
+        O.fused_backward_tail_step(rast_b, vp_b, opt_b, raw_b, *act_b, cam, deg, bg,
                                    forward_generation=rast_b.stats.generation, color_cotangent=color)
         torch.cuda.synchronize()
         assert (rast_a.gstate.radii <= 0).any() and (rast_a.gstate.radii > 0).any()

@@ -1,0 +1,236 @@
+"""CPU tests of the library's POLICIES (include/gsr_policy.h, csrc/gsr_policy.cpp): everything gsr_forward / gsr_backward decide
+from "the previous view" is a pure function of plain numbers, so what a handle will do over a history of views can be replayed
+here without a GPU (round-5 verdict, next #8) — including the (N, D, longest list, tier tiles) history a training run recorded
+on the GPU (tests/golden/train_history.json, written by tools/train_harness.py)."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def P(pkg, tmp_path_factory):
+    """The policy layer built with g++ ALONE (no hipcc, no HIP header, no libamdhip64): it is GPU-free by construction."""
+    L = pkg._lib
+    out = tmp_path_factory.mktemp("policy") / "libgsr_policy_only.so"
+    src = os.path.join(ROOT, "gaussiansplatting.jl_amd", "csrc", "gsr_policy.cpp")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Werror", src, "-o", str(out)], check=True)
+    deps = subprocess.run(["ldd", str(out)], capture_output=True, text=True).stdout
+    assert "hip" not in deps.lower() and "hsa" not in deps.lower(), deps
+    return L.bind_policy(C.CDLL(str(out))), L
+
+
+def new_handle(P, width, height, budget=0, form=-1, **over):
+    lib, L = P
+    cfg, st = L.PolicyConfig(), L.PolicyState()
+    lib.gsr_policy_config_init(C.byref(cfg), width, height, budget, form)
+    lib.gsr_policy_state_init(C.byref(st))
+    assert st.tuner.form == -1 and cfg.form_tuner == 1 and cfg.bwd_split_max_tiles == 256 and cfg.agg_max_bands == 1
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg, st
+
+
+def view(P, cfg, st, n, D, longest, tiers=(0, 0, 0), cap_instances=1 << 32, fused=1, timed_ms=None):
+    """One forward through the two policy calls, exactly as gsr_forward makes them."""
+    lib, L = P
+    plan, oc = L.ViewPlan(), L.ViewOutcome()
+    ms = None if timed_ms is None else (C.c_float * 4)(*timed_ms)
+    lib.gsr_policy_begin_view(C.byref(cfg), C.byref(st), n, ms, C.byref(plan))
+    lib.gsr_policy_end_view(C.byref(cfg), C.byref(st), C.byref(plan), D, longest, tiers[0], tiers[1], tiers[2], cap_instances,
+                            fused, C.byref(oc))
+    return plan, oc
+
+
+def test_library_and_standalone_builds_agree(P, pkg):
+    """libgsr_hip.so exports the same policy functions (they ARE what gsr_forward calls): same answers as the g++-only build."""
+    lib, L = P
+    full = L.load()
+    for args in ((3_888_089, 569, 1920, 1080, 0, 0), (4_032_599, 32_451, 1920, 1080, 0, 0), (1_000_000, 5000, 1920, 1080, 8161 * 8 * 512, 0)):
+        assert lib.gsr_bins_capacity_after(*args) == full.gsr_bins_capacity_after(*args)
+    for gx, gy, pos in ((120, 68, 768), (160, 90, 1024), (240, 135, 1024), (240, 135, 70_000), (8192, 2, 64)):
+        got = []
+        for l_ in (lib, full):
+            nb, br, lds, w16 = C.c_int32(), C.c_int32(), C.c_size_t(), C.c_int32()
+            l_.gsr_policy_agg_plan(gx, gy, pos, C.byref(nb), C.byref(br), C.byref(lds), C.byref(w16))
+            got.append((nb.value, br.value, lds.value, w16.value))
+        assert got[0] == got[1], (gx, gy, pos, got)
+        assert got[0][2] <= 42 * 1024 and got[0][0] * got[0][1] >= gy
+
+
+def test_small_bins_that_cannot_hold_the_longest_list_are_no_bins(P):
+    """ADVICE r5 (gsr_api.cpp:320): T = 8160, a budget of 512 keys per tile, longest list 5000.  Round 5 returned a capacity of
+    512: below the overflow path's 1024, so EVERY view filled the bins, queued a fused launch that bailed out, and was binned
+    again compactly.  Now: 0 = compact mode, sticky; and the handle recovers when the scene changes."""
+    lib, L = P
+    T = 120 * 68
+    budget = (T + 1) * 8 * 512
+    assert lib.gsr_bins_capacity_after(1_000_000, 5000, 1920, 1080, budget, 0) == 0
+    # small bins are kept where they hold every list
+    assert lib.gsr_bins_capacity_after(1_000_000, 400, 1920, 1080, budget, 0) == 512
+    # the budget-limited capacity holds the longest list but not its 25 % slack: kept (one overflow later ends in compact mode)
+    assert lib.gsr_bins_capacity_after(1_000_000, 500, 1920, 1080, budget, 0) == 512
+    cfg, st = new_handle(P, 1920, 1080, budget)
+    hist = [view(P, cfg, st, 1_000_000, 1_000_000, 5000)[1].binning for _ in range(4)]
+    # view 1: the estimated bins (capped at 512) overflow -> ONE compact fallback; from view 2 on: no bins, nothing repeated
+    assert hist == [L_COMPACT, L_COMPACT, L_COMPACT, L_COMPACT]
+    assert st.compact_fallbacks == 1 and st.compact_views == 3 and st.compact_sticky == 1 and st.bin_cap == 0
+    # the hot tile goes away: bins come back
+    plan, oc = view(P, cfg, st, 1_000_000, 1_000_000, 300)
+    assert oc.binning == L_COMPACT and oc.bin_cap_next == 384 and st.compact_sticky == 0
+    plan, oc = view(P, cfg, st, 1_000_000, 1_000_000, 300)
+    assert plan.bin_cap_view == 384 and oc.binning == L_BINS and st.compact_fallbacks == 1
+
+
+L_BINS, L_COMPACT, L_OVERFLOW = 0, 1, 2
+
+
+def test_steady_uniform_scene_moves_nothing_after_the_first_view(P):
+    """Config 3 (1 M Gaussians, 1080p, D = 3.89 M, longest list 569): the first view's estimated bins are regrown once; after
+    that no counter of the history moves, the fused launch is never held, the form is the aggregating one (2 x 32-bit words)."""
+    cfg, st = new_handle(P, 1920, 1080)
+    plans = []
+    for i in range(50):
+        plan, oc = view(P, cfg, st, 1_000_000, 3_888_089 + 1000 * (i % 3), 569 + (i % 5), cap_instances=5_000_000 if i else 0,
+                        fused=1 if i else 0)
+        plans.append((plan.bin_cap_view, plan.form, plan.hold_fused, oc.binning, oc.fused_done))
+    assert plans[0][0] == 1088 and plans[0][3] == L_BINS   # 8 N / T + 64, rounded to 64 keys
+    assert all(p == (1088, 1, 0, L_BINS, 1) for p in plans[1:])   # longest + 25 % = 768 < 1088: nothing to regrow
+    assert (st.bins_regrowths, st.compact_fallbacks, st.compact_views, st.overflow_views, st.tuner_rearms, st.fused_relaunches,
+            st.held_views) == (0, 0, 0, 0, 0, 0, 0)
+
+
+def test_hot_tile_keeps_its_bins_and_holds_the_fused_launch(P):
+    """One tile of 32 451 instances on config 3's scene: bins for it would be 2.6 GB; the view keeps bins sized
+    for the other tiles (overflow path), and from the second view on the fused launch is held for the tier walk."""
+    cfg, st = new_handle(P, 1920, 1080)
+    tiers = (3, 2, 5)
+    seq = [view(P, cfg, st, 1_032_000, 4_032_599, 32_451, tiers, cap_instances=6_000_000) for _ in range(6)]
+    # view 1: estimated bins of 1088 keys >= 1024 -> overflow path at once, never the compact mode
+    assert [oc.binning for _, oc in seq] == [L_OVERFLOW] * 6
+    assert [pl.hold_fused for pl, _ in seq] == [0, 1, 1, 1, 1, 1] and [oc.beside for _, oc in seq] == [0, 1, 1, 1, 1, 1]
+    assert seq[1][0].bin_cap_view == 2496 and st.bins_regrowths == 1 and st.overflow_views == 6 and st.held_views == 5
+    assert st.compact_fallbacks == 0 and seq[1][0].skewed == 1
+    # the tier tiles disappear: the held launch goes out at once, the next view is not held any more
+    pl, oc = view(P, cfg, st, 1_000_000, 3_900_000, 600, (0, 0, 0), cap_instances=6_000_000)
+    assert pl.hold_fused == 1 and oc.beside == 0 and oc.launch_fused_now == 1
+    pl, oc = view(P, cfg, st, 1_000_000, 3_900_000, 600, (0, 0, 0), cap_instances=6_000_000)
+    assert pl.hold_fused == 0 and oc.launch_fused_now == 0 and oc.fused_done == 1
+    # GSR_TIERS_BESIDE_MAX = 0 (A/B knob): never held
+    cfg2, st2 = new_handle(P, 1920, 1080, beside_max_tiles=0)
+    assert [view(P, cfg2, st2, 1_032_000, 4_032_599, 32_451, tiers, cap_instances=6_000_000)[0].hold_fused for _ in range(3)] == [0, 0, 0]
+
+
+def test_buffers_too_small_for_the_early_fused_launch_are_counted(P):
+    cfg, st = new_handle(P, 1920, 1080)
+    view(P, cfg, st, 1_000_000, 3_900_000, 569, cap_instances=0, fused=0)          # first view: no buffers yet
+    pl, oc = view(P, cfg, st, 1_000_000, 6_000_000, 800, cap_instances=4_875_000)  # the scene grew by more than the 25 % slack
+    assert oc.fused_done == 0 and st.fused_relaunches == 1
+    pl, oc = view(P, cfg, st, 1_000_000, 6_000_000, 800, cap_instances=7_500_000)
+    assert oc.fused_done == 1 and st.fused_relaunches == 1
+
+
+def test_form_choice_by_size_grid_and_skew(P):
+    lib, L = P
+    cfg, _ = new_handle(P, 1920, 1080)
+    f = lambda c, req, n, cap, sk: lib.gsr_policy_preprocess_form(C.byref(c), req, n, cap, sk)  # noqa: E731
+    assert f(cfg, -1, 100_000, 768, 0) == 0 and f(cfg, -1, 250_000, 768, 0) == 1   # from 250 k Gaussians: aggregating
+    assert f(cfg, 0, 5_000_000, 768, 1) == 0 and f(cfg, 1, 1000, 768, 0) == 1       # a pinned form is the form
+    c1440, _ = new_handle(P, 2560, 1440)
+    assert f(c1440, -1, 2_000_000, 1024, 0) == 2        # 1440p: 2 x 16-bit words while every position fits them ...
+    assert f(c1440, -1, 2_000_000, 70_000, 0) == 0 and f(c1440, -1, 2_000_000, 70_000, 1) == 3   # ... else two bands: direct unless skewed
+    c4k, _ = new_handle(P, 3840, 2160)
+    assert f(c4k, -1, 5_000_000, 1024, 0) == 0 and f(c4k, -1, 5_000_000, 1024, 1) == 3        # 4K: direct unless skewed (banded)
+    assert lib.gsr_policy_form_is_open(C.byref(c4k), 5_000_000, 1024) == 1
+    assert lib.gsr_policy_form_is_open(C.byref(c4k), 200_000, 1024) == 0 and lib.gsr_policy_form_is_open(C.byref(cfg), 5_000_000, 768) == 0
+
+
+def test_form_tuner_state_machine(P):
+    """4K grid, 5 M Gaussians: the default form is open.  Views 1-2 run the hint's form; views 3-6 are timed direct / aggregating
+    / direct / aggregating; the decision needs all four timings and a 3 % margin for the aggregating form; re-armed by a 25 %
+    change of N or 4096 views, and each re-arm is counted."""
+    lib, L = P
+    cfg, st = new_handle(P, 3840, 2160)
+    n, D, longest = 5_000_000, 28_000_000, 1500
+    seq = [view(P, cfg, st, n, D, longest, cap_instances=40_000_000) for _ in range(2)]
+    assert [pl.timed_slot for pl, _ in seq] == [-1, -1] and [pl.form for pl, _ in seq] == [0, 0]
+    seq = [view(P, cfg, st, n, D, longest, cap_instances=40_000_000) for _ in range(4)]
+    assert [pl.timed_slot for pl, _ in seq] == [0, 1, 2, 3] and [pl.form for pl, _ in seq] == [0, 3, 0, 3]
+    # the events are not ready yet: the hint keeps deciding, nothing is timed twice
+    pl, _ = view(P, cfg, st, n, D, longest, cap_instances=40_000_000)
+    assert pl.timed_slot == -1 and pl.form == 0 and pl.tuner_decided == 0 and st.tuner.phase == 4
+    # ready: aggregating 0.60 / 0.58 against direct 0.59 / 0.61 -> min 0.58 vs 0.59: inside the 3 % margin, direct stays
+    pl, _ = view(P, cfg, st, n, D, longest, cap_instances=40_000_000, timed_ms=(0.59, 0.60, 0.61, 0.58))
+    assert pl.tuner_decided == 1 and st.tuner.form == 0 and pl.form == 0 and st.tuner.phase == 5
+    assert abs(st.tuner.ms[0] - 0.59) < 1e-6 and abs(st.tuner.ms[1] - 0.58) < 1e-6
+    for _ in range(10):
+        pl, _ = view(P, cfg, st, n, D, longest, cap_instances=40_000_000)
+        assert pl.form == 0 and pl.timed_slot == -1
+    # N grows by 20 %: the decision stands; by 30 %: re-armed, four more timed views, then a clear win for the banded form
+    pl, _ = view(P, cfg, st, int(n * 1.2), D, longest, cap_instances=40_000_000)
+    assert st.tuner_rearms == 0 and pl.timed_slot == -1
+    slots = [view(P, cfg, st, int(n * 1.3), D, longest, cap_instances=40_000_000)[0].timed_slot for _ in range(5)]
+    assert st.tuner_rearms == 1 and slots == [0, 1, 2, 3, -1]
+    pl, _ = view(P, cfg, st, int(n * 1.3), D, longest, cap_instances=40_000_000, timed_ms=(0.80, 0.55, 0.78, 0.56))
+    assert st.tuner.form == 1 and pl.form == 3 and st.tuner.n_ref == int(n * 1.3)
+    # 4096 views later it starts over
+    for _ in range(4096):
+        view(P, cfg, st, int(n * 1.3), D, longest, cap_instances=40_000_000)
+    assert st.tuner_rearms == 1
+    pl, _ = view(P, cfg, st, int(n * 1.3), D, longest, cap_instances=40_000_000)
+    assert st.tuner_rearms == 2 and pl.timed_slot == 0
+    # tuner off (gsr_config.form_tuner = GSR_TUNER_OFF / GSR_FORM_TUNER=0): the previous view's skew decides, nothing is timed
+    cfg2, st2 = new_handle(P, 3840, 2160, form_tuner=0)
+    pls = [view(P, cfg2, st2, n, D, 13_000, cap_instances=40_000_000)[0] for _ in range(6)]   # longest = 11 x the mean list
+    assert [p.timed_slot for p in pls] == [-1] * 6 and [p.form for p in pls] == [0, 3, 3, 3, 3, 3]
+    # a pinned form leaves the tuner nothing to decide
+    cfg3, st3 = new_handle(P, 3840, 2160, form=1)
+    assert [view(P, cfg3, st3, n, D, longest, cap_instances=40_000_000)[0].form for _ in range(6)] == [3] * 6 and st3.tuner.phase == 0
+
+
+def test_backward_split_takes_the_deepest_tiers_that_fit(P):
+    lib, L = P
+    cfg, _ = new_handle(P, 1920, 1080)
+
+    def split(n_mid4, n_mid8, n_big):
+        sp = L.BwdSplit()
+        lib.gsr_policy_bwd_split(C.byref(cfg), n_mid4, n_mid8, n_big, C.byref(sp))
+        return sp.n_mid4, sp.n_mid8, sp.n_big, sp.split_len
+
+    assert split(0, 0, 0) == (0, 0, 0, 0xFFFFFFFF)
+    assert split(100, 20, 5) == (100, 20, 5, 1024)          # everything fits 256 tiles: split at 1024
+    assert split(300, 20, 5) == (0, 20, 5, 4096)            # the (1024, 4096] tier is too many: it stays in the main launch
+    assert split(300, 300, 5) == (0, 0, 5, 8192)
+    assert split(10, 10, 300) == (0, 0, 0, 0xFFFFFFFF)      # the deepest tier alone already fills the chip: no split at all
+    assert split(500, 0, 0) == (0, 0, 0, 0xFFFFFFFF)        # dense 4K: thousands of mid tiles, nothing deeper
+
+
+def test_training_history_replay(P):
+    """The view history a training run recorded on the GPU (tools/train_harness.py, reduced size: 20 k -> ~60 k Gaussians, densification
+    every 50 steps) replayed through the policies: per view the same bins capacity, binning mode and form as the library reported,
+    and the assertions of the round-5 verdict (#1a) on the history — after the first view of a densification round no view falls
+    back to the compact mode, the bins are regrown at most once per round, the tuner is never re-armed."""
+    path = os.path.join(ROOT, "tests", "golden", "train_history.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/train_history.json not recorded yet (tools/train_harness.py --record-history on a GPU box)")
+    rec = json.load(open(path))
+    lib, L = P
+    cfg, st = new_handle(P, rec["width"], rec["height"], rec.get("bins_budget_bytes", 0))
+    rounds = set(rec["densify_steps"])
+    regrow_in_round, last_round_start = 0, 0
+    for v in rec["views"]:
+        plan, oc = view(P, cfg, st, v["n"], v["n_rendered"], v["max_tile"], tuple(v["tiers"]))
+        assert plan.bin_cap_view == v["bin_capacity"], v
+        assert oc.binning == v["binning"] and plan.form == v["form"], v
+        if v["step"] - 1 in rounds or v["step"] == 1:   # the first view after a densification (or of the run)
+            regrow_in_round, last_round_start = 0, v["step"]
+        else:
+            assert oc.binning != L_COMPACT or plan.bin_cap_view == 0, f"compact fallback at step {v['step']} (round began at {last_round_start})"
+        regrow_in_round += int(oc.bins_regrown)
+        assert regrow_in_round <= 1, f"bins regrown twice within the round that began at step {last_round_start}"
+        assert (st.bins_regrowths, st.compact_fallbacks, st.tuner_rearms) == (v["bins_regrowths"], v["compact_fallbacks"], v["tuner_rearms"]), v
+    assert st.tuner_rearms == 0

@@ -1,7 +1,7 @@
 // Per-handle behaviour switches under concurrency (ABI 5; round-4 verdict, weak #9): the reference's knobs are constructor
 // keywords (rasterizer.jl:60-65) and a GUI RenderWorker runs next to a trainer in one process (gui/worker.jl:47-58).
-//   thread A: handle created with ssim_precision = 1 (exact), preprocess_form = 0 (direct)
-//   thread B: handle created with ssim_precision = 0 (fast),  preprocess_form = 1 (aggregating)
+//   thread A: handle created with ssim_precision = GSR_SSIM_EXACT, preprocess_form = GSR_PREPROCESS_DIRECT
+//   thread B: handle created with ssim_precision = GSR_SSIM_FAST,  preprocess_form = GSR_PREPROCESS_AGGREGATING
 //   thread C: flips the PROCESS-WIDE defaults (gsr_ssim_precision, gsr_preprocess_form, gsr_host_wait_policy) as fast as it can
 // A and B each run `steps` iterations of gsr_forward + gsr_loss_l1_ssim on their own stream, concurrently, and compare every
 // loss and every pullback BIT FOR BIT with what the same handle produced before thread C existed; a third handle created with
@@ -79,7 +79,7 @@ int main(int argc, char** argv) {
         CK(hipStreamSynchronize(sl.s));
         sl.form = st.preprocess_form;
     };
-    Slot A = make(1, 0), B = make(0, 1), D = make(GSR_DEFAULT, GSR_DEFAULT);
+    Slot A = make(GSR_SSIM_EXACT, GSR_PREPROCESS_DIRECT), B = make(GSR_SSIM_FAST, GSR_PREPROCESS_AGGREGATING), D = make(GSR_DEFAULT, GSR_DEFAULT);
     for (Slot* sl : {&A, &B}) {
         sl->ref_v.resize(P3);
         step(*sl, sl->ref_v, sl->ref_loss);  // twice: the first view sizes the bins

@@ -17,7 +17,8 @@ import json
 import os
 from collections import defaultdict
 
-KERNEL_SOURCES = ("composite.hip", "pergauss.hip", "binning.hip", "wave_reduce.h", "tile_sort_device.h", "tile_mask.h")
+KERNEL_SOURCES = ("composite.hip", "pergauss.hip", "binning.hip", "ssim.hip", "wave_reduce.h", "tile_sort_device.h", "tile_mask.h",
+                  "gsr_kernels.h", "agg_plan.h", "gsr_api.cpp", "gsr_policy.cpp")  # == bench.py PMC_KERNEL_SOURCES
 
 
 def kernel_source_hashes():

@@ -18,7 +18,7 @@ DEFAULT = 0  # GSR_DEFAULT (ABI 6: 0, so that a zero-initialised gsr_config is t
 SSIM_FAST, SSIM_EXACT = 1, 2                      # gsr_config.ssim_precision
 PREPROCESS_DIRECT, PREPROCESS_AGGREGATING = 1, 2  # gsr_config.preprocess_form
 TUNER_OFF, TUNER_ON = 1, 2                        # gsr_config.form_tuner
-GRAD_FP32_REFERENCE = 1                           # gsr_config.grad_precision
+GRAD_FP32_REFERENCE, GRAD_ACCURATE = 1, 2         # gsr_config.grad_precision
 MODES = {"rgb": 3, "rgbd": 5, "rgbdn": 8}
 FORWARD_ONLY = 1  # gsr_aux.flags: no backward state is kept (inference render)
 FLAG_REFERENCE_TILE_LISTS = 2  # flags = 0: exact footprint culling (the default); bit 1 is retired (rejected)

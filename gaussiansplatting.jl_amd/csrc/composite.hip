@@ -335,6 +335,19 @@ template <int C> struct AccRow { static constexpr int N = C == 3 ? 9 : (C == 5 ?
 #endif
 constexpr int BWD_BATCH = GSR_BWD_BATCH;  // splats staged per round (LDS: one accumulator slab per wave)
 
+// ACC — the backward's per-pixel arithmetic in its ACCURATE form (round 6; gsr_config.grad_precision = GSR_GRAD_ACCURATE /
+// GSR_GRAD_FP32_REFERENCE): libm-accurate expf instead of v_exp_f32 on the rounded product sigma x log2(e), IEEE division
+// instead of v_rcp_f32 for T / (1 - alpha) — what the reference's Julia source means by `exp` and `/` (render.jl:236-259).
+// On needle-shaped splats the backward's sums cancel by up to the square of the 2-D axis ratio, and the few-ulp SYSTEMATIC
+// errors of the two fast instructions — fed through the T recursion of hundreds of contributors — are what put ∇means of
+// a 90 : 1 needle of radius 100 px (edge 8498) 4.1e-4 from float64: with ACC 2.3e-5, the oracle's own distance
+// (profiles/r06/experiments/needle_exact_exp_div_variants.txt; the wave reduction round 5 suspected is NOT the source).
+// Costs +12 % of this kernel, so it is a per-handle choice, not the default; gating it per instance on a "needle" bit of the
+// stream was built and dropped: +2.5 % at config 3 (which has no needles), +9 % on the trained-like scene, and with
+// ~1-ulp refinements instead of libm the gain drowned in last-bit noise (needle_gated_refinement_*.txt / .patch).
+template <bool ACC> __device__ __forceinline__ float bwd_exp_neg(float sigma) { return ACC ? expf(-sigma) : __expf(-sigma); }
+template <bool ACC> __device__ __forceinline__ float bwd_rcp(float x) { return ACC ? __fdiv_rn(1.0f, x) : __builtin_amdgcn_rcpf(x); }
+
 // PPL = pixels per lane.  PPL == 1: 4 waves per tile, a wave owns a 16x4 strip.  PPL == 2:
 // 2 waves per tile, a wave owns 16x8 pixels and lane l the pixels (x, y) and (x, y+4).
 // PPL == 4 (default): ONE wave64 per tile, lane l owns (x, y), (x, y+4), (x, y+8), (x, y+12).
@@ -359,7 +372,7 @@ constexpr int BWD_BATCH = GSR_BWD_BATCH;  // splats staged per round (LDS: one a
 // only sees features[1:3] — training.jl:656,684-685: depth / alpha / normal channels of vpixels are exact zeros and their feature
 // gradients too): the pixels' cotangent state, the colour·v dot product and the reduction are the :rgb kernel's; the stream, the
 // blend thresholds and the row layout stay the mode's.
-template <int C, int PPL, bool LISTED, bool BG0, int VC = C>
+template <int C, int PPL, bool LISTED, bool BG0, int VC = C, bool ACC = false>
 __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_kernel(int W, int H, int grid_x,
                                                                 const uint32_t* __restrict__ tile_start,
                                                                 const uint32_t* __restrict__ tile_order,
@@ -522,10 +535,10 @@ __global__ __launch_bounds__(256 / PPL, GSR_BWD_MINWAVES) void composite_bwd_ker
                 // ballots of the bare compares are their SGPR masks; the AND/OR runs on the scalar unit
                 any_active |= wave_ballot(c_live) & wave_ballot(c_touch);
                 if (active) {
-                    const float G = __expf(-sigma);
+                    const float G = bwd_exp_neg<ACC>(sigma);
                     const float alpha = alpha_of(o, G);
                     // T /= (1-α) and -T_final/(1-α) (render.jl:237,259) share one hardware reciprocal
-                    const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
+                    const float rinv = bwd_rcp<ACC>(1.0f - alpha);
                     T[q] = T[q] * rinv;
                     const float fac = alpha * T[q];
                     float cv = f[0] * vp[q][0];
@@ -964,21 +977,21 @@ void gsr_launch_sort_composite_fwd(hipStream_t s, int channels, GsrCam cam, cons
 void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
                               const uint32_t* tile_order, GsrStream stream, const float* background,
                               const float* vpixels, const uint32_t* n_contrib, const float* final_T, GsrInst inst,
-                              uint32_t split_len, bool color_only) {
+                              uint32_t split_len, bool color_only, bool accurate) {
     dim3 grid(cam.grid_x * cam.grid_y), block(256 / GSR_BWD_PPL);
     Bg bg = make_bg(background, channels);
     GsrTierLists none{};
     none.split_len = split_len;
     const bool bg0 = bg_is_zero(bg);
-#define LAUNCH2(CC, ZZ)                                                                                                \
-    hipLaunchKernelGGL((composite_bwd_kernel<CC, GSR_BWD_PPL, false, ZZ>), grid, block, 0, s, cam.width, cam.height,   \
+#define LAUNCH_K(CC, ZZ, VV, AA)                                                                                       \
+    hipLaunchKernelGGL((composite_bwd_kernel<CC, GSR_BWD_PPL, false, ZZ, VV, AA>), grid, block, 0, s, cam.width, cam.height, \
                        cam.grid_x, tile_start, tile_order, stream, bg, vpixels, n_contrib, final_T, inst, none)
+    // accurate: the ACC instantiations (libm exp, IEEE division: gsr_config.grad_precision) — the general-background kernels only
+#define LAUNCH2(CC, ZZ) do { if (accurate) LAUNCH_K(CC, false, CC, true); else LAUNCH_K(CC, ZZ, CC, false); } while (0)
     // the zero-background kernels where they pay (table above the kernel): C == 5 and C == 8 take BG0, C == 3 never does
     // (:rgb capped at six waves with 1.25 KB of unused dynamic LDS per workgroup takes 0.738 ms: it is the code generated under
     //  the tighter register budget that is slower, not the occupancy)
-#define LAUNCH3(CC, ZZ)                                                                                                \
-    hipLaunchKernelGGL((composite_bwd_kernel<CC, GSR_BWD_PPL, false, ZZ, 3>), grid, block, 0, s, cam.width, cam.height, \
-                       cam.grid_x, tile_start, tile_order, stream, bg, vpixels, n_contrib, final_T, inst, none)
+#define LAUNCH3(CC, ZZ) do { if (accurate) LAUNCH_K(CC, false, 3, true); else LAUNCH_K(CC, ZZ, 3, false); } while (0)
     if (channels == 3) LAUNCH2(3, false);
     else if (color_only) {
         // the cotangent of the loss head (channels >= 3 are zeros): the :rgb arithmetic on the mode's stream.  (BG0 as measured
@@ -988,6 +1001,7 @@ void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uin
     else if (channels == 5) { if (bg0) LAUNCH2(5, true); else LAUNCH2(5, false); }
     else if (bg0) LAUNCH2(8, true);
     else LAUNCH2(8, false);
+#undef LAUNCH_K
 #undef LAUNCH2
 #undef LAUNCH3
 }

@@ -51,13 +51,17 @@ struct DevBuf {
     // grow-only, like the reference's scratch (rasterizer.jl:275-278,340-343)
     int ensure(size_t bytes, float slack = 1.0f) {
         if (bytes <= cap) return GSR_OK;
+        size_t want = (size_t)((double)bytes * slack);
         if (p) {
+            // REgrowth of a buffer that is given slack (the per-Gaussian and per-instance scratch of a scene that changes): at
+            // least half again of what is there — the views of a batch differ by a few per cent in their instance count, and a
+            // training run grows; 288 GB of HBM are there to be used, a hipFree + hipMalloc synchronises the device
+            if (slack > 1.0f) want = std::max(want, cap + cap / 2);
             regrowths++;
             HIPCHK(hipFree(p));
             p = nullptr;
             cap = 0;
         }
-        size_t want = (size_t)((double)bytes * slack);
         want = (want + 255) & ~(size_t)255;
         HIPCHK(hipMalloc(&p, want));
         cap = want;
@@ -535,8 +539,9 @@ int gsr_create(const gsr_config* cfg, gsr_handle** out) {
                     "GSR_PREPROCESS_AGGREGATING (2)", cfg->preprocess_form);
     if (cfg->form_tuner < 0 || cfg->form_tuner > GSR_TUNER_ON)
         return fail(GSR_E_INVALID_ARG, "gsr_config.form_tuner = %d: GSR_DEFAULT (0), GSR_TUNER_OFF (1) or GSR_TUNER_ON (2)", cfg->form_tuner);
-    if (cfg->grad_precision < 0 || cfg->grad_precision > GSR_GRAD_FP32_REFERENCE)
-        return fail(GSR_E_INVALID_ARG, "gsr_config.grad_precision = %d: GSR_DEFAULT (0) or GSR_GRAD_FP32_REFERENCE (1)", cfg->grad_precision);
+    if (cfg->grad_precision < 0 || cfg->grad_precision > GSR_GRAD_ACCURATE)
+        return fail(GSR_E_INVALID_ARG, "gsr_config.grad_precision = %d: GSR_DEFAULT (0), GSR_GRAD_FP32_REFERENCE (1) or GSR_GRAD_ACCURATE (2)",
+                    cfg->grad_precision);
     gsr_handle* h = new (std::nothrow) gsr_handle();
     if (!h) return fail(GSR_E_OOM, "host allocation failed");
     h->cfg = *cfg;
@@ -646,9 +651,13 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     const size_t nn = n > 0 ? (size_t)n : 1;
     const int n_blocks = (n + 255) / 256;
     const bool own_radii = !(aux && aux->radii);
-    if ((rc = h->geo.ensure(nn * 64)) || (own_radii && (rc = h->radii.ensure(nn * 4))) ||
-        (rc = h->bsum.ensure((size_t)(n_blocks + 1) * 4)) || (rc = h->bpre.ensure((size_t)(n_blocks + 1) * 4)) || (rc = h->bvis.ensure((size_t)(n_blocks + 1) * 4)) ||
-        (C > 5 && (rc = h->gnormal.ensure(nn * 16))))
+    // per-Gaussian scratch: grow-only with 25 % slack, like the per-instance buffers below — a training run's densification
+    // adds 5-15 % of Gaussians per round (strategy.jl:78-105), and an exact fit made EVERY round's first view reallocate all
+    // five (five hipFree + hipMalloc = device synchronisations: the slowest plain steps of the round-6 training protocol)
+    const float nslack = 1.25f;
+    if ((rc = h->geo.ensure(nn * 64, nslack)) || (own_radii && (rc = h->radii.ensure(nn * 4, nslack))) ||
+        (rc = h->bsum.ensure((size_t)(n_blocks + 1) * 4, nslack)) || (rc = h->bpre.ensure((size_t)(n_blocks + 1) * 4, nslack)) ||
+        (rc = h->bvis.ensure((size_t)(n_blocks + 1) * 4, nslack)) || (C > 5 && (rc = h->gnormal.ensure(nn * 16, nslack))))
         return rc;
     h->radii_cur = own_radii ? h->radii.as<int32_t>() : aux->radii;
     h->vmean2d_cur = nullptr;
@@ -874,6 +883,9 @@ static int launch_composite_bwd(gsr_handle* h, hipStream_t s, int C, const GsrCa
     // which tiers leave the main launch: gsr_policy_bwd_split (GSR_BWD_SPLIT_TILES overrides its limit for A/B runs)
     gsr_bwd_split sp;
     gsr_policy_bwd_split(&h->pcfg, h->pol.tier_n[0], h->pol.tier_n[1], h->pol.tier_n[2], &sp);
+    // (the accurate per-pixel arithmetic exists for the one-wave-per-tile kernel only: such a handle splits nothing)
+    const bool accurate = h->cfg.grad_precision != GSR_DEFAULT;
+    if (accurate) { sp.n_big = sp.n_mid8 = sp.n_mid4 = 0; sp.split_len = 0xFFFFFFFFu; }
     GsrTierLists tiers{h->big_list.as<uint32_t>(), (uint32_t)h->n_tiles, sp.n_big, sp.n_mid8, sp.n_mid4, sp.split_len};
     const uint32_t n = sp.n_big + sp.n_mid8 + sp.n_mid4;
     if (n > 0) {
@@ -888,7 +900,7 @@ static int launch_composite_bwd(gsr_handle* h, hipStream_t s, int C, const GsrCa
         HIPCHK(hipEventRecord(h->ev_join, h->aux_stream));
     }
     gsr_launch_composite_bwd(s, C, k, h->tile_start.as<uint32_t>(), h->tile_order.as<uint32_t>(), stream_of(h), background,
-                             vpixels, h->n_contrib.as<uint32_t>(), h->final_T.as<float>(), inst_of(h), tiers.split_len, color_only);
+                             vpixels, h->n_contrib.as<uint32_t>(), h->final_T.as<float>(), inst_of(h), tiers.split_len, color_only, accurate);
     if (n > 0) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
     return GSR_OK;
 }
@@ -917,7 +929,7 @@ int gsr_backward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, con
     hipStream_t s = (hipStream_t)stream_v;
     const int C = h->cfg.mode, n = in->n;
     if (n == 0) return GSR_OK;
-    if (!g->vmeans2d && (rc = h->vmean2d.ensure((size_t)n * 8))) return rc;
+    if (!g->vmeans2d && (rc = h->vmean2d.ensure((size_t)n * 8, 1.25f))) return rc;
     h->vmean2d_cur = g->vmeans2d ? reinterpret_cast<float2*>(g->vmeans2d) : h->vmean2d.as<float2>();
     // (the gradient rows need no memset: composite_bwd writes the row of every emitted instance,
     // pergauss_bwd skips the slots of culled tiles; only the 12 pose-gradient floats are accumulated into)
@@ -1221,7 +1233,7 @@ int gsr_backward_trainer_tail(gsr_handle* h, const gsr_inputs* in, const gsr_cam
     if (((uintptr_t)st->theta[5] & 15) != 0) return fail(GSR_E_INVALID_ARG, "rotations must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream_v;
     const int C = h->cfg.mode;
-    if (!st->vmeans2d && (rc = h->vmean2d.ensure((size_t)n * 8))) return rc;
+    if (!st->vmeans2d && (rc = h->vmean2d.ensure((size_t)n * 8, 1.25f))) return rc;
     h->vmean2d_cur = st->vmeans2d ? reinterpret_cast<float2*>(st->vmeans2d) : h->vmean2d.as<float2>();
     const bool color_only = (st->flags & GSR_GRADS_COLOR_COTANGENT) != 0u;
     if (color_only && (rc = check_color_cotangent(h, vpixels, s))) return rc;

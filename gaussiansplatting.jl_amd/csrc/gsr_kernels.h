@@ -158,7 +158,9 @@ void gsr_launch_composite_bwd(hipStream_t s, int channels, GsrCam cam, const uin
                               const float* background, const float* vpixels, const uint32_t* n_contrib,
                               const float* final_T, GsrInst inst,
                               uint32_t split_len /* tiles with a longer list are left to the listed launch */,
-                              bool color_only /* channels >= 3 of vpixels are zeros (the loss head's cotangent) */);
+                              bool color_only /* channels >= 3 of vpixels are zeros (the loss head's cotangent) */,
+                              bool accurate /* libm exp + IEEE division per pixel (gsr_config.grad_precision); the caller then
+                                               leaves EVERY tile to this launch (split_len = 0xFFFFFFFF) */);
 void gsr_launch_composite_bwd_listed(hipStream_t s, int channels, GsrCam cam, const uint32_t* tile_start,
                                      GsrTierLists tiers, GsrStream stream, const float* background,
                                      const float* vpixels, const uint32_t* n_contrib, const float* final_T, GsrInst inst,

@@ -187,7 +187,15 @@ void gsr_policy_end_view(const gsr_policy_config* cfg, gsr_policy_state* st, con
     const bool compact = !use_bins || (overflow && !hybrid);
     out->binning = compact ? GSR_BINNING_COMPACT : (hybrid ? GSR_BINNING_OVERFLOW : GSR_BINNING_BINS);
     // capacity for the NEXT view: grow-only while bins are in use
-    const uint32_t want = bins_capacity_after(D, max_tile_instances, T, cfg->bins_budget_bytes);
+    uint32_t want = bins_capacity_after(D, max_tile_instances, T, cfg->bins_budget_bytes);
+    if (use_bins && want > st->bin_cap) {
+        // the bins GROW: by at least a quarter of what is there (within the budget).  A multi-view batch brings a slightly longer
+        // list every few views (round 6, 16 views at reduced size: 2112 -> 2176 -> 2368 keys within one densification round —
+        // three reallocations of the bins for 3 % each); geometric growth bounds their number by the logarithm of the growth.
+        const uint64_t cap = (budget_of(cfg->bins_budget_bytes, D) / (8ull * (T + 1))) & ~63ull;
+        const uint64_t grown = ((uint64_t)st->bin_cap + st->bin_cap / 4 + 63) & ~63ull;
+        want = (uint32_t)std::max<uint64_t>(want, std::min<uint64_t>(std::min<uint64_t>(grown, cap), 1u << 20));
+    }
     if (want == 0u) {
         st->bin_cap = 0; st->compact_sticky = 1;
     } else if (want > st->bin_cap || !use_bins) {

@@ -113,16 +113,18 @@ class GaussianRasterizer:
         #   preprocess_form: None | "direct" | "aggregating" — binning form of the forward's first kernel (same outputs)
         #   form_tuner     : None | False | True — on 4K-class grids the handle times both forms once and keeps the faster
         #                    (None: on unless GSR_FORM_TUNER=0; same outputs either way)
-        #   grad_precision : None | "fp32_reference" — ∇scales / ∇rotations by the reference's own fp32 expression trees instead
-        #                    of the float64 chain (reference-parity runs; needle-shaped splats then carry the reference's 1e-4..1e-3)
+        #   grad_precision : None | "accurate" | "fp32_reference" — the backward's arithmetic on needle-shaped splats (gsr.h):
+        #                    "accurate" = libm exp + IEEE division per pixel (+12 % of ∇render!), "fp32_reference" = that and the
+        #                    reference's own fp32 expression trees for ∇scales / ∇rotations instead of the float64 chain
+        #                    (reference-parity runs)
         try:
             sp = {None: L.DEFAULT, "fast": L.SSIM_FAST, "exact": L.SSIM_EXACT}[ssim_precision]
             pf = {None: L.DEFAULT, "direct": L.PREPROCESS_DIRECT, "aggregating": L.PREPROCESS_AGGREGATING}[preprocess_form]
             ft = {None: L.DEFAULT, False: L.TUNER_OFF, True: L.TUNER_ON}[form_tuner]
-            gp = {None: L.DEFAULT, "float64": L.DEFAULT, "fp32_reference": L.GRAD_FP32_REFERENCE}[grad_precision]
+            gp = {None: L.DEFAULT, "accurate": L.GRAD_ACCURATE, "fp32_reference": L.GRAD_FP32_REFERENCE}[grad_precision]
         except KeyError as e:
             raise ValueError(f"ssim_precision is None / 'fast' / 'exact', preprocess_form None / 'direct' / 'aggregating', "
-                             f"form_tuner None / False / True, grad_precision None / 'float64' / 'fp32_reference': {e}") from None
+                             f"form_tuner None / False / True, grad_precision None / 'accurate' / 'fp32_reference': {e}") from None
         self.ssim_precision, self.preprocess_form = ssim_precision, preprocess_form
         self.form_tuner, self.grad_precision = form_tuner, grad_precision
         # a bare `rasterize` outside autograd renders forward-only (no backward state); False restores the reference's

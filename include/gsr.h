@@ -80,18 +80,26 @@ typedef struct gsr_config {
                               * either way): GSR_DEFAULT (on; GSR_FORM_TUNER=0 in the environment turns the default off),
                               * GSR_TUNER_OFF (the previous view's skew decides, as before the tuner existed), GSR_TUNER_ON.
                               * An explicit preprocess_form pins the form and leaves the tuner nothing to decide. */
-    int32_t grad_precision;  /* ∇scales / ∇rotations of gsr_backward: GSR_DEFAULT = their chain (∇inverse -> ∇perspective ->
-                              * ∇covar_world_to_cam -> ∇quat_scale_to_cov -> ∇unnorm_quat2rot, projection.jl:132-257,
-                              * render.jl:302-366) evaluated in float64 from the raw inputs — on needle-shaped splats the fp32
-                              * chain is 1e-4 .. 1e-3 from float64 whoever evaluates it; GSR_GRAD_FP32_REFERENCE = the
-                              * reference's own fp32 expression trees, operation for operation (reference-parity runs: equal
-                              * to the fp32 CPU oracle to ~1e-6 on well-conditioned Gaussians). */
+    int32_t grad_precision;  /* arithmetic of gsr_backward where fp32 shortcuts show on needle-shaped splats (2-D axis ratio beyond
+                              * ~10 : 1), whose sums cancel by up to the square of that ratio:
+                              *   GSR_DEFAULT: (i) ∇render!'s per-pixel exp / reciprocal are the hardware's fast instructions
+                              *     (v_exp_f32 on sigma x log2 e, v_rcp_f32); (ii) the chain of ∇scales / ∇rotations (∇inverse ->
+                              *     ∇perspective -> ∇covar_world_to_cam -> ∇quat_scale_to_cov -> ∇unnorm_quat2rot, projection.jl:132-257,
+                              *     render.jl:302-366) is evaluated in float64 from the raw inputs.  ∇means of a 90 : 1 needle of
+                              *     radius 100 px is then ~4e-4 from float64 (the reference's fp32 atomics: 0.2 .. 3e-4), everything
+                              *     well conditioned ~1e-6;
+                              *   GSR_GRAD_ACCURATE: (i) libm-accurate exp and IEEE division — what the reference's source means by
+                              *     `exp` and `/` (render.jl:236-259) — with (ii) unchanged: the closest to float64 the library gets
+                              *     (that needle: 2e-5); ∇render! +12 %, and long tile lists are not split along their length;
+                              *   GSR_GRAD_FP32_REFERENCE: (i) as GSR_GRAD_ACCURATE, (ii) the reference's own fp32 expression trees,
+                              *     operation for operation: reference-parity runs (equal to the fp32 CPU oracle to ~1e-6 on
+                              *     well-conditioned Gaussians; on needles ∇rotations carry the fp32 chain's 1e-4 .. 1e-3). */
 } gsr_config;
 #define GSR_DEFAULT 0
 enum { GSR_SSIM_FAST = 1, GSR_SSIM_EXACT = 2 };
 enum { GSR_PREPROCESS_DIRECT = 1, GSR_PREPROCESS_AGGREGATING = 2 };
 enum { GSR_TUNER_OFF = 1, GSR_TUNER_ON = 2 };
-enum { GSR_GRAD_FP32_REFERENCE = 1 };
+enum { GSR_GRAD_FP32_REFERENCE = 1, GSR_GRAD_ACCURATE = 2 };
 
 /* Tile lists.  DEFAULT (flags = 0): exact footprint culling at binning — a (Gaussian, tile)
  * instance none of whose pixels can reach alpha >= 1/255 is not emitted at all.  The reference
@@ -322,7 +330,8 @@ enum {
     GSR_BUF_INSTANCE_AUX = 9   /* 4 x 32-bit (D), sorted instance order (plane s2 of the splat stream):
                                 *   [0] blue, [1] u32 Gaussian-major slot, [2] depth (:rgbd / :rgbdn) or, in :rgb mode, the u32 blend-test
                                 *   threshold X (bits(sigma) < X is the reference's blend test; 0: never blends), [3] u32 footprint masks
-                                *   (bits 0..15 tile rows, 16..19 8x8 quadrants the instance can touch) */
+                                *   (bits 0..15 tile rows, 16..19 8x8 quadrants the instance can touch; bit 20: the splat is a
+                                *   needle — 2-D axis ratio beyond 10 : 1 —, evaluated in the backward's accurate arithmetic) */
 };
 GSR_API int gsr_buffer(const gsr_handle* h, int which, const void** dev_ptr, size_t* bytes);
 /* Copy of one of those buffers into caller memory, enqueued on `stream` by the library's own HIP

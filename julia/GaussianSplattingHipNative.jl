@@ -43,7 +43,8 @@ struct GsrConfig
     ssim_precision::Int32      # per handle: 0 = process default (ssim_exact!), 1 fast, 2 exact            (ABI 6 encoding:
     preprocess_form::Int32     # per handle: 0 = process default (preprocess_form!), 1 direct, 2 aggregating   0 = default)
     form_tuner::Int32          # ABI 6: 0 default (on), 1 off, 2 on — the handle measures the binning form on 4K-class grids
-    grad_precision::Int32      # ABI 6: 0 default (∇scales / ∇rotations through the float64 chain), 1 the reference's fp32 trees
+    grad_precision::Int32      # ABI 6: 0 default, 1 the reference's arithmetic (accurate exp / division per pixel + its fp32 trees for
+                               #        ∇scales / ∇rotations), 2 accurate exp / division + the float64 chain
 end
 struct GsrInputs
     n::Int32; n_coeffs::Int32; sh_degree::Int32
@@ -117,7 +118,7 @@ native(rast::GaussianRasterizer) = lock(() -> get(NATIVE, rast, nothing), NATIVE
 
 """
     enable_hip_native!(rast; reference_tile_lists=false, forward_only_outside_ad=true, ssim_exact=nothing, preprocess_form=nothing,
-                       form_tuner=nothing, grad_fp32_reference=false)
+                       form_tuner=nothing, grad_precision=:default)
 
 Route `rasterize` / `∇rasterize` on this rasterizer through libgsr_hip.so.  Width / height / mode / near / far
 are the rasterizer's own (rasterizer.jl:60-90).  `forward_only_outside_ad`: a `rasterize` that is not being
@@ -126,13 +127,15 @@ differentiated (no `rrule` around it) is rendered with GSR_FORWARD_ONLY — `∇
 rasterizer (ABI 5; constructor keywords, as the reference's knobs are: rasterizer.jl:60-65); `nothing` follows the process-wide
 default (`ssim_exact!`, `preprocess_form!`) — so a GUI render task and a trainer in one process cannot disturb each other.
 `form_tuner` (`nothing` | `false` | `true`): whether the handle measures the binning form on 4K-class grids (same outputs either
-way).  `grad_fp32_reference = true`: ∇scales / ∇rotations by the reference's own fp32 expression trees (projection.jl:132-257,
+way).  `grad_precision` (`:default` | `:accurate` | `:fp32_reference`): the backward's arithmetic on needle-shaped splats —
+`:accurate` = libm exp + IEEE division per pixel (+12 % of ∇render!; ∇means of a 90 : 1 needle 4e-4 -> 2e-5 from float64),
+`:fp32_reference` = that and ∇scales / ∇rotations by the reference's own fp32 expression trees (projection.jl:132-257,
 render.jl:302-366) instead of the library's float64 chain — for reference-parity runs.
 Returns `rast`.
 """
 function enable_hip_native!(rast::GaussianRasterizer; reference_tile_lists::Bool = false, forward_only_outside_ad::Bool = true,
                             ssim_exact::Union{Nothing, Bool} = nothing, preprocess_form::Union{Nothing, Integer} = nothing,
-                            form_tuner::Union{Nothing, Bool} = nothing, grad_fp32_reference::Bool = false)
+                            form_tuner::Union{Nothing, Bool} = nothing, grad_precision::Symbol = :default)
     native(rast) === nothing || return rast
     check_abi()
     c, w, h = size(rast.image)
@@ -142,7 +145,8 @@ function enable_hip_native!(rast::GaussianRasterizer; reference_tile_lists::Bool
                   # ABI 6: 0 = default, 1 / 2 the explicit choices
                   ssim_exact === nothing ? Int32(0) : Int32(ssim_exact ? 2 : 1),
                   preprocess_form === nothing ? Int32(0) : Int32(preprocess_form != 0 ? 2 : 1),
-                  form_tuner === nothing ? Int32(0) : Int32(form_tuner ? 2 : 1), Int32(grad_fp32_reference ? 1 : 0)),
+                  form_tuner === nothing ? Int32(0) : Int32(form_tuner ? 2 : 1),
+                  Int32(grad_precision === :fp32_reference ? 1 : grad_precision === :accurate ? 2 : 0)),
         href))
     st = NativeState(href[], 0, forward_only_outside_ad, false, EMPTY_STATS)
     finalizer(s -> ccall((:gsr_destroy, LIB), Cint, (Ptr{Cvoid},), s.handle), st)

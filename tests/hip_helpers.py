@@ -10,14 +10,14 @@ def dev(a, dtype=torch.float32):
 
 class HipRun:
     def __init__(self, pkg, means, shs, opac, scales, rots, cam, sh_degree, background=(0, 0, 0), mode="rgb",
-                 want_covis=False, want_uncert=False, pose_dev=False, exact_tile_cull=False, bins_budget_bytes=0):
+                 want_covis=False, want_uncert=False, pose_dev=False, exact_tile_cull=False, bins_budget_bytes=0, grad_precision=None):
         R = pkg.rasterizer
         self.pkg, self.cam, self.deg, self.bg, self.mode = pkg, cam, sh_degree, tuple(float(b) for b in background), mode
         self.camera = pkg.Camera(cam.width, cam.height, tuple(cam.focal), tuple(cam.principal), np.asarray(cam.R),
                                  np.asarray(cam.t))
         self.rast = R.GaussianRasterizer(cam.width, cam.height, mode=mode, near_plane=cam.near_plane,
                                          far_plane=cam.far_plane, exact_tile_cull=exact_tile_cull,
-                                         bins_budget_bytes=bins_budget_bytes)
+                                         bins_budget_bytes=bins_budget_bytes, grad_precision=grad_precision)
         self.t = [dev(means), dev(shs), dev(np.asarray(opac).reshape(-1, 1)), dev(scales), dev(rots)]
         n = means.shape[0]
         self.covis = torch.zeros(n, dtype=torch.uint8, device="cuda") if want_covis else None

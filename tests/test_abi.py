@@ -103,7 +103,7 @@ def test_invalid_arguments_fail_before_touching_the_gpu(pkg):
     assert (L.DEFAULT, L.SSIM_FAST, L.SSIM_EXACT, L.PREPROCESS_DIRECT, L.PREPROCESS_AGGREGATING) == (0, 1, 2, 1, 2)
     for sp, pf, ft, gp, word in ((3, 0, 0, 0, b"ssim_precision"), (-1, 0, 0, 0, b"ssim_precision"), (0, 3, 0, 0, b"preprocess_form"),
                                  (1, -1, 0, 0, b"preprocess_form"), (0, 0, 3, 0, b"form_tuner"), (0, 0, -1, 0, b"form_tuner"),
-                                 (0, 0, 0, 2, b"grad_precision"), (0, 0, 0, -1, b"grad_precision")):
+                                 (0, 0, 0, 3, b"grad_precision"), (0, 0, 0, -1, b"grad_precision")):
         cfg = L.Config(64, 48, 3, 0.2, 1000.0, 3, 0.3, 0, 0, sp, pf, ft, gp)
         assert lib.gsr_create(C.byref(cfg), C.byref(h)) == L.GSR_E_INVALID_ARG and word in lib.gsr_last_error_string()
     # the process-wide defaults: getters return what the setters stored; out-of-range values are rejected and change nothing

@@ -6,6 +6,7 @@ import json
 import os
 import subprocess
 import sys
+import time
 
 import pytest
 
@@ -283,3 +284,51 @@ def test_scenes_section_is_merged_and_priced():
     line = {"roofline": {"stages_ms": head}, "config": cfg, "extra_configs": {"scenes": {"a": dict(same), "b": {"error": "x"}}}}
     bench.annotate_predictions(line)
     assert line["extra_configs"]["scenes"]["a"]["vs_config3_cost"]["within_bar"] and "vs_config3_cost" not in line["extra_configs"]["scenes"]["b"]
+
+
+def test_total_budget_bounds_the_run_and_skipped_sections_are_recorded():
+    """Round-5 verdict, next #3: the section limits used to add up to more than the driver's 1800 s.  Now the whole run has ONE
+    budget: a section gets min(its own limit, budget left - 30 s), what no longer fits is {"skipped": "budget"}, the worst-case
+    wall is below the budget by construction, and the merged-so-far line is written out after every section."""
+    import bench
+    # worst case by construction: every section hangs until its limit -> the sum of the limits handed out stays below the budget
+    args = bench.parse_args([])
+    assert args.total_budget == 900.0 and args.total_budget < 1800.0
+    secs = bench.plan_sections(args, 1)
+    assert secs == ["headline", "cpu_baseline", "extras", "scenes", "train_protocol"]
+    left, total = args.total_budget, 0.0
+    for i, _ in enumerate(secs):
+        own = args.section_timeout * (1.5 if i == 0 else 1.0)
+        if i > 0 and left - 30.0 < min(own, 20.0):
+            continue
+        total += min(own, max(left - 30.0, 20.0 if i == 0 else 0.0))
+        left = args.total_budget - total
+    assert total <= args.total_budget - 30.0 + 1e-6
+    # five fake sections of ~7.5 s each under a 62 s budget (30 s of it the reserve): the first ones run, the rest is skipped — and
+    # says so
+    t0 = time.time()
+    p, rep, lines = _fake(["--steps", "3", "--warmup", "1", "--total-budget", "62"], GSR_BENCH_FAKE_SLEEP="7", timeout=200)
+    wall = time.time() - t0
+    assert p.returncode == 0 and len(lines) == 1, p.stderr
+    assert rep["ms_per_step"] == 1.5 and rep["cpu_baseline"]["kind"] == "port"
+    budget = rep["bench_budget"]
+    assert budget["total_budget_s"] == 62.0 and list(budget["sections"]) == secs
+    skipped = [k for k, v in budget["sections"].items() if v == "skipped: budget"]
+    assert skipped and skipped[-1] == "train_protocol" and "headline" not in skipped and "cpu_baseline" not in skipped
+    for k in skipped:
+        where = rep["extra_configs"][k] if k in ("scenes", "train_protocol") else rep.get("extras_error")
+        assert where["skipped"] == "budget"
+    assert wall < 62.0 and rep["bench_wall_s"] < 62.0
+    # the partial line went out after every finished section (stderr; and gpurun_out/bench_partial.json when that directory exists)
+    partial = [ln for ln in p.stderr.splitlines() if ln.startswith("bench.py partial line: ")]
+    assert len(partial) == len(secs) - len(skipped)
+    first = json.loads(partial[0].split(": ", 1)[1])
+    assert first["ms_per_step"] == 1.5 and first["partial"]["sections_done"] == ["headline"] and "cpu_baseline" not in first
+    # a hanging LATE section costs its own limit, never the line; and everything that fits is there
+    p, rep, _ = _fake(["--steps", "3", "--warmup", "1", "--section-timeout", "3"], GSR_BENCH_HANG_FORM="train_protocol")
+    assert p.returncode == 0 and "timeout" in rep["extra_configs"]["train_protocol"] and "hot_tile_32k" in rep["extra_configs"]["scenes"]
+    p, rep, _ = _fake(["--steps", "3", "--warmup", "1"])
+    assert rep["extra_configs"]["train_protocol"]["ms_per_step"]["mean"] == 1.2
+    assert rep["extra_configs"]["scenes"]["trained_by_protocol"]["ms_per_step"] == 1.9   # (c): the trained scene joins the scenes
+    p, rep, _ = _fake(["--steps", "3", "--warmup", "1", "--no-train-protocol"])
+    assert "train_protocol" not in rep["extra_configs"] and "trained_by_protocol" not in rep["extra_configs"]["scenes"]

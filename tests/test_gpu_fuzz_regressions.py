@@ -38,12 +38,13 @@ def _rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
-def three_way(pkg, orc, fs, exact_tile_cull=False):
+def three_way(pkg, orc, fs, exact_tile_cull=False, grad_precision=None):
     """oracle, HIP and float64 gradients of one scene -> {tensor: (oracle, hip, f64) as (N, -1) float64 arrays}, oracle state."""
     st = orc.forward(fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, background=fs.bg, mode=fs.mode)
     vp = fs.cotangent()
     g = orc.backward(st, vp, fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, background=fs.bg)
-    run = HipRun(pkg, fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, fs.bg, fs.mode, exact_tile_cull=exact_tile_cull)
+    run = HipRun(pkg, fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, fs.bg, fs.mode, exact_tile_cull=exact_tile_cull,
+                 grad_precision=grad_precision)
     run.forward()
     out = [o.cpu().numpy() for o in run.backward(vp)[:5]]
     tt = lambda a: torch.tensor(np.asarray(a, np.float64), dtype=DT, requires_grad=True)  # noqa: E731
@@ -56,6 +57,29 @@ def three_way(pkg, orc, fs, exact_tile_cull=False):
     for nm, o, r, leaf in zip(NAMES, out, ref, leaves):
         res[nm] = tuple(np.asarray(x, np.float64).reshape(n, -1) for x in (r, o, leaf.grad.numpy()))
     return res, st
+
+
+def reference_form_distance(orc, fs, st, res, runs=5):
+    """The reference's OWN accumulation form as a fourth column (round-5 verdict, next #2): ∇render!'s per-pixel contributions
+    added with float32 atomics in whatever order the threads arrive (render.jl:242,262-282) — `orc.backward(deterministic=False)`:
+    fp32 `#pragma omp atomic` accumulators under an OpenMP tile loop.  `runs` evaluations (the order differs from run to run and
+    with the thread count); returns {tensor: (best, worst) rel-L2 against float64 over the visible Gaussians}.  DESIGN.md §4.2 had
+    ASSERTED that "the reference's per-pixel fp32 atomics have the same noise or more" than HIP's fp32 wave reduction; this
+    measures it.  `fs`: a FRESH scene object of the case (the campaign's cotangent is its rng's first draw)."""
+    vis = st.radii > 0
+    vp = fs.cotangent()
+    n = fs.means.shape[0]
+    out = {nm: [] for nm in NAMES}
+    threads0 = orc.num_threads()
+    try:
+        for r in range(runs):
+            orc.set_num_threads(max(2, threads0 >> (r % 3)))     # (another thread count = another arrival order)
+            g = orc.backward(st, vp, fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, background=fs.bg, deterministic=False)
+            for nm, a in zip(NAMES, (g.vmeans, g.vshs, g.vopacities, g.vscales, g.vrots)):
+                out[nm].append(_rel(np.asarray(a, np.float64).reshape(n, -1)[vis], res[nm][2][vis]))
+    finally:
+        orc.set_num_threads(threads0)
+    return {nm: (min(v), max(v)) for nm, v in out.items()}
 
 
 def arbitrate(res, st, fs):
@@ -153,6 +177,32 @@ def test_needle_rotation_gradients_meet_the_tolerance_against_float64(pkg, orc, 
         print(f"edge {case} {nm}: HIP-f64 {e_h:.2e}, oracle-f64 {e_o:.2e}")
         assert e_h <= 1e-4, (nm, e_h, e_o)
     print(f"edge {case}", arbitrate(res, st, fs))
+
+
+# round 6 (round-5 verdict, next #2): ∇means of needle-shaped splats.  On edge 8498 / 8112 HIP — not the oracle — is the far side
+# from float64 (4.1e-4 / 2.1e-4 against 2.3e-5 / 9.4e-5).  DESIGN.md §4.2 (round 5) had ASSERTED that "the reference's per-pixel
+# fp32 atomics have the same noise or more"; measured now with the oracle's like-for-like mode (`deterministic=False`: fp32 atomics
+# per pixel, render.jl:242,262-282, five arrival orders): 2e-5 .. 3e-4 on 8498 — the same order, HIP up to 3 x worse than its
+# worst.  And the source is NOT the wave reduction round 5 suspected: it is the two fast hardware functions of the per-pixel
+# body (v_exp_f32 on the rounded product sigma x log2 e, v_rcp_f32 through the T recursion) — with libm exp + IEEE division
+# (gsr_config.grad_precision = GSR_GRAD_ACCURATE, +12 % of ∇render!) 8498 drops to 2.3e-5, the oracle's own figure
+# (profiles/r06/experiments/needle_*.txt).  Asserted: ACCURATE meets 1e-4 against float64 or sits on the fp32 oracle; the DEFAULT
+# stays within 3 x the worst arrival order of the reference's own accumulation form, or 5e-4 (a regression bound: measured 4.1e-4).
+@pytest.mark.parametrize("case", [8498, 8112, 5315, 5457])
+def test_needle_means_gradient_default_and_accurate_arithmetic(pkg, orc, case):
+    fs = fuzz_scenes.edge_scene(pkg, case)
+    res, st = three_way(pkg, orc, fs)
+    res_acc, _ = three_way(pkg, orc, fuzz_scenes.edge_scene(pkg, case), grad_precision="accurate")
+    ref = reference_form_distance(orc, fuzz_scenes.edge_scene(pkg, case), st, res)   # (a fresh scene: the cotangent is its rng's FIRST draw)
+    vis = st.radii > 0
+    for nm in ("vmeans", "vopacities", "vshs", "vscales", "vrots"):
+        o, h, t = res[nm]
+        e_h, e_o, e_a = _rel(h[vis], t[vis]), _rel(o[vis], t[vis]), _rel(res_acc[nm][1][vis], t[vis])
+        print(f"edge {case} {nm}: float64 distance of HIP default {e_h:.2e}, HIP accurate {e_a:.2e}, oracle (double sums) {e_o:.2e}, "
+              f"reference form (fp32 atomics) {ref[nm][0]:.2e} .. {ref[nm][1]:.2e}")
+        if nm in ("vmeans", "vopacities", "vshs"):   # (∇scales / ∇rotations: test_needle_rotation_gradients_... above)
+            assert e_a <= 1e-4 or e_a <= 1.5 * e_o + 2e-5, (nm, e_a, e_o)
+            assert e_h <= 1e-4 or e_h <= max(3.0 * ref[nm][1], 5e-4), (nm, e_h, ref[nm], e_o)
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])

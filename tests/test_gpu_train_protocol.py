@@ -82,7 +82,7 @@ def test_first_steps_of_the_training_chain_equal_the_oracle_chain(pkg, orc):
         # around zero its sign is the summation order's — here as under the reference's float atomics.  Hence per group: 99.8 %
         # of the elements agree to 1e-5 relative, the rest differ by at most the learning-rate steps taken so far, the tensor as
         # a whole stays within 2e-4 (x the number of densification rounds behind it).
-        grow = 1 + sum(1 for d in h.densify_log if d["step"] < step)
+        grow = 1 + sum(1 for d in h.densify_log if d["step"] <= step)
         for k in TH.GROUPS:
             a, b = getattr(h.gs, k).cpu().numpy().reshape(-1), getattr(o.gs, k).reshape(-1)
             worst = float(np.abs(a.astype(np.float64) - b).max()) if a.size else 0.0

@@ -2,7 +2,7 @@
 # On the GPU box: everything the round's profiles/<round>/final directory is built from.   tools/measure_all.sh <tag>
 set -x
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-R=${1:-r05}
+R=${1:-r06}
 O=gpurun_out/$R
 mkdir -p $O
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
@@ -12,6 +12,10 @@ tools/measure_pmc.sh ${R}_cfg2 --gaussians 100000 --no-loss --seed 1002
 tools/measure_pmc.sh ${R}_cfg5 --gaussians 5000000 --width 3840 --height 2160 --no-loss --seed 1005 --steps 3
 # GSR_FORWARD_ONLY (round 4): the fused forward without the backward state; keyed ..._fwdonly
 tools/measure_pmc.sh ${R}_cfg3_fwdonly --forward-only
+# round 6 (round-5 verdict, next #5): what the reference actually trains — :rgbd (its default mode) at config-3 size, and the
+# trained-like 1 M scene of extra_configs.scenes — so that their roofline.traffic / valu_frac stop being null
+tools/measure_pmc.sh ${R}_cfg3_rgbd --mode rgbd
+tools/measure_pmc.sh ${R}_trained_1m_rgbd --mode rgbd --scene trained --seed 1010
 cp profiles/pmc_traffic.json $O/pmc_traffic.json
 # the driver's line (config 3 + extra_configs: config 2, config 5, :rgbd, trainer step both ways + cpu_baseline)
 python bench.py > $O/bench_driver_line.json 2> $O/bench_driver_line.err

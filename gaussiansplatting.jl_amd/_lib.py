@@ -174,7 +174,7 @@ def bind_policy(lib):
     return lib
 
 
-EXPORTS = ["gsr_create", "gsr_destroy", "gsr_release_scene_buffers", "gsr_memory_usage", "gsr_bins_capacity_after", "gsr_forward",
+EXPORTS = ["gsr_create", "gsr_destroy", "gsr_release_scene_buffers", "gsr_memory_usage", "gsr_reserve", "gsr_bins_capacity_after", "gsr_forward",
            "gsr_backward", "gsr_host_wait_policy", "gsr_buffer", "gsr_copy_buffer", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_loss_l1_ssim",
            "gsr_ssim_precision", "gsr_get_ssim_precision", "gsr_preprocess_form", "gsr_get_preprocess_form",
            "gsr_allreduce_grads", "gsr_last_error_string", "gsr_version", "gsr_abi_version", "gsr_check_abi", "gsr_profile_enable",
@@ -226,6 +226,7 @@ def load():
     lib.gsr_release_scene_buffers.argtypes = [vp]
     lib.gsr_memory_usage.argtypes = [vp]
     lib.gsr_memory_usage.restype = C.c_int64
+    lib.gsr_reserve.argtypes = [vp, C.c_int64, C.c_int64]
     bind_policy(lib)
     lib.gsr_forward.argtypes = [vp, C.POINTER(Inputs), C.POINTER(CameraS), vp, C.POINTER(Aux), vp, C.POINTER(Stats)]
     lib.gsr_backward.argtypes = [vp, C.POINTER(Inputs), C.POINTER(CameraS), vp, C.POINTER(Grads), vp]

@@ -254,6 +254,7 @@ struct gsr_handle {
     // the cotangent the handle's loss head wrote, and for which forward (GSR_GRADS_COLOR_COTANGENT is honoured for it only)
     const float* loss_vpixels = nullptr;
     uint64_t loss_generation = 0;
+    uint32_t reserved_regrowths = 0;  // reallocations made by gsr_reserve (not counted in gsr_stats.scratch_regrowths)
     DevBuf dbg_flag;
     Profiler prof;
 
@@ -418,7 +419,7 @@ void fill_history(const gsr_handle* h, gsr_stats* st) {
     st->tuner_rearms = p.tuner_rearms;
     uint32_t grows = 0;
     for (int i = 0; i < h->n_all; i++) grows += h->all[i]->regrowths;
-    st->scratch_regrowths = grows;
+    st->scratch_regrowths = grows - h->reserved_regrowths;  // (inside a view: what gsr_reserve reallocated is not counted)
     st->fused_relaunches = p.fused_relaunches;
     st->held_views = p.held_views;
     const bool decided = p.tuner.phase == GSR_TUNER_TIMED_VIEWS + 1;
@@ -622,6 +623,37 @@ int gsr_release_scene_buffers(gsr_handle* h) {
     h->vmean2d_cur = nullptr;
     h->last_n = 0;
     h->last_D = 0;
+    return GSR_OK;
+}
+
+int gsr_reserve(gsr_handle* h, int64_t n_gaussians, int64_t n_instances) {
+    if (!h) return fail(GSR_E_INVALID_ARG, "null handle");
+    if (n_gaussians < 0 || n_instances < 0 || n_gaussians > 0x7FFFFFFFll || n_instances > 0xFFFFFFFFll)
+        return fail(GSR_E_INVALID_ARG, "gsr_reserve: sizes out of range");
+    const int C = h->cfg.mode;
+    int rc = GSR_OK;
+    struct Uncount {  // reallocations made here are the caller's choice of WHEN, not a forward's surprise: keep them out of the history
+        gsr_handle* h;
+        uint32_t before = 0;
+        uint32_t sum() const { uint32_t g = 0; for (int i = 0; i < h->n_all; i++) g += h->all[i]->regrowths; return g; }
+        explicit Uncount(gsr_handle* h_) : h(h_) { before = sum(); }
+        ~Uncount() { h->reserved_regrowths += sum() - before; }
+    } uncount(h);
+    if (n_gaussians > 0) {
+        const size_t nn = (size_t)n_gaussians, nb = (nn + 255) / 256 + 1;
+        if ((rc = h->geo.ensure(nn * 64)) || (rc = h->radii.ensure(nn * 4)) || (rc = h->bsum.ensure(nb * 4)) ||
+            (rc = h->bpre.ensure(nb * 4)) || (rc = h->bvis.ensure(nb * 4)) || (rc = h->vmean2d.ensure(nn * 8)) ||
+            (C > 5 && (rc = h->gnormal.ensure(nn * 16))))
+            return rc;
+    }
+    if (n_instances > 0) {
+        const size_t D = (size_t)n_instances;
+        // (the gradient rows are indexed by Gaussian-major SLOT: one per emitted tile of a small rect, one per tile of a large one —
+        //  at most ~1.5 x the instance count under exact culling)
+        if ((rc = h->values_sorted.ensure(D * 4)) || (rc = h->s0.ensure(D * 16)) || (rc = h->s1.ensure(D * 16)) ||
+            (rc = h->s2.ensure(D * 16)) || (C > 3 && (rc = h->s3.ensure(D * 16))) || (rc = h->rows.ensure(D * 64 + D * 32)))
+            return rc;
+    }
     return GSR_OK;
 }
 

@@ -291,7 +291,15 @@ def post_train_step(strategy: DefaultStrategy, gs: GaussianModel, optimizers, ra
     densified = step >= strategy.densify_from_iter and step % strategy.densification_interval == 0
     if densified:
         mss = 20 if step > strategy.opacity_reset_interval else 0
+        n_before = max(len(gs), 1)
         densify_and_prune(strategy, gs, optimizers, extent, extent, mss, seed)
+        # The model changed size: let the rasterizer re-size its scratch HERE, with headroom for the next rounds — the reference
+        # empties its allocation cache at this very place (strategy.jl:92: GPUArrays.unsafe_free!(cache)) — instead of inside the
+        # next training step's forward, where a hipFree + hipMalloc pair synchronises the device (round 6: the first step after
+        # a densification took 1.6 x a plain one whenever four per-Gaussian buffers had to grow).
+        if hasattr(rast, "reserve"):
+            grow = len(gs) / n_before
+            rast.reserve(int(1.5 * len(gs)), int(1.5 * max(grow, 1.0) * int(rast.stats.n_rendered)))
     reset = step % strategy.opacity_reset_interval == 0
     if reset:
         reset_opacity(gs)

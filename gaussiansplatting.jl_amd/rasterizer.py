@@ -67,11 +67,15 @@ class GeometryState:
     def __len__(self):  # Base.length(::GeometryState), states.jl
         return self._cap
 
-    def ensure(self, n: int):
-        if self._cap < n:  # rasterizer.jl:275-278: reallocate when the model grew
+    def reserve(self, n: int):
+        if self._cap < n:
             self._radii = torch.zeros(n, dtype=torch.int32, device=self.device)
             self._grad_means_2d = torch.zeros((n, 2), dtype=torch.float32, device=self.device)
             self._cap = n
+
+    def ensure(self, n: int):
+        if self._cap < n:  # rasterizer.jl:275-278: reallocate when the model grew (here: by at least a quarter)
+            self.reserve(max(n, self._cap + self._cap // 4))
         self._n = n
 
     @property
@@ -164,6 +168,14 @@ class GaussianRasterizer:
         L.check(self._lib.gsr_release_scene_buffers(self._h))
         self.gstate = GeometryState(self.device)  # rasterizer.jl:116-117
         self._n = 0
+
+    def reserve(self, n_gaussians: int, n_instances: int = 0):
+        """gsr_reserve: pre-size the grow-only scratch (and `gstate`) for views of up to that many Gaussians / tile instances, so
+        that the forwards that follow allocate nothing (a reallocation inside a forward synchronises the device).  What a trainer
+        calls right after a densification round, with headroom — `densification.post_train_step` does."""
+        with torch.cuda.device(self.device):
+            L.check(self._lib.gsr_reserve(self._h, int(n_gaussians), int(n_instances)))
+        self.gstate.reserve(int(n_gaussians))
 
     def memory_usage(self) -> int:
         """memory_usage(rast) — rasterizer.jl:127-134"""

@@ -264,6 +264,14 @@ GSR_API int gsr_destroy(gsr_handle* h);
 GSR_API int gsr_release_scene_buffers(gsr_handle* h);
 /* memory_usage(rast) — rasterizer.jl:127-134 (device bytes owned by the handle). */
 GSR_API int64_t gsr_memory_usage(const gsr_handle* h);
+/* New in ABI 6 (no reference counterpart: the reference reallocates its states whenever the model or the instance count grew,
+ * rasterizer.jl:275-278,340-343).  Pre-size the handle's grow-only scratch for views of up to n_gaussians Gaussians and
+ * n_instances tile instances, so that the forwards that follow allocate nothing — a reallocation inside gsr_forward is a hipFree
+ * + hipMalloc pair, i.e. a device synchronisation in the middle of a training step.  Where a trainer calls it: right after a
+ * densification round changed the model (the reference empties its allocation cache at the same place, strategy.jl:92), with
+ * headroom for the next rounds; the Python mirror's post_train_step does (1.5 x).  The key bins are not covered: their capacity is
+ * a policy of its own (gsr_policy.h).  Never shrinks; 0 / smaller values are no-ops. */
+GSR_API int gsr_reserve(gsr_handle* h, int64_t n_gaussians, int64_t n_instances);
 /* Memory planning; no GPU needed.  The capacity — keys per tile — of the fixed-capacity key bins gsr_forward chooses for the view
  * AFTER one that rendered n_rendered instances with a longest tile list of max_tile_instances on a width x height image, under
  * bins_budget_bytes (0 = the default budget, see gsr_config) and with bins of current_capacity keys in place (0 = none yet; the

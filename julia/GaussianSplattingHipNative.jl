@@ -291,6 +291,14 @@ function ChainRulesCore.rrule(::typeof(rasterize), means_3d::RM, shs::R3, opacit
     return image, _pullback
 end
 
+# gsr_reserve: pre-size the native scratch for up to n_gaussians / n_instances (call it after a densification round, with headroom:
+# a reallocation inside a forward synchronises the device in the middle of a training step)
+function reserve!(rast::GaussianRasterizer, n_gaussians::Integer, n_instances::Integer = 0)
+    st = native(rast)
+    st === nothing || check(ccall((:gsr_reserve, LIB), Cint, (Ptr{Cvoid}, Int64, Int64), st.handle, n_gaussians, n_instances))
+    return rast
+end
+
 # release_scene_buffers!(rast) (rasterizer.jl:111-123) also has to drop the library's scene-sized scratch
 function release_native_scene_buffers!(rast::GaussianRasterizer)
     st = native(rast)

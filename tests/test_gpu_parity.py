@@ -787,6 +787,39 @@ def test_side_stream_two_handles_and_buffer_growth(pkg, orc):
     ra.profile(False)
 
 
+def test_reserve_makes_the_following_forwards_allocation_free(pkg):
+    """gsr_reserve (ABI 6): after reserving for a model and an instance count, a forward of a scene inside those sizes neither
+    reallocates a buffer nor changes memory_usage, and its image equals a cold handle's bit for bit."""
+    small, big = pkg.synthetic.make_scene(3000, 320, 192, 0, 5), pkg.synthetic.make_scene(40000, 320, 192, 0, 6)
+    cam = pkg.Camera(320, 192, tuple(big.focal))
+    tens = lambda s: [dev(s.means), dev(s.shs), dev(s.opacities.reshape(-1, 1)), dev(s.scales), dev(s.rotations)]
+    cold = pkg.rasterizer.GaussianRasterizer(320, 192, mode="rgbd")
+    ref = cold.forward_raw(*tens(big), cam, 0, (0, 0, 0)).clone()
+    d_big = int(cold.stats.n_rendered)
+    rast = pkg.rasterizer.GaussianRasterizer(320, 192, mode="rgbd")
+    rast.forward_raw(*tens(small), cam, 0, (0, 0, 0))
+    g0 = int(rast.stats.scratch_regrowths)
+    rast.reserve(40000, d_big)
+    mem = rast.memory_usage()
+    img = rast.forward_raw(*tens(big), cam, 0, (0, 0, 0))
+    assert torch.equal(img, ref)
+    assert int(rast.stats.scratch_regrowths) == g0, (g0, int(rast.stats.scratch_regrowths))
+    bins_bytes = lambda r: 8 * int(r.stats.bin_capacity) * ((320 + 15) // 16) * ((192 + 15) // 16)
+    # (the key bins are a policy of their own — and so is the compact binning a view falls back to when they overflowed, which this
+    #  first large view after a small one does: its sort buffers are first allocations, not regrowths)
+    assert rast.memory_usage() <= mem + bins_bytes(rast) + 40 * d_big, (rast.memory_usage(), mem, d_big)
+    # ... and a backward after it works on the reserved buffers
+    vp = torch.ones_like(img)
+    out = rast.backward_raw(vp, *tens(big), cam, 0, (0, 0, 0))
+    want = cold.backward_raw(vp, *tens(big), cam, 0, (0, 0, 0))
+    for a, b in zip(out[:5], want[:5]):
+        assert torch.equal(a, b)
+    with pytest.raises(pkg._lib.GsrError):
+        rast.reserve(-1, 0)
+    rast.reserve(0, 0)   # no-op
+    rast.close(); cold.close()
+
+
 def test_state_errors(pkg):
     """gsr_backward without a matching forward -> GSR_E_STATE; bad shapes -> ValueError."""
     s = pkg.synthetic.make_scene(32, 64, 48, 0, 3)

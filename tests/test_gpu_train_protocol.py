@@ -208,9 +208,10 @@ def test_view_history_of_the_training_run(pkg, run300):
         fallbacks_after_first = rows[-1]["compact_fallbacks"] - rows[0]["compact_fallbacks"]
         relaunch_after_first = rows[-1]["fused_relaunches"] - rows[0]["fused_relaunches"]
         scratch_after_first = rows[-1]["scratch_regrowths"] - rows[0]["scratch_regrowths"]
+        scratch_in_first = rows[0]["scratch_regrowths"] - (hist[s0 - 2]["scratch_regrowths"] if s0 > 1 else 0)
         summary.append(dict(round_start=s0, n=rows[0]["n"], bins_regrown_after_first_view=regrow, compact_fallbacks_after_first_view=fallbacks_after_first,
                             fused_relaunches_after_first_view=relaunch_after_first, scratch_regrowths_after_first_view=scratch_after_first,
-                            longest=max(r["max_tile"] for r in rows), binning=sorted({r["binning"] for r in rows}),
+                            scratch_regrowths_in_first_view=scratch_in_first, longest=max(r["max_tile"] for r in rows), binning=sorted({r["binning"] for r in rows}),
                             bin_capacity=sorted({r["bin_capacity"] for r in rows})))
     print("\nview history per densification round:\n" + "\n".join(json.dumps(s) for s in summary))
     for s in summary:
@@ -219,6 +220,9 @@ def test_view_history_of_the_training_run(pkg, run300):
         assert s["fused_relaunches_after_first_view"] <= 1, s            # ... and so are the per-instance buffers
         assert s["scratch_regrowths_after_first_view"] <= 12, s          # (a dozen grow-only buffers, each at most once per round:
         #                                                                    geometric growth; the views of a batch differ in D)
+    # post_train_step re-sizes the scratch inside the densification step (gsr_reserve, 1.5 x headroom): the first forward of a
+    # round after the first finds every per-Gaussian buffer large enough (the per-instance ones follow the round's longest view)
+    assert sum(s["scratch_regrowths_in_first_view"] for s in summary[1:]) <= len(summary) - 1, summary
     assert hist[-1]["tuner_rearms"] == 0
     # the counters are cumulative and monotone
     for k in ("bins_regrowths", "compact_fallbacks", "tuner_rearms", "scratch_regrowths", "fused_relaunches", "held_views"):

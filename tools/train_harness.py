@@ -293,7 +293,9 @@ class Harness:
         self.last_split_seed = seed
         densified, reset = Dz.post_train_step(s, self.gs, self.opts, self.rast, step, self.extent, seed=seed)
         if densified or reset:
-            self.act = None              # the raw arrays were re-composed / the logits reset: the activated copies are stale
+            # the raw arrays were re-composed / the logits reset: the activated copies are stale.  Re-run the prologue HERE — inside
+            # the step that re-composed them, which is a slow one anyway — so that the step after it is a plain step
+            self.prologue()
         if densified:
             torch.cuda.synchronize()
             ms = 1e3 * (time.perf_counter() - t0)

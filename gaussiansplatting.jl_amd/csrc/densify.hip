@@ -59,7 +59,12 @@ __global__ __launch_bounds__(256) void densify_mask_kernel(int kind, long long n
 //   dst[n_keep + k * n_sel + j] = new_zero ? 0 : src[sel_idx[j]]   j < n_sel, k < reps
 // — `cat(x, x[:, mask])` (clone, reps = 1), `cat(x, repeat(x[:, mask], 1, 2))[:, valid]` (split, reps = 2: the
 // block-repeat order of Julia's `repeat`), `x[:, valid]` (prune, n_sel = 0), with zero rows appended to the
-// moments (_append_optimizer!).  One thread per output word, all arrays in one launch.
+// moments (_append_optimizer!).  All arrays in one launch; a workgroup composes a run of whole output rows of ONE array
+// (about COMPOSE_WORDS words): it stages the rows' source indices in LDS, then its threads walk the run word by word —
+// consecutive lanes store consecutive words, and read consecutive words of (mostly consecutive) source rows.  (Round 6: the
+// first form, one thread per output word with a 64-bit division and modulo each, composed 1.1 M Gaussians' 19 arrays at
+// 1.3 TB/s — 1.2 ms per composition, three per densification round, on the integer pipe.)
+constexpr int COMPOSE_WORDS = 2048;
 struct ComposeGroups {
     const uint32_t* src[GSR_COMPOSE_MAX_GROUPS];
     uint32_t* dst[GSR_COMPOSE_MAX_GROUPS];
@@ -68,29 +73,46 @@ struct ComposeGroups {
     long long block_start[GSR_COMPOSE_MAX_GROUPS + 1];
     int n;
 };
+__host__ __device__ inline int compose_rows_per_block(int rw) { return rw >= COMPOSE_WORDS ? 1 : COMPOSE_WORDS / rw; }
 __global__ __launch_bounds__(256) void compose_rows_kernel(ComposeGroups G, const uint32_t* __restrict__ keep_idx,
                                                            long long n_keep, const uint32_t* __restrict__ sel_idx,
                                                            long long n_sel, int reps) {
+    __shared__ uint32_t src_row[COMPOSE_WORDS];  // source row of each output row of this run; ~0u: a zero row
     int g = 0;
     for (int k = 1; k < G.n; k++)
         if ((long long)blockIdx.x >= G.block_start[k]) g = k;
-    const long long e = ((long long)blockIdx.x - G.block_start[g]) * 256 + threadIdx.x;
     const int rw = G.row_words[g];
+    const int rpb = compose_rows_per_block(rw);
     const long long rows = n_keep + n_sel * reps;
-    if (e >= rows * rw) return;
-    const long long r = e / rw;
-    const int j = (int)(e - r * rw);
-    uint32_t v;
-    if (r < n_keep) {
-        const long long s = keep_idx ? (long long)keep_idx[r] : r;
-        v = G.src[g][s * rw + j];
-    } else if (G.new_zero[g]) {
-        v = 0u;
-    } else {
-        const long long s = (long long)sel_idx[(r - n_keep) % n_sel];
-        v = G.src[g][s * rw + j];
+    const long long r0 = ((long long)blockIdx.x - G.block_start[g]) * rpb;
+    if (r0 >= rows) return;
+    const int nr = (int)(rows - r0 < (long long)rpb ? rows - r0 : (long long)rpb);
+    const bool zero_new = G.new_zero[g] != 0;
+    for (int k = threadIdx.x; k < nr; k += 256) {
+        const long long r = r0 + k;
+        uint32_t sr;
+        if (r < n_keep) {
+            sr = keep_idx ? keep_idx[r] : (uint32_t)r;
+        } else if (zero_new) {
+            sr = ~0u;
+        } else {
+            long long j = r - n_keep;  // block-repeat order: copy k of selected row j sits at n_keep + k * n_sel + j
+            while (j >= n_sel) j -= n_sel;
+            sr = sel_idx[j];
+        }
+        src_row[k] = sr;
     }
-    G.dst[g][e] = v;
+    __syncthreads();
+    const uint32_t* __restrict__ src = G.src[g];
+    uint32_t* __restrict__ dst = G.dst[g] + r0 * rw;
+    const uint32_t urw = (uint32_t)rw;
+    const long long nw = (long long)nr * rw;   // (<= COMPOSE_WORDS unless one row is wider than that)
+    for (long long w = threadIdx.x; w < nw; w += 256) {
+        const uint32_t row = rpb == 1 ? 0u : (uint32_t)w / urw;
+        const uint32_t j = rpb == 1 ? (uint32_t)w : (uint32_t)w - row * urw;
+        const uint32_t sr = src_row[row];
+        dst[w] = sr == ~0u ? 0u : src[(size_t)sr * urw + j];
+    }
 }
 
 // Counter-based generator for the split noise: 32 well-mixed bits from (seed, row, draw) — integer only, so the
@@ -294,7 +316,10 @@ void gsr_launch_compose_rows(hipStream_t s, int n_groups, const void* const* src
         G.row_words[g] = on ? row_words[g] : 1;
         G.new_zero[g] = on ? new_zero[g] : 0;
         G.block_start[g] = blocks;
-        if (on) blocks += (rows * row_words[g] + 255) / 256;
+        if (on) {
+            const int rpb = compose_rows_per_block(row_words[g]);
+            blocks += (rows + rpb - 1) / rpb;
+        }
     }
     G.block_start[GSR_COMPOSE_MAX_GROUPS] = blocks;
     if (blocks == 0) return;

@@ -389,6 +389,11 @@ __attribute__((amdgpu_waves_per_eu(AGG_NT ? 3 * AGG_NT / 256 : 1, AGG_NT ? 8 : 4
     // scan's totals, grows the bins and repeats the pass (first view / a much denser view).
     // exact-cull mode: a tile none of whose pixels can reach alpha >= 1/255 gets no
     // instance (the reference keeps it and skips it pixel by pixel, render.jl:95).
+#ifdef GSR_PRE_NO_BINNING
+    // (A/B builds only — tools/experiments/r06_preprocess_floor.py: projection + SH + records without any instance, the floor under
+    //  every re-formed binning)
+    if (!SCATTER) { area = 0u; rmax[0] = rmin[0]; rmax[1] = rmin[1]; }
+#endif
     const uint64_t key = ((uint64_t)__float_as_uint(mc_z) << 32) | (uint32_t)i;
     // the rect's aligned tile pairs in row-major order: visit(even tile index, bit 0: even tile emitted, bit 1: odd tile)
     // (rects of more than EMIT_COOP tiles are emitted by the whole wave below)

@@ -1105,6 +1105,9 @@ SCENE_SPECS = [
      "procedural trained-like scene, 3M Gaussians, 2560x1440, :rgbd, fwd + loss + bwd"),
 ]
 PREDICTION_BAR = 1.3
+INFINITY_CACHE_BYTES = 256 << 20   # MI355X_MICROARCH.md: 256 MB of MALL in front of HBM
+# stand-alone gsr_loss_l1_ssim, ns per pixel, the slower of :rgb / :rgbd at 1280x720 ... 2576x1440 (round 6 probe)
+LOSS_STANDALONE_NS_PER_PX = {"loss_fwd": 0.031, "loss_bwd": 0.031}
 
 
 def predict_from_headline(rec, head_stages, head_cfg):
@@ -1136,6 +1139,25 @@ def predict_from_headline(rec, head_stages, head_cfg):
         ratio["sort_composite_fwd"][0] = sm.get("tile_sort", 0.0) + max(sm["sort_composite_fwd"], sm["composite_fwd"])
     stages = {k: {"measured_ms": round(m, 4), "predicted_ms": round(p_, 4), "ratio": round(m / p_, 3) if p_ > 0 else None}
               for k, (m, p_) in ratio.items()}
+    # The loss head at config 3 is CACHE-ASSISTED: image + target + the three derivative maps + the pullback are 72 B per pixel
+    # = 149 MB at 1080p, inside the 256 MB Infinity Cache, and `loss_bwd` reads back what `loss_fwd` just wrote (PMC: 157 MB of
+    # HBM traffic against 224 MB algorithmic).  A larger image cannot (2560x1440 :rgbd: 325 MB) and then runs at the stand-alone
+    # per-pixel cost, which is linear in pixels whatever the width / height / tile count (round 6 probe over ten resolutions,
+    # profiles/r06/experiments/loss_bwd_resolution_probe.txt) — so config 3's per-byte price under-predicts it (round-5 verdict
+    # "weak #9": 1.38 x, flagged and unexplained).  Such a stage is priced against the stand-alone cost as well and only named in
+    # `stages_over_bar` when it breaks the bar against BOTH.
+    loss_ws = lambda pix, ch: pix * 4 * (2 * ch + 3 + 9)
+    exempt = set()
+    if loss_ws(P, C) > INFINITY_CACHE_BYTES >= loss_ws(hP, 3):
+        for k in ("loss_fwd", "loss_bwd"):
+            if k in stages:
+                alone = LOSS_STANDALONE_NS_PER_PX[k] * P * 1e-6
+                stages[k]["standalone_predicted_ms"] = round(alone, 4)
+                stages[k]["note"] = ("config 3 runs this stage out of the Infinity Cache; this image's loss working set "
+                                     f"({loss_ws(P, C) / 1e6:.0f} MB) does not fit it: stand-alone cost per pixel "
+                                     "(profiles/r06/experiments/loss_bwd_resolution_probe.txt)")
+                if stages[k]["measured_ms"] <= PREDICTION_BAR * alone:
+                    exempt.add(k)
     tot_p = sum(v["predicted_ms"] for v in stages.values())
     out = {"predicted_ms_per_step": round(tot_p, 4),
            "ratio": round(rec["ms_per_step"] / tot_p, 3) if tot_p > 0 else None, "bar": PREDICTION_BAR, "stages": stages,
@@ -1144,7 +1166,7 @@ def predict_from_headline(rec, head_stages, head_cfg):
                     + ("; the tier walk ran beside the fused launch: measured = tier sorts + the longer of the two)" if overlapped else ")")}
     out["within_bar"] = out["ratio"] is not None and out["ratio"] <= PREDICTION_BAR
     out["stages_over_bar"] = sorted(k for k, v in stages.items() if v["ratio"] and v["ratio"] > PREDICTION_BAR and
-                                    v["measured_ms"] - v["predicted_ms"] > 0.02)
+                                    v["measured_ms"] - v["predicted_ms"] > 0.02 and k not in exempt)
     return out
 
 

@@ -18,4 +18,21 @@ needles)
     GSR_AB_LIBS="tools/bin/libgsr_needles0.so tools/bin/libgsr_needles2.so" tools/ab.sh --scene trained --seed 1010 --mode rgbd > $O/needle_ab_trained.txt 2>&1
     cat $O/needle_ab_cfg3.txt $O/needle_ab_trained.txt
     ;;
+fuzz)
+    # the round's fuzz campaign on the final build: every family, both binning forms, a small bins budget, the fused launch never
+    # held, and the two non-default gradient arithmetics (seeds beyond every earlier round's)
+    G='^FAIL|cases passed|binning mode'
+    timeout 900 python tools/fuzz_parity.py 800 20000 > $O/fz_sweep.txt 2>&1; grep -E "$G" $O/fz_sweep.txt | cut -c1-220
+    timeout 900 python tools/fuzz_parity.py deep 400 9000 > $O/fz_deep.txt 2>&1; grep -E "$G" $O/fz_deep.txt | cut -c1-220
+    timeout 700 python tools/fuzz_parity.py edge 500 10000 > $O/fz_edge.txt 2>&1; grep -E "$G" $O/fz_edge.txt | cut -c1-220
+    GSR_PREPROCESS_AGG=1 timeout 700 python tools/fuzz_parity.py 400 21000 > $O/fz_sweep_agg.txt 2>&1; grep -E "$G" $O/fz_sweep_agg.txt | cut -c1-220
+    GSR_PREPROCESS_AGG=1 GSR_FUZZ_BINS_KEYS=2048 timeout 700 python tools/fuzz_parity.py deep 250 9500 > $O/fz_deep_agg_2048.txt 2>&1; grep -E "$G" $O/fz_deep_agg_2048.txt | cut -c1-220
+    GSR_TIERS_BESIDE_MAX=0 timeout 600 python tools/fuzz_parity.py deep 150 9800 > $O/fz_deep_not_held.txt 2>&1; grep -E "$G" $O/fz_deep_not_held.txt | cut -c1-220
+    GSR_FUZZ_GRAD_PRECISION=accurate timeout 700 python tools/fuzz_parity.py 400 22000 > $O/fz_sweep_accurate.txt 2>&1; grep -E "$G" $O/fz_sweep_accurate.txt | cut -c1-220
+    GSR_FUZZ_GRAD_PRECISION=accurate timeout 700 python tools/fuzz_parity.py edge 300 10600 > $O/fz_edge_accurate.txt 2>&1; grep -E "$G" $O/fz_edge_accurate.txt | cut -c1-220
+    GSR_FUZZ_GRAD_PRECISION=fp32_reference timeout 700 python tools/fuzz_parity.py edge 300 10600 > $O/fz_edge_fp32ref.txt 2>&1; grep -E "$G" $O/fz_edge_fp32ref.txt | cut -c1-220
+    GSR_FUZZ_GRAD_PRECISION=accurate timeout 600 python tools/fuzz_parity.py deep 150 9950 > $O/fz_deep_accurate.txt 2>&1; grep -E "$G" $O/fz_deep_accurate.txt | cut -c1-220
+    timeout 300 python tools/fuzz_parity.py trainer 40 300 > $O/fz_trainer.txt 2>&1; grep -E "$G" $O/fz_trainer.txt | cut -c1-220
+    timeout 300 python tools/fuzz_parity.py ssim 300 2000 > $O/fz_ssim.txt 2>&1; grep -E "$G" $O/fz_ssim.txt | cut -c1-220
+    ;;
 esac

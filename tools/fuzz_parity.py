@@ -44,6 +44,8 @@ import fuzz_scenes  # noqa: E402  (tests/fuzz_scenes.py: the seeded scene famili
 # twice — K >= 1024 with lists beyond it: the second view keeps its bins and scatters the overflowing lists again
 # (gsr_stats.compact_binning == 2); K < 64: compact mode.  The counts of each binning mode are printed at the end.
 BINS_KEYS = int(os.environ.get("GSR_FUZZ_BINS_KEYS", "0"))
+# GSR_FUZZ_GRAD_PRECISION=accurate|fp32_reference: every handle is created with that gsr_config.grad_precision (round 6)
+GRAD_PRECISION = os.environ.get("GSR_FUZZ_GRAD_PRECISION") or None
 BINNING_SEEN = {0: 0, 1: 0, 2: 0}
 
 
@@ -64,7 +66,7 @@ def _scene_case(fs):
     """forward (every field, both list modes) + every gradient of one fuzz scene against the oracle."""
     st = orc.forward(fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, background=fs.bg, mode=fs.mode)
     run = HipRun(pkg, fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, fs.bg, fs.mode, pose_dev=fs.pose,
-                 bins_budget_bytes=_budget(fs.cam))
+                 bins_budget_bytes=_budget(fs.cam), grad_precision=GRAD_PRECISION)
     img = _fwd(run).clone()
     T._compare_forward(st, run, img, fs.opac)
     vp = fs.cotangent()

@@ -35,4 +35,17 @@ fuzz)
     timeout 300 python tools/fuzz_parity.py trainer 40 300 > $O/fz_trainer.txt 2>&1; grep -E "$G" $O/fz_trainer.txt | cut -c1-220
     timeout 300 python tools/fuzz_parity.py ssim 300 2000 > $O/fz_ssim.txt 2>&1; grep -E "$G" $O/fz_ssim.txt | cut -c1-220
     ;;
+arbitrate)
+    # every failing case of the campaign against the float64 autograd model (tools/fuzz_parity.py arbitrate: criteria (a) / (b) / (c))
+    timeout 900 python tools/fuzz_parity.py arbitrate sweep 20093 20308 > $O/arb_sweep.txt 2>&1
+    timeout 900 python tools/fuzz_parity.py arbitrate deep 9026 9030 9094 9163 9259 9394 > $O/arb_deep.txt 2>&1
+    GSR_FUZZ_GRAD_PRECISION=accurate timeout 900 python tools/fuzz_parity.py arbitrate deep 9026 9030 9094 9163 9259 9394 > $O/arb_deep_accurate.txt 2>&1
+    GSR_PREPROCESS_AGG=1 GSR_FUZZ_BINS_KEYS=2048 timeout 600 python tools/fuzz_parity.py arbitrate deep 9587 > $O/arb_deep_agg.txt 2>&1
+    timeout 900 python tools/fuzz_parity.py arbitrate edge 10081 10098 10100 10101 10131 10172 10199 10275 10426 10439 > $O/arb_edge.txt 2>&1
+    GSR_FUZZ_GRAD_PRECISION=accurate timeout 900 python tools/fuzz_parity.py arbitrate sweep 22028 22243 > $O/arb_sweep_accurate.txt 2>&1
+    GSR_FUZZ_GRAD_PRECISION=accurate timeout 900 python tools/fuzz_parity.py arbitrate edge 10603 10625 10649 10652 10657 10674 10854 10873 > $O/arb_edge_accurate.txt 2>&1
+    GSR_FUZZ_GRAD_PRECISION=fp32_reference timeout 900 python tools/fuzz_parity.py arbitrate edge 10603 10625 10649 10652 10657 10674 10854 10873 > $O/arb_edge_fp32ref.txt 2>&1
+    timeout 300 python tools/fuzz_parity.py trainer 40 300 > $O/fz_trainer.txt 2>&1; grep -E "^FAIL|cases passed" $O/fz_trainer.txt | cut -c1-220
+    tail -n 40 $O/arb_deep.txt $O/arb_deep_accurate.txt
+    ;;
 esac

@@ -142,7 +142,7 @@ def trainer_case(case):
     max_deg = int(rng.integers(0, 4))
     deg = int(rng.integers(0, max_deg + 1))
     TT.test_backward_with_the_tail_in_its_epilogue_equals_backward_then_tail(
-        pkg, int(rng.integers(1, 2500)), deg, max_deg, iso, ["rgb", "rgbd", "rgbdn"][case % 3])
+        pkg, int(rng.integers(1, 2500)), deg, max_deg, iso, ["rgb", "rgbd", "rgbdn"][case % 3], bool(case % 3 and case % 2))
     if case % 4 == 0:
         TD.test_densify_and_prune_matches_oracle(pkg, 1 if iso else 3, kr, int(rng.choice([0, 20])))
 
@@ -159,7 +159,7 @@ def _pose_verdict(fs, st, boundary_pair=False):
     import f64_model as fm
     vp = fs.cotangent()
     g = orc.backward(st, vp, fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, background=fs.bg, pose_grad=True)
-    run = HipRun(pkg, fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, fs.bg, fs.mode, pose_dev=True)
+    run = HipRun(pkg, fs.means, fs.shs, fs.opac, fs.scales, fs.rots, fs.cam, fs.deg, fs.bg, fs.mode, pose_dev=True, grad_precision=GRAD_PRECISION)
     run.forward()
     out = run.backward(vp)
     hR, ht = out[5].cpu().numpy().astype(np.float64).reshape(-1), out[6].cpu().numpy().astype(np.float64).reshape(-1)

@@ -194,7 +194,7 @@ def arbitrate_cases(family, cases):
     for case in cases:
         fs = build(pkg, case)
         try:
-            res, st = R.three_way(pkg, orc, fs)
+            res, st = R.three_way(pkg, orc, fs, grad_precision=GRAD_PRECISION)
             verdict = R.arbitrate(res, st, fs)
             if fs.pose:
                 # (a fresh scene object: the campaign's cotangent is its rng's FIRST draw)

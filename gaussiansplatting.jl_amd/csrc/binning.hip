@@ -305,10 +305,17 @@ __global__ __launch_bounds__(64 * RUNS) void tile_sort_runs_kernel(const uint32_
                                                                    const uint64_t* __restrict__ bins, uint32_t bin_cap,
                                                                    const uint64_t* __restrict__ overflow, int grid_x,
                                                                    GsrGeom geom, GsrStream stream,
-                                                                   uint32_t* __restrict__ values_sorted) {
+                                                                   uint32_t* __restrict__ values_sorted, uint32_t first,
+                                                                   const uint32_t* __restrict__ totals, uint32_t cap_instances,
+                                                                   int count_slot) {
     constexpr int NT = 64 * RUNS, CAP = 1024 * RUNS;
     __shared__ uint64_t buf[CAP];
-    const int tile = (int)tier_list[blockIdx.x], tid = threadIdx.x;
+    const uint32_t slot = first + blockIdx.x;
+    // totals != NULL: launched behind the scan BEFORE the host has the counts (gsr_launch_tile_sort_mid): the grid is a guess.
+    // A view that needs more instances than the buffers hold, or whose bins overflowed, is left alone (the host, which sees
+    // the same totals, sorts it after growing / scattering); a workgroup beyond the tier's real count leaves.
+    if (totals && (totals[0] > cap_instances || totals[1] > bin_cap || slot >= totals[count_slot])) return;
+    const int tile = (int)tier_list[slot], tid = threadIdx.x;
     const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
     const uint32_t n = end - start;
     if (n == 0 || n > (uint32_t)CAP) return;
@@ -547,12 +554,13 @@ void gsr_launch_tile_sort(hipStream_t s, int passes, int n_tiles, int grid_x, in
                           uint32_t n_mid4, uint32_t n_mid8,
                           uint32_t n_big, const uint32_t* tier_lists, uint64_t* big_scratch, size_t slab_stride, GsrGeom geom,
                           GsrStream stream, uint32_t* values_sorted, uint32_t* ranges, const uint32_t* totals,
-                          uint32_t cap_instances) {
+                          uint32_t cap_instances, uint32_t first4, uint32_t first8) {
+    // (first4 / first8: the leading tiles of the two mid tier lists that gsr_launch_tile_sort_mid has already sorted)
     // GSR_SORT_TIERS_NETWORK=1: round 2's LDS bitonic network for the (1024, 8192] tiers (A/B runs); default: register runs + merges
     static const bool net = [] { const char* e = getenv("GSR_SORT_TIERS_NETWORK"); return e && e[0] == '1'; }();
 #define LAUNCH_RUNS(CC, RUNSV, GRID, LIST)                                                                        \
     hipLaunchKernelGGL((tile_sort_runs_kernel<CC, RUNSV>), dim3(GRID), dim3(64 * RUNSV), 0, s, tile_start, LIST, bins, \
-                       bin_cap, overflow_keys, grid_x, geom, stream, values_sorted)
+                       bin_cap, overflow_keys, grid_x, geom, stream, values_sorted, 0u, (const uint32_t*)nullptr, 0u, 0)
 #define LAUNCH(CC, CAPV, NTV, GRID, LIST)                                                                        \
     hipLaunchKernelGGL((tile_sort_kernel<CC, CAPV, NTV>), dim3(GRID), dim3(NTV), 0, s, tile_start, LIST, bins,    \
                        bin_cap, overflow_keys, grid_x, geom, stream, values_sorted)
@@ -581,10 +589,10 @@ void gsr_launch_tile_sort(hipStream_t s, int passes, int n_tiles, int grid_x, in
                            tile_count, bins, bin_cap, grid_x, geom, stream, values_sorted, ranges, totals,          \
                            cap_instances, n_tiles);                                                                 \
     if (passes & GSR_SORT_PASS_TIERS) {                                                                           \
-        if (n_mid4 > 0) { if (net) LAUNCH(CC, 4096, 512, n_mid4, tier_lists + 2 * (size_t)n_tiles);              \
-                          else LAUNCH_RUNS(CC, 4, n_mid4, tier_lists + 2 * (size_t)n_tiles); }                     \
-        if (n_mid8 > 0) { if (net) LAUNCH(CC, GSR_SORT_LDS_CAP, 1024, n_mid8, tier_lists + (size_t)n_tiles);      \
-                          else LAUNCH_RUNS(CC, 8, n_mid8, tier_lists + (size_t)n_tiles); }                         \
+        if (n_mid4 > first4) { if (net) LAUNCH(CC, 4096, 512, n_mid4 - first4, tier_lists + 2 * (size_t)n_tiles + first4); \
+                               else LAUNCH_RUNS(CC, 4, n_mid4 - first4, tier_lists + 2 * (size_t)n_tiles + first4); }        \
+        if (n_mid8 > first8) { if (net) LAUNCH(CC, GSR_SORT_LDS_CAP, 1024, n_mid8 - first8, tier_lists + (size_t)n_tiles + first8); \
+                               else LAUNCH_RUNS(CC, 8, n_mid8 - first8, tier_lists + (size_t)n_tiles + first8); }            \
         if (n_big > 0) LAUNCH_BIG(CC);                                                                            \
     }
     if (channels > 5) { ALL(8) } else if (channels > 3) { ALL(5) } else { ALL(3) }
@@ -592,6 +600,29 @@ void gsr_launch_tile_sort(hipStream_t s, int passes, int n_tiles, int grid_x, in
 #undef LAUNCH
 #undef LAUNCH_RUNS
 #undef LAUNCH_BIG
+}
+
+// The two mid tiers' sorts queued BEHIND the scan, before the host has read the counts (round 6): with a held fused launch the
+// GPU used to idle 22-34 us per view between tile_scan and these sorts — the host's reaction plus a launch
+// (profiles/r06/experiments/training_step_idle_time.txt).  The grids are the caller's guesses from the previous view; every
+// workgroup checks the scan's totals (tile_sort_runs_kernel).  Tiles the guess did not cover, lists beyond 8192 and views the
+// guard turned down are sorted by gsr_launch_tile_sort after the read-back (first4 / first8).  Sorting a tile twice is harmless:
+// same keys, same entries.
+void gsr_launch_tile_sort_mid(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start,
+                              const uint64_t* bins, uint32_t bin_cap, uint32_t grid4, uint32_t grid8, const uint32_t* tier_lists,
+                              GsrGeom geom, GsrStream stream, uint32_t* values_sorted, const uint32_t* totals,
+                              uint32_t cap_instances) {
+#define SPEC(CC)                                                                                                          \
+    do {                                                                                                                  \
+        if (grid4) hipLaunchKernelGGL((tile_sort_runs_kernel<CC, 4>), dim3(grid4), dim3(256), 0, s, tile_start,              \
+                                      tier_lists + 2 * (size_t)n_tiles, bins, bin_cap, (const uint64_t*)nullptr, grid_x, geom, \
+                                      stream, values_sorted, 0u, totals, cap_instances, 3 /* totals[3] = n_mid4 */);          \
+        if (grid8) hipLaunchKernelGGL((tile_sort_runs_kernel<CC, 8>), dim3(grid8), dim3(512), 0, s, tile_start,              \
+                                      tier_lists + (size_t)n_tiles, bins, bin_cap, (const uint64_t*)nullptr, grid_x, geom,    \
+                                      stream, values_sorted, 0u, totals, cap_instances, 6 /* totals[6] = n_mid8 */);          \
+    } while (0)
+    if (channels > 5) SPEC(8); else if (channels > 3) SPEC(5); else SPEC(3);
+#undef SPEC
 }
 
 void gsr_launch_fill_background(hipStream_t s, size_t n_pixels, int channels, const float* background, float* image,

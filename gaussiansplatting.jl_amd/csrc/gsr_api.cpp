@@ -776,6 +776,26 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
         sc3.close();
     };
     if (spec && !hold_fused) launch_fused(s);
+    // A held fused launch waits for the tier sorts, and those for the host's read-back: 22-34 us of idle GPU per view (kernel
+    // trace of the training protocol, profiles/r06/experiments/training_step_idle_time.txt).  The two mid tiers' sorts therefore
+    // go out NOW, behind the scan, with grids guessed from the previous view and the scan's totals checked on the device
+    // (gsr_launch_tile_sort_mid); what the guess missed is sorted after the read-back.  Not when the previous view had lists
+    // beyond 8192 (their sort needs scratch sized by the host) and not for forward-only renders (whose stream buffers are not
+    // sized by cap_instances).  GSR_SPEC_TIER_SORTS=0: A/B.
+    static const bool spec_tiers_on = [] { const char* e = getenv("GSR_SPEC_TIER_SORTS"); return !(e && e[0] == '0'); }();
+    uint32_t spec4 = 0, spec8 = 0;
+    if (hold_fused && spec_tiers_on && !fwd_only && h->pol.tier_n[2] == 0) {
+        const auto guess = [&](uint32_t prev) { return prev ? std::min<uint32_t>(prev + prev / 4 + 16u, (uint32_t)h->n_tiles) : 0u; };
+        spec4 = guess(h->pol.tier_n[0]);
+        spec8 = guess(h->pol.tier_n[1]);
+        if (spec4 | spec8) {
+            StageScope scs(h->prof, ST_SORT, s);
+            gsr_launch_tile_sort_mid(s, h->n_tiles, h->grid_x, C, h->tile_start.as<uint32_t>(), h->bins.as<uint64_t>(), bin_cap_view,
+                                     spec4, spec8, h->big_list.as<uint32_t>(), geom_of(h), stream_of(h),
+                                     h->values_sorted.as<uint32_t>(), totals, (uint32_t)cap_instances);
+            scs.close();
+        }
+    }
     if ((rc = wait_totals(h, seq, s))) return rc;
     // What this view turned out to be — bins / overflow tiles / compact; whether the fused launch covers it; where the tier
     // walk goes; the bins' capacity for the next view — is gsr_policy_end_view's decision on the scan's counts.
@@ -844,6 +864,9 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     // now; one that would only find its buffers too small — the kernel checks the same totals — is not launched at all: the
     // main sort pass then re-zeroes the counters and writes the ranges, as in every view without the fused launch)
     if (oc.launch_fused_now) launch_fused(s);
+    // what the speculative mid-tier sorts covered (the kernels' own test, on the same numbers)
+    const bool spec_sorted = (spec4 | spec8) != 0u && D <= cap_instances && max_tile <= bin_cap_view;
+    const uint32_t done4 = spec_sorted ? std::min(spec4, n_mid4) : 0u, done8 = spec_sorted ? std::min(spec8, n_mid8) : 0u;
     if (!fused_done || long_tiles) {
         StageScope sc4(h->prof, ST_SORT, s);
         const uint64_t* keys = h->bins.as<uint64_t>();
@@ -871,7 +894,7 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
                              h->tile_start.as<uint32_t>(), h->tile_count.as<uint32_t>(), keys, key_cap, overflow_keys,
                              n_mid4, n_mid8, n_big, h->big_list.as<uint32_t>(), h->big_scratch.as<uint64_t>(),
                              slab_stride, geom_of(h), stream_of(h), h->values_sorted.as<uint32_t>(), h->ranges.as<uint32_t>(),
-                             nullptr, 0);
+                             nullptr, 0, done4, done8);
         sc4.close();
         // the walk of the tier tiles: beside the held fused launch (second stream, first in the queue), else behind it
         const hipStream_t ws = beside ? h->aux_stream : s;

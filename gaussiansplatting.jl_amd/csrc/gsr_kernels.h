@@ -129,7 +129,14 @@ void gsr_launch_tile_sort(hipStream_t s, int passes, int n_tiles, int grid_x, in
                           uint32_t n_mid4, uint32_t n_mid8, uint32_t n_big, const uint32_t* tier_lists,
                           uint64_t* big_scratch /* 2 slabs of slab_stride keys per tile over 8192 */, size_t slab_stride, GsrGeom geom,
                           GsrStream stream, uint32_t* values_sorted, uint32_t* ranges, const uint32_t* totals,
-                          uint32_t cap_instances);
+                          uint32_t cap_instances, uint32_t first4 = 0, uint32_t first8 = 0 /* leading tiles of the mid tier
+                          lists already sorted by gsr_launch_tile_sort_mid */);
+// the sorts of the (1024, 4096] / (4096, 8192] tiers launched BEFORE the host has the counts: grids are guesses, every workgroup
+// checks `totals` (device) — instances <= cap_instances, longest list <= bin_cap, its slot < the tier's count — else leaves
+void gsr_launch_tile_sort_mid(hipStream_t s, int n_tiles, int grid_x, int channels, const uint32_t* tile_start,
+                              const uint64_t* bins, uint32_t bin_cap, uint32_t grid4, uint32_t grid8, const uint32_t* tier_lists,
+                              GsrGeom geom, GsrStream stream, uint32_t* values_sorted, const uint32_t* totals,
+                              uint32_t cap_instances);
 
 // ---- composite.hip ----
 // Tiles whose list is longer than split_len (a tier boundary of the scan: 1024, 4096, 8192, or 0xFFFFFFFF for none)

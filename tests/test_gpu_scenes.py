@@ -119,3 +119,54 @@ def test_fp32_reference_gradient_precision_pins_the_references_own_arithmetic(pk
         # (one ulp of vconic moves it by 6e-5 on 150 : 1 needles) of the oracle's evaluation of the same trees
         assert v["ref_vs_fp32_oracle"] <= max(1e-4, 0.75 * v["fp32_oracle_vs_f64"]), (nm, v)
         assert v["ref_vs_fp32_oracle"] < v["default_vs_fp32_oracle"], (nm, v)       # ... and closer to it than the default is
+
+
+def test_speculative_mid_tier_sorts_on_one_handle_equal_fresh_handles(pkg, orc):
+    """Round 6: with a held fused launch the sorts of the (1024, 4096] / (4096, 8192] tiers are queued behind the scan BEFORE the
+    host knows the counts, with grids guessed from the previous view and the scan's totals checked on the device
+    (gsr_launch_tile_sort_mid).  One handle renders a sequence of scenes in which the guess is too small (the remainder is sorted
+    after the read-back), exact, too large (surplus workgroups leave), absent for a tier the previous view did not have, and
+    void (no tier tiles after all; lists beyond 8192 in the previous view; an overflowing view): every image, list and gradient
+    equals a fresh handle's, bit for bit."""
+    from hip_helpers import HipRun, dev
+    W, H, deg = 480, 272, 1
+    base = pkg.synthetic.make_scene(20000, W, H, deg, 801)
+    sk = pkg.synthetic.add_skew
+    scenes = dict(none=base, few4=sk(base, "hot:2500", seed=802), many4=sk(base, "dense:0.1:25", seed=803),
+                  some8=sk(base, "dense:0.04:100", seed=804), big=sk(base, "hot:12000", seed=805),
+                  mixed=sk(sk(base, "dense:0.06:25", seed=806), "hot:6000", seed=807))
+    cam = orc.Camera(W, H, base.focal)
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    for mode, budget in (("rgb", 0), ("rgbd", (T + 1) * 8 * 2048)):   # (the second: lists beyond 2048 keys overflow their bins)
+        C = 3 if mode == "rgb" else 5
+        vp = np.random.default_rng(11).standard_normal((H, W, C)).astype(np.float32)
+        ref = {}
+        for name, s in scenes.items():
+            r = HipRun(pkg, s.means, s.shs, s.opacities, s.scales, s.rotations, cam, deg, (0.1, 0.2, 0.3), mode, exact_tile_cull=True)
+            img = r.forward().clone()
+            ref[name] = (img, [g.clone() for g in r.backward(vp)[:5]], r.rast.values_sorted.clone(), r.rast.ranges.clone(),
+                         [int(x) for x in r.rast.stats.tier_tiles])
+            r.rast.close()
+        # the scenes are what the test needs them to be
+        assert ref["none"][4] == [0, 0, 0] and ref["few4"][4][0] > 0 and ref["many4"][4][0] > 2 * ref["few4"][4][0] + 16
+        assert ref["some8"][4][1] > 0 and ref["big"][4][2] > 0 and ref["mixed"][4][0] > 0
+        one = HipRun(pkg, base.means, base.shs, base.opacities, base.scales, base.rotations, cam, deg, (0.1, 0.2, 0.3), mode,
+                     exact_tile_cull=True, bins_budget_bytes=budget)
+        order = ["few4", "many4", "many4", "few4", "some8", "some8", "many4", "none", "few4", "few4", "big", "few4", "mixed", "many4",
+                 "mixed", "some8", "none", "many4", "many4"]
+        held0 = int(one.rast.stats.held_views)
+        seen = set()
+        for name in order:
+            s = scenes[name]
+            one.t = [dev(s.means), dev(s.shs), dev(s.opacities.reshape(-1, 1)), dev(s.scales), dev(s.rotations)]
+            img = one.forward()
+            seen.add(int(one.rast.stats.compact_binning))
+            want = ref[name]
+            assert torch.equal(img, want[0]), (mode, name)
+            assert torch.equal(one.rast.values_sorted, want[2]) and torch.equal(one.rast.ranges, want[3]), (mode, name)
+            for a, b in zip(one.backward(vp)[:5], want[1]):
+                assert torch.equal(a, b), (mode, name)
+        assert int(one.rast.stats.held_views) - held0 >= 10     # most views of the sequence held their fused launch
+        if budget:
+            assert 2 in seen                                    # ... and some of them overflowed their bins (the device guard)
+        one.rast.close()

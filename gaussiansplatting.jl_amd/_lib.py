@@ -133,12 +133,14 @@ class PolicyState(C.Structure):
 
 class ViewPlan(C.Structure):
     _fields_ = [("bin_cap_view", C.c_uint32), ("form_request", C.c_int32), ("form", C.c_int32), ("timed_slot", C.c_int32),
-                ("skewed", C.c_int32), ("hold_fused", C.c_int32), ("tuner_decided", C.c_int32), ("reserved", C.c_int32)]
+                ("skewed", C.c_int32), ("hold_fused", C.c_int32), ("tuner_decided", C.c_int32), ("spec_mid4", C.c_uint32),
+                ("spec_mid8", C.c_uint32), ("reserved", C.c_int32)]
 
 
 class ViewOutcome(C.Structure):
     _fields_ = [("binning", C.c_int32), ("fused_done", C.c_int32), ("long_tiles", C.c_int32), ("beside", C.c_int32),
-                ("launch_fused_now", C.c_int32), ("reserved", C.c_int32), ("bin_cap_next", C.c_uint32), ("bins_regrown", C.c_uint32)]
+                ("launch_fused_now", C.c_int32), ("reserved", C.c_int32), ("sorted_mid4", C.c_uint32), ("sorted_mid8", C.c_uint32),
+                ("bin_cap_next", C.c_uint32), ("bins_regrown", C.c_uint32)]
 
 
 class BwdSplit(C.Structure):

@@ -783,11 +783,10 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     // beyond 8192 (their sort needs scratch sized by the host) and not for forward-only renders (whose stream buffers are not
     // sized by cap_instances).  GSR_SPEC_TIER_SORTS=0: A/B.
     static const bool spec_tiers_on = [] { const char* e = getenv("GSR_SPEC_TIER_SORTS"); return !(e && e[0] == '0'); }();
-    uint32_t spec4 = 0, spec8 = 0;
-    if (hold_fused && spec_tiers_on && !fwd_only && h->pol.tier_n[2] == 0) {
-        const auto guess = [&](uint32_t prev) { return prev ? std::min<uint32_t>(prev + prev / 4 + 16u, (uint32_t)h->n_tiles) : 0u; };
-        spec4 = guess(h->pol.tier_n[0]);
-        spec8 = guess(h->pol.tier_n[1]);
+    // (the guesses are the policy's: gsr_view_plan.spec_mid4 / spec_mid8; what is not launched is zeroed for gsr_policy_end_view)
+    if (!(hold_fused && spec_tiers_on && !fwd_only)) plan.spec_mid4 = plan.spec_mid8 = 0u;
+    const uint32_t spec4 = plan.spec_mid4, spec8 = plan.spec_mid8;
+    {
         if (spec4 | spec8) {
             StageScope scs(h->prof, ST_SORT, s);
             gsr_launch_tile_sort_mid(s, h->n_tiles, h->grid_x, C, h->tile_start.as<uint32_t>(), h->bins.as<uint64_t>(), bin_cap_view,
@@ -864,9 +863,8 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     // now; one that would only find its buffers too small — the kernel checks the same totals — is not launched at all: the
     // main sort pass then re-zeroes the counters and writes the ranges, as in every view without the fused launch)
     if (oc.launch_fused_now) launch_fused(s);
-    // what the speculative mid-tier sorts covered (the kernels' own test, on the same numbers)
-    const bool spec_sorted = (spec4 | spec8) != 0u && D <= cap_instances && max_tile <= bin_cap_view;
-    const uint32_t done4 = spec_sorted ? std::min(spec4, n_mid4) : 0u, done8 = spec_sorted ? std::min(spec8, n_mid8) : 0u;
+    // what the speculative mid-tier sorts covered (gsr_policy_end_view: the kernels' own test, on the same numbers)
+    const uint32_t done4 = oc.sorted_mid4, done8 = oc.sorted_mid8;
     if (!fused_done || long_tiles) {
         StageScope sc4(h->prof, ST_SORT, s);
         const uint64_t* keys = h->bins.as<uint64_t>();

@@ -170,6 +170,15 @@ void gsr_policy_begin_view(const gsr_policy_config* cfg, gsr_policy_state* st, i
     // belongs BESIDE the fused launch: when the previous view had tier tiles the fused launch is held until their sorts have run
     const uint64_t prev_tiers = (uint64_t)st->tier_n[0] + st->tier_n[1] + st->tier_n[2];
     plan->hold_fused = prev_tiers > 0 && prev_tiers <= cfg->beside_max_tiles;
+    // ... and the mid tiers' sorts need not wait for the host either: grids from the previous view's counts, checked on the device
+    const auto guess = [&](uint32_t prev) -> uint32_t {
+        if (!prev) return 0u;
+        const uint64_t g = (uint64_t)prev + prev / 4 + 16u, T = tiles_of(cfg);
+        return (uint32_t)(g < T ? g : T);
+    };
+    const bool spec_sorts = plan->hold_fused && plan->bin_cap_view > 0 && st->tier_n[2] == 0;
+    plan->spec_mid4 = spec_sorts ? guess(st->tier_n[0]) : 0u;
+    plan->spec_mid8 = spec_sorts ? guess(st->tier_n[1]) : 0u;
 }
 
 void gsr_policy_end_view(const gsr_policy_config* cfg, gsr_policy_state* st, const gsr_view_plan* plan, int64_t n_rendered,
@@ -213,6 +222,10 @@ void gsr_policy_end_view(const gsr_policy_config* cfg, gsr_policy_state* st, con
     out->beside = held && out->fused_done && out->long_tiles && tiers <= cfg->beside_max_tiles;
     // (a held fused launch that this view gives no reason to hold any longer: no tier tiles after all, or too many)
     out->launch_fused_now = held && !out->beside && out->fused_done;
+    // what the speculative mid-tier sorts covered: the kernels' own test (tile_sort_runs_kernel), on the same numbers
+    const bool spec_sorted = (plan->spec_mid4 | plan->spec_mid8) != 0u && D <= cap_instances && max_tile_instances <= plan->bin_cap_view;
+    out->sorted_mid4 = spec_sorted ? (plan->spec_mid4 < n_mid4 ? plan->spec_mid4 : n_mid4) : 0u;
+    out->sorted_mid8 = spec_sorted ? (plan->spec_mid8 < n_mid8 ? plan->spec_mid8 : n_mid8) : 0u;
     // history
     if (!use_bins) st->compact_views++;
     else if (overflow && !hybrid) st->compact_fallbacks++;

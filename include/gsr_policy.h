@@ -99,6 +99,11 @@ typedef struct gsr_view_plan {
     int32_t skewed;          /* the previous view's longest list was > 6 x its mean list (hot counter words) */
     int32_t hold_fused;      /* the previous view had tier tiles: hold the fused launch until their sorts have run */
     int32_t tuner_decided;   /* this call took the tuner's decision (from `timed_ms`) */
+    /* Speculative sorts of the two mid tiers (lists of 1024 ... 4096 / ... 8192 keys), queued behind the scan BEFORE the host has the
+     * counts when the fused launch is held: grid sizes guessed from the previous view (count x 1.25 + 16, at most every tile);
+     * 0 = none (no hold, no such tiles last view, or lists beyond 8192 last view: their sort needs host-sized scratch).  The
+     * caller zeroes them when it does not launch (forward-only render) — gsr_policy_end_view reads them back. */
+    uint32_t spec_mid4, spec_mid8;
     int32_t reserved;
 } gsr_view_plan;
 
@@ -110,6 +115,9 @@ typedef struct gsr_view_outcome {
     int32_t beside;          /* the tier walk runs beside the (held) fused launch */
     int32_t launch_fused_now;/* a held fused launch with no reason to be held any longer: launch it before the tier work */
     int32_t reserved;
+    /* leading tiles of the two mid tier lists that the speculative sorts have covered (their device-side guard passed: the view
+     * fits the buffers and no list exceeds the bins' capacity): the host sorts the rest */
+    uint32_t sorted_mid4, sorted_mid8;
     uint32_t bin_cap_next;   /* capacity chosen for the next view (0: compact) */
     uint32_t bins_regrown;   /* this view made the bins grow */
 } gsr_view_outcome;

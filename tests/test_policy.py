@@ -125,6 +125,41 @@ def test_hot_tile_keeps_its_bins_and_holds_the_fused_launch(P):
     assert [view(P, cfg2, st2, 1_032_000, 4_032_599, 32_451, tiers, cap_instances=6_000_000)[0].hold_fused for _ in range(3)] == [0, 0, 0]
 
 
+def test_speculative_mid_tier_sort_grids_and_what_they_covered(P):
+    """Round 6: with a held fused launch the mid tiers' sorts are queued behind the scan before the host has the counts — grids
+    guessed from the previous view (count x 1.25 + 16), validity decided by the same comparisons the kernels make."""
+    cfg, st = new_handle(P, 1920, 1080)
+    big = 6_000_000
+    pl, oc = view(P, cfg, st, 1_000_000, 1_700_000, 2300, (40, 0, 0), cap_instances=big)
+    assert (pl.hold_fused, pl.spec_mid4, pl.spec_mid8, oc.sorted_mid4, oc.sorted_mid8) == (0, 0, 0, 0, 0)   # first view: nothing known
+    pl, oc = view(P, cfg, st, 1_000_000, 1_700_000, 2300, (100, 3, 0), cap_instances=big)
+    assert pl.hold_fused == 1 and (pl.spec_mid4, pl.spec_mid8) == (40 + 10 + 16, 0)       # no (4096, 8192] tiles last view: none guessed
+    assert (oc.sorted_mid4, oc.sorted_mid8) == (66, 0)                                     # guess too small: the host sorts 34 + 3 tiles
+    pl, oc = view(P, cfg, st, 1_000_000, 1_700_000, 2300, (90, 2, 0), cap_instances=big)
+    assert (pl.spec_mid4, pl.spec_mid8) == (141, 19) and (oc.sorted_mid4, oc.sorted_mid8) == (90, 2)   # too large: surplus workgroups leave
+    # the view needs more instances than the buffers hold / a list beyond the bins: the kernels touched nothing
+    pl, oc = view(P, cfg, st, 1_000_000, 1_700_000, 2300, (90, 2, 0), cap_instances=1_600_000)
+    assert pl.spec_mid4 > 0 and (oc.sorted_mid4, oc.sorted_mid8) == (0, 0) and oc.fused_done == 0
+    pl, oc = view(P, cfg, st, 1_000_000, 1_700_000, pl.bin_cap_view + 1, (90, 2, 0), cap_instances=big)
+    assert pl.spec_mid4 > 0 and (oc.sorted_mid4, oc.sorted_mid8) == (0, 0) and oc.binning == L_OVERFLOW
+    # lists beyond 8192 in the previous view (their sort needs host-sized scratch): no guess at all
+    view(P, cfg, st, 1_000_000, 1_700_000, 2300, (90, 2, 1), cap_instances=big)
+    pl, oc = view(P, cfg, st, 1_000_000, 1_700_000, 2300, (90, 2, 0), cap_instances=big)
+    assert pl.hold_fused == 1 and (pl.spec_mid4, pl.spec_mid8) == (0, 0)
+    # a caller that does not launch them (forward-only render) zeroes the plan: nothing counts as sorted
+    lib, L = P
+    plan, oc = L.ViewPlan(), L.ViewOutcome()
+    lib.gsr_policy_begin_view(C.byref(cfg), C.byref(st), 1_000_000, None, C.byref(plan))
+    assert plan.spec_mid4 > 0
+    plan.spec_mid4 = plan.spec_mid8 = 0
+    lib.gsr_policy_end_view(C.byref(cfg), C.byref(st), C.byref(plan), 1_700_000, 2300, 90, 2, 0, big, 1, C.byref(oc))
+    assert (oc.sorted_mid4, oc.sorted_mid8) == (0, 0)
+    # the guess never exceeds the grid
+    cfg3, st3 = new_handle(P, 64, 48)
+    view(P, cfg3, st3, 50_000, 30_000, 3000, (12, 0, 0), cap_instances=big)
+    assert view(P, cfg3, st3, 50_000, 30_000, 3000, (12, 0, 0), cap_instances=big)[0].spec_mid4 == 12
+
+
 def test_buffers_too_small_for_the_early_fused_launch_are_counted(P):
     cfg, st = new_handle(P, 1920, 1080)
     view(P, cfg, st, 1_000_000, 3_900_000, 569, cap_instances=0, fused=0)          # first view: no buffers yet

@@ -120,7 +120,7 @@ struct Profiler {
     bool in_range = false;
     bool rec_open = false;
     uint32_t mask = ~0u;  // stages that get an event pair (gsr_profile_stages)
-    struct Rec { int stage; hipEvent_t a, b; };
+    struct Rec { int stage; hipEvent_t a, b; bool extra; };  // extra: a second launch group of a stage inside ONE call (time, not count)
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
     hipEvent_t get() {
@@ -131,7 +131,7 @@ struct Profiler {
         (void)hipEventCreateWithFlags(&e, hipEventDisableSystemFence);
         return e;
     }
-    void begin(int stage, hipStream_t s);
+    void begin(int stage, hipStream_t s, bool extra = false);
     void end(hipStream_t s) {
         if (in_range) { g_roctx.pop(); in_range = false; }
         if (!rec_open) return;
@@ -159,7 +159,7 @@ struct Profiler {
     }
 };
 
-void Profiler::begin(int stage, hipStream_t s) {
+void Profiler::begin(int stage, hipStream_t s, bool extra) {
     if ((ranges || roctx_env()) && g_roctx.load()) {
         char name[48];
         snprintf(name, sizeof name, "gsr:%s", kStageNames[stage]);
@@ -167,7 +167,7 @@ void Profiler::begin(int stage, hipStream_t s) {
         in_range = true;
     }
     if (!on || !((mask >> stage) & 1u)) return;
-    Rec r{stage, get(), get()};
+    Rec r{stage, get(), get(), extra};
     (void)hipEventRecord(r.a, s);
     recs.push_back(r);
     rec_open = true;
@@ -179,7 +179,7 @@ struct StageScope {
     Profiler& p;
     hipStream_t s;
     bool open = true;
-    StageScope(Profiler& prof, int stage, hipStream_t stream) : p(prof), s(stream) { p.begin(stage, s); }
+    StageScope(Profiler& prof, int stage, hipStream_t stream, bool extra = false) : p(prof), s(stream) { p.begin(stage, s, extra); }
     void close() { if (open) { p.end(s); open = false; } }
     ~StageScope() { if (open) p.abort(); }
     StageScope(const StageScope&) = delete;
@@ -779,16 +779,16 @@ int gsr_forward(gsr_handle* h, const gsr_inputs* in, const gsr_camera* cam, floa
     // A held fused launch waits for the tier sorts, and those for the host's read-back: 22-34 us of idle GPU per view (kernel
     // trace of the training protocol, profiles/r06/experiments/training_step_idle_time.txt).  The two mid tiers' sorts therefore
     // go out NOW, behind the scan, with grids guessed from the previous view and the scan's totals checked on the device
-    // (gsr_launch_tile_sort_mid); what the guess missed is sorted after the read-back.  Not when the previous view had lists
-    // beyond 8192 (their sort needs scratch sized by the host) and not for forward-only renders (whose stream buffers are not
-    // sized by cap_instances).  GSR_SPEC_TIER_SORTS=0: A/B.
+    // (gsr_launch_tile_sort_mid); what the guess missed — and every list beyond 8192, whose chain needs host-sized scratch — is
+    // sorted after the read-back.  Not for forward-only renders (whose stream buffers are not sized by cap_instances).
+    // GSR_SPEC_TIER_SORTS=0: A/B.
     static const bool spec_tiers_on = [] { const char* e = getenv("GSR_SPEC_TIER_SORTS"); return !(e && e[0] == '0'); }();
     // (the guesses are the policy's: gsr_view_plan.spec_mid4 / spec_mid8; what is not launched is zeroed for gsr_policy_end_view)
     if (!(hold_fused && spec_tiers_on && !fwd_only)) plan.spec_mid4 = plan.spec_mid8 = 0u;
     const uint32_t spec4 = plan.spec_mid4, spec8 = plan.spec_mid8;
     {
         if (spec4 | spec8) {
-            StageScope scs(h->prof, ST_SORT, s);
+            StageScope scs(h->prof, ST_SORT, s, /*extra=*/true);  // (the stage's time; the call after the read-back counts the launch)
             gsr_launch_tile_sort_mid(s, h->n_tiles, h->grid_x, C, h->tile_start.as<uint32_t>(), h->bins.as<uint64_t>(), bin_cap_view,
                                      spec4, spec8, h->big_list.as<uint32_t>(), geom_of(h), stream_of(h),
                                      h->values_sorted.as<uint32_t>(), totals, (uint32_t)cap_instances);
@@ -1143,7 +1143,7 @@ int gsr_profile_read(gsr_handle* h, double* ms_sum, int* launches, int reset) {
         HIPCHK(hipEventSynchronize(r.b));
         HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
         ms_sum[r.stage] += ms;
-        launches[r.stage] += 1;
+        if (!r.extra) launches[r.stage] += 1;
     }
     if (reset) h->prof.clear();
     return GSR_OK;
@@ -1155,7 +1155,7 @@ int gsr_profile_read_intervals(gsr_handle* h, int stage, double* ms_out, int max
     int n = 0;
     hipEvent_t prev = nullptr;
     for (auto& r : h->prof.recs) {
-        if (r.stage != stage) continue;
+        if (r.stage != stage || r.extra) continue;
         if (prev) {
             if (n < max_n) {
                 float ms = 0.0f;

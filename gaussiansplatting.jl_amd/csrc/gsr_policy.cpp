@@ -176,7 +176,8 @@ void gsr_policy_begin_view(const gsr_policy_config* cfg, gsr_policy_state* st, i
         const uint64_t g = (uint64_t)prev + prev / 4 + 16u, T = tiles_of(cfg);
         return (uint32_t)(g < T ? g : T);
     };
-    const bool spec_sorts = plan->hold_fused && plan->bin_cap_view > 0 && st->tier_n[2] == 0;
+    // (lists beyond 8192, if the view has any, are sorted after the read-back as before: their chain needs host-sized scratch)
+    const bool spec_sorts = plan->hold_fused && plan->bin_cap_view > 0;
     plan->spec_mid4 = spec_sorts ? guess(st->tier_n[0]) : 0u;
     plan->spec_mid8 = spec_sorts ? guess(st->tier_n[1]) : 0u;
 }

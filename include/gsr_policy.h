@@ -101,7 +101,7 @@ typedef struct gsr_view_plan {
     int32_t tuner_decided;   /* this call took the tuner's decision (from `timed_ms`) */
     /* Speculative sorts of the two mid tiers (lists of 1024 ... 4096 / ... 8192 keys), queued behind the scan BEFORE the host has the
      * counts when the fused launch is held: grid sizes guessed from the previous view (count x 1.25 + 16, at most every tile);
-     * 0 = none (no hold, no such tiles last view, or lists beyond 8192 last view: their sort needs host-sized scratch).  The
+     * 0 = none (no hold, or no such tiles last view).  Lists beyond 8192 are always sorted after the read-back.  The
      * caller zeroes them when it does not launch (forward-only render) — gsr_policy_end_view reads them back. */
     uint32_t spec_mid4, spec_mid8;
     int32_t reserved;

@@ -142,10 +142,10 @@ def test_speculative_mid_tier_sort_grids_and_what_they_covered(P):
     assert pl.spec_mid4 > 0 and (oc.sorted_mid4, oc.sorted_mid8) == (0, 0) and oc.fused_done == 0
     pl, oc = view(P, cfg, st, 1_000_000, 1_700_000, pl.bin_cap_view + 1, (90, 2, 0), cap_instances=big)
     assert pl.spec_mid4 > 0 and (oc.sorted_mid4, oc.sorted_mid8) == (0, 0) and oc.binning == L_OVERFLOW
-    # lists beyond 8192 in the previous view (their sort needs host-sized scratch): no guess at all
+    # lists beyond 8192 (sorted after the read-back, their chain needs host-sized scratch) do not stop the mid tiers' guesses
     view(P, cfg, st, 1_000_000, 1_700_000, 2300, (90, 2, 1), cap_instances=big)
-    pl, oc = view(P, cfg, st, 1_000_000, 1_700_000, 2300, (90, 2, 0), cap_instances=big)
-    assert pl.hold_fused == 1 and (pl.spec_mid4, pl.spec_mid8) == (0, 0)
+    pl, oc = view(P, cfg, st, 1_000_000, 1_700_000, 2300, (90, 2, 1), cap_instances=big)
+    assert pl.hold_fused == 1 and (pl.spec_mid4, pl.spec_mid8) == (128, 18) and (oc.sorted_mid4, oc.sorted_mid8) == (90, 2)
     # a caller that does not launch them (forward-only render) zeroes the plan: nothing counts as sorted
     lib, L = P
     plan, oc = L.ViewPlan(), L.ViewOutcome()

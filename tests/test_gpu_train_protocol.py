@@ -29,7 +29,7 @@ pytestmark = pytest.mark.gpu
 
 # 50 k -> ~200 k Gaussians in 300 steps: the reference's schedule compressed 10 x (densify from 100 every 50, SH ramp every 100) and
 # a densification threshold that makes the model grow 20-40 % per round at this image size (tools/experiments/r06_growth_sweep.py)
-SMALL = dict(width=480, height=272, n_gt=150_000, n_init=50_000, n_views=16, densify_from_iter=100, densification_interval=50,
+SMALL = dict(torch_pool_gb=1, width=480, height=272, n_gt=150_000, n_init=50_000, n_views=16, densify_from_iter=100, densification_interval=50,
              sh_ramp_interval=100, densify_grad_threshold=2.5e-5, seed=2024)
 
 
@@ -50,7 +50,7 @@ def test_first_steps_of_the_training_chain_equal_the_oracle_chain(pkg, orc):
     zero in that arithmetic (V32 - V23 of a symmetric matrix), while the default float64 chain leaves ~1e-17 of rounding noise
     that NU.Adam's eps = 1e-15 (training.jl:229) turns into steps of up to the full learning rate in a gauge direction."""
     from train_oracle_chain import OracleChain
-    p = TH.Protocol(width=256, height=160, n_gt=15_000, n_init=6_000, n_views=8, densify_from_iter=3, densification_interval=3,
+    p = TH.Protocol(torch_pool_gb=0, width=256, height=160, n_gt=15_000, n_init=6_000, n_views=8, densify_from_iter=3, densification_interval=3,
                     opacity_reset_interval=4, sh_ramp_interval=2, densify_grad_threshold=1e-4, dense_percent=0.05, seed=77,
                     grad_precision="fp32_reference")
     h = TH.Harness(pkg, p)

@@ -75,6 +75,10 @@ class Protocol:
                                       # chain leaves 1e-17-level noise that NU.Adam's eps = 1e-15 turns into visible steps)
     init_jitter: float = 0.01
     init_color_noise: float = 0.05
+    torch_pool_gb: int = 8            # device memory the harness takes from the driver ONCE, up front, and hands to torch's caching
+                                      # allocator (1 GiB blocks): a densification round composes ~60 arrays of sizes no earlier round
+                                      # had, and every one would otherwise be a hipMalloc inside a training step (the reference's
+                                      # allocation cache plays the same role, strategy.jl:92).  0: off
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -184,6 +188,9 @@ class Harness:
         self.cams = [pkg.Camera(W, H, self.focal, (0.5, 0.5), Rm, t) for Rm, t in self.poses]
         self.rast = R.GaussianRasterizer(W, H, mode=p.mode, device=self.dev, bins_budget_bytes=p.bins_budget_bytes,
                                          grad_precision=p.grad_precision)
+        if p.torch_pool_gb and torch.cuda.memory_reserved(self.dev) < (p.torch_pool_gb << 30):
+            pool = [torch.empty(1 << 30, dtype=torch.uint8, device=self.dev) for _ in range(p.torch_pool_gb)]
+            del pool
         self.eval_rast = None    # evaluation renders take a handle of their own: the training handle's view history stays the run's
         self.bg = (0.0, 0.0, 0.0)
         to = self.to = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(self.dev)  # noqa: E731
